@@ -1,0 +1,206 @@
+"""ctypes binding of libcfhost.so (include/cfhost.h): NCRF ingestion + synthetic generator.
+
+Host-side only; no GPU involved.  The library is built in-tree by
+``centroflye_amd/csrc/Makefile`` (``__graft_entry__.build()``) and must be present — there
+is no pure-Python fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcfhost.so")
+
+
+class SynthParams(C.Structure):
+    """Mirror of ``cfh_synth_params`` (include/cfhost.h)."""
+    _fields_ = [
+        ("seed", C.c_uint64), ("unit_len", C.c_int32), ("monomer_len", C.c_int32),
+        ("monomer_div", C.c_double), ("n_units", C.c_int64), ("flank", C.c_int64),
+        ("unit_div", C.c_double), ("n_reads", C.c_int64), ("mean_len", C.c_double),
+        ("sigma", C.c_double), ("min_len", C.c_int64), ("max_len", C.c_int64),
+        ("p_del", C.c_double), ("p_sub", C.c_double), ("p_ins", C.c_double),
+        ("min_aligned", C.c_int64), ("n_prefix", C.c_int32), ("n_suffix", C.c_int32),
+        ("prefix_threshold", C.c_int64), ("p_split", C.c_double), ("n_threads", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_PATH} is missing: build it with `make -C centroflye_amd/csrc host` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`)")
+    L = C.CDLL(_LIB_PATH)
+    P = C.c_void_p
+    i64, i32 = C.c_int64, C.c_int32
+    pi64 = C.POINTER(C.c_int64)
+    L.cfh_synth_defaults.argtypes = [C.POINTER(SynthParams)]
+    L.cfh_synth_defaults.restype = None
+    L.cfh_synth.argtypes = [C.POINTER(SynthParams), C.c_char_p, C.c_int, C.POINTER(P), C.c_char_p, C.c_int]
+    L.cfh_parse_report.argtypes = [C.c_char_p, i64, C.c_int, C.c_int, C.POINTER(P), C.c_char_p, C.c_int]
+    L.cfh_pack_free.argtypes = [P]
+    L.cfh_pack_free.restype = None
+    for name in ("cfh_n_reads", "cfh_n_bases", "cfh_n_seen"):
+        getattr(L, name).argtypes = [P]
+        getattr(L, name).restype = i64
+    L.cfh_non_acgt.argtypes = [P]
+    L.cfh_non_acgt.restype = i32
+    for name in ("cfh_bases", "cfh_read_off", "cfh_ids", "cfh_id_off", "cfh_meta"):
+        getattr(L, name).argtypes = [P]
+        getattr(L, name).restype = C.c_void_p
+    L.cfh_n_motifs.argtypes = [P]
+    L.cfh_n_motifs.restype = i32
+    L.cfh_motif.argtypes = [P, i32, pi64]
+    L.cfh_motif.restype = C.c_void_p
+    L.cfh_discarded.argtypes = [P, pi64]
+    L.cfh_discarded.restype = C.c_void_p
+    L.cfh_units.argtypes = [P, i32, pi64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                            C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
+    L.cfh_classify.argtypes = [P, i64, i64, C.c_void_p]
+    L.cfh_row.argtypes = [P, i64, i32, pi64]
+    L.cfh_row.restype = C.c_void_p
+    L.cfh_write_kmers.argtypes = [C.c_char_p, C.c_void_p, i64, i32, C.c_char_p, C.c_int]
+    L.cfh_write_edges.argtypes = [C.c_char_p, C.c_int, C.c_void_p, i32, C.c_void_p, i64, C.c_char_p, C.c_int]
+    L.cfh_read_kmers.argtypes = [C.c_char_p, i32, C.c_void_p, i64, pi64, C.c_char_p, C.c_int]
+    _lib = L
+    return L
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def _check(rc, err):
+    if rc != 0:
+        raise HostError(f"cfhost error {rc}: {err.value.decode(errors='replace')}")
+
+
+def _view(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class PackedReads:
+    """Flat-array form of an NCRF report.
+
+    Attributes (numpy views borrowed from the native pack; valid while this object lives):
+      bases     uint8[N_b]  ASCII de-gapped oriented read rows
+      read_off  int64[R+1]
+      ids       list[str]   read ids in record order
+      meta      int64[R,8]  r_len, r_al_len, r_st, r_en, strand(0/1), n_alignments, ncols, motif id
+    """
+
+    def __init__(self, handle):
+        self._h = handle
+        L = lib()
+        self.n_reads = int(L.cfh_n_reads(handle))
+        self.n_bases = int(L.cfh_n_bases(handle))
+        self.non_acgt = bool(L.cfh_non_acgt(handle))
+        R = self.n_reads
+        self.bases = _view(L.cfh_bases(handle), self.n_bases, np.uint8)
+        self.read_off = _view(L.cfh_read_off(handle), R + 1, np.int64)
+        id_off = _view(L.cfh_id_off(handle), R + 1, np.int64)
+        raw = _view(L.cfh_ids(handle), int(id_off[-1]) if R else 0, np.uint8).tobytes()
+        self.ids = [raw[id_off[i]:id_off[i + 1]].decode() for i in range(R)]
+        self.meta = _view(L.cfh_meta(handle), R * 8, np.int64).reshape(R, 8)
+        self.motifs = []
+        for m in range(L.cfh_n_motifs(handle)):
+            n = C.c_int64()
+            p = L.cfh_motif(handle, m, C.byref(n))
+            self.motifs.append(C.string_at(p, n.value).decode())
+        n = C.c_int64()
+        p = L.cfh_discarded(handle, C.byref(n))
+        self.discarded_reads = [x for x in C.string_at(p, n.value).decode().split("\n") if x] if n.value else []
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.cfh_pack_free(h)
+
+    def units(self, n=1):
+        """(unit_ptr[R+1], unit_start[U], unit_end[U], unit_col[U,2]) for n_motif = n."""
+        L = lib()
+        err = C.create_string_buffer(512)
+        nu = C.c_int64()
+        p = [C.c_void_p() for _ in range(4)]
+        _check(L.cfh_units(self._h, n, C.byref(nu), C.byref(p[0]), C.byref(p[1]), C.byref(p[2]),
+                           C.byref(p[3]), err, 512), err)
+        U = nu.value
+        return (_view(p[0].value, self.n_reads + 1, np.int64), _view(p[1].value, U, np.int64),
+                _view(p[2].value, U, np.int64), _view(p[3].value, 2 * U, np.int64).reshape(U, 2))
+
+    def classify(self, large_threshold, small_threshold=1000):
+        """uint8[R]: 0 prefix, 1 internal, 2 suffix (reference ncrf_parser.py:120-145)."""
+        out = np.zeros(self.n_reads, dtype=np.uint8)
+        lib().cfh_classify(self._h, int(large_threshold), int(small_threshold), out.ctypes.data)
+        return out
+
+    def row(self, r, which):
+        n = C.c_int64()
+        p = lib().cfh_row(self._h, r, which, C.byref(n))
+        if not p:
+            raise HostError("alignment rows were not kept (parse with keep_rows=True)")
+        return C.string_at(p, n.value).decode()
+
+
+def parse_report(path, min_record_len=5000, keep_rows=True, n_threads=0):
+    L = lib()
+    err = C.create_string_buffer(512)
+    h = C.c_void_p()
+    _check(L.cfh_parse_report(os.fsencode(path), min_record_len, int(keep_rows), n_threads,
+                              C.byref(h), err, 512), err)
+    return PackedReads(h)
+
+
+def synth_params(**kw):
+    sp = SynthParams()
+    lib().cfh_synth_defaults(C.byref(sp))
+    for k, v in kw.items():
+        if not hasattr(sp, k):
+            raise TypeError(f"unknown synth parameter {k}")
+        setattr(sp, k, v)
+    return sp
+
+
+def synth(report_path=None, pack=True, keep_rows=False, **kw):
+    """Run the synthetic generator; returns PackedReads (or None when pack=False)."""
+    L = lib()
+    sp = synth_params(**kw)
+    err = C.create_string_buffer(512)
+    h = C.c_void_p()
+    _check(L.cfh_synth(C.byref(sp), os.fsencode(report_path) if report_path else None,
+                       int(keep_rows), C.byref(h) if pack else None, err, 512), err)
+    return PackedReads(h) if pack else None
+
+
+def write_kmers(path, kmers, k):
+    kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+    err = C.create_string_buffer(512)
+    _check(lib().cfh_write_kmers(os.fsencode(path), kmers.ctypes.data, kmers.size, k, err, 512), err)
+
+
+def write_edges(path, rare_kmers, k, edges, append=False):
+    rare_kmers = np.ascontiguousarray(rare_kmers, dtype=np.uint64)
+    edges = np.ascontiguousarray(edges, dtype=np.uint32).reshape(-1, 4)
+    err = C.create_string_buffer(512)
+    _check(lib().cfh_write_edges(os.fsencode(path), int(append), rare_kmers.ctypes.data, k,
+                                 edges.ctypes.data, edges.shape[0], err, 512), err)
+
+
+def read_kmers(path, k):
+    L = lib()
+    err = C.create_string_buffer(512)
+    n = C.c_int64()
+    _check(L.cfh_read_kmers(os.fsencode(path), k, None, 0, C.byref(n), err, 512), err)
+    out = np.zeros(n.value, dtype=np.uint64)
+    _check(L.cfh_read_kmers(os.fsencode(path), k, out.ctypes.data, out.size, C.byref(n), err, 512), err)
+    return out

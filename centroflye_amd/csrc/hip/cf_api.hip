@@ -1,0 +1,305 @@
+// cf_api.hip — context management, hand-over of the packed reads, getters (C ABI: include/cfhip.h).
+#include "cf_common.h"
+
+int cf_fail(cf_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+int cf_alloc(cf_ctx* ctx, void** p, size_t bytes, const char* what) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess || !*p) {
+        *p = nullptr;
+        return cf_fail(ctx, -12, std::string("hipMalloc of ") + std::to_string(bytes) + " bytes for " + what + ": " + hipGetErrorString(e));
+    }
+    ctx->live += bytes;
+    return 0;
+}
+
+void cf_release(cf_ctx* ctx, void* p, size_t bytes) {
+    if (!p) return;
+    if (bytes == 0) bytes = 16;
+    (void)hipFree(p);
+    ctx->live -= bytes < ctx->live ? bytes : ctx->live;
+}
+
+static void free_reads(cf_ctx* c) {
+    cf_release_t(c, c->d_bases, (size_t)c->n_bases);
+    cf_release_t(c, c->d_read_off, (size_t)c->n_reads + 1);
+}
+static void free_units(cf_ctx* c) {
+    cf_release_t(c, c->d_unit_ptr, (size_t)c->n_reads + 1);
+    cf_release_t(c, c->d_unit_start, (size_t)c->n_units);
+    cf_release_t(c, c->d_unit_end, (size_t)c->n_units);
+}
+void cf_free_table(cf_ctx* c) {
+    if (c->d_table) { cf_release(c, c->d_table, (size_t)c->table_cap * sizeof(cf_slot)); c->d_table = nullptr; }
+    c->table_cap = 0;
+}
+void cf_free_kmers(cf_ctx* c) {
+    cf_release_t(c, c->d_kmers, (size_t)c->n_kmers);
+    cf_release_t(c, c->d_lut_keys, (size_t)c->lut_cap);
+    cf_release_t(c, c->d_lut_vals, (size_t)c->lut_cap);
+    cf_release_t(c, c->d_unique_bits, (size_t)c->unique_words);
+    c->n_kmers = 0; c->lut_cap = 0; c->unique_words = 0;
+}
+void cf_free_clouds(cf_ctx* c) {
+    cf_release_t(c, c->d_cloud_ptr, (size_t)c->n_units + 1);
+    cf_release_t(c, c->d_entries, (size_t)c->n_entries);
+    c->n_entries = 0; c->have_clouds = false;
+}
+void cf_free_edges(cf_ctx* c) {
+    cf_release_t(c, c->d_edges, (size_t)c->edge_cap * 4);
+    c->edge_cap = 0; c->n_edges_stored = 0;
+}
+
+extern "C" {
+
+int cf_create(int device, cf_ctx** out) {
+    if (!out) return -22;
+    *out = nullptr;
+    cf_ctx* ctx = new (std::nothrow) cf_ctx();
+    if (!ctx) return -12;
+    *out = ctx;  // returned even on failure so the caller can read the error
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return cf_fail(ctx, -19, "no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return cf_fail(ctx, -22, "device index out of range");
+    ctx->device = device;
+    CF_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CF_HIP(hipGetDeviceProperties(&prop, device));
+    ctx->n_cu = prop.multiProcessorCount;
+    ctx->hbm_total = (int64_t)prop.totalGlobalMem;
+    CF_HIP(hipStreamCreate(&ctx->stream));
+    CF_HIP(hipEventCreate(&ctx->ev0));
+    CF_HIP(hipEventCreate(&ctx->ev1));
+    CF_HIP(hipEventCreate(&ctx->ev2));
+    CF_HIP(hipEventCreate(&ctx->ev3));
+    return 0;
+}
+
+void cf_destroy(cf_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    cf_free_edges(ctx);
+    cf_free_clouds(ctx);
+    cf_free_kmers(ctx);
+    cf_free_table(ctx);
+    free_units(ctx);
+    free_reads(ctx);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+    if (ctx->ev3) (void)hipEventDestroy(ctx->ev3);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* cf_last_error(const cf_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int cf_device_info(cf_ctx* ctx, char* name, int name_len, int64_t* hbm_bytes, int32_t* n_cu) {
+    if (!ctx) return -22;
+    hipDeviceProp_t prop;
+    CF_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len > 0) std::snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    return 0;
+}
+
+static int load_units(cf_ctx* ctx, const int64_t* unit_ptr, const int64_t* unit_start, const int64_t* unit_end) {
+    const int64_t R = ctx->n_reads;
+    if (unit_ptr[0] != 0) return cf_fail(ctx, -22, "unit_ptr[0] must be 0");
+    for (int64_t r = 0; r < R; ++r)
+        if (unit_ptr[r + 1] < unit_ptr[r]) return cf_fail(ctx, -22, "unit_ptr must be non-decreasing");
+    const int64_t U = unit_ptr[R];
+    if (U >= (int64_t)1 << 31) return cf_fail(ctx, -22, "more than 2^31 units");
+    for (int64_t r = 0; r < R; ++r) {
+        for (int64_t u = unit_ptr[r]; u < unit_ptr[r + 1]; ++u) {
+            if (unit_start[u] < ctx->h_read_off[(size_t)r] || unit_end[u] > ctx->h_read_off[(size_t)r + 1] || unit_end[u] < unit_start[u])
+                return cf_fail(ctx, -22, "unit " + std::to_string(u) + " lies outside its read");
+        }
+    }
+    cf_free_clouds(ctx);
+    free_units(ctx);
+    ctx->n_units = U;
+    ctx->h_unit_ptr.assign(unit_ptr, unit_ptr + R + 1);
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_unit_ptr, (size_t)R + 1, "unit_ptr"));
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_unit_start, (size_t)U, "unit_start"));
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_unit_end, (size_t)U, "unit_end"));
+    CF_HIP(hipMemcpyAsync(ctx->d_unit_ptr, unit_ptr, (size_t)(R + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (U) {
+        CF_HIP(hipMemcpyAsync(ctx->d_unit_start, unit_start, (size_t)U * 8, hipMemcpyHostToDevice, ctx->stream));
+        CF_HIP(hipMemcpyAsync(ctx->d_unit_end, unit_end, (size_t)U * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    CF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stats.n_units = U;
+    return 0;
+}
+
+int cf_load_reads(cf_ctx* ctx, const uint8_t* bases, const int64_t* read_off, int64_t n_reads,
+                  const int64_t* unit_ptr, const int64_t* unit_start, const int64_t* unit_end) {
+    if (!ctx) return -22;
+    if (!read_off || n_reads < 0 || !unit_ptr) return cf_fail(ctx, -22, "cf_load_reads: null argument");
+    if (n_reads >= (int64_t)1 << 31) return cf_fail(ctx, -22, "more than 2^31 reads");
+    if (read_off[0] != 0) return cf_fail(ctx, -22, "read_off[0] must be 0");
+    for (int64_t r = 0; r < n_reads; ++r)
+        if (read_off[r + 1] < read_off[r]) return cf_fail(ctx, -22, "read_off must be non-decreasing");
+    const int64_t nb = read_off[n_reads];
+    // alphabet check on the host (never silently 2-bit-encode other symbols)
+    {
+        unsigned char bad = 0;
+        for (int64_t i = 0; i < nb; ++i) {
+            const unsigned char c = bases[i];
+            bad |= (unsigned char)!(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+        }
+        if (bad) return cf_fail(ctx, -22, "read bases outside upper-case ACGT: the device path refuses them (no silent 2-bit encoding)");
+    }
+    CF_HIP(hipSetDevice(ctx->device));
+    CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    cf_free_edges(ctx);
+    cf_free_clouds(ctx);
+    cf_free_table(ctx);
+    free_units(ctx);
+    free_reads(ctx);
+    ctx->n_reads = n_reads;
+    ctx->n_bases = nb;
+    ctx->h_read_off.assign(read_off, read_off + n_reads + 1);
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_bases, (size_t)nb + 64, "bases"));
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_read_off, (size_t)n_reads + 1, "read_off"));
+    // note: d_bases was allocated with +64 slack; account it under n_bases for release
+    ctx->live -= 64;
+    if (nb) CF_HIP(hipMemcpyAsync(ctx->d_bases, bases, (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+    CF_HIP(hipMemcpyAsync(ctx->d_read_off, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    CF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stats = cf_stats{};
+    ctx->stats.n_reads = n_reads;
+    ctx->stats.n_bases = nb;
+    CF_TRY(load_units(ctx, unit_ptr, unit_start, unit_end));
+    CF_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    CF_HIP(hipEventSynchronize(ctx->ev1));
+    CF_HIP(hipEventElapsedTime(&ctx->times.load_ms, ctx->ev0, ctx->ev1));
+    return 0;
+}
+
+int cf_load_units(cf_ctx* ctx, const int64_t* unit_ptr, const int64_t* unit_start, const int64_t* unit_end) {
+    if (!ctx) return -22;
+    if (!ctx->d_read_off) return cf_fail(ctx, -22, "cf_load_units: no reads loaded");
+    CF_HIP(hipSetDevice(ctx->device));
+    return load_units(ctx, unit_ptr, unit_start, unit_end);
+}
+
+int cf_get_kmers(cf_ctx* ctx, uint64_t* out, int64_t cap) {
+    if (!ctx) return -22;
+    if (cap < ctx->n_kmers) return cf_fail(ctx, -22, "cf_get_kmers: buffer too small");
+    if (ctx->n_kmers) CF_HIP(hipMemcpy(out, ctx->d_kmers, (size_t)ctx->n_kmers * 8, hipMemcpyDefault));
+    return 0;
+}
+
+int cf_get_clouds(cf_ctx* ctx, int64_t* cloud_ptr, int32_t* entries, int64_t cap) {
+    if (!ctx) return -22;
+    if (!ctx->have_clouds) return cf_fail(ctx, -22, "cf_get_clouds: no clouds built");
+    if (cap < ctx->n_entries) return cf_fail(ctx, -22, "cf_get_clouds: buffer too small");
+    CF_HIP(hipMemcpy(cloud_ptr, ctx->d_cloud_ptr, (size_t)(ctx->n_units + 1) * 8, hipMemcpyDefault));
+    if (ctx->n_entries) CF_HIP(hipMemcpy(entries, ctx->d_entries, (size_t)ctx->n_entries * 4, hipMemcpyDefault));
+    return 0;
+}
+
+int cf_set_clouds(cf_ctx* ctx, const int64_t* cloud_ptr, const int32_t* entries, int64_t n_entries) {
+    if (!ctx) return -22;
+    if (!ctx->d_unit_ptr) return cf_fail(ctx, -22, "cf_set_clouds: no units loaded");
+    CF_HIP(hipSetDevice(ctx->device));
+    cf_free_clouds(ctx);
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_cloud_ptr, (size_t)ctx->n_units + 1, "cloud_ptr"));
+    ctx->n_entries = n_entries;
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_entries, (size_t)n_entries, "cloud entries"));
+    CF_HIP(hipMemcpy(ctx->d_cloud_ptr, cloud_ptr, (size_t)(ctx->n_units + 1) * 8, hipMemcpyDefault));
+    if (n_entries) CF_HIP(hipMemcpy(ctx->d_entries, entries, (size_t)n_entries * 4, hipMemcpyDefault));
+    ctx->have_clouds = true;
+    ctx->stats.n_cloud_entries = n_entries;
+    return 0;
+}
+
+int cf_get_edges(cf_ctx* ctx, uint32_t* out, int64_t cap) {
+    if (!ctx) return -22;
+    if (cap < ctx->n_edges_stored) return cf_fail(ctx, -22, "cf_get_edges: buffer too small");
+    if (ctx->n_edges_stored) CF_HIP(hipMemcpy(out, ctx->d_edges, (size_t)ctx->n_edges_stored * 16, hipMemcpyDefault));
+    return 0;
+}
+
+int cf_get_stats(cf_ctx* ctx, cf_stats* out) {
+    if (!ctx || !out) return -22;
+    ctx->stats.hbm_bytes_live = (int64_t)ctx->live;
+    ctx->stats.table_capacity = (int64_t)ctx->table_cap;
+    ctx->stats.n_kmers = ctx->n_kmers;
+    *out = ctx->stats;
+    return 0;
+}
+
+int cf_get_times(cf_ctx* ctx, cf_times* out) {
+    if (!ctx || !out) return -22;
+    *out = ctx->times;
+    return 0;
+}
+
+int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return -22;
+    const std::string n(name);
+    if (n == "dist_block") {
+        if (value < 64 || value > 1024 || value % 64) return cf_fail(ctx, -22, "dist_block must be a multiple of 64 in [64, 1024]");
+        ctx->dist_block = (int)value;
+    } else if (n == "dist_slots") {
+        if (value < 256 || value * 8 > 156 * 1024) return cf_fail(ctx, -22, "dist_slots out of range (256 .. 19968)");
+        ctx->dist_slots = (int)value;
+    } else if (n == "count_slots") {
+        if (value < 256 || (value & (value - 1)) || value * 8 > 128 * 1024) return cf_fail(ctx, -22, "count_slots must be a power of two in [256, 16384]");
+        ctx->count_slots = (int)value;
+    } else if (n == "count_tile") {
+        if (value < 1 || value > 64) return cf_fail(ctx, -22, "count_tile out of range");
+        ctx->count_tile = (int)value;
+    } else return cf_fail(ctx, -22, "unknown parameter " + n);
+    return 0;
+}
+
+int cf_selftest_sort(cf_ctx* ctx, const uint64_t* keys, int64_t n, int32_t bits, uint64_t* out) {
+    if (!ctx) return -22;
+    CF_HIP(hipSetDevice(ctx->device));
+    unsigned long long *a = nullptr, *b = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &a, (size_t)n, "selftest keys"));
+    int rc = cf_alloc_t(ctx, &b, (size_t)n, "selftest tmp");
+    if (rc == 0 && n) {
+        if (hipMemcpy(a, keys, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) rc = cf_fail(ctx, -5, "selftest copy");
+    }
+    if (rc == 0) rc = cf_radix_sort_u64(ctx, a, b, n, bits);
+    if (rc == 0 && n) {
+        if (hipMemcpy(out, a, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = cf_fail(ctx, -5, "selftest copy back");
+    }
+    if (b) cf_release_t(ctx, b, (size_t)n);
+    cf_release_t(ctx, a, (size_t)n);
+    return rc;
+}
+
+int cf_selftest_scan(cf_ctx* ctx, const int64_t* in, int64_t n, int64_t* out) {
+    if (!ctx) return -22;
+    CF_HIP(hipSetDevice(ctx->device));
+    int64_t *a = nullptr, *b = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &a, (size_t)n + 1, "selftest in"));
+    int rc = cf_alloc_t(ctx, &b, (size_t)n + 1, "selftest out");
+    int64_t total = 0;
+    if (rc == 0 && n) {
+        if (hipMemcpy(a, in, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) rc = cf_fail(ctx, -5, "selftest copy");
+    }
+    if (rc == 0) rc = cf_scan_exclusive_i64(ctx, a, b, n, &total);
+    if (rc == 0 && n) {
+        if (hipMemcpy(out, b, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = cf_fail(ctx, -5, "selftest copy back");
+    }
+    if (rc == 0) out[n] = total;
+    if (b) cf_release_t(ctx, b, (size_t)n + 1);
+    cf_release_t(ctx, a, (size_t)n + 1);
+    return rc;
+}
+
+}  // extern "C"

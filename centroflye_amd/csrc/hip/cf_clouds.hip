@@ -1,0 +1,424 @@
+// cf_clouds.hip — k-mer set installation, A3 per-unit clouds, A4 multiplicity filter, unique mask.
+//
+// Reference:
+//   A3 scripts/read_kmer_cloud.py:17-40: for each HOR unit of each read, the SET of k-mers of the
+//      unit's de-gapped row (windows inside the unit only) that belong to the given k-mer set.
+//   A4 scripts/read_kmer_cloud.py:43-54: keep k-mers present in >= min_mult (<= max_mult) clouds.
+//
+// Device design: one 256-thread workgroup per unit.  The unit's bases are staged through LDS
+// (coalesced byte loads, sliding window), every window is looked up in an open-addressed HBM
+// table of the k-mer set (key -> rank), hits are de-duplicated in an LDS set, compacted and
+// bitonic-sorted in LDS, and written as one CSR row.  Two launches: sizes, then rows.
+#include "cf_common.h"
+
+void cf_free_kmers(cf_ctx* c);
+void cf_free_clouds(cf_ctx* c);
+
+#define CL_THREADS 256
+#define CL_TILE_W 8
+#define CL_SET 8192
+#define CL_EMPTY 0xFFFFFFFFu
+
+__global__ void __launch_bounds__(256)
+cf_lut_build_kernel(const unsigned long long* __restrict__ kmers, int64_t n, unsigned long long* __restrict__ keys,
+                    uint32_t* __restrict__ vals, uint64_t mask, unsigned int* __restrict__ flags) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned long long want = kmers[i] | CF_OCC;
+        uint64_t h = cf_mix64(kmers[i]) & mask;
+        bool done = false;
+        for (uint64_t probe = 0; probe <= mask; ++probe) {
+            const unsigned long long cur = atomicCAS(&keys[h], 0ull, want);
+            if (cur == 0ull) { vals[h] = (uint32_t)i; done = true; break; }
+            if (cur == want) { atomicOr(flags, 2u); done = true; break; }  // duplicate in the set
+            h = (h + 1) & mask;
+        }
+        if (!done) atomicOr(flags, 1u);
+        if (i > 0 && kmers[i - 1] >= kmers[i]) atomicOr(flags, 4u);      // not sorted ascending
+    }
+}
+
+__device__ __forceinline__ uint32_t cf_lut_find(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                uint64_t mask, unsigned long long code) {
+    const unsigned long long want = code | CF_OCC;
+    uint64_t h = cf_mix64(code) & mask;
+    for (uint64_t probe = 0; probe <= mask; ++probe) {
+        const unsigned long long cur = keys[h];
+        if (cur == want) return vals[h];
+        if (cur == 0ull) return CL_EMPTY;
+        h = (h + 1) & mask;
+    }
+    return CL_EMPTY;
+}
+
+// mode 0: sizes[u] = |cloud(u)|; mode 1: entries[cloud_ptr[u] ...] = sorted cloud
+__global__ void __launch_bounds__(CL_THREADS)
+cf_cloud_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ unit_start, const int64_t* __restrict__ unit_end,
+                int64_t n_units, int k, const unsigned long long* __restrict__ lut_keys, const uint32_t* __restrict__ lut_vals,
+                uint64_t lut_mask, int mode, uint32_t* __restrict__ sizes, const int64_t* __restrict__ cloud_ptr,
+                int32_t* __restrict__ entries, unsigned int* __restrict__ flags) {
+    uint32_t* set = (uint32_t*)cf_lds;                         // CL_SET
+    uint32_t* list = set + CL_SET;                             // CL_SET
+    uint8_t* stage = (uint8_t*)(list + CL_SET);                // CL_THREADS * CL_TILE_W + 64
+    unsigned int* counters = (unsigned int*)(stage + CL_THREADS * CL_TILE_W + 64);
+    const int t = threadIdx.x;
+    const unsigned long long kmask = (1ull << (2 * k)) - 1ull;
+    const int tile = CL_THREADS * CL_TILE_W;
+    for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const int64_t b0 = unit_start[u], b1 = unit_end[u];
+        const int64_t n_win = b1 - b0 - k + 1;
+        for (int s = t; s < CL_SET; s += CL_THREADS) set[s] = CL_EMPTY;
+        if (t == 0) { counters[0] = 0; counters[1] = 0; counters[2] = 0; }
+        __syncthreads();
+        for (int64_t w0 = 0; w0 < n_win; w0 += tile) {
+            const int64_t nb = min((int64_t)tile + k - 1, b1 - b0 - w0);
+            for (int64_t i = t; i < nb; i += CL_THREADS) stage[i] = bases[b0 + w0 + i];
+            __syncthreads();
+            const int64_t my0 = (int64_t)t * CL_TILE_W;
+            const int64_t my_n = min((int64_t)CL_TILE_W, n_win - w0 - my0);
+            if (my_n > 0) {
+                unsigned long long code = 0;
+                for (int j = 0; j < k - 1; ++j) code = (code << 2) | cf_base2(stage[my0 + j]);
+                for (int64_t i = 0; i < my_n; ++i) {
+                    code = ((code << 2) | cf_base2(stage[my0 + i + k - 1])) & kmask;
+                    const uint32_t idx = cf_lut_find(lut_keys, lut_vals, lut_mask, code);
+                    if (idx == CL_EMPTY) continue;
+                    uint32_t h = cf_mix32(idx) & (CL_SET - 1);
+                    bool done = false;
+                    for (int probe = 0; probe < CL_SET; ++probe) {
+                        uint32_t cur = set[h];
+                        if (cur == CL_EMPTY) {
+                            cur = atomicCAS(&set[h], CL_EMPTY, idx);
+                            if (cur == CL_EMPTY) { atomicAdd(&counters[0], 1u); done = true; break; }
+                        }
+                        if (cur == idx) { done = true; break; }
+                        h = (h + 1) & (CL_SET - 1);
+                    }
+                    if (!done) counters[1] = 1;
+                }
+            }
+            __syncthreads();
+        }
+        const uint32_t cnt = counters[0];
+        if (counters[1] || cnt > CL_SET * 3 / 4) {
+            if (t == 0) atomicOr(flags, 1u);
+        } else if (mode == 0) {
+            if (t == 0) sizes[u] = cnt;
+        } else if (cnt > 0) {
+            for (int s = t; s < CL_SET; s += CL_THREADS) {
+                const uint32_t v = set[s];
+                if (v != CL_EMPTY) list[atomicAdd(&counters[2], 1u)] = v;
+            }
+            uint32_t n2 = 1;
+            while (n2 < cnt) n2 <<= 1;
+            __syncthreads();
+            for (uint32_t s = cnt + t; s < n2; s += CL_THREADS) list[s] = CL_EMPTY;
+            for (uint32_t size = 2; size <= n2; size <<= 1) {
+                for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                    __syncthreads();
+                    for (uint32_t i = t; i < (n2 >> 1); i += CL_THREADS) {
+                        const uint32_t j = i & (stride - 1);
+                        const uint32_t lo = 2 * i - j, hi = lo + stride;
+                        const uint32_t a = list[lo], b = list[hi];
+                        const bool up = (lo & size) == 0;
+                        if ((a > b) == up) { list[lo] = b; list[hi] = a; }
+                    }
+                }
+            }
+            __syncthreads();
+            const int64_t o = cloud_ptr[u];
+            for (uint32_t s = t; s < cnt; s += CL_THREADS) entries[o + s] = (int32_t)list[s];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cf_mult_hist_kernel(const int32_t* __restrict__ entries, int64_t n, uint32_t* __restrict__ mult) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&mult[entries[i]], 1u);
+}
+
+// one wave per unit; mode 0: sizes, mode 1: ordered compaction
+__global__ void __launch_bounds__(256)
+cf_mult_filter_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ entries, int64_t n_units,
+                      const uint32_t* __restrict__ mult, uint32_t min_mult, uint32_t max_mult, int mode,
+                      uint32_t* __restrict__ sizes, const int64_t* __restrict__ new_ptr, int32_t* __restrict__ new_entries) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = wave; u < n_units; u += n_waves) {
+        const int64_t e0 = cloud_ptr[u], e1 = cloud_ptr[u + 1];
+        uint32_t kept = 0;
+        const int64_t rounds = (e1 - e0 + 63) / 64;
+        for (int64_t rd = 0; rd < rounds; ++rd) {
+            const int64_t e = e0 + rd * 64 + lane;
+            bool keep = false;
+            int32_t x = 0;
+            if (e < e1) {
+                x = entries[e];
+                const uint32_t m = mult[x];
+                keep = m >= min_mult && (max_mult == 0 || m <= max_mult);
+            }
+            const unsigned long long b = __ballot(keep);
+            if (mode == 1 && keep) new_entries[new_ptr[u] + kept + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = x;
+            kept += (uint32_t)__popcll(b);
+        }
+        if (mode == 0 && lane == 0) sizes[u] = kept;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cf_bits_expand_kernel(const uint32_t* __restrict__ bits, int64_t n, uint8_t* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (bits[i >> 5] >> (i & 31)) & 1u;
+}
+__global__ void __launch_bounds__(256)
+cf_bits_or_kernel(uint32_t* __restrict__ bits, int64_t n, const uint8_t* __restrict__ in) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (in[i]) atomicOr(&bits[i >> 5], 1u << (i & 31));
+}
+__global__ void __launch_bounds__(256)
+cf_bits_count_kernel(const uint32_t* __restrict__ bits, int64_t words, unsigned long long* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) c += (unsigned long long)__popc(bits[i]);
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, (unsigned)d);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// Build the lookup table and the unique bitmap for ctx->d_kmers (already on the device, sorted).
+int cf_install_kmers(cf_ctx* ctx, int32_t k) {
+    const int64_t n = ctx->n_kmers;
+    ctx->set_k = k;
+    ctx->lut_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(2 * n, 1024));
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_lut_keys, (size_t)ctx->lut_cap, "k-mer lookup keys"));
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_lut_vals, (size_t)ctx->lut_cap, "k-mer lookup values"));
+    ctx->unique_words = (n + 31) / 32 + 1;
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_unique_bits, (size_t)ctx->unique_words, "unique bitmap"));
+    CF_HIP(hipMemsetAsync(ctx->d_lut_keys, 0, (size_t)ctx->lut_cap * 8, ctx->stream));
+    CF_HIP(hipMemsetAsync(ctx->d_unique_bits, 0, (size_t)ctx->unique_words * 4, ctx->stream));
+    ctx->stats.n_unique = 0;
+    unsigned int* d_flags = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &d_flags, 4, "lut flags"));
+    unsigned int flags = 0;
+    int rc = 0;
+    hipError_t e = hipMemsetAsync(d_flags, 0, 16, ctx->stream);
+    if (e == hipSuccess && n) {
+        const int grid = cf_grid_for(n, 256, std::max(1, ctx->n_cu) * 8);
+        hipLaunchKernelGGL(cf_lut_build_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->d_kmers,
+                           n, ctx->d_lut_keys, ctx->d_lut_vals, (uint64_t)(ctx->lut_cap - 1), d_flags);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&flags, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = cf_fail(ctx, -5, std::string("k-mer lookup build: ") + hipGetErrorString(e));
+    cf_release_t(ctx, d_flags, 4);
+    if (rc) return rc;
+    if (flags & 1u) return cf_fail(ctx, -34, "k-mer lookup table overflow");
+    if (flags & 6u) return cf_fail(ctx, -22, "k-mer set must be sorted ascending and unique");
+    cf_free_clouds(ctx);
+    return 0;
+}
+
+// popcount of the unique bitmap -> stats.n_unique
+int cf_refresh_unique_count(cf_ctx* ctx) {
+    if (!ctx->d_unique_bits) { ctx->stats.n_unique = 0; return 0; }
+    unsigned long long* d_u = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &d_u, 2, "unique count"));
+    unsigned long long hu = 0;
+    hipError_t e = hipMemsetAsync(d_u, 0, 16, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(cf_bits_count_kernel, dim3((unsigned)cf_grid_for(ctx->unique_words, 256, std::max(1, ctx->n_cu) * 8)), dim3(256), 0,
+                           ctx->stream, (const uint32_t*)ctx->d_unique_bits, ctx->unique_words, d_u);
+        e = hipMemcpy(&hu, d_u, 8, hipMemcpyDeviceToHost);
+    }
+    cf_release_t(ctx, d_u, 2);
+    if (e != hipSuccess) return cf_fail(ctx, -5, std::string("unique count: ") + hipGetErrorString(e));
+    ctx->stats.n_unique = (int64_t)hu;
+    return 0;
+}
+
+extern "C" {
+
+int cf_set_kmers(cf_ctx* ctx, const uint64_t* kmers, int64_t n, int32_t k) {
+    if (!ctx) return -22;
+    if (k < 1 || k > 31) return cf_fail(ctx, -22, "k must be in [1, 31]");
+    if (n < 0 || n >= (int64_t)1 << 31) return cf_fail(ctx, -22, "bad k-mer count");
+    CF_HIP(hipSetDevice(ctx->device));
+    cf_free_kmers(ctx);
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_kmers, (size_t)n, "k-mer set"));
+    ctx->n_kmers = n;
+    if (n) CF_HIP(hipMemcpy(ctx->d_kmers, kmers, (size_t)n * 8, hipMemcpyDefault));
+    return cf_install_kmers(ctx, k);
+}
+
+int cf_build_clouds(cf_ctx* ctx, int64_t* n_entries) {
+    if (!ctx) return -22;
+    if (!ctx->d_unit_ptr) return cf_fail(ctx, -22, "cf_build_clouds: no reads loaded");
+    if (!ctx->d_lut_keys) return cf_fail(ctx, -22, "cf_build_clouds: no k-mer set installed");
+    CF_HIP(hipSetDevice(ctx->device));
+    CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    cf_free_clouds(ctx);
+    const int64_t U = ctx->n_units;
+    uint32_t* d_sizes = nullptr;
+    unsigned int* d_flags = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_cloud_ptr, (size_t)U + 1, "cloud_ptr"));
+    CF_TRY(cf_alloc_t(ctx, &d_sizes, (size_t)U + 1, "cloud sizes"));
+    int rc = cf_alloc_t(ctx, &d_flags, 4, "cloud flags");
+    const size_t lds = (size_t)CL_SET * 8 + CL_THREADS * CL_TILE_W + 64 + 16;
+    const int grid = (int)std::min<int64_t>(std::max<int64_t>(U, 1), (int64_t)std::max(1, ctx->n_cu) * 16);
+    int64_t total = 0;
+    unsigned int flags = 0;
+    do {
+        if (rc) break;
+        hipError_t e = hipMemsetAsync(d_flags, 0, 16, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_sizes, 0, (size_t)(U + 1) * 4, ctx->stream);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cf_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_build_clouds setup: ") + hipGetErrorString(e)); break; }
+        if (U) {
+            hipLaunchKernelGGL(cf_cloud_kernel, dim3((unsigned)grid), dim3(CL_THREADS), lds, ctx->stream, (const uint8_t*)ctx->d_bases,
+                               (const int64_t*)ctx->d_unit_start, (const int64_t*)ctx->d_unit_end, U, ctx->set_k,
+                               (const unsigned long long*)ctx->d_lut_keys, (const uint32_t*)ctx->d_lut_vals, (uint64_t)(ctx->lut_cap - 1),
+                               0, d_sizes, (const int64_t*)nullptr, (int32_t*)nullptr, d_flags);
+            e = hipGetLastError();
+            if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_cloud_kernel: ") + hipGetErrorString(e)); break; }
+        }
+        if ((rc = cf_scan_exclusive_u32_to_i64(ctx, d_sizes, ctx->d_cloud_ptr, U + 1, &total))) break;
+        if (hipMemcpy(&flags, d_flags, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "cloud flags copy"); break; }
+        if (flags & 1u) { rc = cf_fail(ctx, -34, "a unit holds more distinct set k-mers than the LDS cloud set (6144)"); break; }
+        ctx->n_entries = total;
+        if ((rc = cf_alloc_t(ctx, &ctx->d_entries, (size_t)total, "cloud entries"))) break;
+        if (U && total) {
+            hipLaunchKernelGGL(cf_cloud_kernel, dim3((unsigned)grid), dim3(CL_THREADS), lds, ctx->stream, (const uint8_t*)ctx->d_bases,
+                               (const int64_t*)ctx->d_unit_start, (const int64_t*)ctx->d_unit_end, U, ctx->set_k,
+                               (const unsigned long long*)ctx->d_lut_keys, (const uint32_t*)ctx->d_lut_vals, (uint64_t)(ctx->lut_cap - 1),
+                               1, d_sizes, (const int64_t*)ctx->d_cloud_ptr, ctx->d_entries, d_flags);
+            e = hipGetLastError();
+            if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_cloud_kernel: ") + hipGetErrorString(e)); break; }
+        }
+        e = hipEventRecord(ctx->ev1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+        if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_build_clouds sync: ") + hipGetErrorString(e)); break; }
+        (void)hipEventElapsedTime(&ctx->times.clouds_ms, ctx->ev0, ctx->ev1);
+    } while (0);
+    if (d_flags) cf_release_t(ctx, d_flags, 4);
+    cf_release_t(ctx, d_sizes, (size_t)U + 1);
+    if (rc) { cf_free_clouds(ctx); return rc; }
+    ctx->have_clouds = true;
+    ctx->stats.n_cloud_entries = total;
+    if (n_entries) *n_entries = total;
+    return 0;
+}
+
+int cf_filter_clouds(cf_ctx* ctx, uint32_t min_mult, uint32_t max_mult, int64_t* n_entries) {
+    if (!ctx) return -22;
+    if (!ctx->have_clouds) return cf_fail(ctx, -22, "cf_filter_clouds: no clouds built");
+    CF_HIP(hipSetDevice(ctx->device));
+    CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    const int64_t U = ctx->n_units, N = ctx->n_entries, K = ctx->n_kmers;
+    uint32_t *d_mult = nullptr, *d_sizes = nullptr;
+    int64_t* d_new_ptr = nullptr;
+    int32_t* d_new_entries = nullptr;
+    int64_t total = 0;
+    int rc = 0;
+    const int grid_e = cf_grid_for(N, 256, std::max(1, ctx->n_cu) * 8);
+    const int grid_u = cf_grid_for(U * 64, 256, std::max(1, ctx->n_cu) * 8);
+    do {
+        if ((rc = cf_alloc_t(ctx, &d_mult, (size_t)K + 1, "k-mer multiplicities"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_sizes, (size_t)U + 1, "filtered sizes"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_new_ptr, (size_t)U + 1, "filtered cloud_ptr"))) break;
+        hipError_t e = hipMemsetAsync(d_mult, 0, (size_t)(K + 1) * 4, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_sizes, 0, (size_t)(U + 1) * 4, ctx->stream);
+        if (e != hipSuccess) { rc = cf_fail(ctx, -5, "cf_filter_clouds memset"); break; }
+        if (N) hipLaunchKernelGGL(cf_mult_hist_kernel, dim3((unsigned)grid_e), dim3(256), 0, ctx->stream, (const int32_t*)ctx->d_entries, N, d_mult);
+        if (U) hipLaunchKernelGGL(cf_mult_filter_kernel, dim3((unsigned)grid_u), dim3(256), 0, ctx->stream, (const int64_t*)ctx->d_cloud_ptr,
+                                  (const int32_t*)ctx->d_entries, U, (const uint32_t*)d_mult, min_mult, max_mult, 0, d_sizes,
+                                  (const int64_t*)nullptr, (int32_t*)nullptr);
+        if ((rc = cf_scan_exclusive_u32_to_i64(ctx, d_sizes, d_new_ptr, U + 1, &total))) break;
+        if ((rc = cf_alloc_t(ctx, &d_new_entries, (size_t)total, "filtered entries"))) break;
+        if (U && total)
+            hipLaunchKernelGGL(cf_mult_filter_kernel, dim3((unsigned)grid_u), dim3(256), 0, ctx->stream, (const int64_t*)ctx->d_cloud_ptr,
+                               (const int32_t*)ctx->d_entries, U, (const uint32_t*)d_mult, min_mult, max_mult, 1, d_sizes,
+                               (const int64_t*)d_new_ptr, d_new_entries);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+        if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_filter_clouds: ") + hipGetErrorString(e)); break; }
+        (void)hipEventElapsedTime(&ctx->times.filter_ms, ctx->ev0, ctx->ev1);
+    } while (0);
+    if (d_sizes) cf_release_t(ctx, d_sizes, (size_t)U + 1);
+    if (d_mult) cf_release_t(ctx, d_mult, (size_t)K + 1);
+    if (rc) {
+        if (d_new_entries) cf_release_t(ctx, d_new_entries, (size_t)total);
+        if (d_new_ptr) cf_release_t(ctx, d_new_ptr, (size_t)U + 1);
+        return rc;
+    }
+    cf_release_t(ctx, ctx->d_cloud_ptr, (size_t)U + 1);
+    cf_release_t(ctx, ctx->d_entries, (size_t)N);
+    ctx->d_cloud_ptr = d_new_ptr;
+    ctx->d_entries = d_new_entries;
+    ctx->n_entries = total;
+    ctx->stats.n_cloud_entries = total;
+    if (n_entries) *n_entries = total;
+    return 0;
+}
+
+int cf_get_unique_mask(cf_ctx* ctx, uint8_t* mask) {
+    if (!ctx) return -22;
+    if (!ctx->d_unique_bits) return cf_fail(ctx, -22, "cf_get_unique_mask: no k-mer set");
+    const int64_t n = ctx->n_kmers;
+    if (!n) return 0;
+    CF_HIP(hipSetDevice(ctx->device));
+    uint8_t* d_tmp = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &d_tmp, (size_t)n, "unique mask bytes"));
+    const int grid = cf_grid_for(n, 256, std::max(1, ctx->n_cu) * 8);
+    hipLaunchKernelGGL(cf_bits_expand_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_unique_bits, n, d_tmp);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(mask, d_tmp, (size_t)n, hipMemcpyDefault);
+    cf_release_t(ctx, d_tmp, (size_t)n);
+    if (e != hipSuccess) return cf_fail(ctx, -5, std::string("cf_get_unique_mask: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int cf_or_unique_mask(cf_ctx* ctx, const uint8_t* mask) {
+    if (!ctx) return -22;
+    if (!ctx->d_unique_bits) return cf_fail(ctx, -22, "cf_or_unique_mask: no k-mer set");
+    const int64_t n = ctx->n_kmers;
+    if (!n) return 0;
+    CF_HIP(hipSetDevice(ctx->device));
+    uint8_t* d_tmp = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &d_tmp, (size_t)n, "unique mask bytes"));
+    int rc = cf_alloc_t(ctx, &d_cnt, 2, "unique count");
+    unsigned long long h = 0;
+    if (rc == 0) {
+        hipError_t e = hipMemcpy(d_tmp, mask, (size_t)n, hipMemcpyDefault);
+        if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 16, ctx->stream);
+        if (e == hipSuccess) {
+            const int grid = cf_grid_for(n, 256, std::max(1, ctx->n_cu) * 8);
+            hipLaunchKernelGGL(cf_bits_or_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ctx->d_unique_bits, n, (const uint8_t*)d_tmp);
+            hipLaunchKernelGGL(cf_bits_count_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_unique_bits,
+                               ctx->unique_words, d_cnt);
+            e = hipMemcpy(&h, d_cnt, 8, hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) rc = cf_fail(ctx, -5, std::string("cf_or_unique_mask: ") + hipGetErrorString(e));
+        else ctx->stats.n_unique = (int64_t)h;
+    }
+    if (d_cnt) cf_release_t(ctx, d_cnt, 2);
+    cf_release_t(ctx, d_tmp, (size_t)n);
+    return rc;
+}
+
+int cf_reset_unique(cf_ctx* ctx) {
+    if (!ctx) return -22;
+    if (!ctx->d_unique_bits) return 0;
+    CF_HIP(hipSetDevice(ctx->device));
+    CF_HIP(hipMemsetAsync(ctx->d_unique_bits, 0, (size_t)ctx->unique_words * 4, ctx->stream));
+    CF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stats.n_unique = 0;
+    return 0;
+}
+
+}  // extern "C"

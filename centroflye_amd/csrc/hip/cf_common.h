@@ -1,0 +1,151 @@
+// cf_common.h — shared declarations of the gfx950 device pipeline (libcfhip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cfhip.h"
+
+// Every kernel uses one dynamic-LDS window and carves it up itself.
+extern __shared__ __attribute__((aligned(16))) unsigned char cf_lds[];
+
+#define CF_WAVE 64
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ uint64_t cf_mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+__device__ __forceinline__ uint32_t cf_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+// ASCII base -> 2-bit code with A<C<G<T (A 0x41, C 0x43, G 0x47, T 0x54)
+__device__ __forceinline__ uint32_t cf_base2(uint32_t c) { return ((c >> 1) ^ (c >> 2)) & 3u; }
+
+// bit 63 marks an occupied slot in every k-mer keyed table (k <= 31 -> key < 2^62)
+#define CF_OCC (1ull << 63)
+
+// 16-byte slot of the HBM k-mer table: key | CF_OCC, then pres (low 32) | multi (high 32)
+struct cf_slot {
+    unsigned long long key;
+    unsigned long long val;
+};
+
+// ---------------------------------------------------------------- host side
+struct cf_devbuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct cf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    std::string err;
+    int n_cu = 0;
+    int64_t hbm_total = 0;
+    size_t live = 0;
+
+    // reads / units
+    uint8_t* d_bases = nullptr;
+    int64_t* d_read_off = nullptr;
+    int64_t* d_unit_ptr = nullptr;
+    int64_t* d_unit_start = nullptr;
+    int64_t* d_unit_end = nullptr;
+    std::vector<int64_t> h_read_off, h_unit_ptr;
+    int64_t n_reads = 0, n_bases = 0, n_units = 0;
+
+    // A1 table
+    cf_slot* d_table = nullptr;
+    uint64_t table_cap = 0;
+    int k = 0;
+
+    // k-mer set + lookup table
+    unsigned long long* d_kmers = nullptr;
+    int64_t n_kmers = 0;
+    int set_k = 0;
+    unsigned long long* d_lut_keys = nullptr;
+    uint32_t* d_lut_vals = nullptr;
+    uint64_t lut_cap = 0;
+
+    // clouds
+    int64_t* d_cloud_ptr = nullptr;  // U+1
+    int32_t* d_entries = nullptr;
+    int64_t n_entries = 0;
+    bool have_clouds = false;
+
+    // edges / unique bitmap
+    uint32_t* d_edges = nullptr;  // n x 4
+    int64_t edge_cap = 0, n_edges_stored = 0;
+    uint32_t* d_unique_bits = nullptr;
+    int64_t unique_words = 0;
+
+    cf_stats stats{};
+    cf_times times{};
+
+    // knobs
+    int dist_block = 512;
+    int dist_slots = 16384;
+    int count_slots = 8192;
+    int count_tile = 16;
+};
+
+int cf_fail(cf_ctx* ctx, int code, const std::string& msg);
+int cf_alloc(cf_ctx* ctx, void** p, size_t bytes, const char* what);
+void cf_release(cf_ctx* ctx, void* p, size_t bytes);
+
+template <class T>
+inline int cf_alloc_t(cf_ctx* ctx, T** p, size_t n, const char* what) {
+    return cf_alloc(ctx, (void**)p, n * sizeof(T), what);
+}
+template <class T>
+inline void cf_release_t(cf_ctx* ctx, T*& p, size_t n) {
+    cf_release(ctx, (void*)p, n * sizeof(T));
+    p = nullptr;
+}
+
+#define CF_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return cf_fail(ctx, -5, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+#define CF_TRY(expr)                  \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != 0) return rc_;     \
+    } while (0)
+#define CF_KERNEL_CHECK(name)                                                                 \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess)                                                                 \
+            return cf_fail(ctx, -5, std::string("launch of ") + name + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+static inline uint64_t cf_pow2_ceil(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+static inline int cf_grid_for(int64_t items, int per_block, int max_blocks) {
+    int64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+// primitives (cf_prims.hip)
+int cf_scan_exclusive_i64(cf_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_t n, int64_t* total);
+int cf_scan_exclusive_u32_to_i64(cf_ctx* ctx, const uint32_t* d_in, int64_t* d_out, int64_t n, int64_t* total);
+// LSD radix sort of 64-bit keys on `bits` low bits; result lands in d_keys (d_tmp is scratch)
+int cf_radix_sort_u64(cf_ctx* ctx, unsigned long long* d_keys, unsigned long long* d_tmp, int64_t n, int bits);

@@ -1,0 +1,396 @@
+// cf_count.hip — A1 (presence / multi-occurrence table) and A2 (rare window select).
+//
+// Reference: scripts/distance_based_kmer_recruitment.py:39-63 builds, read by read, a dict of
+// per-read k-mer multiplicities and from it `all_kmers[x]` = number of reads containing x,
+// dropping x once it occurs >= 2x inside more than max_nonuniq reads.  Closed form used here
+// (order independent): pres[x] = #reads containing x, multi[x] = #reads where x occurs >= 2x;
+// the result is {x: pres[x] | multi[x] <= max_nonuniq}; :66-82 then keeps lo <= pres <= hi.
+//
+// Device design (MI355X):
+//   * work item = (read, hash class p of P): the item streams the whole read (coalesced byte
+//     loads staged through LDS as a sliding window), keeps the k-mers whose class is p and
+//     de-duplicates them in an LDS open-addressed set (one 64-bit CAS per window).  All
+//     occurrences of a k-mer inside a read fall into the same item, so the per-read
+//     statistics (present / occurs twice) are exact without any cross-item traffic.
+//   * the set is then flushed into the HBM table: one 16-byte slot touch per distinct
+//     (read, k-mer): a 64-bit CAS to claim the key and ONE 64-bit atomic add carrying
+//     pres (+1, low half) and multi (+1 if seen twice, high half).
+//   * A2 is a table scan with wave-ballot compaction, then the LSD radix sort of cf_prims.
+#include "cf_common.h"
+
+void cf_free_table(cf_ctx* c);
+void cf_free_kmers(cf_ctx* c);
+int cf_install_kmers(cf_ctx* ctx, int32_t k);  // cf_clouds.hip: builds the lookup table for ctx->d_kmers
+
+#define CNT_THREADS 256
+#define CNT_DUP (1ull << 62)
+
+struct cf_count_item {
+    int32_t read;
+    int32_t cls;
+    int32_t n_cls;
+    int32_t pad;
+};
+
+__device__ __forceinline__ void cf_table_add(cf_slot* __restrict__ table, uint64_t mask, unsigned long long key,
+                                             unsigned long long inc, unsigned int* __restrict__ flags) {
+    const unsigned long long want = key | CF_OCC;
+    uint64_t h = cf_mix64(key) & mask;
+    for (uint64_t probe = 0; probe <= mask; ++probe) {
+        unsigned long long cur = table[h].key;
+        if (cur == 0ull) cur = atomicCAS(&table[h].key, 0ull, want);
+        if (cur == 0ull || cur == want) {
+            atomicAdd(&table[h].val, inc);
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+    atomicOr(flags, 1u);  // table full
+}
+
+__global__ void __launch_bounds__(CNT_THREADS)
+cf_count_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ read_off,
+                const cf_count_item* __restrict__ items, int n_items, int k, int slots, int tile_w,
+                cf_slot* __restrict__ table, uint64_t tmask, unsigned long long* __restrict__ n_rk,
+                unsigned int* __restrict__ flags) {
+    unsigned long long* set = (unsigned long long*)cf_lds;            // slots x 8 B
+    uint8_t* stage = cf_lds + (size_t)slots * 8;                       // tile + k - 1 bases
+    unsigned int* counters = (unsigned int*)(stage + ((CNT_THREADS * tile_w + 64 + 15) & ~15));
+    const int t = threadIdx.x;
+    const uint32_t smask = (uint32_t)slots - 1u;
+    const unsigned long long kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const int tile = CNT_THREADS * tile_w;
+
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const cf_count_item item = items[it];
+        const int64_t r0 = read_off[item.read], r1 = read_off[item.read + 1];
+        const int64_t n_win = r1 - r0 - k + 1;
+        for (int s = t; s < slots; s += CNT_THREADS) set[s] = 0ull;
+        if (t == 0) { counters[0] = 0; counters[1] = 0; }
+        __syncthreads();
+        for (int64_t w0 = 0; w0 < n_win; w0 += tile) {
+            // stage bases [w0, w0 + tile + k - 1) of the read
+            const int64_t nb = min((int64_t)tile + k - 1, r1 - r0 - w0);
+            for (int64_t i = t; i < nb; i += CNT_THREADS) stage[i] = bases[r0 + w0 + i];
+            __syncthreads();
+            const int64_t my0 = (int64_t)t * tile_w;
+            const int64_t my_n = min((int64_t)tile_w, n_win - w0 - my0);
+            if (my_n > 0) {
+                unsigned long long code = 0;
+                for (int j = 0; j < k - 1; ++j) code = (code << 2) | cf_base2(stage[my0 + j]);
+                for (int64_t i = 0; i < my_n; ++i) {
+                    code = ((code << 2) | cf_base2(stage[my0 + i + k - 1])) & kmask;
+                    const uint64_t hh = cf_mix64(code);
+                    if ((int)((hh >> 40) % (uint64_t)item.n_cls) != item.cls) continue;
+                    const unsigned long long want = code | CF_OCC;
+                    uint32_t h = (uint32_t)hh & smask;
+                    bool done = false;
+                    for (int probe = 0; probe < slots; ++probe) {
+                        unsigned long long cur = set[h];
+                        if (cur == 0ull) {
+                            cur = atomicCAS(&set[h], 0ull, want);
+                            if (cur == 0ull) { atomicAdd(&counters[0], 1u); done = true; break; }
+                        }
+                        if ((cur & ~CNT_DUP) == want) {
+                            if (!(cur & CNT_DUP)) atomicOr(&set[h], CNT_DUP);
+                            done = true;
+                            break;
+                        }
+                        h = (h + 1) & smask;
+                    }
+                    if (!done) counters[1] = 1;  // LDS set full
+                }
+            }
+            __syncthreads();
+        }
+        if (counters[1]) {
+            if (t == 0) atomicOr(flags, 2u);
+        } else {
+            for (int s = t; s < slots; s += CNT_THREADS) {
+                const unsigned long long v = set[s];
+                if (v) cf_table_add(table, tmask, v & ~(CF_OCC | CNT_DUP), 1ull + ((v & CNT_DUP) ? (1ull << 32) : 0ull), flags);
+            }
+            if (t == 0) atomicAdd(n_rk, (unsigned long long)counters[0]);
+        }
+        __syncthreads();
+    }
+}
+
+// mode 0: count {occupied, kept, selected}; mode 1: write selected keys (wave-ballot compaction)
+__global__ void __launch_bounds__(256)
+cf_select_kernel(const cf_slot* __restrict__ table, uint64_t cap, uint32_t max_nonuniq, uint32_t lo, uint32_t hi,
+                 int mode, unsigned long long* __restrict__ counts, unsigned long long* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long occ = 0, kept = 0, sel = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t rounds = (cap + stride - 1) / stride;
+    for (uint64_t rd = 0; rd < rounds; ++rd) {
+        const uint64_t i = rd * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        bool s = false;
+        unsigned long long key = 0;
+        if (i < cap) {
+            const cf_slot sl = table[i];
+            if (sl.key) {
+                const uint32_t pres = (uint32_t)sl.val, multi = (uint32_t)(sl.val >> 32);
+                ++occ;
+                if (multi <= max_nonuniq) {
+                    ++kept;
+                    if (pres >= lo && pres <= hi) { s = true; key = sl.key & ~CF_OCC; ++sel; }
+                }
+            }
+        }
+        if (mode == 1) {
+            const unsigned long long m = __ballot(s);
+            if (m) {
+                unsigned long long base = 0;
+                const int leader = __ffsll((long long)m) - 1;
+                if (lane == leader) base = atomicAdd(&counts[3], (unsigned long long)__popcll(m));
+                base = __shfl(base, leader);
+                if (s) out[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = key;
+            }
+        }
+    }
+    if (mode == 0) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            occ += __shfl_down(occ, (unsigned)d);
+            kept += __shfl_down(kept, (unsigned)d);
+            sel += __shfl_down(sel, (unsigned)d);
+        }
+        if (lane == 0) {
+            if (occ) atomicAdd(&counts[0], occ);
+            if (kept) atomicAdd(&counts[1], kept);
+            if (sel) atomicAdd(&counts[2], sel);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cf_table_dump_kernel(const cf_slot* __restrict__ table, uint64_t cap, unsigned long long* __restrict__ counter,
+                     unsigned long long* __restrict__ keys, uint32_t* __restrict__ pres, uint32_t* __restrict__ multi,
+                     unsigned long long out_cap) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) {
+        const cf_slot sl = table[i];
+        if (sl.key) {
+            const unsigned long long p = atomicAdd(counter, 1ull);
+            if (p < out_cap) { keys[p] = sl.key & ~CF_OCC; pres[p] = (uint32_t)sl.val; multi[p] = (uint32_t)(sl.val >> 32); }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cf_table_merge_kernel(cf_slot* __restrict__ table, uint64_t tmask, const unsigned long long* __restrict__ keys,
+                      const uint32_t* __restrict__ pres, const uint32_t* __restrict__ multi, int64_t n,
+                      unsigned int* __restrict__ flags) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        cf_table_add(table, tmask, keys[i], (unsigned long long)pres[i] | ((unsigned long long)multi[i] << 32), flags);
+}
+
+static int ensure_table(cf_ctx* ctx, uint64_t want_cap) {
+    if (ctx->d_table && ctx->table_cap == want_cap) return 0;
+    cf_free_table(ctx);
+    CF_TRY(cf_alloc(ctx, (void**)&ctx->d_table, (size_t)want_cap * sizeof(cf_slot), "k-mer table"));
+    ctx->table_cap = want_cap;
+    return 0;
+}
+
+extern "C" {
+
+int cf_count_kmers(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi) {
+    if (!ctx) return -22;
+    if (!ctx->d_read_off) return cf_fail(ctx, -22, "cf_count_kmers: no reads loaded");
+    if (k < 1 || k > 31) return cf_fail(ctx, -22, "k must be in [1, 31]");
+    CF_HIP(hipSetDevice(ctx->device));
+    if (read_lo < 0) read_lo = 0;
+    if (read_hi > ctx->n_reads) read_hi = ctx->n_reads;
+    int64_t n_w = 0;
+    for (int64_t r = read_lo; r < read_hi; ++r) {
+        const int64_t len = ctx->h_read_off[(size_t)r + 1] - ctx->h_read_off[(size_t)r];
+        if (len >= k) n_w += len - k + 1;
+    }
+    uint64_t cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(n_w, 1024));
+    if (2 * k < 62 && cap > (2ull << (2 * k))) cap = cf_pow2_ceil(2ull << (2 * k));
+    ctx->k = k;
+    ctx->stats.n_windows = n_w;
+    const int slots = ctx->count_slots;
+    int shrink = 0;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        CF_TRY(ensure_table(ctx, cap));
+        // items: each read is split into n_cls hash classes so that a class fits the LDS set
+        const int64_t per_cls = std::max<int64_t>(32, ((int64_t)slots * 3 / 8) >> shrink);
+        std::vector<cf_count_item> items;
+        for (int64_t r = read_lo; r < read_hi; ++r) {
+            const int64_t len = ctx->h_read_off[(size_t)r + 1] - ctx->h_read_off[(size_t)r];
+            if (len < k) continue;
+            const int64_t nw = len - k + 1;
+            const int n_cls = (int)((nw + per_cls - 1) / per_cls);
+            for (int c = 0; c < n_cls; ++c) items.push_back({(int32_t)r, c, n_cls, 0});
+        }
+        CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+        CF_HIP(hipMemsetAsync(ctx->d_table, 0, (size_t)cap * sizeof(cf_slot), ctx->stream));
+        cf_count_item* d_items = nullptr;
+        unsigned long long* d_cnt = nullptr;
+        CF_TRY(cf_alloc_t(ctx, &d_items, items.size(), "count items"));
+        int rc = cf_alloc_t(ctx, &d_cnt, 2, "count counters");
+        unsigned long long h_cnt[2] = {0, 0};
+        if (rc == 0) {
+            hipError_t e = hipMemsetAsync(d_cnt, 0, 16, ctx->stream);
+            if (e == hipSuccess && !items.empty())
+                e = hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(cf_count_item), hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess && !items.empty()) {
+                const int tile_w = ctx->count_tile;
+                const size_t lds = (size_t)slots * 8 + (size_t)((CNT_THREADS * tile_w + 64 + 15) & ~15) + 16;
+                const int grid = (int)std::min<int64_t>((int64_t)items.size(), (int64_t)std::max(1, ctx->n_cu) * 8);
+                if (lds > 64 * 1024)
+                    e = hipFuncSetAttribute((const void*)cf_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e == hipSuccess) {
+                    (void)hipEventRecord(ctx->ev2, ctx->stream);
+                    hipLaunchKernelGGL(cf_count_kernel, dim3((unsigned)grid), dim3(CNT_THREADS), lds, ctx->stream,
+                                       (const uint8_t*)ctx->d_bases, (const int64_t*)ctx->d_read_off, (const cf_count_item*)d_items,
+                                       (int)items.size(), (int)k, slots, tile_w, ctx->d_table, (uint64_t)(cap - 1), d_cnt,
+                                       (unsigned int*)(d_cnt + 1));
+                    e = hipGetLastError();
+                    (void)hipEventRecord(ctx->ev3, ctx->stream);
+                }
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+            if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+            if (e != hipSuccess) rc = cf_fail(ctx, -5, std::string("cf_count_kmers: ") + hipGetErrorString(e));
+        }
+        if (d_cnt) cf_release_t(ctx, d_cnt, 2);
+        cf_release_t(ctx, d_items, items.size());
+        if (rc) return rc;
+        const unsigned int flags = (unsigned int)h_cnt[1];
+        if (flags & 1u) { cap *= 2; continue; }            // HBM table full: retry larger
+        if (flags & 2u) { ++shrink; continue; }            // an LDS set overflowed: more classes per read
+        ctx->stats.n_read_kmers = (int64_t)h_cnt[0];
+        (void)hipEventElapsedTime(&ctx->times.count_ms, ctx->ev0, ctx->ev1);
+        if (!items.empty()) (void)hipEventElapsedTime(&ctx->times.count_kernel_ms, ctx->ev2, ctx->ev3);
+        return 0;
+    }
+    return cf_fail(ctx, -34, "cf_count_kmers: k-mer table kept overflowing");
+}
+
+int cf_get_table(cf_ctx* ctx, uint64_t* keys, uint32_t* pres, uint32_t* multi, int64_t cap, int64_t* n_out) {
+    if (!ctx || !n_out) return -22;
+    if (!ctx->d_table) return cf_fail(ctx, -22, "cf_get_table: no table");
+    CF_HIP(hipSetDevice(ctx->device));
+    unsigned long long* d_cnt = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &d_cnt, 4, "dump counters"));
+    int rc = 0;
+    unsigned long long h[4] = {0, 0, 0, 0};
+    unsigned long long* d_keys = nullptr; uint32_t *d_pres = nullptr, *d_multi = nullptr;
+    const int grid = std::max(1, ctx->n_cu) * 8;
+    do {
+        if (hipMemsetAsync(d_cnt, 0, 32, ctx->stream) != hipSuccess) { rc = cf_fail(ctx, -5, "memset"); break; }
+        if (!keys) {
+            hipLaunchKernelGGL(cf_select_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const cf_slot*)ctx->d_table,
+                               (uint64_t)ctx->table_cap, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0, d_cnt, (unsigned long long*)nullptr);
+            if (hipMemcpy(h, d_cnt, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "copy"); break; }
+            *n_out = (int64_t)h[0];
+            break;
+        }
+        if ((rc = cf_alloc_t(ctx, &d_keys, (size_t)cap, "dump keys"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_pres, (size_t)cap, "dump pres"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_multi, (size_t)cap, "dump multi"))) break;
+        hipLaunchKernelGGL(cf_table_dump_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const cf_slot*)ctx->d_table,
+                           (uint64_t)ctx->table_cap, d_cnt, d_keys, d_pres, d_multi, (unsigned long long)cap);
+        if (hipMemcpy(h, d_cnt, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "copy"); break; }
+        *n_out = (int64_t)h[0];
+        if ((int64_t)h[0] > cap) { rc = cf_fail(ctx, -22, "cf_get_table: buffer too small"); break; }
+        if (h[0]) {
+            hipError_t e = hipMemcpy(keys, d_keys, (size_t)h[0] * 8, hipMemcpyDefault);
+            if (e == hipSuccess) e = hipMemcpy(pres, d_pres, (size_t)h[0] * 4, hipMemcpyDefault);
+            if (e == hipSuccess) e = hipMemcpy(multi, d_multi, (size_t)h[0] * 4, hipMemcpyDefault);
+            if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_get_table copy: ") + hipGetErrorString(e)); break; }
+        }
+    } while (0);
+    if (d_multi) cf_release_t(ctx, d_multi, (size_t)cap);
+    if (d_pres) cf_release_t(ctx, d_pres, (size_t)cap);
+    if (d_keys) cf_release_t(ctx, d_keys, (size_t)cap);
+    cf_release_t(ctx, d_cnt, 4);
+    return rc;
+}
+
+int cf_merge_table(cf_ctx* ctx, const uint64_t* keys, const uint32_t* pres, const uint32_t* multi, int64_t n) {
+    if (!ctx) return -22;
+    if (!ctx->d_table) return cf_fail(ctx, -22, "cf_merge_table: no table (call cf_count_kmers first)");
+    if (n <= 0) return 0;
+    CF_HIP(hipSetDevice(ctx->device));
+    unsigned long long* d_keys = nullptr; uint32_t *d_pres = nullptr, *d_multi = nullptr; unsigned int* d_flags = nullptr;
+    int rc = 0;
+    unsigned int flags = 0;
+    do {
+        if ((rc = cf_alloc_t(ctx, &d_keys, (size_t)n, "merge keys"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_pres, (size_t)n, "merge pres"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_multi, (size_t)n, "merge multi"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_flags, 4, "merge flags"))) break;
+        hipError_t e = hipMemcpy(d_keys, keys, (size_t)n * 8, hipMemcpyDefault);
+        if (e == hipSuccess) e = hipMemcpy(d_pres, pres, (size_t)n * 4, hipMemcpyDefault);
+        if (e == hipSuccess) e = hipMemcpy(d_multi, multi, (size_t)n * 4, hipMemcpyDefault);
+        if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, 16, ctx->stream);
+        if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_merge_table copy: ") + hipGetErrorString(e)); break; }
+        const int grid = cf_grid_for(n, 256, std::max(1, ctx->n_cu) * 8);
+        hipLaunchKernelGGL(cf_table_merge_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, ctx->d_table,
+                           (uint64_t)(ctx->table_cap - 1), (const unsigned long long*)d_keys, (const uint32_t*)d_pres,
+                           (const uint32_t*)d_multi, n, d_flags);
+        if (hipMemcpy(&flags, d_flags, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "cf_merge_table sync"); break; }
+        if (flags & 1u) rc = cf_fail(ctx, -34, "cf_merge_table: table full");
+    } while (0);
+    if (d_flags) cf_release_t(ctx, d_flags, 4);
+    if (d_multi) cf_release_t(ctx, d_multi, (size_t)n);
+    if (d_pres) cf_release_t(ctx, d_pres, (size_t)n);
+    if (d_keys) cf_release_t(ctx, d_keys, (size_t)n);
+    return rc;
+}
+
+int cf_select_rare(cf_ctx* ctx, int32_t max_nonuniq, uint32_t lo, uint32_t hi, int64_t* n_out) {
+    if (!ctx) return -22;
+    if (!ctx->d_table) return cf_fail(ctx, -22, "cf_select_rare: no table (call cf_count_kmers first)");
+    CF_HIP(hipSetDevice(ctx->device));
+    const uint32_t mn = max_nonuniq < 0 ? 0u : (uint32_t)max_nonuniq;
+    if (max_nonuniq < 0) hi = 0, lo = 1;  // multi <= negative is never true: empty set
+    CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    unsigned long long* d_cnt = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &d_cnt, 4, "select counters"));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    const int grid = std::max(1, ctx->n_cu) * 8;
+    int rc = 0;
+    unsigned long long *d_keys = nullptr, *d_tmp = nullptr;
+    int64_t n_sel = 0;
+    do {
+        if (hipMemsetAsync(d_cnt, 0, 32, ctx->stream) != hipSuccess) { rc = cf_fail(ctx, -5, "memset"); break; }
+        hipLaunchKernelGGL(cf_select_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const cf_slot*)ctx->d_table,
+                           (uint64_t)ctx->table_cap, mn, lo, hi, 0, d_cnt, (unsigned long long*)nullptr);
+        if (hipMemcpy(h, d_cnt, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "cf_select_rare count"); break; }
+        ctx->stats.n_distinct = (int64_t)h[0];
+        ctx->stats.n_kept = (int64_t)h[1];
+        n_sel = (int64_t)h[2];
+        if (n_sel >= (int64_t)1 << 31) { rc = cf_fail(ctx, -34, "more than 2^31 selected k-mers"); break; }
+        if ((rc = cf_alloc_t(ctx, &d_keys, (size_t)n_sel, "selected k-mers"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_tmp, (size_t)n_sel, "sort scratch"))) break;
+        if (n_sel) {
+            hipLaunchKernelGGL(cf_select_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const cf_slot*)ctx->d_table,
+                               (uint64_t)ctx->table_cap, mn, lo, hi, 1, d_cnt, d_keys);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_select_kernel: ") + hipGetErrorString(e)); break; }
+            if ((rc = cf_radix_sort_u64(ctx, d_keys, d_tmp, n_sel, 2 * ctx->k))) break;
+        }
+    } while (0);
+    if (d_tmp) cf_release_t(ctx, d_tmp, (size_t)n_sel);
+    cf_release_t(ctx, d_cnt, 4);
+    if (rc) { if (d_keys) cf_release_t(ctx, d_keys, (size_t)n_sel); return rc; }
+    cf_free_kmers(ctx);
+    ctx->d_kmers = d_keys;
+    ctx->n_kmers = n_sel;
+    CF_TRY(cf_install_kmers(ctx, ctx->k));
+    CF_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    CF_HIP(hipEventSynchronize(ctx->ev1));
+    CF_HIP(hipEventElapsedTime(&ctx->times.select_ms, ctx->ev0, ctx->ev1));
+    if (n_out) *n_out = n_sel;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,322 @@
+// cf_dist.hip — A5 (k-mer pair / unit-distance histogram) fused with A6 (edge filter).
+//
+// Reference: scripts/distance_based_kmer_recruitment.py:85-128 counts, for every read, every
+// pair of unit clouds d units apart (min_d <= d <= max_d) and every ordered pair (a in C_i,
+// b in C_{i+d}, a != b), cnt[d][a][b] += 1; :131-149 keeps (d, a, b, cnt) with cnt >= min_cov
+// and cnt / sum_d' cnt[d'][a][b] >= 0.8 (true division), and marks a and b as selected.
+//
+// Device design (the dominant kernel of the path; HBM/L2 streaming + LDS atomics, no MFMA):
+//   * dist_cnt[d][a] is owned by the first k-mer a in the reference; so is it here: one
+//     workgroup owns one a at a time (dynamic queue), walks a's posting list
+//     (the (read, unit) clouds that contain a), streams the later unit clouds of those reads
+//     (contiguous int32 CSR ranges, coalesced, 4 B per pair emission) and counts (b, d) in an
+//     LDS open-addressed table of 64-bit slots [b:32 | d:8 | cnt:24] with one LDS atomic per
+//     emission.  The slot hash depends on b only, so all d of one b share a probe chain and
+//     sum_d cnt is a chain walk — both filters run in LDS and only selected edges reach HBM.
+//   * a table that would overflow is split by a second hash of b into 2, 4, ... partitions,
+//     each processed (re-streamed) on its own: exact, no HBM spill.
+//   * first k-mers partition across GPUs (a % n_parts == part) with no reduction.
+#include "cf_common.h"
+
+void cf_free_edges(cf_ctx* c);
+int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
+
+#define DIST_NP_CAP 512
+#define DIST_STACK 40
+
+__global__ void __launch_bounds__(256)
+cf_post_hist_kernel(const int32_t* __restrict__ entries, int64_t e0, int64_t e1, uint32_t* __restrict__ cnt) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e1; i += stride) atomicAdd(&cnt[entries[i]], 1u);
+}
+
+__global__ void __launch_bounds__(256)
+cf_post_fill_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ entries, int64_t u0, int64_t u1,
+                    const int64_t* __restrict__ post_ptr, uint32_t* __restrict__ cursor, int32_t* __restrict__ post) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = u0 + wave; u < u1; u += n_waves) {
+        const int64_t a = cloud_ptr[u], b = cloud_ptr[u + 1];
+        for (int64_t e = a + lane; e < b; e += 64) {
+            const int32_t x = entries[e];
+            post[post_ptr[x] + atomicAdd(&cursor[x], 1u)] = (int32_t)u;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cf_unit_rend_kernel(const int64_t* __restrict__ unit_ptr, int64_t n_reads, int32_t* __restrict__ rend) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += stride) {
+        const int64_t a = unit_ptr[r], b = unit_ptr[r + 1];
+        for (int64_t u = a; u < b; ++u) rend[u] = (int32_t)b;
+    }
+}
+
+struct cf_dist_args {
+    const int64_t* post_ptr;
+    const int32_t* post;
+    const int64_t* cloud_ptr;
+    const int32_t* entries;
+    const int32_t* unit_rend;
+    int64_t n_kmers;
+    int32_t part, n_parts;
+    int32_t min_d, max_d;       // min_d already clamped to >= 1
+    uint32_t min_cov;
+    double thr;
+    int32_t slots;
+    uint32_t fill_limit;
+    uint32_t* edges;
+    unsigned long long edge_cap;
+    unsigned long long* counters;  // [0] edges, [1] emissions, [2] spilled a, [3] queue head, [4] error flags
+    uint32_t* unique_bits;
+};
+
+__device__ __forceinline__ uint32_t cf_dist_home(uint32_t b, uint32_t slots) {
+    return (uint32_t)(((unsigned long long)cf_mix32(b) * (unsigned long long)slots) >> 32);
+}
+
+__global__ void cf_dist_kernel(cf_dist_args A) {
+    unsigned long long* tab = (unsigned long long*)cf_lds;
+    int32_t* pg = (int32_t*)(cf_lds + (size_t)A.slots * 8);   // posting unit
+    int32_t* pjlo = pg + DIST_NP_CAP;                          // first partner unit
+    uint32_t* pre = (uint32_t*)(pjlo + DIST_NP_CAP);           // prefix of partner-unit counts (NP_CAP + 1)
+    uint32_t* stack = pre + DIST_NP_CAP + 1;                   // (P, idx) pairs
+    uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] n_used [1] overflow [2] sp [3] P [4] idx [5] a_idx lo [6] a_idx hi [7] E of leaf
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6, nt = blockDim.x;
+    const uint32_t slots = (uint32_t)A.slots;
+    const int64_t n_a = (A.n_kmers > A.part) ? (A.n_kmers - A.part + A.n_parts - 1) / A.n_parts : 0;
+
+    while (true) {
+        __syncthreads();
+        if (t == 0) {
+            const unsigned long long q = atomicAdd(&A.counters[3], 1ull);
+            sh[5] = (uint32_t)q; sh[6] = (uint32_t)(q >> 32);
+        }
+        __syncthreads();
+        const int64_t ai = (int64_t)(((unsigned long long)sh[6] << 32) | sh[5]);
+        if (ai >= n_a) break;
+        const uint32_t a = (uint32_t)(A.part + ai * A.n_parts);
+        const int64_t pp0 = A.post_ptr[a], pp1 = A.post_ptr[a + 1];
+        if (pp1 == pp0) continue;
+        if (t == 0) { sh[2] = 1; stack[0] = 1; stack[1] = 0; }
+        bool spilled = false;
+        while (true) {
+            __syncthreads();
+            const uint32_t sp_now = sh[2];
+            __syncthreads();  // everyone has read the stack pointer before thread 0 pops
+            if (sp_now == 0) break;
+            if (t == 0) { const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[1] = 0; sh[7] = 0; }
+            for (uint32_t s = t; s < slots; s += nt) tab[s] = 0ull;
+            __syncthreads();
+            const uint32_t P = sh[3], pidx = sh[4];
+            uint32_t my_e = 0;
+            // ---- stream the partner clouds of every posting of a, in chunks of DIST_NP_CAP postings
+            for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
+                const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
+                for (int p = t; p < np; p += nt) {
+                    const int32_t g = A.post[c0 + p];
+                    const int32_t jlo = g + A.min_d;
+                    const int32_t jhi = min(A.unit_rend[g] - 1, g + A.max_d);
+                    pg[p] = g; pjlo[p] = jlo;
+                    pre[p + 1] = jhi >= jlo ? (uint32_t)(jhi - jlo + 1) : 0u;
+                }
+                __syncthreads();
+                if (t == 0) { pre[0] = 0; for (int p = 0; p < np; ++p) pre[p + 1] += pre[p]; }
+                __syncthreads();
+                const uint32_t n_pairs = pre[np];
+                for (uint32_t q = wave; q < n_pairs; q += nwaves) {
+                    if (sh[1]) break;
+                    int lo = 0, hi = np - 1;  // largest p with pre[p] <= q
+                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= q) lo = mid; else hi = mid - 1; }
+                    const int32_t g = pg[lo];
+                    const int32_t j = pjlo[lo] + (int32_t)(q - pre[lo]);
+                    const uint32_t dd = (uint32_t)(j - g);
+                    const int64_t e0 = A.cloud_ptr[j], e1 = A.cloud_ptr[j + 1];
+                    for (int64_t e = e0 + lane; e < e1; e += 64) {
+                        const uint32_t b = (uint32_t)A.entries[e];
+                        if (b == a) continue;
+                        if (P > 1 && ((cf_mix32(b ^ 0x9E3779B9u) >> 4) & (P - 1)) != pidx) continue;
+                        ++my_e;
+                        const unsigned long long key = ((unsigned long long)b << 32) | ((unsigned long long)dd << 24);
+                        uint32_t h = cf_dist_home(b, slots);
+                        for (uint32_t probe = 0; probe < slots; ++probe) {
+                            unsigned long long cur = tab[h];
+                            if (cur == 0ull) {
+                                cur = atomicCAS(&tab[h], 0ull, key | 1ull);
+                                if (cur == 0ull) { if (atomicAdd(&sh[0], 1u) >= A.fill_limit) sh[1] = 1; break; }
+                            }
+                            if ((cur >> 24) == (key >> 24)) { atomicAdd(&tab[h], 1ull); break; }
+                            h = (h + 1 == slots) ? 0u : h + 1;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (sh[1]) {  // overflow: split this partition in two
+                if (t == 0) {
+                    uint32_t sp = sh[2];
+                    if (P >= (1u << 20) || sp + 2 > DIST_STACK) { atomicOr(&A.counters[4], 1ull); }
+                    else { stack[2 * sp] = 2 * P; stack[2 * sp + 1] = pidx; stack[2 * sp + 2] = 2 * P; stack[2 * sp + 3] = pidx + P; sh[2] = sp + 2; }
+                }
+                spilled = true;
+                continue;
+            }
+            // ---- leaf done: count emissions, filter in LDS, write selected edges
+            for (int d = 32; d >= 1; d >>= 1) my_e += __shfl_down(my_e, (unsigned)d);
+            if (lane == 0 && my_e) atomicAdd(&sh[7], my_e);
+            bool any_edge = false;
+            const uint32_t rounds = (slots + nt - 1) / nt;
+            for (uint32_t rd = 0; rd < rounds; ++rd) {
+                const uint32_t s = rd * nt + t;
+                bool sel = false;
+                uint32_t b = 0, dd = 0, cnt = 0;
+                if (s < slots) {
+                    const unsigned long long v = tab[s];
+                    cnt = (uint32_t)v & 0xFFFFFFu;
+                    if (v != 0ull && cnt >= A.min_cov) {
+                        b = (uint32_t)(v >> 32); dd = (uint32_t)(v >> 24) & 0xFFu;
+                        unsigned long long total = 0;
+                        uint32_t h = cf_dist_home(b, slots);
+                        for (uint32_t probe = 0; probe < slots; ++probe) {
+                            const unsigned long long w = tab[h];
+                            if (w == 0ull) break;
+                            if ((uint32_t)(w >> 32) == b) total += w & 0xFFFFFFull;
+                            h = (h + 1 == slots) ? 0u : h + 1;
+                        }
+                        sel = ((double)cnt / (double)total) >= A.thr;
+                    }
+                }
+                const unsigned long long m = __ballot(sel);
+                if (m) {
+                    unsigned long long base = 0;
+                    const int leader = __ffsll((long long)m) - 1;
+                    if (lane == leader) base = atomicAdd(&A.counters[0], (unsigned long long)__popcll(m));
+                    base = __shfl(base, leader);
+                    if (sel) {
+                        const unsigned long long o = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                        if (o < A.edge_cap) { uint32_t* E = A.edges + 4 * o; E[0] = dd; E[1] = a; E[2] = b; E[3] = cnt; }
+                        const uint32_t bit = 1u << (b & 31);
+                        if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
+                        any_edge = true;
+                    }
+                }
+            }
+            if (__any(any_edge) && lane == 0) {
+                const uint32_t bit = 1u << (a & 31);
+                if (!(A.unique_bits[a >> 5] & bit)) atomicOr(&A.unique_bits[a >> 5], bit);
+            }
+            __syncthreads();
+            if (t == 0 && sh[7]) atomicAdd(&A.counters[1], (unsigned long long)sh[7]);
+        }
+        if (spilled && t == 0) atomicAdd(&A.counters[2], 1ull);
+    }
+}
+
+extern "C" {
+
+int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int32_t max_d, uint32_t min_cov,
+                  double rel_threshold, int32_t part, int32_t n_parts, int64_t edge_cap, int64_t* n_edges) {
+    if (!ctx) return -22;
+    if (!ctx->have_clouds) return cf_fail(ctx, -22, "cf_dist_edges: no clouds built");
+    if (n_parts < 1 || part < 0 || part >= n_parts) return cf_fail(ctx, -22, "cf_dist_edges: bad partition");
+    if (max_d > 255) return cf_fail(ctx, -22, "cf_dist_edges: max_d > 255 does not fit the 8-bit distance field");
+    if (edge_cap < 0) edge_cap = 0;
+    CF_HIP(hipSetDevice(ctx->device));
+    CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    const int64_t R = ctx->n_reads, U = ctx->n_units, K = ctx->n_kmers;
+    // Python slice semantics of itertools.islice(items, min_n, max_n) for non-negative bounds
+    if (min_n < 0) min_n = 0;
+    if (max_n > R) max_n = R;
+    if (max_n < min_n) max_n = min_n;
+    if (min_n > R) min_n = R;
+    const int64_t u0 = ctx->h_unit_ptr[(size_t)min_n], u1 = ctx->h_unit_ptr[(size_t)max_n];
+    const int32_t min_d_eff = min_d < 1 ? 1 : min_d;  // kmer_clouds[:-0] is empty: d = 0 emits nothing
+
+    uint32_t *d_pcnt = nullptr, *d_cursor = nullptr;
+    int64_t* d_post_ptr = nullptr;
+    int32_t *d_post = nullptr, *d_rend = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    int64_t n_post = 0;
+    int rc = 0;
+    unsigned long long h_cnt[8] = {0};
+    const int max_blocks = std::max(1, ctx->n_cu) * 8;
+    do {
+        cf_free_edges(ctx);
+        if ((rc = cf_alloc_t(ctx, &ctx->d_edges, (size_t)edge_cap * 4, "edges"))) break;
+        ctx->edge_cap = edge_cap;
+        if ((rc = cf_alloc_t(ctx, &d_pcnt, (size_t)K + 1, "posting counts"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_cursor, (size_t)K + 1, "posting cursors"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_post_ptr, (size_t)K + 1, "posting offsets"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_rend, (size_t)U + 1, "unit read ends"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_cnt, 8, "dist counters"))) break;
+        hipError_t e = hipMemsetAsync(d_pcnt, 0, (size_t)(K + 1) * 4, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, (size_t)(K + 1) * 4, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 64, ctx->stream);
+        if (e != hipSuccess) { rc = cf_fail(ctx, -5, "cf_dist_edges memset"); break; }
+        int64_t e0 = 0, e1 = 0;
+        {
+            int64_t tmp[2] = {0, 0};
+            if (hipMemcpy(&tmp[0], ctx->d_cloud_ptr + u0, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(&tmp[1], ctx->d_cloud_ptr + u1, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "cloud_ptr read"); break; }
+            e0 = tmp[0]; e1 = tmp[1];
+        }
+        if (e1 > e0)
+            hipLaunchKernelGGL(cf_post_hist_kernel, dim3((unsigned)cf_grid_for(e1 - e0, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                               (const int32_t*)ctx->d_entries, e0, e1, d_pcnt);
+        if ((rc = cf_scan_exclusive_u32_to_i64(ctx, d_pcnt, d_post_ptr, K + 1, &n_post))) break;
+        if ((rc = cf_alloc_t(ctx, &d_post, (size_t)n_post, "postings"))) break;
+        if (u1 > u0 && n_post)
+            hipLaunchKernelGGL(cf_post_fill_kernel, dim3((unsigned)cf_grid_for((u1 - u0) * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                               (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries, u0, u1, (const int64_t*)d_post_ptr, d_cursor, d_post);
+        if (R)
+            hipLaunchKernelGGL(cf_unit_rend_kernel, dim3((unsigned)cf_grid_for(R, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                               (const int64_t*)ctx->d_unit_ptr, R, d_rend);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
+        if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("postings: ") + hipGetErrorString(e)); break; }
+
+        cf_dist_args A;
+        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = ctx->d_cloud_ptr; A.entries = ctx->d_entries; A.unit_rend = d_rend;
+        A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
+        A.slots = ctx->dist_slots; A.fill_limit = (uint32_t)((int64_t)ctx->dist_slots * 3 / 4);
+        A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
+        const size_t lds = (size_t)A.slots * 8 + (size_t)(3 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 8) * 4 + 16;
+        const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / ctx->dist_block));
+        const int64_t n_a = (K > part) ? (K - part + n_parts - 1) / n_parts : 0;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_a, (int64_t)std::max(1, ctx->n_cu) * per_cu));
+        e = hipFuncSetAttribute((const void*)cf_dist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("dist LDS attribute: ") + hipGetErrorString(e)); break; }
+        if (n_a > 0 && max_d >= min_d_eff && n_post > 0) {
+            hipLaunchKernelGGL(cf_dist_kernel, dim3((unsigned)grid), dim3((unsigned)ctx->dist_block), lds, ctx->stream, A);
+            e = hipGetLastError();
+            if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_dist_kernel: ") + hipGetErrorString(e)); break; }
+        }
+        e = hipEventRecord(ctx->ev3, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 64, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+        if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_dist_edges: ") + hipGetErrorString(e)); break; }
+        if (h_cnt[4]) { rc = cf_fail(ctx, -34, "cf_dist_edges: (b,d) table could not be partitioned far enough"); break; }
+        (void)hipEventElapsedTime(&ctx->times.dist_ms, ctx->ev0, ctx->ev1);
+        (void)hipEventElapsedTime(&ctx->times.postings_ms, ctx->ev0, ctx->ev2);
+        (void)hipEventElapsedTime(&ctx->times.dist_kernel_ms, ctx->ev2, ctx->ev3);
+    } while (0);
+    if (d_cnt) cf_release_t(ctx, d_cnt, 8);
+    if (d_rend) cf_release_t(ctx, d_rend, (size_t)U + 1);
+    if (d_post) cf_release_t(ctx, d_post, (size_t)n_post);
+    if (d_post_ptr) cf_release_t(ctx, d_post_ptr, (size_t)K + 1);
+    if (d_cursor) cf_release_t(ctx, d_cursor, (size_t)K + 1);
+    if (d_pcnt) cf_release_t(ctx, d_pcnt, (size_t)K + 1);
+    if (rc) return rc;
+    ctx->stats.n_edges = (int64_t)h_cnt[0];
+    ctx->stats.n_emissions = (int64_t)h_cnt[1];
+    ctx->stats.n_spilled = (int64_t)h_cnt[2];
+    ctx->n_edges_stored = std::min<int64_t>((int64_t)h_cnt[0], edge_cap);
+    CF_TRY(cf_refresh_unique_count(ctx));
+    if (n_edges) *n_edges = (int64_t)h_cnt[0];
+    return 0;
+}
+
+}  // extern "C"

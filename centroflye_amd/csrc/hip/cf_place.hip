@@ -1,0 +1,421 @@
+// cf_place.hip — A8 + A9: cloud contig and greedy read placement, device resident.
+//
+// Reference:
+//   scripts/cloud_contig.py:26-41  CloudContig.add_read: count[(pos, kmer)] += 1 for every k-mer of
+//       every unit cloud; exactly when a count EQUALS max(1, min_cloud_kmer_freq) the pair
+//       becomes "frequent" and is reported.
+//   scripts/cloud_contig.py:87-95  update_mapping_scores: each reported (kmer, q) adds 1 to
+//       scores[read][q - i][i] for every posting (read, i) of kmer with q >= i.
+//   scripts/read_placer.py:35-94   prefix reads at position 0; per stage (internal, suffix):
+//       postings over the stage's reads, seed = every (kmer, pos) with kmer frequent anywhere and
+//       pos any position the k-mer was ever added at (:54-57, over-inclusive on purpose), then
+//       repeatedly place the arg-max read over (s0 = #units hit, s1 = total hits, offset, then
+//       smaller r_id) among entries with s0 >= min_unit, s0 * min_prop <= s1, s1 >= min_inters;
+//       if none qualifies all remaining reads of the stage are written as None.
+//
+// Device design: everything lives in HBM hash tables — contig (pos,kmer)->count, score
+// (read,offset)->(s0,s1), a seen-set of (score slot, unit) for s0.  One iteration = 4 small
+// kernels enqueued back to back with NO host round trip: apply events -> block arg-max ->
+// final arg-max (records the placement, device-side) -> add the chosen read (emits the next
+// events).  The host only polls a done flag every few hundred iterations.
+#include "cf_common.h"
+
+#define PL_THREADS 256
+
+struct cf_cand {
+    uint32_t s0, s1, off, rank;  // rank: smaller id wins
+    uint32_t read;
+    uint32_t valid;
+};
+
+__device__ __forceinline__ bool cf_cand_better(const cf_cand& a, const cf_cand& b) {
+    // is a strictly better than b?
+    if (!a.valid) return false;
+    if (!b.valid) return true;
+    if (a.s0 != b.s0) return a.s0 > b.s0;
+    if (a.s1 != b.s1) return a.s1 > b.s1;
+    if (a.off != b.off) return a.off > b.off;
+    return a.rank < b.rank;
+}
+
+struct cf_place_state {
+    // clouds
+    const int64_t* unit_ptr;
+    const int64_t* cloud_ptr;
+    const int32_t* entries;
+    const int32_t* unit2read;
+    // contig map
+    unsigned long long* ckeys; uint32_t* ccnt; uint64_t cmask;
+    uint8_t* freq_flag;
+    // postings of the stage
+    const int64_t* post_ptr; const int32_t* post;
+    // score map: key (read<<32|off)|OCC, s0, s1
+    unsigned long long* skeys; uint32_t* s0; uint32_t* s1; uint64_t smask;
+    // seen set of (score slot << 32 | unit index)
+    unsigned long long* seen; uint64_t seen_mask;
+    // events (kmer << 32 | pos)
+    unsigned long long* events; unsigned long long* n_events;  // n_events[0] = count
+    // control: [0] done, [1] n_out, [2] error flags, [3] thr
+    unsigned int* ctl;
+    const uint8_t* used_in; uint8_t* used;
+    const int32_t* id_rank;
+    cf_cand* block_best; cf_cand* best;
+    int64_t* out_read; int64_t* out_pos; int32_t* out_s0; int32_t* out_s1;
+    uint32_t thr, min_unit, min_inters, min_prop;
+};
+
+// ---- add one read at a position: thread-block grid over units of the read
+__device__ __forceinline__ void cf_contig_add(const cf_place_state& S, uint32_t x, uint32_t q) {
+    const unsigned long long want = (((unsigned long long)q << 32) | x) | CF_OCC;
+    uint64_t h = cf_mix64(want) & S.cmask;
+    for (uint64_t probe = 0; probe <= S.cmask; ++probe) {
+        unsigned long long cur = S.ckeys[h];
+        if (cur == 0ull) cur = atomicCAS(&S.ckeys[h], 0ull, want);
+        if (cur == 0ull || cur == want) {
+            const uint32_t c = atomicAdd(&S.ccnt[h], 1u) + 1u;
+            if (c == S.thr) {
+                S.freq_flag[x] = 1;
+                const unsigned long long p = atomicAdd(S.n_events, 1ull);
+                S.events[p] = ((unsigned long long)x << 32) | q;
+            }
+            return;
+        }
+        h = (h + 1) & S.cmask;
+    }
+    atomicOr(&S.ctl[2], 1u);
+}
+
+// mode 0: add read `fixed_read` at position 0 (prefix reads); mode 1: add the read in S.best
+__global__ void __launch_bounds__(PL_THREADS)
+cf_place_add_kernel(cf_place_state S, int mode, int64_t fixed_read) {
+    if (mode == 1 && (S.ctl[0] || !S.best->valid)) return;
+    const int64_t r = mode == 0 ? fixed_read : (int64_t)S.best->read;
+    const uint32_t p = mode == 0 ? 0u : S.best->off;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t u0 = S.unit_ptr[r], u1 = S.unit_ptr[r + 1];
+    for (int64_t u = u0 + wave; u < u1; u += n_waves) {
+        const uint32_t q = p + (uint32_t)(u - u0);
+        for (int64_t e = S.cloud_ptr[u] + lane; e < S.cloud_ptr[u + 1]; e += 64) cf_contig_add(S, (uint32_t)S.entries[e], q);
+    }
+}
+
+// seed of a stage: every (kmer, pos) of the contig whose k-mer is frequent anywhere
+__global__ void __launch_bounds__(PL_THREADS)
+cf_place_seed_kernel(cf_place_state S) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= S.cmask; i += stride) {
+        const unsigned long long k = S.ckeys[i];
+        if (!k) continue;
+        const uint32_t x = (uint32_t)k, q = (uint32_t)((k & ~CF_OCC) >> 32);
+        if (S.freq_flag[x]) {
+            const unsigned long long p = atomicAdd(S.n_events, 1ull);
+            S.events[p] = ((unsigned long long)x << 32) | q;
+        }
+    }
+}
+
+// apply the pending events to the scores: one wave per event, lanes over the k-mer's postings
+__global__ void __launch_bounds__(PL_THREADS)
+cf_place_update_kernel(cf_place_state S) {
+    if (S.ctl[0]) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t n_ev = (int64_t)S.n_events[0];
+    for (int64_t ev = wave; ev < n_ev; ev += n_waves) {
+        const unsigned long long E = S.events[ev];
+        const uint32_t x = (uint32_t)(E >> 32), q = (uint32_t)E;
+        const int64_t p0 = S.post_ptr[x], p1 = S.post_ptr[x + 1];
+        for (int64_t pp = p0 + lane; pp < p1; pp += 64) {
+            const int32_t g = S.post[pp];
+            const uint32_t r = (uint32_t)S.unit2read[g];
+            const uint32_t i = (uint32_t)(g - S.unit_ptr[r]);
+            if (q < i) continue;
+            const uint32_t off = q - i;
+            const unsigned long long want = (((unsigned long long)r << 32) | off) | CF_OCC;
+            uint64_t h = cf_mix64(want) & S.smask;
+            bool ok = false;
+            for (uint64_t probe = 0; probe <= S.smask; ++probe) {
+                unsigned long long cur = S.skeys[h];
+                if (cur == 0ull) cur = atomicCAS(&S.skeys[h], 0ull, want);
+                if (cur == 0ull || cur == want) { ok = true; break; }
+                h = (h + 1) & S.smask;
+            }
+            if (!ok) { atomicOr(&S.ctl[2], 2u); continue; }
+            atomicAdd(&S.s1[h], 1u);
+            // first hit of unit i at this (read, offset)?
+            const unsigned long long sk = ((((unsigned long long)h) << 24) ^ ((unsigned long long)i)) | CF_OCC;  // slot < 2^38, i < 2^24
+            uint64_t hs = cf_mix64(sk) & S.seen_mask;
+            bool fresh = false, placed = false;
+            for (uint64_t probe = 0; probe <= S.seen_mask; ++probe) {
+                unsigned long long cur = S.seen[hs];
+                if (cur == 0ull) { cur = atomicCAS(&S.seen[hs], 0ull, sk); if (cur == 0ull) { fresh = true; placed = true; break; } }
+                if (cur == sk) { placed = true; break; }
+                hs = (hs + 1) & S.seen_mask;
+            }
+            if (!placed) atomicOr(&S.ctl[2], 4u);
+            if (fresh) atomicAdd(&S.s0[h], 1u);
+        }
+    }
+}
+
+__device__ __forceinline__ cf_cand cf_cand_shfl_down(const cf_cand& c, unsigned d) {
+    cf_cand o;
+    o.s0 = __shfl_down(c.s0, d); o.s1 = __shfl_down(c.s1, d); o.off = __shfl_down(c.off, d);
+    o.rank = __shfl_down(c.rank, d); o.read = __shfl_down(c.read, d); o.valid = __shfl_down(c.valid, d);
+    return o;
+}
+
+__device__ __forceinline__ cf_cand cf_block_best(cf_cand mine) {
+    cf_cand* sh = (cf_cand*)cf_lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int d = 32; d >= 1; d >>= 1) {
+        cf_cand o = cf_cand_shfl_down(mine, (unsigned)d);
+        if (lane + d < 64 && cf_cand_better(o, mine)) mine = o;
+    }
+    if (lane == 0) sh[wave] = mine;
+    __syncthreads();
+    cf_cand best = sh[0];
+    for (int w = 1; w < nw; ++w) if (cf_cand_better(sh[w], best)) best = sh[w];
+    __syncthreads();
+    return best;
+}
+
+__global__ void __launch_bounds__(PL_THREADS)
+cf_place_argmax_kernel(cf_place_state S) {
+    cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
+    if (!S.ctl[0]) {
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= S.smask; i += stride) {
+            const unsigned long long k = S.skeys[i];
+            if (!k) continue;
+            const uint32_t r = (uint32_t)((k & ~CF_OCC) >> 32), off = (uint32_t)k;
+            if (S.used[r]) continue;
+            const uint32_t v0 = S.s0[i], v1 = S.s1[i];
+            if (v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters) {
+                cf_cand c; c.s0 = v0; c.s1 = v1; c.off = off; c.rank = (uint32_t)S.id_rank[r]; c.read = r; c.valid = 1;
+                if (cf_cand_better(c, mine)) mine = c;
+            }
+        }
+    }
+    const cf_cand b = cf_block_best(mine);
+    if (threadIdx.x == 0) S.block_best[blockIdx.x] = b;
+}
+
+// single block: reduce the block candidates, record the placement, reset the event list
+__global__ void __launch_bounds__(PL_THREADS)
+cf_place_final_kernel(cf_place_state S, int n_blocks) {
+    if (S.ctl[0]) return;
+    cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
+    for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) if (cf_cand_better(S.block_best[i], mine)) mine = S.block_best[i];
+    const cf_cand b = cf_block_best(mine);
+    if (threadIdx.x == 0) {
+        *S.best = b;
+        S.n_events[0] = 0ull;
+        if (!b.valid) S.ctl[0] = 1;
+        else {
+            const unsigned int o = S.ctl[1]++;
+            S.out_read[o] = (int64_t)b.read; S.out_pos[o] = (int64_t)b.off; S.out_s0[o] = (int32_t)b.s0; S.out_s1[o] = (int32_t)b.s1;
+            S.used[b.read] = 1;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+cf_unit2read_kernel(const int64_t* __restrict__ unit_ptr, int64_t n_reads, int32_t* __restrict__ u2r) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += stride)
+        for (int64_t u = unit_ptr[r]; u < unit_ptr[r + 1]; ++u) u2r[u] = (int32_t)r;
+}
+
+// postings over the reads of one class: mode 0 histogram, mode 1 fill
+__global__ void __launch_bounds__(256)
+cf_place_post_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ entries, const int32_t* __restrict__ u2r,
+                     const uint8_t* __restrict__ cls, int want_cls, int64_t n_units, int mode, uint32_t* __restrict__ cnt,
+                     const int64_t* __restrict__ post_ptr, int32_t* __restrict__ post) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = wave; u < n_units; u += n_waves) {
+        if (cls[u2r[u]] != want_cls) continue;
+        for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) {
+            const int32_t x = entries[e];
+            if (mode == 0) atomicAdd(&cnt[x], 1u);
+            else post[post_ptr[x] + atomicAdd(&cnt[x], 1u)] = (int32_t)u;
+        }
+    }
+}
+
+namespace {
+
+struct Bufs {
+    cf_ctx* ctx;
+    std::vector<std::pair<void*, size_t>> owned;
+    template <class T> int get(T** p, size_t n, const char* what) {
+        int rc = cf_alloc_t(ctx, p, n, what);
+        if (rc == 0) owned.emplace_back((void*)*p, n * sizeof(T));
+        return rc;
+    }
+    ~Bufs() { for (auto it = owned.rbegin(); it != owned.rend(); ++it) cf_release(ctx, it->first, it->second); }
+};
+
+}  // namespace
+
+// One attempt with given table sizes; returns 1 if a table overflowed (caller retries larger).
+static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int32_t min_freq, int32_t min_unit,
+                         int32_t min_inters, int32_t min_prop, uint64_t score_cap, uint64_t seen_cap,
+                         std::vector<int64_t>& o_read, std::vector<int64_t>& o_pos, std::vector<int32_t>& o_s0, std::vector<int32_t>& o_s1) {
+    const int64_t R = ctx->n_reads, U = ctx->n_units, N = ctx->n_entries, K = ctx->n_kmers;
+    Bufs B{ctx, {}};
+    cf_place_state S;
+    std::memset(&S, 0, sizeof S);
+    S.unit_ptr = ctx->d_unit_ptr; S.cloud_ptr = ctx->d_cloud_ptr; S.entries = ctx->d_entries;
+    S.thr = (uint32_t)std::max(1, min_freq); S.min_unit = (uint32_t)std::max(0, min_unit);
+    S.min_inters = (uint32_t)std::max(0, min_inters); S.min_prop = (uint32_t)std::max(0, min_prop);
+    int32_t *d_u2r = nullptr, *d_post = nullptr, *d_rank = nullptr;
+    uint8_t *d_cls = nullptr, *d_used = nullptr;
+    uint32_t* d_pcnt = nullptr;
+    int64_t* d_post_ptr = nullptr;
+    const uint64_t ccap = cf_pow2_ceil((uint64_t)std::max<int64_t>(2 * N, 1024));
+    CF_TRY(B.get(&d_u2r, (size_t)U + 1, "unit2read"));
+    CF_TRY(B.get(&d_cls, (size_t)R + 1, "classes"));
+    CF_TRY(B.get(&d_used, (size_t)R + 1, "used flags"));
+    CF_TRY(B.get(&d_rank, (size_t)R + 1, "id ranks"));
+    CF_TRY(B.get(&S.ckeys, (size_t)ccap, "contig keys"));
+    CF_TRY(B.get(&S.ccnt, (size_t)ccap, "contig counts"));
+    CF_TRY(B.get(&S.freq_flag, (size_t)K + 1, "frequent flags"));
+    CF_TRY(B.get(&d_pcnt, (size_t)K + 1, "stage posting counts"));
+    CF_TRY(B.get(&d_post_ptr, (size_t)K + 1, "stage posting offsets"));
+    CF_TRY(B.get(&d_post, (size_t)N + 1, "stage postings"));
+    CF_TRY(B.get(&S.skeys, (size_t)score_cap, "score keys"));
+    CF_TRY(B.get(&S.s0, (size_t)score_cap, "score s0"));
+    CF_TRY(B.get(&S.s1, (size_t)score_cap, "score s1"));
+    CF_TRY(B.get(&S.seen, (size_t)seen_cap, "seen set"));
+    CF_TRY(B.get(&S.events, (size_t)N + 1, "events"));
+    CF_TRY(B.get(&S.n_events, 2, "event count"));
+    CF_TRY(B.get(&S.ctl, 8, "control"));
+    const int n_blocks = std::max(1, ctx->n_cu) * 4;
+    CF_TRY(B.get(&S.block_best, (size_t)n_blocks, "block candidates"));
+    CF_TRY(B.get(&S.best, 1, "best candidate"));
+    CF_TRY(B.get(&S.out_read, (size_t)R + 1, "out_read"));
+    CF_TRY(B.get(&S.out_pos, (size_t)R + 1, "out_pos"));
+    CF_TRY(B.get(&S.out_s0, (size_t)R + 1, "out_s0"));
+    CF_TRY(B.get(&S.out_s1, (size_t)R + 1, "out_s1"));
+    S.unit2read = d_u2r; S.cmask = ccap - 1; S.smask = score_cap - 1; S.seen_mask = seen_cap - 1;
+    S.used = d_used; S.id_rank = d_rank; S.post_ptr = d_post_ptr; S.post = d_post;
+    hipStream_t st = ctx->stream;
+    CF_HIP(hipMemcpyAsync(d_cls, cls, (size_t)R, hipMemcpyHostToDevice, st));
+    CF_HIP(hipMemcpyAsync(d_rank, id_rank, (size_t)R * 4, hipMemcpyHostToDevice, st));
+    CF_HIP(hipMemsetAsync(d_used, 0, (size_t)R + 1, st));
+    CF_HIP(hipMemsetAsync(S.ckeys, 0, (size_t)ccap * 8, st));
+    CF_HIP(hipMemsetAsync(S.ccnt, 0, (size_t)ccap * 4, st));
+    CF_HIP(hipMemsetAsync(S.freq_flag, 0, (size_t)K + 1, st));
+    CF_HIP(hipMemsetAsync(S.n_events, 0, 16, st));
+    CF_HIP(hipMemsetAsync(S.ctl, 0, 32, st));
+    const int g_units = cf_grid_for(std::max<int64_t>(U, 1) * 64, 256, n_blocks);
+    if (R) hipLaunchKernelGGL(cf_unit2read_kernel, dim3((unsigned)cf_grid_for(R, 256, n_blocks)), dim3(256), 0, st, (const int64_t*)ctx->d_unit_ptr, R, d_u2r);
+    // prefix reads at position 0, in record order (reference read_placer.py:35-40)
+    o_read.clear(); o_pos.clear(); o_s0.clear(); o_s1.clear();
+    for (int64_t r = 0; r < R; ++r) {
+        if (cls[r] != 0) continue;
+        hipLaunchKernelGGL(cf_place_add_kernel, dim3(8), dim3(PL_THREADS), 0, st, S, 0, r);
+        o_read.push_back(r); o_pos.push_back(0); o_s0.push_back(-1); o_s1.push_back(-1);
+    }
+    CF_KERNEL_CHECK("cf_place_add_kernel");
+    for (int stage_cls = 1; stage_cls <= 2; ++stage_cls) {
+        std::vector<int64_t> stage_reads;
+        for (int64_t r = 0; r < R; ++r) if (cls[r] == stage_cls) stage_reads.push_back(r);
+        if (stage_reads.empty()) continue;
+        // postings of the stage
+        CF_HIP(hipMemsetAsync(d_pcnt, 0, (size_t)(K + 1) * 4, st));
+        hipLaunchKernelGGL(cf_place_post_kernel, dim3((unsigned)g_units), dim3(256), 0, st, (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries,
+                           (const int32_t*)d_u2r, (const uint8_t*)d_cls, stage_cls, U, 0, d_pcnt, (const int64_t*)nullptr, (int32_t*)nullptr);
+        int64_t n_post = 0;
+        CF_TRY(cf_scan_exclusive_u32_to_i64(ctx, d_pcnt, d_post_ptr, K + 1, &n_post));
+        CF_HIP(hipMemsetAsync(d_pcnt, 0, (size_t)(K + 1) * 4, st));
+        hipLaunchKernelGGL(cf_place_post_kernel, dim3((unsigned)g_units), dim3(256), 0, st, (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries,
+                           (const int32_t*)d_u2r, (const uint8_t*)d_cls, stage_cls, U, 1, d_pcnt, (const int64_t*)d_post_ptr, d_post);
+        // fresh scores, seed events
+        CF_HIP(hipMemsetAsync(S.skeys, 0, (size_t)score_cap * 8, st));
+        CF_HIP(hipMemsetAsync(S.s0, 0, (size_t)score_cap * 4, st));
+        CF_HIP(hipMemsetAsync(S.s1, 0, (size_t)score_cap * 4, st));
+        CF_HIP(hipMemsetAsync(S.seen, 0, (size_t)seen_cap * 8, st));
+        CF_HIP(hipMemsetAsync(S.n_events, 0, 16, st));
+        CF_HIP(hipMemsetAsync(S.ctl, 0, 8, st));  // done = 0, n_out = 0 (error flags kept)
+        hipLaunchKernelGGL(cf_place_seed_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
+        CF_KERNEL_CHECK("cf_place_seed_kernel");
+        unsigned int h_ctl[4] = {0, 0, 0, 0};
+        const int64_t n_iter = (int64_t)stage_reads.size();
+        for (int64_t it = 0; it < n_iter; ++it) {
+            hipLaunchKernelGGL(cf_place_update_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
+            hipLaunchKernelGGL(cf_place_argmax_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S);
+            hipLaunchKernelGGL(cf_place_final_kernel, dim3(1), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S, n_blocks);
+            hipLaunchKernelGGL(cf_place_add_kernel, dim3(8), dim3(PL_THREADS), 0, st, S, 1, (int64_t)0);
+            if ((it & 255) == 255 || it + 1 == n_iter) {
+                CF_KERNEL_CHECK("placement iteration");
+                CF_HIP(hipMemcpyAsync(h_ctl, S.ctl, 16, hipMemcpyDeviceToHost, st));
+                CF_HIP(hipStreamSynchronize(st));
+                if (h_ctl[2]) return 1;
+                if (h_ctl[0]) break;
+            }
+        }
+        const unsigned int n_out = h_ctl[1];
+        std::vector<int64_t> t_read(n_out), t_pos(n_out);
+        std::vector<int32_t> t_s0(n_out), t_s1(n_out);
+        if (n_out) {
+            CF_HIP(hipMemcpy(t_read.data(), S.out_read, (size_t)n_out * 8, hipMemcpyDeviceToHost));
+            CF_HIP(hipMemcpy(t_pos.data(), S.out_pos, (size_t)n_out * 8, hipMemcpyDeviceToHost));
+            CF_HIP(hipMemcpy(t_s0.data(), S.out_s0, (size_t)n_out * 4, hipMemcpyDeviceToHost));
+            CF_HIP(hipMemcpy(t_s1.data(), S.out_s1, (size_t)n_out * 4, hipMemcpyDeviceToHost));
+        }
+        std::vector<uint8_t> placed((size_t)R, 0);
+        for (unsigned int i = 0; i < n_out; ++i) {
+            o_read.push_back(t_read[i]); o_pos.push_back(t_pos[i]); o_s0.push_back(t_s0[i]); o_s1.push_back(t_s1[i]);
+            placed[(size_t)t_read[i]] = 1;
+        }
+        // None tail of the stage, ordered by read id (the reference's order is set-iteration order)
+        std::vector<int64_t> rest;
+        for (int64_t r : stage_reads) if (!placed[(size_t)r]) rest.push_back(r);
+        std::sort(rest.begin(), rest.end(), [&](int64_t a, int64_t b) { return id_rank[a] < id_rank[b]; });
+        for (int64_t r : rest) { o_read.push_back(r); o_pos.push_back(-1); o_s0.push_back(-1); o_s1.push_back(-1); }
+    }
+    unsigned int h_ctl[4] = {0, 0, 0, 0};
+    CF_HIP(hipMemcpy(h_ctl, S.ctl, 16, hipMemcpyDeviceToHost));
+    if (h_ctl[2]) return 1;
+    return 0;
+}
+
+extern "C" {
+
+int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int32_t min_cloud_kmer_freq,
+                   int32_t min_unit, int32_t min_inters, int32_t min_prop,
+                   int64_t* out_read, int64_t* out_pos, int32_t* out_s0, int32_t* out_s1) {
+    if (!ctx) return -22;
+    if (!ctx->have_clouds) return cf_fail(ctx, -22, "cf_place_reads: no clouds built");
+    if (!cls || !id_rank || !out_read || !out_pos || !out_s0 || !out_s1) return cf_fail(ctx, -22, "cf_place_reads: null argument");
+    CF_HIP(hipSetDevice(ctx->device));
+    CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    const int64_t R = ctx->n_reads;
+    for (int64_t r = 0; r < R; ++r) if (cls[r] > 2) return cf_fail(ctx, -22, "cf_place_reads: class must be 0, 1 or 2");
+    uint64_t score_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(64 * R, 1 << 14));
+    uint64_t seen_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(4 * ctx->n_entries, 1 << 14));
+    std::vector<int64_t> o_read, o_pos;
+    std::vector<int32_t> o_s0, o_s1;
+    int rc = 1;
+    for (int attempt = 0; attempt < 6 && rc == 1; ++attempt) {
+        rc = place_attempt(ctx, cls, id_rank, min_cloud_kmer_freq, min_unit, min_inters, min_prop, score_cap, seen_cap, o_read, o_pos, o_s0, o_s1);
+        if (rc == 1) { score_cap *= 4; seen_cap *= 4; }
+    }
+    if (rc == 1) return cf_fail(ctx, -34, "cf_place_reads: score tables kept overflowing");
+    if (rc) return rc;
+    if ((int64_t)o_read.size() != R) return cf_fail(ctx, -5, "cf_place_reads: internal error, output count != reads");
+    for (int64_t i = 0; i < R; ++i) { out_read[i] = o_read[(size_t)i]; out_pos[i] = o_pos[(size_t)i]; out_s0[i] = o_s0[(size_t)i]; out_s1[i] = o_s1[(size_t)i]; }
+    CF_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    CF_HIP(hipEventSynchronize(ctx->ev1));
+    CF_HIP(hipEventElapsedTime(&ctx->times.place_ms, ctx->ev0, ctx->ev1));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,809 @@
+// cfhost.cpp — host-side ingestion of NCRF reports and the synthetic read generator.
+// C ABI in include/cfhost.h.  Plain C++17; no GPU code here.
+//
+// Reference behaviour restated (never copied) from:
+//   scripts/ncrf_parser.py:61-118  record selection / orientation
+//   scripts/ncrf_parser.py:28-59   unit split (regex "base([-]*)" x len(motif) x n)
+//   scripts/ncrf_parser.py:120-145 classify
+//   scripts/utils/bio.py:27-29     RC
+#include "cfhost.h"
+
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+void set_err(char* err, int errlen, const std::string& msg) {
+    if (err && errlen > 0) {
+        std::snprintf(err, (size_t)errlen, "%s", msg.c_str());
+    }
+}
+
+// ---------------------------------------------------------------- small helpers
+inline char rc_char(char c) {
+    // translate 'ATGCatgc-' -> 'TACGtacg-'; everything else passes through
+    switch (c) {
+        case 'A': return 'T'; case 'T': return 'A'; case 'G': return 'C'; case 'C': return 'G';
+        case 'a': return 't'; case 't': return 'a'; case 'g': return 'c'; case 'c': return 'g';
+        default: return c;
+    }
+}
+void rc_inplace(std::string& s) {
+    std::reverse(s.begin(), s.end());
+    for (auto& c : s) c = rc_char(c);
+}
+inline char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
+
+// One alignment as it stands in the file (read orientation for '-').
+struct FileRecord {
+    std::string r_id;
+    int64_t r_len = 0, r_al_len = 0, r_st = 0, r_en = 0;
+    std::string r_al, m_al, motif;
+    char strand = '+';
+    int64_t m_al_len = 0, score = 0;
+};
+
+// Result of the heavy per-record work (orientation + de-gap + unit split for n = 1).
+struct Staged {
+    std::string bases;               // de-gapped oriented r_al
+    std::string r_al, m_al;          // oriented rows (kept only when requested)
+    std::vector<int64_t> col_bounds; // unit boundaries as alignment columns (n = 1)
+    std::vector<int64_t> pos_bounds; // same boundaries in de-gapped read coordinates
+    int64_t ncols = 0;
+    bool non_acgt = false;
+};
+
+// Unit split: leftmost non-overlapping matches of motif*n in the de-gapped, upper-cased
+// motif row; a match ends after the gap columns that follow its last base.
+void split_units(const std::string& r_al, const std::string& m_al, const std::string& motif,
+                 int n, std::vector<int64_t>& col_bounds) {
+    col_bounds.clear();
+    const int64_t ncols = (int64_t)m_al.size();
+    std::string s;
+    std::vector<int64_t> cols;
+    s.reserve(m_al.size());
+    cols.reserve(m_al.size());
+    for (int64_t c = 0; c < ncols; ++c) {
+        if (m_al[c] != '-') { s.push_back(up(m_al[c])); cols.push_back(c); }
+    }
+    std::string pat;
+    for (int i = 0; i < n; ++i) pat += motif;
+    if (pat.empty()) return;
+    std::vector<int64_t> starts;
+    int64_t last_end = -1;
+    size_t pos = 0;
+    while (true) {
+        size_t p = s.find(pat, pos);
+        if (p == std::string::npos) break;
+        int64_t st = cols[p];
+        int64_t en = cols[p + pat.size() - 1] + 1;
+        while (en < ncols && m_al[en] == '-') ++en;
+        starts.push_back(st);
+        last_end = en;
+        pos = p + pat.size();
+    }
+    if (starts.empty()) return;
+    const double cut = (double)motif.size() * 0.2;
+    if ((double)starts[0] > cut) col_bounds.push_back(0);
+    for (auto v : starts) col_bounds.push_back(v);
+    col_bounds.push_back(last_end);
+    if ((double)last_end < (double)r_al.size() - cut) col_bounds.push_back((int64_t)r_al.size());
+}
+
+void cols_to_pos(const std::string& r_al, const std::vector<int64_t>& col_bounds,
+                 std::vector<int64_t>& pos_bounds) {
+    pos_bounds.resize(col_bounds.size());
+    size_t bi = 0;
+    int64_t cnt = 0;
+    const int64_t ncols = (int64_t)r_al.size();
+    for (int64_t c = 0; c <= ncols && bi < col_bounds.size(); ++c) {
+        while (bi < col_bounds.size() && col_bounds[bi] == c) pos_bounds[bi++] = cnt;
+        if (c < ncols && r_al[c] != '-') ++cnt;
+    }
+}
+
+void stage_record(FileRecord& fr, bool keep_rows, Staged& out) {
+    if (fr.strand == '-') { rc_inplace(fr.r_al); rc_inplace(fr.m_al); }
+    out.ncols = (int64_t)fr.r_al.size();
+    out.bases.clear();
+    out.bases.reserve(fr.r_al.size());
+    out.non_acgt = false;
+    for (char c : fr.r_al) {
+        if (c == '-') continue;
+        out.bases.push_back(c);
+        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) out.non_acgt = true;
+    }
+    split_units(fr.r_al, fr.m_al, fr.motif, 1, out.col_bounds);
+    cols_to_pos(fr.r_al, out.col_bounds, out.pos_bounds);
+    if (keep_rows) { out.r_al = std::move(fr.r_al); out.m_al = std::move(fr.m_al); }
+}
+
+struct AlnKey {  // (r_st, r_en, strand) tuple ordering as Python sorts it
+    int64_t st, en; char strand;
+    bool operator<(const AlnKey& o) const {
+        if (st != o.st) return st < o.st;
+        if (en != o.en) return en < o.en;
+        return strand < o.strand;
+    }
+};
+
+struct SeenRead {
+    int64_t read_len = 0;   // read_lens[r_id]: value of the LAST alignment seen
+    AlnKey first{}, last{}; // min / max of positions_all_alignments[r_id]
+    int64_t n_aln = 0;
+    int64_t rec = -1;       // index into records (kept), -1 if none
+};
+
+}  // namespace
+
+struct cfh_pack {
+    // kept records
+    std::vector<int64_t> meta;      // R x 8
+    std::string ids;
+    std::vector<int64_t> id_off{0};
+    std::string bases;
+    std::vector<int64_t> read_off{0};
+    std::vector<std::string> rows_r, rows_m;
+    bool keep_rows = false;
+    bool non_acgt = false;
+    std::vector<std::string> motifs;
+    std::unordered_map<std::string, int32_t> motif_ids;
+    // n = 1 units
+    std::vector<int64_t> u1_ptr{0}, u1_start, u1_end, u1_col;
+    // cache for other n
+    std::map<int32_t, std::array<std::vector<int64_t>, 4>> units_n;
+    // all reads seen
+    std::unordered_map<std::string, int64_t> seen_idx;
+    std::vector<SeenRead> seen;
+    std::vector<int64_t> rec_seen;  // kept record -> seen index
+    std::string discarded;
+
+    int64_t n_reads() const { return (int64_t)read_off.size() - 1; }
+};
+
+namespace {
+
+// Light-weight header view of a file record used for the keep decision.
+struct Header {
+    std::string r_id;
+    int64_t r_len, r_al_len, r_st, r_en;
+    char strand;
+};
+
+// Sequential dictionary logic of NCRF_Report.__init__ (ncrf_parser.py:88-111).
+// Returns: -1 skip, otherwise the kept-record slot this alignment (re)fills.
+struct Selector {
+    cfh_pack* P;
+    int64_t min_record_len;
+    std::vector<int64_t> rec_al_len;  // r_al_len of the currently kept record
+    int64_t offer(const Header& h) {
+        auto it = P->seen_idx.find(h.r_id);
+        int64_t si;
+        if (it == P->seen_idx.end()) {
+            si = (int64_t)P->seen.size();
+            P->seen_idx.emplace(h.r_id, si);
+            P->seen.emplace_back();
+        } else si = it->second;
+        SeenRead& s = P->seen[si];
+        AlnKey key{h.r_st, h.r_en, h.strand};
+        if (s.n_aln == 0) { s.first = key; s.last = key; }
+        else { if (key < s.first) s.first = key; if (s.last < key) s.last = key; }
+        s.n_aln++;
+        s.read_len = h.r_len;
+        if (s.rec < 0 || rec_al_len[s.rec] < h.r_al_len) {
+            if (h.r_al_len < min_record_len) return -1;
+            if (s.rec < 0) {
+                s.rec = (int64_t)rec_al_len.size();
+                rec_al_len.push_back(h.r_al_len);
+                P->rec_seen.push_back(si);
+            } else rec_al_len[s.rec] = h.r_al_len;
+            return s.rec;
+        }
+        return -1;
+    }
+};
+
+struct Winner {  // final content of one kept slot
+    FileRecord fr;
+    bool set = false;
+};
+
+void finalize_pack(cfh_pack* P, std::vector<Winner>& winners, int n_threads) {
+    const int64_t R = (int64_t)winners.size();
+    std::vector<Staged> staged((size_t)R);
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, R));
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        while (true) {
+            int64_t i = next.fetch_add(1);
+            if (i >= R) break;
+            stage_record(winners[(size_t)i].fr, P->keep_rows, staged[(size_t)i]);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+
+    int64_t nb = 0, nu = 0;
+    for (auto& s : staged) { nb += (int64_t)s.bases.size(); nu += s.pos_bounds.empty() ? 0 : (int64_t)s.pos_bounds.size() - 1; }
+    P->bases.reserve((size_t)nb);
+    P->u1_start.reserve((size_t)nu); P->u1_end.reserve((size_t)nu); P->u1_col.reserve((size_t)nu * 2);
+    P->meta.resize((size_t)R * 8);
+    for (int64_t i = 0; i < R; ++i) {
+        FileRecord& fr = winners[(size_t)i].fr;
+        Staged& s = staged[(size_t)i];
+        const int64_t base0 = (int64_t)P->bases.size();
+        P->bases += s.bases;
+        P->read_off.push_back((int64_t)P->bases.size());
+        P->ids += fr.r_id;
+        P->id_off.push_back((int64_t)P->ids.size());
+        int64_t r_st = fr.r_st, r_en = fr.r_en;
+        if (fr.strand == '-') { r_st = fr.r_len - fr.r_en; r_en = fr.r_len - fr.r_st; }
+        int32_t mid;
+        auto it = P->motif_ids.find(fr.motif);
+        if (it == P->motif_ids.end()) { mid = (int32_t)P->motifs.size(); P->motif_ids.emplace(fr.motif, mid); P->motifs.push_back(fr.motif); }
+        else mid = it->second;
+        int64_t* m = &P->meta[(size_t)i * 8];
+        m[0] = fr.r_len; m[1] = fr.r_al_len; m[2] = r_st; m[3] = r_en;
+        m[4] = fr.strand == '-' ? 1 : 0; m[5] = P->seen[(size_t)P->rec_seen[(size_t)i]].n_aln;
+        m[6] = s.ncols; m[7] = mid;
+        for (size_t b = 0; b + 1 < s.pos_bounds.size(); ++b) {
+            P->u1_start.push_back(base0 + s.pos_bounds[b]);
+            P->u1_end.push_back(base0 + s.pos_bounds[b + 1]);
+            P->u1_col.push_back(s.col_bounds[b]);
+            P->u1_col.push_back(s.col_bounds[b + 1]);
+        }
+        P->u1_ptr.push_back((int64_t)P->u1_start.size());
+        if (s.non_acgt) P->non_acgt = true;
+        if (P->keep_rows) { P->rows_r.push_back(std::move(s.r_al)); P->rows_m.push_back(std::move(s.m_al)); }
+        s = Staged();
+    }
+    // discarded reads: seen but never kept (order is not defined by the reference: it goes through set())
+    for (auto& kv : P->seen_idx) {
+        if (P->seen[(size_t)kv.second].rec < 0) { P->discarded += kv.first; P->discarded.push_back('\n'); }
+    }
+}
+
+// ---------------------------------------------------------------- text parsing
+bool parse_int(const char*& p, const char* end, int64_t& v) {
+    if (p >= end || *p < '0' || *p > '9') return false;
+    v = 0;
+    while (p < end && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); ++p; }
+    return true;
+}
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n' || c == '\f' || c == '\v'; }
+bool skip_ws1(const char*& p, const char* end) {  // \s+
+    if (p >= end || !is_ws(*p)) return false;
+    while (p < end && is_ws(*p)) ++p;
+    return true;
+}
+
+// ^([^ ]+)\s+(\d+)\s+(\d+)bp\s+(\d+)-(\d+)\s+(.+)$
+bool parse_first(const char* b, const char* e, FileRecord& fr, const char*& al_b, const char*& al_e) {
+    const char* p = b;
+    while (p < e && *p != ' ') ++p;
+    if (p == b) return false;
+    // [^ ]+ is greedy but must be followed by \s+; with tabs inside the id the regex would
+    // backtrack — ids with embedded whitespace other than ' ' are not produced by NCRF.
+    fr.r_id.assign(b, p);
+    if (!skip_ws1(p, e)) return false;
+    if (!parse_int(p, e, fr.r_len)) return false;
+    if (!skip_ws1(p, e)) return false;
+    if (!parse_int(p, e, fr.r_al_len)) return false;
+    if (e - p < 2 || p[0] != 'b' || p[1] != 'p') return false;
+    p += 2;
+    if (!skip_ws1(p, e)) return false;
+    if (!parse_int(p, e, fr.r_st)) return false;
+    if (p >= e || *p != '-') return false;
+    ++p;
+    if (!parse_int(p, e, fr.r_en)) return false;
+    if (!skip_ws1(p, e)) return false;
+    if (p >= e) return false;
+    al_b = p; al_e = e;
+    return true;
+}
+// ^([^+-]+)([+-])\s+(\d+)bp\s+score=(\d+)\s+(.+)$
+bool parse_second(const char* b, const char* e, FileRecord& fr, const char*& al_b, const char*& al_e) {
+    const char* p = b;
+    while (p < e && *p != '+' && *p != '-') ++p;
+    if (p == b || p >= e) return false;
+    fr.motif.assign(b, p);
+    fr.strand = *p++;
+    if (!skip_ws1(p, e)) return false;
+    if (!parse_int(p, e, fr.m_al_len)) return false;
+    if (e - p < 2 || p[0] != 'b' || p[1] != 'p') return false;
+    p += 2;
+    if (!skip_ws1(p, e)) return false;
+    if (e - p < 6 || std::strncmp(p, "score=", 6) != 0) return false;
+    p += 6;
+    if (!parse_int(p, e, fr.score)) return false;
+    if (!skip_ws1(p, e)) return false;
+    if (p >= e) return false;
+    al_b = p; al_e = e;
+    return true;
+}
+
+// ---------------------------------------------------------------- PRNG
+struct Rng {
+    uint64_t s[4];
+    static uint64_t splitmix(uint64_t& x) {
+        uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    explicit Rng(uint64_t seed, uint64_t stream = 0) {
+        uint64_t x = seed * 0xD1342543DE82EF95ull + stream * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+        for (auto& v : s) v = splitmix(x);
+    }
+    static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {
+        const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+        s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+        return r;
+    }
+    double uniform() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+    uint64_t below(uint64_t n) { return n ? (uint64_t)(uniform() * (double)n) % n : 0; }
+    double normal() {
+        double u1 = uniform(), u2 = uniform();
+        if (u1 < 1e-300) u1 = 1e-300;
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    }
+    char base() { return "ACGT"[next() >> 62]; }
+    char other(char c) {
+        while (true) { char b = base(); if (b != c) return b; }
+    }
+};
+
+struct Genome {
+    std::string seq;      // flank + array + flank
+    std::string motif;    // consensus HOR unit
+    int64_t a0 = 0, a1 = 0;
+};
+
+Genome make_genome(const cfh_synth_params& sp) {
+    Genome g;
+    Rng rng(sp.seed, 1);
+    std::string anc((size_t)sp.monomer_len, 'A');
+    for (auto& c : anc) c = rng.base();
+    while ((int64_t)g.motif.size() + sp.monomer_len <= sp.unit_len) {
+        std::string m = anc;
+        for (auto& c : m) if (rng.uniform() < sp.monomer_div) c = rng.other(c);
+        g.motif += m;
+    }
+    while ((int64_t)g.motif.size() < sp.unit_len) g.motif.push_back(rng.base());
+    g.seq.reserve((size_t)(2 * sp.flank + sp.n_units * sp.unit_len));
+    for (int64_t i = 0; i < sp.flank; ++i) g.seq.push_back(rng.base());
+    g.a0 = (int64_t)g.seq.size();
+    for (int64_t u = 0; u < sp.n_units; ++u) {
+        Rng ur(sp.seed, 1000 + (uint64_t)u);
+        for (char c : g.motif) g.seq.push_back(ur.uniform() < sp.unit_div ? ur.other(c) : c);
+    }
+    g.a1 = (int64_t)g.seq.size();
+    Rng fr(sp.seed, 2);
+    for (int64_t i = 0; i < sp.flank; ++i) g.seq.push_back(fr.base());
+    return g;
+}
+
+// Simulate candidate read c; fills recs with 0 (rejected), 1 or 2 file records.
+void simulate_read(const cfh_synth_params& sp, const Genome& g, int64_t c, std::vector<FileRecord>& recs) {
+    recs.clear();
+    Rng rng(sp.seed, 100000 + (uint64_t)c);
+    const int64_t G = (int64_t)g.seq.size();
+    int64_t len, start;
+    if (c < sp.n_prefix) {
+        int64_t delta = 1000 + (int64_t)rng.below(2000);
+        int64_t inside = 8000 + (int64_t)rng.below(22000);
+        inside = std::min(inside, g.a1 - g.a0);
+        start = g.a0 - sp.prefix_threshold - delta;
+        len = sp.prefix_threshold + delta + inside;
+    } else if (c < sp.n_prefix + sp.n_suffix) {
+        int64_t delta = 1000 + (int64_t)rng.below(2000);
+        int64_t inside = 8000 + (int64_t)rng.below(22000);
+        inside = std::min(inside, g.a1 - g.a0);
+        start = g.a1 - inside;
+        len = sp.prefix_threshold + delta + inside;
+    } else {
+        double mu = std::log(sp.mean_len) - 0.5 * sp.sigma * sp.sigma;
+        double l = std::exp(mu + sp.sigma * rng.normal());
+        len = (int64_t)l;
+        len = std::max(sp.min_len, std::min(sp.max_len, len));
+        len = std::min(len, G);
+        start = (int64_t)rng.below((uint64_t)(G - len + 1));
+    }
+    if (start < 0) start = 0;
+    if (start + len > G) len = G - start;
+    const bool minus = (rng.next() >> 63) != 0;
+    // overlap with the array
+    const int64_t o0 = std::max(start, g.a0), o1 = std::min(start + len, g.a1);
+    if (o1 - o0 < sp.min_aligned / 2) return;  // cannot reach min_aligned
+    // walk the genome segment in forward orientation
+    std::string r_al, m_al;
+    r_al.reserve((size_t)((o1 - o0) * 11 / 10));
+    m_al.reserve((size_t)((o1 - o0) * 11 / 10));
+    int64_t before = 0, aligned = 0, after = 0;  // read bases before / inside / after the array
+    const int64_t ulen = (int64_t)g.motif.size();
+    for (int64_t p = start; p < start + len; ++p) {
+        const bool in_arr = p >= g.a0 && p < g.a1;
+        const char gb = g.seq[(size_t)p];
+        const char mb = in_arr ? g.motif[(size_t)((p - g.a0) % ulen)] : 0;
+        if (rng.uniform() < sp.p_del) {
+            if (in_arr) { r_al.push_back('-'); m_al.push_back(mb); }
+        } else {
+            char rb = rng.uniform() < sp.p_sub ? rng.other(gb) : gb;
+            if (in_arr) { r_al.push_back(rb); m_al.push_back(mb); ++aligned; }
+            else if (p < g.a0) ++before; else ++after;
+        }
+        if (rng.uniform() < sp.p_ins) {
+            char ib = rng.base();
+            // insertions at the very edge of the array belong to the flank part
+            if (in_arr && p + 1 < g.a1 && p + 1 < start + len) { r_al.push_back(ib); m_al.push_back('-'); ++aligned; }
+            else if (p < g.a0) ++before; else ++after;
+        }
+    }
+    // trim alignment so it neither starts nor ends with a gap column in either row
+    size_t lo = 0, hi = r_al.size();
+    while (lo < hi && (r_al[lo] == '-' || m_al[lo] == '-')) { if (r_al[lo] != '-') { --aligned; ++before; } ++lo; }
+    while (hi > lo && (r_al[hi - 1] == '-' || m_al[hi - 1] == '-')) { if (r_al[hi - 1] != '-') { --aligned; ++after; } --hi; }
+    r_al = r_al.substr(lo, hi - lo);
+    m_al = m_al.substr(lo, hi - lo);
+    if (aligned < sp.min_aligned) return;
+    const int64_t r_len = before + aligned + after;
+
+    // describe as one or two records (forward coordinates first)
+    struct Piece { size_t c0, c1; int64_t st, en; };
+    std::vector<Piece> pieces;
+    bool split = sp.p_split > 0 && rng.uniform() < sp.p_split && r_al.size() > 4000;
+    if (split) {
+        size_t cut = r_al.size() / 5 + (size_t)rng.below((uint64_t)(r_al.size() * 3 / 5));
+        while (cut < r_al.size() && (r_al[cut] == '-' || m_al[cut] == '-' || r_al[cut - 1] == '-' || m_al[cut - 1] == '-')) ++cut;
+        if (cut + 10 >= r_al.size()) split = false;
+        else {
+            int64_t n1 = 0;
+            for (size_t i = 0; i < cut; ++i) n1 += r_al[i] != '-';
+            pieces.push_back({0, cut, before, before + n1});
+            pieces.push_back({cut, r_al.size(), before + n1, before + aligned});
+        }
+    }
+    if (!split) pieces.push_back({0, r_al.size(), before, before + aligned});
+    char idbuf[64];
+    std::snprintf(idbuf, sizeof idbuf, "read_%08lld", (long long)c);
+    for (auto& pc : pieces) {
+        FileRecord fr;
+        fr.r_id = idbuf;
+        fr.r_len = r_len;
+        fr.r_al = r_al.substr(pc.c0, pc.c1 - pc.c0);
+        fr.m_al = m_al.substr(pc.c0, pc.c1 - pc.c0);
+        fr.r_al_len = pc.en - pc.st;
+        fr.m_al_len = 0;
+        for (char ch : fr.m_al) fr.m_al_len += ch != '-';
+        fr.motif = g.motif;
+        fr.score = fr.r_al_len;
+        if (minus) {
+            fr.strand = '-';
+            fr.r_st = r_len - pc.en; fr.r_en = r_len - pc.st;
+            rc_inplace(fr.r_al); rc_inplace(fr.m_al);
+        } else {
+            fr.strand = '+';
+            fr.r_st = pc.st; fr.r_en = pc.en;
+        }
+        recs.push_back(std::move(fr));
+    }
+}
+
+void write_record(FILE* f, const FileRecord& fr) {
+    std::fprintf(f, "%s %lld %lldbp %lld-%lld %s\n", fr.r_id.c_str(), (long long)fr.r_len,
+                 (long long)fr.r_al_len, (long long)fr.r_st, (long long)fr.r_en, fr.r_al.c_str());
+    std::fprintf(f, "%s%c %lldbp score=%lld %s\n\n", fr.motif.c_str(), fr.strand,
+                 (long long)fr.m_al_len, (long long)fr.score, fr.m_al.c_str());
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+extern "C" {
+
+void cfh_synth_defaults(cfh_synth_params* p) {
+    std::memset(p, 0, sizeof *p);
+    p->seed = 1; p->unit_len = 2055; p->monomer_len = 171; p->monomer_div = 0.25;
+    p->n_units = 300; p->flank = 200000; p->unit_div = 0.01; p->n_reads = 1000;
+    p->mean_len = 20000; p->sigma = 0.5; p->min_len = 6000; p->max_len = 200000;
+    p->p_del = 0.02; p->p_sub = 0.02; p->p_ins = 0.015; p->min_aligned = 5000;
+    p->n_prefix = 8; p->n_suffix = 8; p->prefix_threshold = 50000; p->p_split = 0.0;
+    p->n_threads = 0;
+}
+
+int cfh_synth(const cfh_synth_params* sp, const char* report_path, int keep_rows,
+              cfh_pack** out, char* err, int errlen) {
+    try {
+        if (sp->unit_len <= 0 || sp->n_units <= 0 || sp->n_reads < 0 || sp->monomer_len <= 0) {
+            set_err(err, errlen, "cfh_synth: bad parameters"); return -22;
+        }
+        Genome g = make_genome(*sp);
+        FILE* f = nullptr;
+        if (report_path) {
+            f = std::fopen(report_path, "w");
+            if (!f) { set_err(err, errlen, std::string("cfh_synth: cannot open ") + report_path); return -2; }
+            std::fprintf(f, "# synthetic NCRF-format report: seed=%llu unit_len=%d n_units=%lld\n",
+                         (unsigned long long)sp->seed, sp->unit_len, (long long)sp->n_units);
+        }
+        std::unique_ptr<cfh_pack> P;
+        Selector sel{nullptr, 5000, {}};  // NCRF_Report's default min_record_len
+        std::vector<Winner> winners;
+        if (out) { P.reset(new cfh_pack()); P->keep_rows = keep_rows != 0; sel.P = P.get(); }
+        int nt = sp->n_threads > 0 ? sp->n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+        int64_t emitted = 0, cand = 0;
+        const int64_t batch = 256;
+        int64_t guard = 0;
+        while (emitted < sp->n_reads) {
+            std::vector<std::vector<FileRecord>> res((size_t)batch);
+            std::atomic<int64_t> next{0};
+            auto work = [&]() {
+                while (true) {
+                    int64_t i = next.fetch_add(1);
+                    if (i >= batch) break;
+                    simulate_read(*sp, g, cand + i, res[(size_t)i]);
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) th.emplace_back(work);
+            work();
+            for (auto& t : th) t.join();
+            int64_t got = 0;
+            for (int64_t i = 0; i < batch && emitted < sp->n_reads; ++i) {
+                auto& rs = res[(size_t)i];
+                if (rs.empty()) continue;
+                ++got;
+                for (auto& fr : rs) {
+                    if (f) write_record(f, fr);
+                    if (P) {
+                        Header h{fr.r_id, fr.r_len, fr.r_al_len, fr.r_st, fr.r_en, fr.strand};
+                        int64_t slot = sel.offer(h);
+                        if (slot >= 0) {
+                            if ((int64_t)winners.size() <= slot) winners.resize((size_t)slot + 1);
+                            winners[(size_t)slot].fr = std::move(fr);
+                            winners[(size_t)slot].set = true;
+                        }
+                    }
+                }
+                ++emitted;
+            }
+            cand += batch;
+            guard = got ? 0 : guard + 1;
+            if (guard > 2000) { if (f) std::fclose(f); set_err(err, errlen, "cfh_synth: no read reaches min_aligned"); return -34; }
+        }
+        if (f) std::fclose(f);
+        if (P) { finalize_pack(P.get(), winners, nt); *out = P.release(); }
+        return 0;
+    } catch (const std::exception& e) {
+        set_err(err, errlen, std::string("cfh_synth: ") + e.what());
+        return -12;
+    }
+}
+
+int cfh_parse_report(const char* path, int64_t min_record_len, int keep_rows, int n_threads,
+                     cfh_pack** out, char* err, int errlen) {
+    try {
+        FILE* f = std::fopen(path, "rb");
+        if (!f) { set_err(err, errlen, std::string("cannot open NCRF report ") + path); return -2; }
+        std::unique_ptr<cfh_pack> P(new cfh_pack());
+        P->keep_rows = keep_rows != 0;
+        Selector sel{P.get(), min_record_len, {}};
+        std::vector<Winner> winners;
+        // getline-based streaming reader; alignment rows can be hundreds of kB
+        char* line = nullptr; size_t cap = 0; ssize_t n;
+        std::string first; bool have_first = false;
+        int64_t lineno = 0;
+        while ((n = getline(&line, &cap, f)) >= 0) {
+            ++lineno;
+            const char* b = line; const char* e = line + n;
+            while (b < e && is_ws(*b)) ++b;
+            while (e > b && is_ws(e[-1])) --e;
+            if (b == e || *b == '#') continue;
+            if (!have_first) { first.assign(b, e); have_first = true; continue; }
+            have_first = false;
+            FileRecord fr;
+            const char *a1b, *a1e, *a2b, *a2e;
+            if (!parse_first(first.data(), first.data() + first.size(), fr, a1b, a1e) ||
+                !parse_second(b, e, fr, a2b, a2e)) {
+                std::free(line); std::fclose(f);
+                set_err(err, errlen, "malformed NCRF record ending at line " + std::to_string(lineno) + " of " + path);
+                return -22;
+            }
+            Header h{fr.r_id, fr.r_len, fr.r_al_len, fr.r_st, fr.r_en, fr.strand};
+            int64_t slot = sel.offer(h);
+            if (slot >= 0) {
+                fr.r_al.assign(a1b, a1e);
+                fr.m_al.assign(a2b, a2e);
+                if ((int64_t)winners.size() <= slot) winners.resize((size_t)slot + 1);
+                winners[(size_t)slot].fr = std::move(fr);
+                winners[(size_t)slot].set = true;
+            }
+        }
+        std::free(line);
+        std::fclose(f);
+        if (have_first) { set_err(err, errlen, std::string("odd number of record lines in ") + path); return -22; }
+        finalize_pack(P.get(), winners, n_threads);
+        *out = P.release();
+        return 0;
+    } catch (const std::exception& e) {
+        set_err(err, errlen, std::string("cfh_parse_report: ") + e.what());
+        return -12;
+    }
+}
+
+void cfh_pack_free(cfh_pack* p) { delete p; }
+
+int64_t cfh_n_reads(const cfh_pack* p) { return p->n_reads(); }
+int64_t cfh_n_bases(const cfh_pack* p) { return (int64_t)p->bases.size(); }
+int64_t cfh_n_seen(const cfh_pack* p) { return (int64_t)p->seen.size(); }
+int32_t cfh_non_acgt(const cfh_pack* p) { return p->non_acgt ? 1 : 0; }
+const uint8_t* cfh_bases(const cfh_pack* p) { return (const uint8_t*)p->bases.data(); }
+const int64_t* cfh_read_off(const cfh_pack* p) { return p->read_off.data(); }
+const char* cfh_ids(const cfh_pack* p) { return p->ids.data(); }
+const int64_t* cfh_id_off(const cfh_pack* p) { return p->id_off.data(); }
+const int64_t* cfh_meta(const cfh_pack* p) { return p->meta.data(); }
+int32_t cfh_n_motifs(const cfh_pack* p) { return (int32_t)p->motifs.size(); }
+const char* cfh_motif(const cfh_pack* p, int32_t id, int64_t* len) {
+    if (id < 0 || id >= (int32_t)p->motifs.size()) { if (len) *len = 0; return nullptr; }
+    if (len) *len = (int64_t)p->motifs[(size_t)id].size();
+    return p->motifs[(size_t)id].data();
+}
+const char* cfh_discarded(const cfh_pack* p, int64_t* len) {
+    if (len) *len = (int64_t)p->discarded.size();
+    return p->discarded.data();
+}
+
+int cfh_units(cfh_pack* p, int32_t n, int64_t* n_units, const int64_t** unit_ptr,
+              const int64_t** unit_start, const int64_t** unit_end, const int64_t** unit_col,
+              char* err, int errlen) {
+    try {
+        if (n < 1) { set_err(err, errlen, "cfh_units: n must be >= 1"); return -22; }
+        if (n == 1) {
+            *n_units = (int64_t)p->u1_start.size();
+            *unit_ptr = p->u1_ptr.data(); *unit_start = p->u1_start.data();
+            *unit_end = p->u1_end.data(); *unit_col = p->u1_col.data();
+            return 0;
+        }
+        auto it = p->units_n.find(n);
+        if (it == p->units_n.end()) {
+            if (!p->keep_rows) { set_err(err, errlen, "cfh_units: n != 1 needs a pack built with keep_rows"); return -22; }
+            std::array<std::vector<int64_t>, 4> a;
+            a[0].push_back(0);
+            std::vector<int64_t> cb, pb;
+            const int64_t R = p->n_reads();
+            for (int64_t r = 0; r < R; ++r) {
+                const std::string& motif = p->motifs[(size_t)p->meta[(size_t)r * 8 + 7]];
+                split_units(p->rows_r[(size_t)r], p->rows_m[(size_t)r], motif, n, cb);
+                cols_to_pos(p->rows_r[(size_t)r], cb, pb);
+                const int64_t base0 = p->read_off[(size_t)r];
+                for (size_t b = 0; b + 1 < pb.size(); ++b) {
+                    a[1].push_back(base0 + pb[b]); a[2].push_back(base0 + pb[b + 1]);
+                    a[3].push_back(cb[b]); a[3].push_back(cb[b + 1]);
+                }
+                a[0].push_back((int64_t)a[1].size());
+            }
+            it = p->units_n.emplace(n, std::move(a)).first;
+        }
+        *n_units = (int64_t)it->second[1].size();
+        *unit_ptr = it->second[0].data(); *unit_start = it->second[1].data();
+        *unit_end = it->second[2].data(); *unit_col = it->second[3].data();
+        return 0;
+    } catch (const std::exception& e) {
+        set_err(err, errlen, std::string("cfh_units: ") + e.what());
+        return -12;
+    }
+}
+
+int cfh_classify(const cfh_pack* p, int64_t large, int64_t small, uint8_t* cls) {
+    const int64_t R = p->n_reads();
+    for (int64_t r = 0; r < R; ++r) {
+        const SeenRead& s = p->seen[(size_t)p->rec_seen[(size_t)r]];
+        const int64_t* m = &p->meta[(size_t)r * 8];
+        const int64_t r_len = s.read_len;
+        int64_t left, right;
+        if (m[4] == 0) { left = s.first.st; right = s.last.en; }
+        else { left = r_len - s.last.en; right = r_len - s.first.st; }
+        if (left > large && right > r_len - small && right == m[3]) cls[r] = 0;
+        else if (right < r_len - large && left < small && left == m[2]) cls[r] = 2;
+        else cls[r] = 1;
+    }
+    return 0;
+}
+
+const char* cfh_row(const cfh_pack* p, int64_t r, int32_t which, int64_t* len) {
+    if (!p->keep_rows || r < 0 || r >= p->n_reads()) { if (len) *len = 0; return nullptr; }
+    const std::string& s = which ? p->rows_m[(size_t)r] : p->rows_r[(size_t)r];
+    if (len) *len = (int64_t)s.size();
+    return s.data();
+}
+
+static void decode_kmer(uint64_t code, int k, char* out) {
+    for (int i = k - 1; i >= 0; --i) { out[i] = "ACGT"[code & 3]; code >>= 2; }
+}
+
+int cfh_write_kmers(const char* path, const uint64_t* kmers, int64_t n, int32_t k, char* err, int errlen) {
+    if (k < 1 || k > 32) { set_err(err, errlen, "cfh_write_kmers: k out of range"); return -22; }
+    FILE* f = std::fopen(path, "w");
+    if (!f) { set_err(err, errlen, std::string("cannot open ") + path); return -2; }
+    std::vector<char> buf;
+    buf.reserve(1 << 20);
+    char tmp[40];
+    for (int64_t i = 0; i < n; ++i) {
+        decode_kmer(kmers[i], k, tmp);
+        tmp[k] = '\n';
+        buf.insert(buf.end(), tmp, tmp + k + 1);
+        if (buf.size() > (1u << 20) - 64) { std::fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+    }
+    std::fwrite(buf.data(), 1, buf.size(), f);
+    if (std::fclose(f) != 0) { set_err(err, errlen, std::string("write failed: ") + path); return -5; }
+    return 0;
+}
+
+int cfh_write_edges(const char* path, int append, const uint64_t* rare, int32_t k,
+                    const uint32_t* edges, int64_t n, char* err, int errlen) {
+    if (k < 1 || k > 32) { set_err(err, errlen, "cfh_write_edges: k out of range"); return -22; }
+    FILE* f = std::fopen(path, append ? "a" : "w");
+    if (!f) { set_err(err, errlen, std::string("cannot open ") + path); return -2; }
+    std::vector<char> buf;
+    buf.reserve(1 << 20);
+    char tmp[128];
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t* e = edges + 4 * i;
+        int len = std::snprintf(tmp, sizeof tmp, "%u ", e[0]);
+        decode_kmer(rare[e[1]], k, tmp + len); len += k; tmp[len++] = ' ';
+        decode_kmer(rare[e[2]], k, tmp + len); len += k;
+        len += std::snprintf(tmp + len, sizeof tmp - (size_t)len, " %u\n", e[3]);
+        buf.insert(buf.end(), tmp, tmp + len);
+        if (buf.size() > (1u << 20) - 256) { std::fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+    }
+    std::fwrite(buf.data(), 1, buf.size(), f);
+    if (std::fclose(f) != 0) { set_err(err, errlen, std::string("write failed: ") + path); return -5; }
+    return 0;
+}
+
+int cfh_read_kmers(const char* path, int32_t k, uint64_t* out, int64_t cap, int64_t* n_out,
+                   char* err, int errlen) {
+    if (k < 1 || k > 32) { set_err(err, errlen, "cfh_read_kmers: k out of range"); return -22; }
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { set_err(err, errlen, std::string("cannot open ") + path); return -2; }
+    char* line = nullptr; size_t lcap = 0; ssize_t n;
+    int64_t cnt = 0, lineno = 0;
+    int rc = 0;
+    while ((n = getline(&line, &lcap, f)) >= 0) {
+        ++lineno;
+        const char* b = line; const char* e = line + n;
+        while (b < e && is_ws(*b)) ++b;
+        while (e > b && is_ws(e[-1])) --e;
+        // the reference keeps every stripped line (read_placer.py:23-25); a line that is not
+        // a k-long ACGT word can never equal a k-mer window of an ACGT read, so it is inert
+        if (e - b != k) continue;
+        uint64_t code = 0; bool ok = true;
+        for (const char* p = b; p < e; ++p) {
+            int v = *p == 'A' ? 0 : *p == 'C' ? 1 : *p == 'G' ? 2 : *p == 'T' ? 3 : -1;
+            if (v < 0) { ok = false; break; }
+            code = (code << 2) | (uint64_t)v;
+        }
+        if (!ok) continue;
+        if (out && cnt < cap) out[cnt] = code;
+        ++cnt;
+    }
+    std::free(line);
+    std::fclose(f);
+    *n_out = cnt;
+    return rc;
+}
+
+}  // extern "C"

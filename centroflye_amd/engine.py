@@ -1,0 +1,225 @@
+"""Thin numpy-facing wrapper over the C ABI of the device pipeline (include/cfhip.h).
+
+One ``Engine`` = one ``cf_ctx`` = one GPU.  Every method maps 1:1 onto a C entry point; the
+mirrors of the reference's modules (``distance_based_kmer_recruitment``, ``read_kmer_cloud``,
+``cloud_contig``, ``read_placer``) are written on top of this class.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Engine:
+    def __init__(self, device=0, lib=None):
+        self._lib = lib if lib is not None else _lib.load()
+        self._ctx = C.c_void_p()
+        rc = self._lib.cf_create(int(device), C.byref(self._ctx))
+        if rc != 0:
+            msg = self._lib.cf_last_error(self._ctx).decode(errors="replace") if self._ctx else "allocation failed"
+            if self._ctx:
+                self._lib.cf_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+            raise DeviceError(f"cf_create({device}) failed ({rc}): {msg}")
+        self.k = None
+        self.n_reads = 0
+        self.n_units = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        ctx, self._ctx = getattr(self, "_ctx", None), None
+        if ctx:
+            self._lib.cf_destroy(ctx)
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise DeviceError(f"{what} failed ({rc}): {self._lib.cf_last_error(self._ctx).decode(errors='replace')}")
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        hbm, cu = C.c_int64(), C.c_int32()
+        self._check(self._lib.cf_device_info(self._ctx, name, 256, C.byref(hbm), C.byref(cu)), "cf_device_info")
+        return dict(name=name.value.decode(), hbm_bytes=hbm.value, n_cu=cu.value)
+
+    def set_param(self, name, value):
+        self._check(self._lib.cf_set_param(self._ctx, name.encode(), int(value)), f"cf_set_param({name})")
+
+    def stats(self):
+        s = _lib.Stats()
+        self._check(self._lib.cf_get_stats(self._ctx, C.byref(s)), "cf_get_stats")
+        return s.as_dict()
+
+    def times(self):
+        t = _lib.Times()
+        self._check(self._lib.cf_get_times(self._ctx, C.byref(t)), "cf_get_times")
+        return t.as_dict()
+
+    # ------------------------------------------------------------------ A0 hand-over
+    def load_arrays(self, bases, read_off, unit_ptr, unit_start, unit_end):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        unit_ptr = np.ascontiguousarray(unit_ptr, dtype=np.int64)
+        unit_start = np.ascontiguousarray(unit_start, dtype=np.int64)
+        unit_end = np.ascontiguousarray(unit_end, dtype=np.int64)
+        R = read_off.size - 1
+        if unit_ptr.size != R + 1 or unit_start.size != unit_end.size or (R >= 0 and unit_start.size != unit_ptr[-1]):
+            raise ValueError("inconsistent read / unit arrays")
+        self._check(self._lib.cf_load_reads(self._ctx, _ptr(bases), _ptr(read_off), R, _ptr(unit_ptr),
+                                            _ptr(unit_start), _ptr(unit_end)), "cf_load_reads")
+        self.n_reads, self.n_units = R, int(unit_start.size)
+
+    def load(self, packed, n_motif=1):
+        """packed: centroflye_amd._host.PackedReads."""
+        unit_ptr, unit_start, unit_end, _ = packed.units(n_motif)
+        self.load_arrays(packed.bases, packed.read_off, unit_ptr, unit_start, unit_end)
+
+    def load_units(self, unit_ptr, unit_start, unit_end):
+        unit_ptr = np.ascontiguousarray(unit_ptr, dtype=np.int64)
+        unit_start = np.ascontiguousarray(unit_start, dtype=np.int64)
+        unit_end = np.ascontiguousarray(unit_end, dtype=np.int64)
+        self._check(self._lib.cf_load_units(self._ctx, _ptr(unit_ptr), _ptr(unit_start), _ptr(unit_end)), "cf_load_units")
+        self.n_units = int(unit_start.size)
+
+    # ------------------------------------------------------------------ A1 / A2
+    def count_kmers(self, k, read_lo=0, read_hi=None):
+        self._check(self._lib.cf_count_kmers(self._ctx, int(k), int(read_lo),
+                                             int(self.n_reads if read_hi is None else read_hi)), "cf_count_kmers")
+        self.k = int(k)
+
+    def table(self, sort=True):
+        """(keys uint64, pres uint32, multi uint32) of every k-mer seen."""
+        n = C.c_int64()
+        self._check(self._lib.cf_get_table(self._ctx, None, None, None, 0, C.byref(n)), "cf_get_table")
+        keys = np.zeros(n.value, np.uint64)
+        pres = np.zeros(n.value, np.uint32)
+        multi = np.zeros(n.value, np.uint32)
+        if n.value:
+            self._check(self._lib.cf_get_table(self._ctx, _ptr(keys), _ptr(pres), _ptr(multi), n.value, C.byref(n)), "cf_get_table")
+        if sort:
+            o = np.argsort(keys, kind="stable")
+            keys, pres, multi = keys[o], pres[o], multi[o]
+        return keys, pres, multi
+
+    def merge_table(self, keys, pres, multi):
+        keys = np.ascontiguousarray(keys, np.uint64)
+        pres = np.ascontiguousarray(pres, np.uint32)
+        multi = np.ascontiguousarray(multi, np.uint32)
+        self._check(self._lib.cf_merge_table(self._ctx, _ptr(keys), _ptr(pres), _ptr(multi), keys.size), "cf_merge_table")
+
+    def select_rare(self, max_nonuniq, lo, hi):
+        n = C.c_int64()
+        lo, hi = max(0, int(lo)), int(hi)
+        if hi < lo or hi < 0:
+            lo, hi = 1, 0
+        self._check(self._lib.cf_select_rare(self._ctx, int(max_nonuniq), lo, min(hi, 2 ** 32 - 1), C.byref(n)), "cf_select_rare")
+        return n.value
+
+    def set_kmers(self, kmers, k):
+        kmers = np.ascontiguousarray(kmers, np.uint64)
+        self._check(self._lib.cf_set_kmers(self._ctx, _ptr(kmers), kmers.size, int(k)), "cf_set_kmers")
+        self.k = int(k)
+
+    def kmers(self):
+        n = self.stats()["n_kmers"]
+        out = np.zeros(n, np.uint64)
+        self._check(self._lib.cf_get_kmers(self._ctx, _ptr(out), n), "cf_get_kmers")
+        return out
+
+    # ------------------------------------------------------------------ A3 / A4
+    def build_clouds(self):
+        n = C.c_int64()
+        self._check(self._lib.cf_build_clouds(self._ctx, C.byref(n)), "cf_build_clouds")
+        return n.value
+
+    def filter_clouds(self, min_mult=2, max_mult=0):
+        n = C.c_int64()
+        self._check(self._lib.cf_filter_clouds(self._ctx, int(min_mult), int(max_mult), C.byref(n)), "cf_filter_clouds")
+        return n.value
+
+    def clouds(self):
+        """(cloud_ptr int64[U+1], entries int32[N_ce])."""
+        n = self.stats()["n_cloud_entries"]
+        ptr = np.zeros(self.n_units + 1, np.int64)
+        ent = np.zeros(n, np.int32)
+        self._check(self._lib.cf_get_clouds(self._ctx, _ptr(ptr), _ptr(ent), n), "cf_get_clouds")
+        return ptr, ent
+
+    def set_clouds(self, cloud_ptr, entries):
+        cloud_ptr = np.ascontiguousarray(cloud_ptr, np.int64)
+        entries = np.ascontiguousarray(entries, np.int32)
+        self._check(self._lib.cf_set_clouds(self._ctx, _ptr(cloud_ptr), _ptr(entries), entries.size), "cf_set_clouds")
+
+    # ------------------------------------------------------------------ A5 + A6
+    def dist_edges(self, min_n=0, max_n=2 ** 62, min_d=1, max_d=150, min_cov=4, rel_threshold=0.8,
+                   part=0, n_parts=1, edge_cap=None):
+        n = C.c_int64()
+        if edge_cap is None:
+            edge_cap = 0
+        self._check(self._lib.cf_dist_edges(self._ctx, int(min_n), int(min(max_n, 2 ** 62)), int(min_d), int(max_d),
+                                            int(min_cov), float(rel_threshold), int(part), int(n_parts), int(edge_cap),
+                                            C.byref(n)), "cf_dist_edges")
+        return n.value
+
+    def edges(self, n):
+        out = np.zeros((n, 4), np.uint32)
+        self._check(self._lib.cf_get_edges(self._ctx, _ptr(out), n), "cf_get_edges")
+        return out
+
+    def unique_mask(self):
+        n = self.stats()["n_kmers"]
+        out = np.zeros(n, np.uint8)
+        self._check(self._lib.cf_get_unique_mask(self._ctx, _ptr(out)), "cf_get_unique_mask")
+        return out.astype(bool)
+
+    def or_unique_mask(self, mask):
+        mask = np.ascontiguousarray(mask, np.uint8)
+        self._check(self._lib.cf_or_unique_mask(self._ctx, _ptr(mask)), "cf_or_unique_mask")
+
+    def reset_unique(self):
+        self._check(self._lib.cf_reset_unique(self._ctx), "cf_reset_unique")
+
+    # ------------------------------------------------------------------ A8 + A9
+    def place_reads(self, classes, id_rank, min_cloud_kmer_freq=2, min_unit=2, min_inters=10, min_prop=3):
+        """Returns (read, pos, s0, s1) arrays in the order the reference writes read_positions.csv;
+        pos = -1 means None; s0 = -1 marks a prefix read (line 'r_id 0')."""
+        R = self.n_reads
+        classes = np.ascontiguousarray(classes, np.uint8)
+        id_rank = np.ascontiguousarray(id_rank, np.int32)
+        out_read = np.zeros(R, np.int64)
+        out_pos = np.zeros(R, np.int64)
+        out_s0 = np.zeros(R, np.int32)
+        out_s1 = np.zeros(R, np.int32)
+        self._check(self._lib.cf_place_reads(self._ctx, _ptr(classes), _ptr(id_rank), int(min_cloud_kmer_freq), int(min_unit),
+                                             int(min_inters), int(min_prop), _ptr(out_read), _ptr(out_pos), _ptr(out_s0),
+                                             _ptr(out_s1)), "cf_place_reads")
+        return out_read, out_pos, out_s0, out_s1
+
+    # ------------------------------------------------------------------ self tests of primitives
+    def selftest_sort(self, keys, bits=64):
+        keys = np.ascontiguousarray(keys, np.uint64)
+        out = np.zeros_like(keys)
+        self._check(self._lib.cf_selftest_sort(self._ctx, _ptr(keys), keys.size, int(bits), _ptr(out)), "cf_selftest_sort")
+        return out
+
+    def selftest_scan(self, vals):
+        vals = np.ascontiguousarray(vals, np.int64)
+        out = np.zeros(vals.size + 1, np.int64)
+        self._check(self._lib.cf_selftest_scan(self._ctx, _ptr(vals), vals.size, _ptr(out)), "cf_selftest_scan")
+        return out

@@ -1,0 +1,132 @@
+/*
+ * cfhip.h — C ABI of libcfhip.so: the MI355X (gfx950) device pipeline of centroflye_amd.
+ *
+ * This is the drop-in boundary of the hot path.  The reference has no FFI:
+ * its stage scripts are pure Python, so the entry points below are what a ctypes binding
+ * inside the reference's own functions would call.  Each entry point cites the reference
+ * code it replaces (paths relative to the reference repository root):
+ *
+ *   cf_load_reads      hand-over of what scripts/ncrf_parser.py:61-118 / :28-59 produce
+ *   cf_count_kmers     scripts/distance_based_kmer_recruitment.py:39-63  (A1)
+ *   cf_select_rare     scripts/distance_based_kmer_recruitment.py:66-82  (A2)
+ *   cf_set_kmers       scripts/read_placer.py:20-27 (genomic k-mer set given from a file)
+ *   cf_build_clouds    scripts/read_kmer_cloud.py:17-40                  (A3)
+ *   cf_filter_clouds   scripts/read_kmer_cloud.py:43-54                  (A4)
+ *   cf_dist_edges      scripts/distance_based_kmer_recruitment.py:85-128 (A5) fused with
+ *                      :131-149 (A6)
+ *   cf_place_reads     scripts/cloud_contig.py:26-41, :87-95 (A8) and
+ *                      scripts/read_placer.py:35-94 (A9)
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 or a negative
+ * errno-style code and never throws or aborts; cf_last_error() gives the message; the
+ * caller allocates every output buffer; the opaque context owns all device memory; one
+ * context per process and device, calls serialised by the caller; one HIP stream inside.
+ * Host pointers are borrowed for the duration of the call only.
+ *
+ * k-mers are 2-bit packed, A=0 C=1 G=2 T=3, first base in the most significant position, so
+ * unsigned integer order equals the string order the reference sorts by.  Forward strand
+ * only — the reference never canonicalises.  1 <= k <= 31.
+ */
+#ifndef CFHIP_H
+#define CFHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cf_ctx cf_ctx;
+
+/* Work counters; identical for the oracle and the HIP path on one input. */
+typedef struct cf_stats {
+    int64_t n_reads, n_bases, n_units;
+    int64_t n_windows;      /* N_w  = sum max(0, len - k + 1)                       */
+    int64_t n_read_kmers;   /* N_rk = sum over reads of #distinct k-mers             */
+    int64_t n_distinct;     /* K_dist = distinct k-mers seen                         */
+    int64_t n_kept;         /* k-mers surviving the multi-occurrence cut             */
+    int64_t n_kmers;        /* size of the current k-mer set (rare / genomic)        */
+    int64_t n_cloud_entries;/* N_ce                                                  */
+    int64_t n_emissions;    /* E = pair emissions of the last cf_dist_edges          */
+    int64_t n_edges;        /* selected edges of the last cf_dist_edges              */
+    int64_t n_unique;       /* selected ("unique") k-mers so far                     */
+    int64_t table_capacity; /* slots of the HBM k-mer table                          */
+    int64_t n_spilled;      /* first k-mers whose (b,d) table had to be partitioned  */
+    int64_t hbm_bytes_live; /* device memory currently owned by the context          */
+} cf_stats;
+
+/* Device time (HIP events on the context's stream) of the last call of each stage. */
+typedef struct cf_times {
+    float load_ms, count_ms, select_ms, clouds_ms, filter_ms, postings_ms, dist_ms, place_ms;
+    float dist_kernel_ms;   /* the cf_dist_edges main kernel alone                          */
+    float count_kernel_ms;  /* the cf_count_kmers main kernel alone                         */
+} cf_times;
+
+int  cf_create(int device, cf_ctx** out);
+void cf_destroy(cf_ctx* ctx);
+const char* cf_last_error(const cf_ctx* ctx);
+int  cf_device_info(cf_ctx* ctx, char* name, int name_len, int64_t* hbm_bytes, int32_t* n_cu);
+
+/* Reads: ASCII bases (upper-case ACGT only, else -EINVAL), read_off[R+1]; units: unit_ptr[R+1]
+ * indexes global units, unit_start/unit_end are absolute offsets into bases. */
+int cf_load_reads(cf_ctx* ctx, const uint8_t* bases, const int64_t* read_off, int64_t n_reads,
+                  const int64_t* unit_ptr, const int64_t* unit_start, const int64_t* unit_end);
+/* Replace the unit table only (n_motif change). */
+int cf_load_units(cf_ctx* ctx, const int64_t* unit_ptr, const int64_t* unit_start, const int64_t* unit_end);
+
+/* A1: presence / multi-occurrence table over the reads [read_lo, read_hi) (the whole set when
+ * read_lo = 0, read_hi >= R). */
+int cf_count_kmers(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi);
+/* Dump the occupied slots, unordered (tests, multi-GPU merge): size-query with keys == NULL. */
+int cf_get_table(cf_ctx* ctx, uint64_t* keys, uint32_t* pres, uint32_t* multi, int64_t cap, int64_t* n_out);
+/* Add (key, pres, multi) triples into the table (owner-side merge of the multi-GPU exchange). */
+int cf_merge_table(cf_ctx* ctx, const uint64_t* keys, const uint32_t* pres, const uint32_t* multi, int64_t n);
+
+/* A2: k-mer set := { x : multi[x] <= max_nonuniq, lo <= pres[x] <= hi }, sorted ascending. */
+int cf_select_rare(cf_ctx* ctx, int32_t max_nonuniq, uint32_t lo, uint32_t hi, int64_t* n_out);
+/* Install a k-mer set (sorted ascending, unique). */
+int cf_set_kmers(cf_ctx* ctx, const uint64_t* kmers, int64_t n, int32_t k);
+int cf_get_kmers(cf_ctx* ctx, uint64_t* out, int64_t cap);
+
+/* A3: per-unit clouds of the current k-mer set as CSR (entries = indices into the set, sorted
+ * unique inside each unit). */
+int cf_build_clouds(cf_ctx* ctx, int64_t* n_entries);
+/* A4: keep k-mers present in [min_mult, max_mult] clouds overall (max_mult = 0: no upper bound). */
+int cf_filter_clouds(cf_ctx* ctx, uint32_t min_mult, uint32_t max_mult, int64_t* n_entries);
+int cf_get_clouds(cf_ctx* ctx, int64_t* cloud_ptr /* U+1 */, int32_t* entries, int64_t cap);
+/* Install clouds computed elsewhere (multi-GPU all-gather of per-shard clouds). */
+int cf_set_clouds(cf_ctx* ctx, const int64_t* cloud_ptr, const int32_t* entries, int64_t n_entries);
+
+/* A5+A6: for first k-mers a with a % n_parts == part: histogram over (b, d) of the reads
+ * [min_n, max_n), then keep (d, a, b, cnt) with cnt >= min_cov and
+ * (double)cnt / (double)sum_d cnt >= rel_threshold.  Up to edge_cap edges are stored on the
+ * device (all are counted); the unique-k-mer bitmap accumulates across calls until
+ * cf_reset_unique(). */
+int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int32_t max_d,
+                  uint32_t min_cov, double rel_threshold, int32_t part, int32_t n_parts,
+                  int64_t edge_cap, int64_t* n_edges);
+int cf_get_edges(cf_ctx* ctx, uint32_t* out /* n x 4: d, a, b, cnt */, int64_t cap);
+int cf_get_unique_mask(cf_ctx* ctx, uint8_t* mask /* n_kmers bytes of 0/1 */);
+int cf_or_unique_mask(cf_ctx* ctx, const uint8_t* mask);
+int cf_reset_unique(cf_ctx* ctx);
+
+/* A8+A9: greedy placement.  cls[r]: 0 prefix, 1 internal, 2 suffix; id_rank[r] = rank of the
+ * read id in ascending string order (tie-break).  Outputs, in the order the reference writes
+ * the file: out_read[i], out_pos[i] (-1 = None), out_s0[i], out_s1[i] for i < R. */
+int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int32_t min_cloud_kmer_freq,
+                   int32_t min_unit, int32_t min_inters, int32_t min_prop,
+                   int64_t* out_read, int64_t* out_pos, int32_t* out_s0, int32_t* out_s1);
+
+int cf_get_stats(cf_ctx* ctx, cf_stats* out);
+int cf_get_times(cf_ctx* ctx, cf_times* out);
+
+/* Tuning knobs (defaults are chosen for gfx950): name in {"dist_block", "dist_slots",
+ * "count_slots", "count_tile"}. */
+int cf_set_param(cf_ctx* ctx, const char* name, int64_t value);
+
+/* Self-tests of the device primitives against host results (used by tests/ only). */
+int cf_selftest_sort(cf_ctx* ctx, const uint64_t* keys, int64_t n, int32_t bits, uint64_t* out);
+int cf_selftest_scan(cf_ctx* ctx, const int64_t* in, int64_t n, int64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,73 @@
+"""Seeded fixtures shared by the golden-capture script and the tests.
+
+A fixture is (generator parameters, stage-2 parameters, stage-3 parameters).  The NCRF report
+text is regenerated from the seed by the deterministic native generator (include/cfhost.h);
+its SHA-256 is stored in the golden file so drift of the generator is detected.
+"""
+import hashlib
+import os
+
+FIXTURES = {
+    # 200-bp unit, ~33 units per read: exercises large d, partial units, split records
+    "tiny": dict(
+        synth=dict(seed=11, unit_len=200, monomer_len=50, n_units=60, flank=60000, n_reads=30,
+                   mean_len=6500, sigma=0.2, min_len=6000, max_len=7000, unit_div=0.03,
+                   n_prefix=3, n_suffix=3, prefix_threshold=50000, p_split=0.15),
+        stage2=dict(k=19, coverage=14, min_coverage=3, max_distance=150),
+        stage3=dict(prefix_threshold=50000),
+    ),
+    # DXZ1-sized unit (2055 bp), ~5 units per read
+    "hor2055": dict(
+        synth=dict(seed=12, unit_len=2055, monomer_len=171, n_units=16, flank=70000, n_reads=40,
+                   mean_len=9000, sigma=0.3, min_len=7000, max_len=12000, n_prefix=3, n_suffix=3,
+                   prefix_threshold=50000, p_split=0.1),
+        stage2=dict(k=19, coverage=12, min_coverage=3, max_distance=150),
+        stage3=dict(prefix_threshold=50000),
+    ),
+    # low coverage + strict placer threshold: the placer runs out of qualifying reads and
+    # writes a None tail after placing most reads
+    "lowcov": dict(
+        synth=dict(seed=13, unit_len=200, monomer_len=50, n_units=100, flank=60000, n_reads=20,
+                   mean_len=6500, sigma=0.2, min_len=6000, max_len=7000, unit_div=0.015,
+                   n_prefix=2, n_suffix=2, prefix_threshold=50000, p_split=0.1),
+        stage2=dict(k=19, coverage=10, min_coverage=3, max_distance=150),
+        stage3=dict(prefix_threshold=50000, min_inters=80),
+    ),
+}
+
+STAGE2_DEFAULTS = dict(k=19, min_coverage=4, min_nreads=0, max_nreads=2 ** 63 - 1, min_distance=1,
+                       max_distance=150, bottom=0.9, top=3.0, kmer_survival_rate=0.34, max_nonuniq=3)
+STAGE3_DEFAULTS = dict(n_motif=1, k_cloud=19, min_cloud_kmer_freq=2, min_kmer_mult=2, min_unit=2,
+                       min_inters=10, prefix_threshold=50000)
+
+
+def stage2_params(name):
+    p = dict(STAGE2_DEFAULTS)
+    p.update(FIXTURES[name]["stage2"])
+    return p
+
+
+def stage3_params(name):
+    p = dict(STAGE3_DEFAULTS)
+    p.update(FIXTURES[name]["stage3"])
+    return p
+
+
+def make_report(name, outdir):
+    """Write the fixture's NCRF report into outdir; returns its path."""
+    from centroflye_amd import _host
+    tag = hashlib.sha1(repr(sorted(FIXTURES[name]["synth"].items())).encode()).hexdigest()[:10]
+    path = os.path.join(outdir, f"{name}_{tag}.ncrf")
+    if not os.path.exists(path):
+        tmp = path + f".tmp{os.getpid()}"
+        _host.synth(report_path=tmp, pack=False, **FIXTURES[name]["synth"])
+        os.replace(tmp, path)
+    return path
+
+
+def sha256_file(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
