@@ -23,6 +23,7 @@ class SynthParams(C.Structure):
         ("p_del", C.c_double), ("p_sub", C.c_double), ("p_ins", C.c_double),
         ("min_aligned", C.c_int64), ("n_prefix", C.c_int32), ("n_suffix", C.c_int32),
         ("prefix_threshold", C.c_int64), ("p_split", C.c_double), ("n_threads", C.c_int32),
+        ("var_len", C.c_int32), ("cand_offset", C.c_int32), ("cand_stride", C.c_int32),
     ]
 
 

@@ -17,7 +17,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_reads", "n_bases", "n_units", "n_windows", "n_read_kmers", "n_distinct", "n_kept",
         "n_kmers", "n_cloud_entries", "n_emissions", "n_edges", "n_unique", "table_capacity",
-        "n_spilled", "hbm_bytes_live")]
+        "n_spilled", "hbm_bytes_live", "n_dist_passes")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -44,6 +44,7 @@ PROTOTYPES = {
     "cf_load_reads": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "cf_load_units": (C.c_int, [_P, _P, _P, _P]),
     "cf_count_kmers": (C.c_int, [_P, _I32, _I64, _I64]),
+    "cf_reset_table": (C.c_int, [_P, _I32, _I64]),
     "cf_get_table": (C.c_int, [_P, _P, _P, _P, _I64, _PI64]),
     "cf_merge_table": (C.c_int, [_P, _P, _P, _P, _I64]),
     "cf_select_rare": (C.c_int, [_P, _I32, _U32, _U32, _PI64]),

@@ -273,6 +273,18 @@ int cf_count_kmers(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi) {
     return cf_fail(ctx, -34, "cf_count_kmers: k-mer table kept overflowing");
 }
 
+int cf_reset_table(cf_ctx* ctx, int32_t k, int64_t expected_keys) {
+    if (!ctx) return -22;
+    if (k < 1 || k > 31) return cf_fail(ctx, -22, "k must be in [1, 31]");
+    CF_HIP(hipSetDevice(ctx->device));
+    const uint64_t cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(2 * expected_keys, 1024));
+    CF_TRY(ensure_table(ctx, cap));
+    CF_HIP(hipMemsetAsync(ctx->d_table, 0, (size_t)cap * sizeof(cf_slot), ctx->stream));
+    CF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->k = k;
+    return 0;
+}
+
 int cf_get_table(cf_ctx* ctx, uint64_t* keys, uint32_t* pres, uint32_t* multi, int64_t cap, int64_t* n_out) {
     if (!ctx || !n_out) return -22;
     if (!ctx->d_table) return cf_fail(ctx, -22, "cf_get_table: no table");

@@ -22,7 +22,7 @@ void cf_free_edges(cf_ctx* c);
 int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 
 #define DIST_NP_CAP 512
-#define DIST_STACK 40
+#define DIST_STACK 112
 
 __global__ void __launch_bounds__(256)
 cf_post_hist_kernel(const int32_t* __restrict__ entries, int64_t e0, int64_t e1, uint32_t* __restrict__ cnt) {
@@ -100,7 +100,26 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
         const uint32_t a = (uint32_t)(A.part + ai * A.n_parts);
         const int64_t pp0 = A.post_ptr[a], pp1 = A.post_ptr[a + 1];
         if (pp1 == pp0) continue;
-        if (t == 0) { sh[2] = 1; stack[0] = 1; stack[1] = 0; }
+        // upper bound of the emissions of a -> initial number of partitions of its (b, d) table
+        if (t == 0) sh[7] = 0;
+        __syncthreads();
+        {
+            unsigned long long em = 0;
+            for (int64_t p = pp0 + t; p < pp1; p += nt) {
+                const int32_t g = A.post[p];
+                const int32_t jlo = g + A.min_d, jhi = min(A.unit_rend[g] - 1, g + A.max_d);
+                if (jhi >= jlo) em += (unsigned long long)(A.cloud_ptr[jhi + 1] - A.cloud_ptr[jlo]);
+            }
+            for (int d = 32; d >= 1; d >>= 1) em += __shfl_down(em, (unsigned)d);
+            if (lane == 0 && em) atomicAdd(&sh[7], (uint32_t)min(em, 0x3FFFFFFFull));
+        }
+        __syncthreads();
+        if (t == 0) {
+            uint32_t P0 = 1;
+            while (P0 < 64u && (unsigned long long)sh[7] * 4ull > (unsigned long long)A.fill_limit * 5ull * P0) P0 <<= 1;
+            for (uint32_t i = 0; i < P0; ++i) { stack[2 * i] = P0; stack[2 * i + 1] = i; }
+            sh[2] = P0;
+        }
         bool spilled = false;
         while (true) {
             __syncthreads();
@@ -208,7 +227,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                 if (!(A.unique_bits[a >> 5] & bit)) atomicOr(&A.unique_bits[a >> 5], bit);
             }
             __syncthreads();
-            if (t == 0 && sh[7]) atomicAdd(&A.counters[1], (unsigned long long)sh[7]);
+            if (t == 0) { if (sh[7]) atomicAdd(&A.counters[1], (unsigned long long)sh[7]); atomicAdd(&A.counters[5], 1ull); }
         }
         if (spilled && t == 0) atomicAdd(&A.counters[2], 1ull);
     }
@@ -313,6 +332,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     ctx->stats.n_edges = (int64_t)h_cnt[0];
     ctx->stats.n_emissions = (int64_t)h_cnt[1];
     ctx->stats.n_spilled = (int64_t)h_cnt[2];
+    ctx->stats.n_dist_passes = (int64_t)h_cnt[5];
     ctx->n_edges_stored = std::min<int64_t>((int64_t)h_cnt[0], edge_cap);
     CF_TRY(cf_refresh_unique_count(ctx));
     if (n_edges) *n_edges = (int64_t)h_cnt[0];

@@ -389,7 +389,19 @@ Genome make_genome(const cfh_synth_params& sp) {
     g.a0 = (int64_t)g.seq.size();
     for (int64_t u = 0; u < sp.n_units; ++u) {
         Rng ur(sp.seed, 1000 + (uint64_t)u);
-        for (char c : g.motif) g.seq.push_back(ur.uniform() < sp.unit_div ? ur.other(c) : c);
+        // copy-specific variants: at each chosen site replace var_len consecutive bases (the first
+        // always changes).  var_len = 1 is the point-substitution model of
+        // simulate_tandem_repeat.py:15-30; longer variants keep copy-specific k-mers unique when
+        // the array has 10^4-10^5 copies (only 3 * unit_len distinct point substitutions exist).
+        const int64_t ulen = (int64_t)g.motif.size();
+        const int vl = sp.var_len > 1 ? sp.var_len : 1;
+        const size_t u0 = g.seq.size();
+        g.seq.append(g.motif);
+        for (int64_t i = 0; i < ulen; ++i) {
+            if (!(ur.uniform() < sp.unit_div)) continue;
+            g.seq[u0 + (size_t)i] = ur.other(g.motif[(size_t)i]);
+            for (int j = 1; j < vl && i + j < ulen; ++j) g.seq[u0 + (size_t)(i + j)] = ur.base();
+        }
     }
     g.a1 = (int64_t)g.seq.size();
     Rng fr(sp.seed, 2);
@@ -522,7 +534,7 @@ void cfh_synth_defaults(cfh_synth_params* p) {
     p->mean_len = 20000; p->sigma = 0.5; p->min_len = 6000; p->max_len = 200000;
     p->p_del = 0.02; p->p_sub = 0.02; p->p_ins = 0.015; p->min_aligned = 5000;
     p->n_prefix = 8; p->n_suffix = 8; p->prefix_threshold = 50000; p->p_split = 0.0;
-    p->n_threads = 0;
+    p->n_threads = 0; p->var_len = 1; p->cand_offset = 0; p->cand_stride = 1;
 }
 
 int cfh_synth(const cfh_synth_params* sp, const char* report_path, int keep_rows,
@@ -554,7 +566,7 @@ int cfh_synth(const cfh_synth_params* sp, const char* report_path, int keep_rows
                 while (true) {
                     int64_t i = next.fetch_add(1);
                     if (i >= batch) break;
-                    simulate_read(*sp, g, cand + i, res[(size_t)i]);
+                    simulate_read(*sp, g, (int64_t)sp->cand_offset + (cand + i) * (int64_t)(sp->cand_stride > 0 ? sp->cand_stride : 1), res[(size_t)i]);
                 }
             };
             std::vector<std::thread> th;

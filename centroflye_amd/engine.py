@@ -117,6 +117,44 @@ class Engine:
             keys, pres, multi = keys[o], pres[o], multi[o]
         return keys, pres, multi
 
+    def reset_table(self, k, expected_keys):
+        self._check(self._lib.cf_reset_table(self._ctx, int(k), int(expected_keys)), "cf_reset_table")
+        self.k = int(k)
+
+    def table_size(self):
+        n = C.c_int64()
+        self._check(self._lib.cf_get_table(self._ctx, None, None, None, 0, C.byref(n)), "cf_get_table")
+        return n.value
+
+    # raw-pointer variants: the buffers may live on the host or on this GPU (e.g. torch tensors used
+    # for the RCCL exchange); the library copies with hipMemcpyDefault
+    def table_into(self, keys_ptr, pres_ptr, multi_ptr, cap):
+        n = C.c_int64()
+        self._check(self._lib.cf_get_table(self._ctx, keys_ptr, pres_ptr, multi_ptr, int(cap), C.byref(n)), "cf_get_table")
+        return n.value
+
+    def merge_table_ptr(self, keys_ptr, pres_ptr, multi_ptr, n):
+        self._check(self._lib.cf_merge_table(self._ctx, keys_ptr, pres_ptr, multi_ptr, int(n)), "cf_merge_table")
+
+    def kmers_into(self, ptr, cap):
+        self._check(self._lib.cf_get_kmers(self._ctx, ptr, int(cap)), "cf_get_kmers")
+
+    def set_kmers_ptr(self, ptr, n, k):
+        self._check(self._lib.cf_set_kmers(self._ctx, ptr, int(n), int(k)), "cf_set_kmers")
+        self.k = int(k)
+
+    def clouds_into(self, cloud_ptr_ptr, entries_ptr, cap):
+        self._check(self._lib.cf_get_clouds(self._ctx, cloud_ptr_ptr, entries_ptr, int(cap)), "cf_get_clouds")
+
+    def set_clouds_ptr(self, cloud_ptr_ptr, entries_ptr, n_entries):
+        self._check(self._lib.cf_set_clouds(self._ctx, cloud_ptr_ptr, entries_ptr, int(n_entries)), "cf_set_clouds")
+
+    def unique_mask_into(self, ptr):
+        self._check(self._lib.cf_get_unique_mask(self._ctx, ptr), "cf_get_unique_mask")
+
+    def or_unique_mask_ptr(self, ptr):
+        self._check(self._lib.cf_or_unique_mask(self._ctx, ptr), "cf_or_unique_mask")
+
     def merge_table(self, keys, pres, multi):
         keys = np.ascontiguousarray(keys, np.uint64)
         pres = np.ascontiguousarray(pres, np.uint32)

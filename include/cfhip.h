@@ -51,6 +51,7 @@ typedef struct cf_stats {
     int64_t table_capacity; /* slots of the HBM k-mer table                          */
     int64_t n_spilled;      /* first k-mers whose (b,d) table had to be partitioned  */
     int64_t hbm_bytes_live; /* device memory currently owned by the context          */
+    int64_t n_dist_passes;  /* (first k-mer, partition) table passes of the last cf_dist_edges */
 } cf_stats;
 
 /* Device time (HIP events on the context's stream) of the last call of each stage. */
@@ -75,6 +76,9 @@ int cf_load_units(cf_ctx* ctx, const int64_t* unit_ptr, const int64_t* unit_star
 /* A1: presence / multi-occurrence table over the reads [read_lo, read_hi) (the whole set when
  * read_lo = 0, read_hi >= R). */
 int cf_count_kmers(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi);
+/* Start an empty table for keys of length k sized for about expected_keys distinct k-mers (owner side of
+ * the multi-GPU exchange, followed by cf_merge_table). */
+int cf_reset_table(cf_ctx* ctx, int32_t k, int64_t expected_keys);
 /* Dump the occupied slots, unordered (tests, multi-GPU merge): size-query with keys == NULL. */
 int cf_get_table(cf_ctx* ctx, uint64_t* keys, uint32_t* pres, uint32_t* multi, int64_t cap, int64_t* n_out);
 /* Add (key, pres, multi) triples into the table (owner-side merge of the multi-GPU exchange). */

@@ -47,6 +47,8 @@ typedef struct cfh_synth_params {
     int64_t prefix_threshold;/* 50000 */
     double  p_split;         /* probability that a read's alignment is reported as two records */
     int32_t n_threads;       /* worker threads (0 = hardware concurrency) */
+    int32_t var_len;         /* bases replaced per copy-specific variant (1 = point substitution) */
+    int32_t cand_offset, cand_stride; /* simulate read candidates offset, offset+stride, ... (rank sharding) */
 } cfh_synth_params;
 
 void cfh_synth_defaults(cfh_synth_params* p);

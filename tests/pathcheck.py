@@ -1,0 +1,78 @@
+"""Shared parity checks: drive the device pipeline through the C ABI (centroflye_amd.engine.Engine)
+and compare with the oracle.  Used by the CPU suite on the host-emulated build of the kernels
+(small cases) and by the `-m gpu` suite on a real MI355X (all cases)."""
+import numpy as np
+
+from centroflye_amd import _host
+from conftest import lines_from_placement
+from oracle import placer, recruit
+
+
+def sorted_edges(e):
+    e = np.asarray(e).astype(np.int64).reshape(-1, 4)
+    return e[np.lexsort((e[:, 2], e[:, 1], e[:, 0]))]
+
+
+def check_stage2(engine, report_path, oracle_tuple, n_parts=1, check_table=True):
+    """A1..A6 of one fixture; oracle_tuple from the oracle_stage2 fixture."""
+    records, alns, lens, res, p2 = oracle_tuple
+    pk = _host.parse_report(report_path)
+    engine.load(pk, 1)
+    engine.count_kmers(p2["k"])
+    st = engine.stats()
+    cn = res["counters"]
+    assert (st["n_bases"], st["n_windows"], st["n_read_kmers"]) == (cn["n_b"], cn["n_w"], cn["n_rk"])
+    if check_table:
+        keys, pres, multi = engine.table()
+        assert keys.size == cn["n_distinct"]
+        ok = multi <= p2["max_nonuniq"]
+        assert np.array_equal(keys[ok], res["keys"]), "A1 keys"
+        assert np.array_equal(pres[ok].astype(np.int64), res["pres"]), "A1 presence counts"
+    n = engine.select_rare(p2["max_nonuniq"], cn["lo"], cn["hi"])
+    assert n == res["rare"].size
+    assert np.array_equal(engine.kmers(), res["rare"]), "A2 rare set (sorted)"
+    assert engine.stats()["n_distinct"] == cn["n_distinct"]
+    nce = engine.build_clouds()
+    cp, ent = engine.clouds()
+    assert nce == res["entries"].size
+    assert np.array_equal(cp, res["cloud_ptr"]) and np.array_equal(ent, res["entries"]), "A3 clouds"
+    engine.reset_unique()
+    parts = []
+    E = 0
+    for part in range(n_parts):
+        ne = engine.dist_edges(p2["min_nreads"], p2["max_nreads"], p2["min_distance"], p2["max_distance"],
+                               p2["min_coverage"], 0.8, part, n_parts, edge_cap=res["edges"].shape[0] + 8)
+        parts.append(engine.edges(ne))
+        E += engine.stats()["n_emissions"]
+    ed = sorted_edges(np.concatenate(parts))
+    assert E == cn["E"], "pair emissions"
+    assert np.array_equal(ed, res["edges"]), "A5+A6 selected edges"
+    assert np.array_equal(np.flatnonzero(engine.unique_mask()), res["unique"]), "A6 unique k-mers"
+    assert engine.stats()["n_unique"] == res["unique"].size
+    return pk
+
+
+def check_stage3(engine, pk, records, alns, lens, genomic_kmers, p3, expect_lines=None):
+    """A3 (placer k-mer set), A4, A8, A9."""
+    r3 = placer.stage3(records, alns, lens, genomic_kmers, n_motif=p3["n_motif"], k_cloud=p3["k_cloud"],
+                       min_cloud_kmer_freq=p3["min_cloud_kmer_freq"], min_kmer_mult=p3["min_kmer_mult"],
+                       min_unit=p3["min_unit"], min_inters=p3["min_inters"], prefix_threshold=p3["prefix_threshold"])
+    engine.load(pk, p3["n_motif"])
+    engine.set_kmers(genomic_kmers, p3["k_cloud"])
+    engine.build_clouds()
+    cp, ent = engine.clouds()
+    assert np.array_equal(cp, r3["cloud_ptr"]) and np.array_equal(ent, r3["entries"]), "A3 clouds (placer set)"
+    engine.filter_clouds(p3["min_kmer_mult"])
+    cp, ent = engine.clouds()
+    assert np.array_equal(cp, r3["f_cloud_ptr"]) and np.array_equal(ent, r3["f_entries"]), "A4 filtered clouds"
+    cls = pk.classify(p3["prefix_threshold"])
+    assert np.array_equal(cls.astype(np.int64), r3["classes"])
+    rank = np.argsort(np.argsort(np.array(pk.ids))).astype(np.int32)
+    rd, pos, s0, s1 = engine.place_reads(cls, rank, p3["min_cloud_kmer_freq"], p3["min_unit"], p3["min_inters"], 3)
+    lines = lines_from_placement(pk.ids, rd, pos, s0, s1)
+    assert lines == r3["lines"], "A9 read_positions.csv lines"
+    if expect_lines is not None:
+        placed = [ln for ln in lines if not ln.endswith(" None")]
+        none = sorted(ln for ln in lines if ln.endswith(" None"))
+        assert placed == expect_lines["placed"] and none == expect_lines["none"], "A9 vs reference golden"
+    return lines

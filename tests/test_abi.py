@@ -1,0 +1,58 @@
+"""The C-ABI libraries load and export every symbol their headers declare (no compute calls:
+there is no GPU here), and the device library refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from centroflye_amd import _host, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header, prefix):
+    with open(os.path.join(ROOT, "include", header)) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
+
+
+def test_cfhip_exports_every_declared_symbol():
+    names = declared("cfhip.h", "cf_")
+    assert len(names) >= 25
+    lib = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.PROTOTYPES) == names  # the binding covers exactly the header
+
+
+def test_cfhost_exports_every_declared_symbol():
+    names = declared("cfhost.h", "cfh_")
+    lib = _host.lib()
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_missing_extension_fails_loudly(tmp_path):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load(str(tmp_path / "libcfhip.so"))
+
+
+def test_no_gpu_is_an_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from centroflye_amd.engine import DeviceError, Engine
+    with pytest.raises(DeviceError, match="no HIP device"):
+        Engine(0)
+
+
+def test_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "centroflye_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                with open(os.path.join(dirpath, fn)) as f:
+                    text = f.read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn
+                assert "libcforacle" not in text and "libcfhip_emu" not in text, fn

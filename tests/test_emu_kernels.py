@@ -1,0 +1,98 @@
+"""Kernel LOGIC on the CPU: the unmodified HIP sources compiled against the host emulator
+(tests/emu) and driven through the same C ABI.  Small cases only (the emulator runs every GPU
+thread as a fiber); the real parity suite is tests/test_gpu_parity.py on an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+import fixtures
+import pathcheck
+from centroflye_amd.engine import DeviceError, Engine
+from oracle import recruit
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def engine(emu_lib):
+    e = Engine(0, emu_lib)
+    yield e
+    e.close()
+
+
+def test_scan_and_sort(engine):
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 63, 2048, 2049, 20011):
+        v = rng.integers(0, 1000, n)
+        assert np.array_equal(engine.selftest_scan(v), np.concatenate([[0], np.cumsum(v)]))
+        k = rng.integers(0, 2 ** 38, n, dtype=np.uint64)
+        assert np.array_equal(engine.selftest_sort(k, 38), np.sort(k))
+    k = rng.integers(0, 7, 5000, dtype=np.uint64)  # heavy duplicates
+    assert np.array_equal(engine.selftest_sort(k, 8), np.sort(k))
+
+
+def test_stage2_small(engine, report, oracle_stage2):
+    # max_distance 2 keeps the emulated dist kernel to a few 10^5 emissions
+    tup = oracle_stage2("lowcov", max_distance=2)
+    engine.set_param("dist_slots", 2048)
+    engine.set_param("dist_block", 128)
+    pathcheck.check_stage2(engine, report("lowcov"), tup)
+    assert engine.stats()["n_spilled"] == 0
+
+
+def test_stage2_spill_and_partition(engine, report, oracle_stage2):
+    tup = oracle_stage2("lowcov", max_distance=2)
+    engine.set_param("dist_slots", 256)   # forces the (b, d) table to be split by a second hash of b
+    engine.set_param("dist_block", 64)
+    pathcheck.check_stage2(engine, report("lowcov"), tup, n_parts=3, check_table=False)
+    assert engine.stats()["n_spilled"] > 0
+
+
+def test_stage3_against_reference_golden(engine, report, golden):
+    from centroflye_amd import _host
+    from oracle import ncrf
+    name = "lowcov"
+    g = golden(name)
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.unique_kmers.txt")) as f:
+        gk = np.array(sorted(recruit.encode_kmer(x.strip()) for x in f if x.strip()), dtype=np.uint64)
+    records, alns, lens = ncrf.parse_report(report(name))
+    pk = _host.parse_report(report(name))
+    lines = pathcheck.check_stage3(engine, pk, records, alns, lens, gk, g["stage3"], expect_lines=g["read_positions"])
+    assert any(ln.endswith(" None") for ln in lines)
+
+
+def test_errors(engine):
+    bases = np.frombuffer(b"ACGTNACGT", np.uint8)
+    with pytest.raises(DeviceError, match="ACGT"):
+        engine.load_arrays(bases, [0, 9], [0, 1], [0], [9])
+    engine.load_arrays(np.frombuffer(b"ACGTACGTAC", np.uint8), [0, 10], [0, 1], [0], [10])
+    with pytest.raises(DeviceError):
+        engine.count_kmers(32)
+    with pytest.raises(DeviceError, match="unit"):
+        engine.load_arrays(np.frombuffer(b"ACGT", np.uint8), [0, 4], [0, 1], [0], [9])
+    with pytest.raises(DeviceError, match="sorted"):
+        engine.set_kmers(np.array([5, 3], np.uint64), 4)
+
+
+def test_degenerate_inputs(engine):
+    # no reads at all
+    engine.load_arrays(np.zeros(0, np.uint8), [0], [0], [], [])
+    engine.count_kmers(19)
+    assert engine.select_rare(3, 1, 10) == 0
+    assert engine.build_clouds() == 0
+    assert engine.dist_edges(0, 10, 1, 150, 1, 0.8) == 0
+    # reads shorter than k, a unit shorter than k, a read without units
+    seq = b"ACGTACGTACGTACGTACGTACGTAAAC" + b"ACGTA" + b"TTGACCA"
+    engine.load_arrays(np.frombuffer(seq, np.uint8), [0, 28, 33, 40], [0, 2, 2, 3], [0, 20, 33], [20, 28, 40])
+    engine.count_kmers(19)
+    st = engine.stats()
+    codes, cnt = np.unique(recruit.encode_windows(seq[:28], 19), return_counts=True)   # only read 0 has windows
+    assert st["n_windows"] == 10 and st["n_read_kmers"] == codes.size == 7
+    keys, pres, multi = engine.table()
+    assert np.array_equal(keys, codes) and (pres == 1).all() and np.array_equal(multi, (cnt > 1).astype(np.uint32))
+    assert engine.select_rare(0, 1, 1) == int((cnt == 1).sum())    # max_nonuniq = 0 drops the repeated k-mers
+    assert engine.select_rare(3, 1, 1) == 7
+    assert engine.build_clouds() == 2                              # unit 0 (20 bases) has 2 windows; units 1, 2 are shorter than k
+    cp, ent = engine.clouds()
+    assert cp.tolist() == [0, 2, 2, 2]

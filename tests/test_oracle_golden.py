@@ -1,0 +1,120 @@
+"""The oracle (numpy + C) against golden vectors captured from the REFERENCE ITSELF
+(tests/golden/make_golden.py).  CPU only."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import canon
+import fixtures
+from oracle import cport, ncrf, placer, recruit
+
+NAMES = list(fixtures.FIXTURES)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_fixture_report_is_the_one_the_golden_was_made_from(name, report, golden):
+    assert fixtures.sha256_file(report(name)) == golden(name)["report_sha256"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_G0_records_units_classes(name, report, golden):
+    g = golden(name)
+    records, alns, lens = ncrf.parse_report(report(name))
+    assert [r for r in records] == [x["r_id"] for x in g["records"]]
+    for rec, x in zip(records.values(), g["records"]):
+        assert (rec.strand, rec.r_len, rec.r_al_len, rec.r_st, rec.r_en) == (x["strand"], x["r_len"], x["r_al_len"], x["r_st"], x["r_en"])
+        assert hashlib.sha1(rec.r_al.encode()).hexdigest() == x["r_al_sha1"]
+        assert hashlib.sha1(rec.m_al.encode()).hexdigest() == x["m_al_sha1"]
+        assert ncrf.unit_columns(rec, 1) == x["unit_cols"]
+    for r_id, cols in g["unit_cols_n2"].items():
+        assert ncrf.unit_columns(records[r_id], 2) == cols
+    pre, mid, suf = ncrf.classify(records, alns, lens, g["stage3"]["prefix_threshold"])
+    assert (pre, mid, suf) == (g["classify"]["prefix"], g["classify"]["internal"], g["classify"]["suffix"])
+    seen = set(alns)
+    assert sorted(seen - set(records)) == g["discarded"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_G1_to_G5_stage2(name, oracle_stage2, golden):
+    g = golden(name)
+    records, alns, lens, res, p2 = oracle_stage2(name)
+    k = p2["k"]
+    dec = lambda arr: [recruit.decode_kmer(c, k) for c in arr]
+    assert len(res["keys"]) == g["presence"]["n"]
+    assert canon.presence_digest(zip(dec(res["keys"]), (int(v) for v in res["pres"]))) == g["presence"]["digest"]
+    rare_s = dec(res["rare"])
+    assert len(rare_s) == g["rare"]["n"] and canon.set_digest(rare_s) == g["rare"]["digest"]
+    up, cp, ent = res["unit_ptr"], res["cloud_ptr"], res["entries"]
+    clouds = [[[rare_s[i] for i in ent[cp[u]:cp[u + 1]]] for u in range(up[r], up[r + 1])] for r in range(len(up) - 1)]
+    assert [[len(c) for c in units] for units in clouds] == g["clouds2"]["sizes"]
+    assert canon.clouds_digest(clouds) == g["clouds2"]["digest"]
+    a, b, d, cnt = res["hist"]
+    assert res["counters"]["E"] == g["hist"]["E"] and len(a) == g["hist"]["n_keys"]
+    assert canon.hist_digest((rare_s[x], rare_s[y], int(z), int(w)) for x, y, z, w in zip(a, b, d, cnt)) == g["hist"]["digest"]
+    assert res["edges"].shape[0] == g["edges"]["n"]
+    assert canon.edge_lines_digest(recruit.edges_file_lines(res["rare"], res["edges"], k)) == g["edges"]["digest"]
+    text = recruit.kmers_file_text(res["rare"], res["unique"], k)
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.unique_kmers.txt")) as f:
+        assert text == f.read()
+    assert hashlib.sha256(text.encode()).hexdigest() == g["unique_kmers"]["sha256"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_G3_G6_stage3(name, report, golden):
+    g = golden(name)
+    p3 = g["stage3"]
+    records, alns, lens = ncrf.parse_report(report(name))
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.unique_kmers.txt")) as f:
+        gk = np.array(sorted(recruit.encode_kmer(x.strip()) for x in f if x.strip()), dtype=np.uint64)
+    r3 = placer.stage3(records, alns, lens, gk, n_motif=p3["n_motif"], k_cloud=p3["k_cloud"],
+                       min_cloud_kmer_freq=p3["min_cloud_kmer_freq"], min_kmer_mult=p3["min_kmer_mult"],
+                       min_unit=p3["min_unit"], min_inters=p3["min_inters"], prefix_threshold=p3["prefix_threshold"])
+    ks = [recruit.decode_kmer(c, p3["k_cloud"]) for c in gk]
+    up = r3["unit_ptr"]
+
+    def as_clouds(cp, ent):
+        return [[[ks[i] for i in ent[cp[u]:cp[u + 1]]] for u in range(up[r], up[r + 1])] for r in range(len(up) - 1)]
+    assert canon.clouds_digest(as_clouds(r3["cloud_ptr"], r3["entries"])) == g["clouds3"]["digest"]
+    cf = as_clouds(r3["f_cloud_ptr"], r3["f_entries"])
+    assert [[len(c) for c in units] for units in cf] == g["clouds3_filtered"]["sizes"]
+    assert canon.clouds_digest(cf) == g["clouds3_filtered"]["digest"]
+    placed = [ln for ln in r3["lines"] if not ln.endswith(" None")]
+    none = sorted(ln for ln in r3["lines"] if ln.endswith(" None"))
+    assert placed == g["read_positions"]["placed"]      # byte-for-byte, in order
+    assert none == g["read_positions"]["none"]          # as a sorted set (reference order is hash-seed dependent)
+
+
+def test_lowcov_golden_has_a_none_tail(golden):
+    assert len(golden("lowcov")["read_positions"]["none"]) > 0
+
+
+def test_rare_bounds_follow_python_doubles():
+    assert recruit.rare_bounds(0.9, 3.0, 32, 0.34) == (10, 32)     # 9.792 .. 32.64
+    assert recruit.rare_bounds(0.9, 3.0, 10, 0.34) == (4, 10)      # 3.06 .. 10.2
+    assert recruit.rare_bounds(1.0, 2.0, 10, 0.5) == (5, 10)       # exact integers are inclusive
+    lo, hi = recruit.rare_bounds(0.0, 0.0, 32, 0.34)
+    assert (lo, hi) == (0, 0)
+
+
+@pytest.mark.parametrize("name", ["lowcov"])
+def test_c_oracle_equals_numpy_oracle(name, report, oracle_stage2):
+    from centroflye_amd import _host
+    records, alns, lens, res, p2 = oracle_stage2(name)
+    pk = _host.parse_report(report(name))
+    up, us, ue, _ = pk.units(1)
+    c, a = cport.stage2(pk.bases, pk.read_off, up, us, ue, p2["k"], p2["max_nonuniq"], res["counters"]["lo"], res["counters"]["hi"],
+                        0, 2 ** 62, p2["min_distance"], p2["max_distance"], p2["min_coverage"], 0.8, want_arrays=True)
+    assert np.array_equal(a["rare"], res["rare"])
+    assert np.array_equal(a["cloud_ptr"], res["cloud_ptr"]) and np.array_equal(a["entries"], res["entries"])
+    ed = a["edges"].astype(np.int64)
+    ed = ed[np.lexsort((ed[:, 2], ed[:, 1], ed[:, 0]))]
+    assert np.array_equal(ed, res["edges"])
+    assert np.array_equal(np.flatnonzero(a["unique"]), res["unique"])
+    cn = res["counters"]
+    assert (c["n_windows"], c["n_read_kmers"], c["n_distinct"], c["n_emissions"]) == (cn["n_w"], cn["n_rk"], cn["n_distinct"], cn["E"])
+    assert c["edge_checksum"] == cport.edge_checksum(res["edges"])
+    assert c["rare_checksum"] == cport.rare_checksum(res["rare"])
+    assert c["cloud_checksum"] == cport.cloud_checksum(res["cloud_ptr"], res["entries"])
