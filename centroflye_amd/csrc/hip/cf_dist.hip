@@ -23,6 +23,8 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 
 #define DIST_NP_CAP 512
 #define DIST_STACK 112
+#define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
+#define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
 
 __global__ void __launch_bounds__(256)
 cf_post_hist_kernel(const int32_t* __restrict__ entries, int64_t e0, int64_t e1, uint32_t* __restrict__ cnt) {
@@ -87,6 +89,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6, nt = blockDim.x;
     const uint32_t slots = (uint32_t)A.slots;
     const int64_t n_a = (A.n_kmers > A.part) ? (A.n_kmers - A.part + A.n_parts - 1) / A.n_parts : 0;
+    unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
 
     while (true) {
         __syncthreads();
@@ -126,7 +129,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             const uint32_t sp_now = sh[2];
             __syncthreads();  // everyone has read the stack pointer before thread 0 pops
             if (sp_now == 0) break;
-            if (t == 0) { const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[1] = 0; sh[7] = 0; }
+            if (t == 0) { const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[1] = 0; sh[7] = 0; sh[8] = 0; }
             for (uint32_t s = t; s < slots; s += nt) tab[s] = 0ull;
             __syncthreads();
             const uint32_t P = sh[3], pidx = sh[4];
@@ -182,54 +185,80 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                 spilled = true;
                 continue;
             }
-            // ---- leaf done: count emissions, filter in LDS, write selected edges
+            // ---- leaf done: count emissions, filter in LDS (pass 1 marks the selected slots with bit 23
+            // of the count field), reserve the edge range with ONE global atomic, then write (pass 2)
             for (int d = 32; d >= 1; d >>= 1) my_e += __shfl_down(my_e, (unsigned)d);
             if (lane == 0 && my_e) atomicAdd(&sh[7], my_e);
-            bool any_edge = false;
             const uint32_t rounds = (slots + nt - 1) / nt;
             for (uint32_t rd = 0; rd < rounds; ++rd) {
                 const uint32_t s = rd * nt + t;
                 bool sel = false;
-                uint32_t b = 0, dd = 0, cnt = 0;
                 if (s < slots) {
                     const unsigned long long v = tab[s];
-                    cnt = (uint32_t)v & 0xFFFFFFu;
+                    const uint32_t cnt = (uint32_t)v & DIST_CNT_MASK;
                     if (v != 0ull && cnt >= A.min_cov) {
-                        b = (uint32_t)(v >> 32); dd = (uint32_t)(v >> 24) & 0xFFu;
+                        const uint32_t b = (uint32_t)(v >> 32);
                         unsigned long long total = 0;
                         uint32_t h = cf_dist_home(b, slots);
                         for (uint32_t probe = 0; probe < slots; ++probe) {
                             const unsigned long long w = tab[h];
                             if (w == 0ull) break;
-                            if ((uint32_t)(w >> 32) == b) total += w & 0xFFFFFFull;
+                            if ((uint32_t)(w >> 32) == b) total += w & DIST_CNT_MASK;
                             h = (h + 1 == slots) ? 0u : h + 1;
                         }
                         sel = ((double)cnt / (double)total) >= A.thr;
+                        if (sel) tab[s] = v | DIST_SEL_BIT;
                     }
                 }
                 const unsigned long long m = __ballot(sel);
-                if (m) {
-                    unsigned long long base = 0;
-                    const int leader = __ffsll((long long)m) - 1;
-                    if (lane == leader) base = atomicAdd(&A.counters[0], (unsigned long long)__popcll(m));
-                    base = __shfl(base, leader);
-                    if (sel) {
-                        const unsigned long long o = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-                        if (o < A.edge_cap) { uint32_t* E = A.edges + 4 * o; E[0] = dd; E[1] = a; E[2] = b; E[3] = cnt; }
-                        const uint32_t bit = 1u << (b & 31);
-                        if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
-                        any_edge = true;
+                if (m && lane == 0) atomicAdd(&sh[8], (uint32_t)__popcll(m));
+            }
+            __syncthreads();
+            const uint32_t n_sel = sh[8];
+            __syncthreads();  // everyone has read the count before thread 0 reuses the word as a cursor
+            if (t == 0) {
+                acc_E += sh[7]; ++acc_pass;
+                if (n_sel) {
+                    const unsigned long long base = atomicAdd(&A.counters[0], (unsigned long long)n_sel);
+                    sh[9] = (uint32_t)base; sh[10] = (uint32_t)(base >> 32);
+                    const uint32_t bit = 1u << (a & 31);
+                    if (!(A.unique_bits[a >> 5] & bit)) atomicOr(&A.unique_bits[a >> 5], bit);
+                }
+                sh[8] = 0;
+            }
+            __syncthreads();
+            if (n_sel) {
+                const unsigned long long base = ((unsigned long long)sh[10] << 32) | sh[9];
+                for (uint32_t rd = 0; rd < rounds; ++rd) {
+                    const uint32_t s = rd * nt + t;
+                    const unsigned long long v = s < slots ? tab[s] : 0ull;
+                    const bool sel = (v & DIST_SEL_BIT) != 0ull;
+                    const unsigned long long m = __ballot(sel);
+                    if (m) {
+                        uint32_t off = 0;
+                        const int leader = __ffsll((long long)m) - 1;
+                        if (lane == leader) off = atomicAdd(&sh[8], (uint32_t)__popcll(m));
+                        off = __shfl(off, leader);
+                        if (sel) {
+                            const unsigned long long o = base + off + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                            const uint32_t b = (uint32_t)(v >> 32);
+                            if (o < A.edge_cap) {
+                                uint32_t* E = A.edges + 4 * o;
+                                E[0] = (uint32_t)(v >> 24) & 0xFFu; E[1] = a; E[2] = b; E[3] = (uint32_t)v & DIST_CNT_MASK;
+                            }
+                            const uint32_t bit = 1u << (b & 31);
+                            if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
+                        }
                     }
                 }
             }
-            if (__any(any_edge) && lane == 0) {
-                const uint32_t bit = 1u << (a & 31);
-                if (!(A.unique_bits[a >> 5] & bit)) atomicOr(&A.unique_bits[a >> 5], bit);
-            }
-            __syncthreads();
-            if (t == 0) { if (sh[7]) atomicAdd(&A.counters[1], (unsigned long long)sh[7]); atomicAdd(&A.counters[5], 1ull); }
         }
-        if (spilled && t == 0) atomicAdd(&A.counters[2], 1ull);
+        if (spilled && t == 0) ++acc_spill;
+    }
+    if (t == 0) {
+        if (acc_E) atomicAdd(&A.counters[1], acc_E);
+        if (acc_spill) atomicAdd(&A.counters[2], acc_spill);
+        if (acc_pass) atomicAdd(&A.counters[5], acc_pass);
     }
 }
 
@@ -301,7 +330,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
         A.slots = ctx->dist_slots; A.fill_limit = (uint32_t)((int64_t)ctx->dist_slots * 3 / 4);
         A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
-        const size_t lds = (size_t)A.slots * 8 + (size_t)(3 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 8) * 4 + 16;
+        const size_t lds = (size_t)A.slots * 8 + (size_t)(3 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 16) * 4 + 16;
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / ctx->dist_block));
         const int64_t n_a = (K > part) ? (K - part + n_parts - 1) / n_parts : 0;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_a, (int64_t)std::max(1, ctx->n_cu) * per_cu));
