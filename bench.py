@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--reads", type=int, default=50000, help="reads per GPU")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--edge-cap", type=int, default=1 << 26, help="edges stored per GPU (all are counted)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=90)
+    ap.add_argument("--cpu-sample-reads", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--param", action="append", default=[], help="library knob name=value (cf_set_param)")
     a = ap.parse_args()

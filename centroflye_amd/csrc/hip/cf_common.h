@@ -94,8 +94,8 @@ struct cf_ctx {
     cf_times times{};
 
     // knobs
-    int dist_block = 512;
-    int dist_slots = 16384;
+    int dist_block = 1024;
+    int dist_slots = 19456;
     int count_slots = 8192;
     int count_tile = 16;
 };
