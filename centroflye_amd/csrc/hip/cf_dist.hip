@@ -23,6 +23,7 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 
 #define DIST_NP_CAP 512
 #define DIST_STACK 112
+#define DIST_UNROLL 4
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
 #define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
 
@@ -34,7 +35,8 @@ cf_post_hist_kernel(const int32_t* __restrict__ entries, int64_t e0, int64_t e1,
 
 __global__ void __launch_bounds__(256)
 cf_post_fill_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ entries, int64_t u0, int64_t u1,
-                    const int64_t* __restrict__ post_ptr, uint32_t* __restrict__ cursor, int32_t* __restrict__ post) {
+                    const int64_t* __restrict__ post_ptr, uint32_t* __restrict__ cursor, int32_t* __restrict__ post,
+                    uint32_t* __restrict__ first_unit) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -43,6 +45,7 @@ cf_post_fill_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __rest
         for (int64_t e = a + lane; e < b; e += 64) {
             const int32_t x = entries[e];
             post[post_ptr[x] + atomicAdd(&cursor[x], 1u)] = (int32_t)u;
+            if (first_unit[x] > (uint32_t)u) atomicMin(&first_unit[x], (uint32_t)u);
         }
     }
 }
@@ -54,6 +57,32 @@ cf_unit_rend_kernel(const int64_t* __restrict__ unit_ptr, int64_t n_reads, int32
         const int64_t a = unit_ptr[r], b = unit_ptr[r + 1];
         for (int64_t u = a; u < b; ++u) rend[u] = (int32_t)b;
     }
+}
+
+// keys (first posting unit << 32 | a) of the first k-mers of this partition that have postings
+__global__ void __launch_bounds__(256)
+cf_order_keys_kernel(const uint32_t* __restrict__ pcnt, const uint32_t* __restrict__ first_unit, int64_t n_kmers, int part, int n_parts,
+                     unsigned long long* __restrict__ keys, unsigned long long* __restrict__ n_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t rounds = (n_kmers + stride - 1) / stride;
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t a = rd * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool take = a < n_kmers && (a % n_parts) == part && pcnt[a] > 0;
+        const unsigned long long m = __ballot(take);
+        if (m) {
+            unsigned long long base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
+            base = __shfl(base, leader);
+            if (take) keys[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)first_unit[a] << 32) | (unsigned long long)a;
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+cf_order_extract_kernel(const unsigned long long* __restrict__ keys, int64_t n, int32_t* __restrict__ order) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) order[i] = (int32_t)(keys[i] & 0xFFFFFFFFull);
 }
 
 struct cf_dist_args {
@@ -71,7 +100,9 @@ struct cf_dist_args {
     uint32_t fill_limit;
     uint32_t* edges;
     unsigned long long edge_cap;
-    unsigned long long* counters;  // [0] edges, [1] emissions, [2] spilled a, [3] queue head, [4] error flags
+    const int32_t* order;          // first k-mers of this partition, sorted by their first posting (locality)
+    int64_t n_order;
+    unsigned long long* counters;  // [0] edges [1] emissions [2] spilled a [4] error flags [5] passes; [16 + 16 x] queue head x
     uint32_t* unique_bits;
 };
 
@@ -88,19 +119,28 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
     uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] n_used [1] overflow [2] sp [3] P [4] idx [5] a_idx lo [6] a_idx hi [7] E of leaf
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6, nt = blockDim.x;
     const uint32_t slots = (uint32_t)A.slots;
-    const int64_t n_a = (A.n_kmers > A.part) ? (A.n_kmers - A.part + A.n_parts - 1) / A.n_parts : 0;
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
 
     while (true) {
         __syncthreads();
         if (t == 0) {
-            const unsigned long long q = atomicAdd(&A.counters[3], 1ull);
-            sh[5] = (uint32_t)q; sh[6] = (uint32_t)(q >> 32);
+            // 8 ticket queues over 8 contiguous ranges of the locality-sorted first k-mers: workgroups with
+            // equal blockIdx % 8 (observed to share an XCD, i.e. an L2) drain one range; idle ones steal
+            long long idx = -1;
+            const int64_t per = (A.n_order + 7) / 8;
+            for (int s8 = 0; s8 < 8 && idx < 0; ++s8) {
+                const int x = (int)((blockIdx.x + s8) & 7);
+                const int64_t lo = x * per, hi = min((int64_t)(x + 1) * per, A.n_order);
+                if (lo >= hi) continue;
+                const unsigned long long q = atomicAdd(&A.counters[16 + 16 * x], 1ull);
+                if (lo + (int64_t)q < hi) idx = lo + (int64_t)q;
+            }
+            sh[5] = (uint32_t)(unsigned long long)idx; sh[6] = (uint32_t)((unsigned long long)idx >> 32);
         }
         __syncthreads();
         const int64_t ai = (int64_t)(((unsigned long long)sh[6] << 32) | sh[5]);
-        if (ai >= n_a) break;
-        const uint32_t a = (uint32_t)(A.part + ai * A.n_parts);
+        if (ai < 0) break;
+        const uint32_t a = (uint32_t)A.order[ai];
         const int64_t pp0 = A.post_ptr[a], pp1 = A.post_ptr[a + 1];
         if (pp1 == pp0) continue;
         // upper bound of the emissions of a -> initial number of partitions of its (b, d) table
@@ -156,21 +196,31 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     const int32_t j = pjlo[lo] + (int32_t)(q - pre[lo]);
                     const uint32_t dd = (uint32_t)(j - g);
                     const int64_t e0 = A.cloud_ptr[j], e1 = A.cloud_ptr[j + 1];
-                    for (int64_t e = e0 + lane; e < e1; e += 64) {
-                        const uint32_t b = (uint32_t)A.entries[e];
-                        if (b == a) continue;
-                        if (P > 1 && ((cf_mix32(b ^ 0x9E3779B9u) >> 4) & (P - 1)) != pidx) continue;
-                        ++my_e;
-                        const unsigned long long key = ((unsigned long long)b << 32) | ((unsigned long long)dd << 24);
-                        uint32_t h = cf_dist_home(b, slots);
-                        for (uint32_t probe = 0; probe < slots; ++probe) {
-                            unsigned long long cur = tab[h];
-                            if (cur == 0ull) {
-                                cur = atomicCAS(&tab[h], 0ull, key | 1ull);
-                                if (cur == 0ull) { if (atomicAdd(&sh[0], 1u) >= A.fill_limit) sh[1] = 1; break; }
+                    // 4 independent coalesced loads in flight per lane before the first LDS access
+                    for (int64_t e = e0 + lane; e < e1; e += 64 * DIST_UNROLL) {
+                        uint32_t bb[DIST_UNROLL];
+#pragma unroll
+                        for (int u = 0; u < DIST_UNROLL; ++u) {
+                            const int64_t ee = e + 64 * u;
+                            bb[u] = ee < e1 ? (uint32_t)A.entries[ee] : a;   // a itself is never counted: skip marker
+                        }
+#pragma unroll
+                        for (int u = 0; u < DIST_UNROLL; ++u) {
+                            const uint32_t b = bb[u];
+                            if (b == a) continue;
+                            if (P > 1 && ((cf_mix32(b ^ 0x9E3779B9u) >> 4) & (P - 1)) != pidx) continue;
+                            ++my_e;
+                            const unsigned long long key = ((unsigned long long)b << 32) | ((unsigned long long)dd << 24);
+                            uint32_t h = cf_dist_home(b, slots);
+                            for (uint32_t probe = 0; probe < slots; ++probe) {
+                                unsigned long long cur = tab[h];
+                                if (cur == 0ull) {
+                                    cur = atomicCAS(&tab[h], 0ull, key | 1ull);
+                                    if (cur == 0ull) { if (atomicAdd(&sh[0], 1u) >= A.fill_limit) sh[1] = 1; break; }
+                                }
+                                if ((cur >> 24) == (key >> 24)) { atomicAdd(&tab[h], 1ull); break; }
+                                h = (h + 1 == slots) ? 0u : h + 1;
                             }
-                            if ((cur >> 24) == (key >> 24)) { atomicAdd(&tab[h], 1ull); break; }
-                            h = (h + 1 == slots) ? 0u : h + 1;
                         }
                     }
                 }
@@ -282,13 +332,17 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     const int64_t u0 = ctx->h_unit_ptr[(size_t)min_n], u1 = ctx->h_unit_ptr[(size_t)max_n];
     const int32_t min_d_eff = min_d < 1 ? 1 : min_d;  // kmer_clouds[:-0] is empty: d = 0 emits nothing
 
-    uint32_t *d_pcnt = nullptr, *d_cursor = nullptr;
+    uint32_t *d_pcnt = nullptr, *d_cursor = nullptr, *d_first = nullptr;
+    unsigned long long *d_okeys = nullptr, *d_otmp = nullptr;
+    int32_t* d_order = nullptr;
+    int64_t n_order = 0, n_a_alloc = 0;
     int64_t* d_post_ptr = nullptr;
     int32_t *d_post = nullptr, *d_rend = nullptr;
     unsigned long long* d_cnt = nullptr;
     int64_t n_post = 0;
     int rc = 0;
     unsigned long long h_cnt[8] = {0};
+    const size_t n_cnt = 8 + 16 * 9;   // counters + 8 queue heads on their own cache lines
     const int max_blocks = std::max(1, ctx->n_cu) * 8;
     do {
         cf_free_edges(ctx);
@@ -298,10 +352,12 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if ((rc = cf_alloc_t(ctx, &d_cursor, (size_t)K + 1, "posting cursors"))) break;
         if ((rc = cf_alloc_t(ctx, &d_post_ptr, (size_t)K + 1, "posting offsets"))) break;
         if ((rc = cf_alloc_t(ctx, &d_rend, (size_t)U + 1, "unit read ends"))) break;
-        if ((rc = cf_alloc_t(ctx, &d_cnt, 8, "dist counters"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_cnt, n_cnt, "dist counters"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_first, (size_t)K + 1, "first posting units"))) break;
         hipError_t e = hipMemsetAsync(d_pcnt, 0, (size_t)(K + 1) * 4, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, (size_t)(K + 1) * 4, ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 64, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, n_cnt * 8, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_first, 0xFF, (size_t)(K + 1) * 4, ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, "cf_dist_edges memset"); break; }
         int64_t e0 = 0, e1 = 0;
         {
@@ -317,7 +373,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if ((rc = cf_alloc_t(ctx, &d_post, (size_t)n_post, "postings"))) break;
         if (u1 > u0 && n_post)
             hipLaunchKernelGGL(cf_post_fill_kernel, dim3((unsigned)cf_grid_for((u1 - u0) * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries, u0, u1, (const int64_t*)d_post_ptr, d_cursor, d_post);
+                               (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries, u0, u1, (const int64_t*)d_post_ptr, d_cursor, d_post, d_first);
         if (R)
             hipLaunchKernelGGL(cf_unit_rend_kernel, dim3((unsigned)cf_grid_for(R, 256, max_blocks)), dim3(256), 0, ctx->stream,
                                (const int64_t*)ctx->d_unit_ptr, R, d_rend);
@@ -332,8 +388,28 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
         const size_t lds = (size_t)A.slots * 8 + (size_t)(3 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 16) * 4 + 16;
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / ctx->dist_block));
-        const int64_t n_a = (K > part) ? (K - part + n_parts - 1) / n_parts : 0;
+        // locality order of the first k-mers: sort (first posting unit, a); k-mers without postings drop out
+        n_a_alloc = (K > part) ? (K - part + n_parts - 1) / n_parts : 0;
+        if ((rc = cf_alloc_t(ctx, &d_okeys, (size_t)n_a_alloc, "order keys"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_otmp, (size_t)n_a_alloc, "order scratch"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_order, (size_t)n_a_alloc, "order"))) break;
+        if (K) {
+            hipLaunchKernelGGL(cf_order_keys_kernel, dim3((unsigned)cf_grid_for(K, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                               (const uint32_t*)d_pcnt, (const uint32_t*)d_first, K, (int)part, (int)n_parts, d_okeys, d_cnt + 6);
+            unsigned long long h_n = 0;
+            if (hipMemcpy(&h_n, d_cnt + 6, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "order count"); break; }
+            n_order = (int64_t)h_n;
+            if ((rc = cf_radix_sort_u64(ctx, d_okeys, d_otmp, n_order, 63))) break;
+            if (n_order)
+                hipLaunchKernelGGL(cf_order_extract_kernel, dim3((unsigned)cf_grid_for(n_order, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                                   (const unsigned long long*)d_okeys, n_order, d_order);
+        }
+        A.order = d_order; A.n_order = n_order;
+        const int64_t n_a = n_order;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_a, (int64_t)std::max(1, ctx->n_cu) * per_cu));
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
+        if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("order: ") + hipGetErrorString(e)); break; }
         e = hipFuncSetAttribute((const void*)cf_dist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("dist LDS attribute: ") + hipGetErrorString(e)); break; }
         if (n_a > 0 && max_d >= min_d_eff && n_post > 0) {
@@ -351,7 +427,11 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         (void)hipEventElapsedTime(&ctx->times.postings_ms, ctx->ev0, ctx->ev2);
         (void)hipEventElapsedTime(&ctx->times.dist_kernel_ms, ctx->ev2, ctx->ev3);
     } while (0);
-    if (d_cnt) cf_release_t(ctx, d_cnt, 8);
+    if (d_order) cf_release_t(ctx, d_order, (size_t)n_a_alloc);
+    if (d_otmp) cf_release_t(ctx, d_otmp, (size_t)n_a_alloc);
+    if (d_okeys) cf_release_t(ctx, d_okeys, (size_t)n_a_alloc);
+    if (d_first) cf_release_t(ctx, d_first, (size_t)K + 1);
+    if (d_cnt) cf_release_t(ctx, d_cnt, n_cnt);
     if (d_rend) cf_release_t(ctx, d_rend, (size_t)U + 1);
     if (d_post) cf_release_t(ctx, d_post, (size_t)n_post);
     if (d_post_ptr) cf_release_t(ctx, d_post_ptr, (size_t)K + 1);
