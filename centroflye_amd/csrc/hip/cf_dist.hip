@@ -51,11 +51,23 @@ cf_post_fill_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __rest
 }
 
 __global__ void __launch_bounds__(256)
-cf_unit_rend_kernel(const int64_t* __restrict__ unit_ptr, int64_t n_reads, int32_t* __restrict__ rend) {
+cf_unit_rend_kernel(const int64_t* __restrict__ unit_ptr, int64_t n_reads, int32_t* __restrict__ rend, int32_t* __restrict__ rbeg) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += stride) {
         const int64_t a = unit_ptr[r], b = unit_ptr[r + 1];
-        for (int64_t u = a; u < b; ++u) rend[u] = (int32_t)b;
+        for (int64_t u = a; u < b; ++u) { rend[u] = (int32_t)b; rbeg[u] = (int32_t)a; }
+    }
+}
+
+// per cloud entry the index of its unit inside its read (one wave per unit)
+__global__ void __launch_bounds__(256)
+cf_entry_unit_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ rbeg, int64_t n_units, uint16_t* __restrict__ entry_i) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = wave; u < n_units; u += n_waves) {
+        const uint16_t i = (uint16_t)(u - rbeg[u]);
+        for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) entry_i[e] = i;
     }
 }
 
@@ -90,7 +102,9 @@ struct cf_dist_args {
     const int32_t* post;
     const int64_t* cloud_ptr;
     const int32_t* entries;
-    const int32_t* unit_rend;
+    const int32_t* unit_rend;      // one past the last unit of the unit's read
+    const int32_t* unit_rbeg;      // first unit of the unit's read
+    const uint16_t* entry_i;       // per cloud entry: index of its unit inside its read
     int64_t n_kmers;
     int32_t part, n_parts;
     int32_t min_d, max_d;       // min_d already clamped to >= 1
@@ -112,12 +126,12 @@ __device__ __forceinline__ uint32_t cf_dist_home(uint32_t b, uint32_t slots) {
 
 __global__ void cf_dist_kernel(cf_dist_args A) {
     unsigned long long* tab = (unsigned long long*)cf_lds;
-    int32_t* pg = (int32_t*)(cf_lds + (size_t)A.slots * 8);   // posting unit
-    int32_t* pjlo = pg + DIST_NP_CAP;                          // first partner unit
-    uint32_t* pre = (uint32_t*)(pjlo + DIST_NP_CAP);           // prefix of partner-unit counts (NP_CAP + 1)
+    int64_t* pE0 = (int64_t*)(cf_lds + (size_t)A.slots * 8);  // first partner entry of each posting
+    int32_t* pig = (int32_t*)(pE0 + DIST_NP_CAP);              // unit index of the posting inside its read
+    uint32_t* pre = (uint32_t*)(pig + DIST_NP_CAP);            // prefix of partner-entry counts (NP_CAP + 1)
     uint32_t* stack = pre + DIST_NP_CAP + 1;                   // (P, idx) pairs
     uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] n_used [1] overflow [2] sp [3] P [4] idx [5] a_idx lo [6] a_idx hi [7] E of leaf
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = blockDim.x >> 6, nt = blockDim.x;
+    const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
     const uint32_t slots = (uint32_t)A.slots;
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
 
@@ -174,53 +188,57 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             __syncthreads();
             const uint32_t P = sh[3], pidx = sh[4];
             uint32_t my_e = 0;
-            // ---- stream the partner clouds of every posting of a, in chunks of DIST_NP_CAP postings
+            // ---- stream the partner clouds of every posting of a, in chunks of DIST_NP_CAP postings.
+            // The units g+min_d .. min(read end, g+max_d) of a posting are ONE contiguous range of the
+            // CSR; the ranges of all postings are concatenated into a flat index space that all threads
+            // sweep with coalesced loads (entry rank + the entry's unit index inside its read), several
+            // loads in flight per lane.
             for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
                 const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
                 for (int p = t; p < np; p += nt) {
                     const int32_t g = A.post[c0 + p];
                     const int32_t jlo = g + A.min_d;
                     const int32_t jhi = min(A.unit_rend[g] - 1, g + A.max_d);
-                    pg[p] = g; pjlo[p] = jlo;
-                    pre[p + 1] = jhi >= jlo ? (uint32_t)(jhi - jlo + 1) : 0u;
+                    int64_t E0 = 0, E1 = 0;
+                    if (jhi >= jlo) { E0 = A.cloud_ptr[jlo]; E1 = A.cloud_ptr[jhi + 1]; }
+                    pE0[p] = E0; pig[p] = g - A.unit_rbeg[g];
+                    pre[p + 1] = (uint32_t)(E1 - E0);
                 }
                 __syncthreads();
                 if (t == 0) { pre[0] = 0; for (int p = 0; p < np; ++p) pre[p + 1] += pre[p]; }
                 __syncthreads();
-                const uint32_t n_pairs = pre[np];
-                for (uint32_t q = wave; q < n_pairs; q += nwaves) {
+                const uint32_t total = pre[np];
+                int p_cur = 0;
+                for (uint32_t f0 = 0; f0 < total; f0 += (uint32_t)nt * DIST_UNROLL) {
                     if (sh[1]) break;
-                    int lo = 0, hi = np - 1;  // largest p with pre[p] <= q
-                    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= q) lo = mid; else hi = mid - 1; }
-                    const int32_t g = pg[lo];
-                    const int32_t j = pjlo[lo] + (int32_t)(q - pre[lo]);
-                    const uint32_t dd = (uint32_t)(j - g);
-                    const int64_t e0 = A.cloud_ptr[j], e1 = A.cloud_ptr[j + 1];
-                    // 4 independent coalesced loads in flight per lane before the first LDS access
-                    for (int64_t e = e0 + lane; e < e1; e += 64 * DIST_UNROLL) {
-                        uint32_t bb[DIST_UNROLL];
+                    uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
 #pragma unroll
-                        for (int u = 0; u < DIST_UNROLL; ++u) {
-                            const int64_t ee = e + 64 * u;
-                            bb[u] = ee < e1 ? (uint32_t)A.entries[ee] : a;   // a itself is never counted: skip marker
+                    for (int u = 0; u < DIST_UNROLL; ++u) {
+                        const uint32_t f = f0 + (uint32_t)u * nt + t;
+                        bb[u] = a; dd_[u] = 0;                     // a itself is never counted: skip marker
+                        if (f < total) {
+                            while (pre[p_cur + 1] <= f) ++p_cur;   // monotone: f only grows
+                            const int64_t e = pE0[p_cur] + (int64_t)(f - pre[p_cur]);
+                            bb[u] = (uint32_t)A.entries[e];
+                            dd_[u] = (uint32_t)((int32_t)A.entry_i[e] - pig[p_cur]);
                         }
+                    }
 #pragma unroll
-                        for (int u = 0; u < DIST_UNROLL; ++u) {
-                            const uint32_t b = bb[u];
-                            if (b == a) continue;
-                            if (P > 1 && ((cf_mix32(b ^ 0x9E3779B9u) >> 4) & (P - 1)) != pidx) continue;
-                            ++my_e;
-                            const unsigned long long key = ((unsigned long long)b << 32) | ((unsigned long long)dd << 24);
-                            uint32_t h = cf_dist_home(b, slots);
-                            for (uint32_t probe = 0; probe < slots; ++probe) {
-                                unsigned long long cur = tab[h];
-                                if (cur == 0ull) {
-                                    cur = atomicCAS(&tab[h], 0ull, key | 1ull);
-                                    if (cur == 0ull) { if (atomicAdd(&sh[0], 1u) >= A.fill_limit) sh[1] = 1; break; }
-                                }
-                                if ((cur >> 24) == (key >> 24)) { atomicAdd(&tab[h], 1ull); break; }
-                                h = (h + 1 == slots) ? 0u : h + 1;
+                    for (int u = 0; u < DIST_UNROLL; ++u) {
+                        const uint32_t b = bb[u];
+                        if (b == a) continue;
+                        if (P > 1 && ((cf_mix32(b ^ 0x9E3779B9u) >> 4) & (P - 1)) != pidx) continue;
+                        ++my_e;
+                        const unsigned long long key = ((unsigned long long)b << 32) | ((unsigned long long)dd_[u] << 24);
+                        uint32_t h = cf_dist_home(b, slots);
+                        for (uint32_t probe = 0; probe < slots; ++probe) {
+                            unsigned long long cur = tab[h];
+                            if (cur == 0ull) {
+                                cur = atomicCAS(&tab[h], 0ull, key | 1ull);
+                                if (cur == 0ull) { if (atomicAdd(&sh[0], 1u) >= A.fill_limit) sh[1] = 1; break; }
                             }
+                            if ((cur >> 24) == (key >> 24)) { atomicAdd(&tab[h], 1ull); break; }
+                            h = (h + 1 == slots) ? 0u : h + 1;
                         }
                     }
                 }
@@ -321,6 +339,9 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     if (n_parts < 1 || part < 0 || part >= n_parts) return cf_fail(ctx, -22, "cf_dist_edges: bad partition");
     if (max_d > 255) return cf_fail(ctx, -22, "cf_dist_edges: max_d > 255 does not fit the 8-bit distance field");
     if (edge_cap < 0) edge_cap = 0;
+    for (int64_t r = 0; r < ctx->n_reads; ++r)
+        if (ctx->h_unit_ptr[(size_t)r + 1] - ctx->h_unit_ptr[(size_t)r] > 65535)
+            return cf_fail(ctx, -22, "cf_dist_edges: a read has more than 65535 units (16-bit unit index per cloud entry)");
     CF_HIP(hipSetDevice(ctx->device));
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     const int64_t R = ctx->n_reads, U = ctx->n_units, K = ctx->n_kmers;
@@ -337,7 +358,8 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     int32_t* d_order = nullptr;
     int64_t n_order = 0, n_a_alloc = 0;
     int64_t* d_post_ptr = nullptr;
-    int32_t *d_post = nullptr, *d_rend = nullptr;
+    int32_t *d_post = nullptr, *d_rend = nullptr, *d_rbeg = nullptr;
+    uint16_t* d_entry_i = nullptr;
     unsigned long long* d_cnt = nullptr;
     int64_t n_post = 0;
     int rc = 0;
@@ -352,6 +374,8 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if ((rc = cf_alloc_t(ctx, &d_cursor, (size_t)K + 1, "posting cursors"))) break;
         if ((rc = cf_alloc_t(ctx, &d_post_ptr, (size_t)K + 1, "posting offsets"))) break;
         if ((rc = cf_alloc_t(ctx, &d_rend, (size_t)U + 1, "unit read ends"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_rbeg, (size_t)U + 1, "unit read begins"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_entry_i, (size_t)ctx->n_entries + 1, "entry unit indices"))) break;
         if ((rc = cf_alloc_t(ctx, &d_cnt, n_cnt, "dist counters"))) break;
         if ((rc = cf_alloc_t(ctx, &d_first, (size_t)K + 1, "first posting units"))) break;
         hipError_t e = hipMemsetAsync(d_pcnt, 0, (size_t)(K + 1) * 4, ctx->stream);
@@ -376,17 +400,20 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                                (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries, u0, u1, (const int64_t*)d_post_ptr, d_cursor, d_post, d_first);
         if (R)
             hipLaunchKernelGGL(cf_unit_rend_kernel, dim3((unsigned)cf_grid_for(R, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const int64_t*)ctx->d_unit_ptr, R, d_rend);
+                               (const int64_t*)ctx->d_unit_ptr, R, d_rend, d_rbeg);
+        if (U && ctx->n_entries)
+            hipLaunchKernelGGL(cf_entry_unit_kernel, dim3((unsigned)cf_grid_for(U * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                               (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)d_rbeg, U, d_entry_i);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("postings: ") + hipGetErrorString(e)); break; }
 
         cf_dist_args A;
-        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = ctx->d_cloud_ptr; A.entries = ctx->d_entries; A.unit_rend = d_rend;
+        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = ctx->d_cloud_ptr; A.entries = ctx->d_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.entry_i = d_entry_i;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
         A.slots = ctx->dist_slots; A.fill_limit = (uint32_t)((int64_t)ctx->dist_slots * 3 / 4);
         A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
-        const size_t lds = (size_t)A.slots * 8 + (size_t)(3 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 16) * 4 + 16;
+        const size_t lds = (size_t)A.slots * 8 + (size_t)(4 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 16) * 4 + 16;
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / ctx->dist_block));
         // locality order of the first k-mers: sort (first posting unit, a); k-mers without postings drop out
         n_a_alloc = (K > part) ? (K - part + n_parts - 1) / n_parts : 0;
@@ -432,6 +459,8 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     if (d_okeys) cf_release_t(ctx, d_okeys, (size_t)n_a_alloc);
     if (d_first) cf_release_t(ctx, d_first, (size_t)K + 1);
     if (d_cnt) cf_release_t(ctx, d_cnt, n_cnt);
+    if (d_entry_i) cf_release_t(ctx, d_entry_i, (size_t)ctx->n_entries + 1);
+    if (d_rbeg) cf_release_t(ctx, d_rbeg, (size_t)U + 1);
     if (d_rend) cf_release_t(ctx, d_rend, (size_t)U + 1);
     if (d_post) cf_release_t(ctx, d_post, (size_t)n_post);
     if (d_post_ptr) cf_release_t(ctx, d_post_ptr, (size_t)K + 1);
