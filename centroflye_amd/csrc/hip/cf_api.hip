@@ -252,7 +252,7 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
         if (value < 64 || value > 1024 || value % 64) return cf_fail(ctx, -22, "dist_block must be a multiple of 64 in [64, 1024]");
         ctx->dist_block = (int)value;
     } else if (n == "dist_slots") {
-        if (value < 256 || value * 8 > 156 * 1024) return cf_fail(ctx, -22, "dist_slots out of range (256 .. 19968)");
+        if (value < 256 || value > 19200) return cf_fail(ctx, -22, "dist_slots out of range (256 .. 19200: table + work lists must fit the 160 KiB LDS)");
         ctx->dist_slots = (int)value;
     } else if (n == "count_slots") {
         if (value < 256 || (value & (value - 1)) || value * 8 > 128 * 1024) return cf_fail(ctx, -22, "count_slots must be a power of two in [256, 16384]");

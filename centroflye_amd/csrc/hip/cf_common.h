@@ -95,7 +95,7 @@ struct cf_ctx {
 
     // knobs
     int dist_block = 1024;
-    int dist_slots = 19456;
+    int dist_slots = 19200;
     int count_slots = 8192;
     int count_tile = 16;
 };

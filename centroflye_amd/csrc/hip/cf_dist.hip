@@ -414,6 +414,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.slots = ctx->dist_slots; A.fill_limit = (uint32_t)((int64_t)ctx->dist_slots * 3 / 4);
         A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
         const size_t lds = (size_t)A.slots * 8 + (size_t)(4 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 16) * 4 + 16;
+        if (lds > 160 * 1024) { rc = cf_fail(ctx, -22, "cf_dist_edges: LDS request exceeds 160 KiB"); break; }
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / ctx->dist_block));
         // locality order of the first k-mers: sort (first posting unit, a); k-mers without postings drop out
         n_a_alloc = (K > part) ? (K - part + n_parts - 1) / n_parts : 0;
