@@ -120,8 +120,41 @@ struct cf_dist_args {
     uint32_t* unique_bits;
 };
 
-__device__ __forceinline__ uint32_t cf_dist_home(uint32_t b, uint32_t slots) {
-    return (uint32_t)(((unsigned long long)cf_mix32(b) * (unsigned long long)slots) >> 32);
+// The (b, d) table is organised in buckets of 4 x 64-bit slots (32 B, two ds_read_b128): a probe
+// inspects a whole bucket with straight-line code, so a wave does not iterate a per-lane probe loop
+// in the common case.  A key lives in the first bucket, starting at home(b), that held a match or an
+// empty slot when it was inserted; buckets never lose entries, so every (b, .) key sits between
+// home(b) and the first bucket that still has an empty slot.
+struct alignas(16) cf_u64x2 { unsigned long long x, y; };
+
+__device__ __forceinline__ uint32_t cf_dist_home(uint32_t b, uint32_t n_buckets) {
+    return (uint32_t)(((unsigned long long)cf_mix32(b) * (unsigned long long)n_buckets) >> 32);
+}
+// index (0..3) of the slot of bucket v that holds key (ignoring count and flag bits), or -1
+__device__ __forceinline__ int cf_bucket_match(const cf_u64x2& lo, const cf_u64x2& hi, unsigned long long key24) {
+    return (lo.x >> 24) == key24 ? 0 : (lo.y >> 24) == key24 ? 1 : (hi.x >> 24) == key24 ? 2 : (hi.y >> 24) == key24 ? 3 : -1;
+}
+__device__ __forceinline__ int cf_bucket_empty(const cf_u64x2& lo, const cf_u64x2& hi) {
+    return lo.x == 0ull ? 0 : lo.y == 0ull ? 1 : hi.x == 0ull ? 2 : hi.y == 0ull ? 3 : -1;
+}
+// general insert: walk buckets from bk; claims an empty slot with a CAS when the key is absent
+__device__ __forceinline__ void cf_dist_insert(unsigned long long* tab, uint32_t n_buckets, uint32_t bk, unsigned long long key,
+                                               uint32_t* sh, uint32_t fill_limit) {
+    const unsigned long long key24 = key >> 24;
+    for (uint32_t tries = 0; tries < 5 * n_buckets; ++tries) {
+        const cf_u64x2 lo = *(const cf_u64x2*)&tab[4 * bk], hi = *(const cf_u64x2*)&tab[4 * bk + 2];
+        const int m = cf_bucket_match(lo, hi, key24);
+        if (m >= 0) { atomicAdd(&tab[4 * bk + m], 1ull); return; }
+        const int e = cf_bucket_empty(lo, hi);
+        if (e >= 0) {
+            const unsigned long long old = atomicCAS(&tab[4 * bk + e], 0ull, key | 1ull);
+            if (old == 0ull) { if (atomicAdd(&sh[0], 1u) >= fill_limit) sh[1] = 1; return; }
+            if ((old >> 24) == key24) { atomicAdd(&tab[4 * bk + e], 1ull); return; }
+            continue;   // another key took the slot: look at the same bucket again
+        }
+        bk = bk + 1 == n_buckets ? 0u : bk + 1;
+    }
+    sh[1] = 1;   // table full (cannot happen below the fill limit)
 }
 
 __global__ void cf_dist_kernel(cf_dist_args A) {
@@ -132,7 +165,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
     uint32_t* stack = pre + DIST_NP_CAP + 1;                   // (P, idx) pairs
     uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] n_used [1] overflow [2] sp [3] P [4] idx [5] a_idx lo [6] a_idx hi [7] E of leaf
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
-    const uint32_t slots = (uint32_t)A.slots;
+    const uint32_t slots = (uint32_t)A.slots, n_buckets = slots >> 2;   // slots is a multiple of 4
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
 
     while (true) {
@@ -223,23 +256,27 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                             dd_[u] = (uint32_t)((int32_t)A.entry_i[e] - pig[p_cur]);
                         }
                     }
+                    // bucket reads of all unrolled emissions first (independent LDS reads in flight), then resolve
+                    unsigned long long key_[DIST_UNROLL];
+                    uint32_t bk_[DIST_UNROLL];
+                    cf_u64x2 lo_[DIST_UNROLL], hi_[DIST_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         const uint32_t b = bb[u];
-                        if (b == a) continue;
-                        if (P > 1 && ((cf_mix32(b ^ 0x9E3779B9u) >> 4) & (P - 1)) != pidx) continue;
+                        const uint32_t hb = cf_mix32(b);
+                        const bool live = b != a && (P == 1 || ((cf_mix32(b ^ 0x9E3779B9u) >> 4) & (P - 1)) == pidx);
+                        key_[u] = live ? (((unsigned long long)b << 32) | ((unsigned long long)dd_[u] << 24)) : 0ull;
+                        bk_[u] = (uint32_t)(((unsigned long long)hb * (unsigned long long)n_buckets) >> 32);
+                        lo_[u] = *(const cf_u64x2*)&tab[4 * bk_[u]];
+                        hi_[u] = *(const cf_u64x2*)&tab[4 * bk_[u] + 2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < DIST_UNROLL; ++u) {
+                        if (key_[u] == 0ull) continue;
                         ++my_e;
-                        const unsigned long long key = ((unsigned long long)b << 32) | ((unsigned long long)dd_[u] << 24);
-                        uint32_t h = cf_dist_home(b, slots);
-                        for (uint32_t probe = 0; probe < slots; ++probe) {
-                            unsigned long long cur = tab[h];
-                            if (cur == 0ull) {
-                                cur = atomicCAS(&tab[h], 0ull, key | 1ull);
-                                if (cur == 0ull) { if (atomicAdd(&sh[0], 1u) >= A.fill_limit) sh[1] = 1; break; }
-                            }
-                            if ((cur >> 24) == (key >> 24)) { atomicAdd(&tab[h], 1ull); break; }
-                            h = (h + 1 == slots) ? 0u : h + 1;
-                        }
+                        const int m = cf_bucket_match(lo_[u], hi_[u], key_[u] >> 24);
+                        if (m >= 0) atomicAdd(&tab[4 * bk_[u] + m], 1ull);          // common case: the pair was seen before
+                        else cf_dist_insert(tab, n_buckets, bk_[u], key_[u], sh, A.fill_limit);
                     }
                 }
                 __syncthreads();
@@ -267,12 +304,15 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     if (v != 0ull && cnt >= A.min_cov) {
                         const uint32_t b = (uint32_t)(v >> 32);
                         unsigned long long total = 0;
-                        uint32_t h = cf_dist_home(b, slots);
-                        for (uint32_t probe = 0; probe < slots; ++probe) {
-                            const unsigned long long w = tab[h];
-                            if (w == 0ull) break;
-                            if ((uint32_t)(w >> 32) == b) total += w & DIST_CNT_MASK;
-                            h = (h + 1 == slots) ? 0u : h + 1;
+                        uint32_t bk = cf_dist_home(b, n_buckets);
+                        for (uint32_t probe = 0; probe < n_buckets; ++probe) {
+                            const cf_u64x2 lo = *(const cf_u64x2*)&tab[4 * bk], hi = *(const cf_u64x2*)&tab[4 * bk + 2];
+                            if ((uint32_t)(lo.x >> 32) == b && lo.x) total += lo.x & DIST_CNT_MASK;
+                            if ((uint32_t)(lo.y >> 32) == b && lo.y) total += lo.y & DIST_CNT_MASK;
+                            if ((uint32_t)(hi.x >> 32) == b && hi.x) total += hi.x & DIST_CNT_MASK;
+                            if ((uint32_t)(hi.y >> 32) == b && hi.y) total += hi.y & DIST_CNT_MASK;
+                            if (cf_bucket_empty(lo, hi) >= 0) break;
+                            bk = bk + 1 == n_buckets ? 0u : bk + 1;
                         }
                         sel = ((double)cnt / (double)total) >= A.thr;
                         if (sel) tab[s] = v | DIST_SEL_BIT;
@@ -411,7 +451,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         cf_dist_args A;
         A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = ctx->d_cloud_ptr; A.entries = ctx->d_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.entry_i = d_entry_i;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
-        A.slots = ctx->dist_slots; A.fill_limit = (uint32_t)((int64_t)ctx->dist_slots * 3 / 4);
+        A.slots = ctx->dist_slots & ~3; A.fill_limit = (uint32_t)((int64_t)ctx->dist_slots * 3 / 4);
         A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
         const size_t lds = (size_t)A.slots * 8 + (size_t)(4 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 16) * 4 + 16;
         if (lds > 160 * 1024) { rc = cf_fail(ctx, -22, "cf_dist_edges: LDS request exceeds 160 KiB"); break; }
