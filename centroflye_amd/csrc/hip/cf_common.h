@@ -96,6 +96,7 @@ struct cf_ctx {
     // knobs
     int dist_block = 1024;
     int dist_slots = 19200;
+    int dist_stage = 2048;   // selected edges staged in LDS per table pass (0 forces the table sweep)
     int count_slots = 8192;
     int count_tile = 16;
 };

@@ -21,7 +21,8 @@
 void cf_free_edges(cf_ctx* c);
 int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 
-#define DIST_NP_CAP 512
+#define DIST_NP_CAP 256
+#define DIST_STAGE_CAP 2048              /* selected slots staged per table pass (u16 slot indices) */
 #define DIST_STACK 112
 #define DIST_UNROLL 4
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
@@ -112,6 +113,7 @@ struct cf_dist_args {
     double thr;
     int32_t slots;
     uint32_t fill_limit;
+    uint32_t stage_cap;            // <= DIST_STAGE_CAP
     uint32_t* edges;
     unsigned long long edge_cap;
     const int32_t* order;          // first k-mers of this partition, sorted by their first posting (locality)
@@ -164,6 +166,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
     uint32_t* pre = (uint32_t*)(pig + DIST_NP_CAP);            // prefix of partner-entry counts (NP_CAP + 1)
     uint32_t* stack = pre + DIST_NP_CAP + 1;                   // (P, idx) pairs
     uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] n_used [1] overflow [2] sp [3] P [4] idx [5] a_idx lo [6] a_idx hi [7] E of leaf
+    uint16_t* stage = (uint16_t*)(sh + 16);                    // slot indices of the selected edges of a pass
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots >> 2;   // slots is a multiple of 4
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
@@ -242,6 +245,9 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                 __syncthreads();
                 const uint32_t total = pre[np];
                 int p_cur = 0;
+                uint32_t r_lo = 0, r_hi = pre[1];          // flat range of posting p_cur, cached in registers
+                int64_t r_e0 = pE0[0];
+                int32_t r_ig = pig[0];
                 for (uint32_t f0 = 0; f0 < total; f0 += (uint32_t)nt * DIST_UNROLL) {
                     if (sh[1]) break;
                     uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
@@ -250,10 +256,13 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                         const uint32_t f = f0 + (uint32_t)u * nt + t;
                         bb[u] = a; dd_[u] = 0;                     // a itself is never counted: skip marker
                         if (f < total) {
-                            while (pre[p_cur + 1] <= f) ++p_cur;   // monotone: f only grows
-                            const int64_t e = pE0[p_cur] + (int64_t)(f - pre[p_cur]);
+                            if (f >= r_hi) {                       // monotone: f only grows
+                                while (pre[p_cur + 1] <= f) ++p_cur;
+                                r_lo = pre[p_cur]; r_hi = pre[p_cur + 1]; r_e0 = pE0[p_cur]; r_ig = pig[p_cur];
+                            }
+                            const int64_t e = r_e0 + (int64_t)(f - r_lo);
                             bb[u] = (uint32_t)A.entries[e];
-                            dd_[u] = (uint32_t)((int32_t)A.entry_i[e] - pig[p_cur]);
+                            dd_[u] = (uint32_t)((int32_t)A.entry_i[e] - r_ig);
                         }
                     }
                     // bucket reads of all unrolled emissions first (independent LDS reads in flight), then resolve
@@ -264,7 +273,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         const uint32_t b = bb[u];
                         const uint32_t hb = cf_mix32(b);
-                        const bool live = b != a && (P == 1 || ((cf_mix32(b ^ 0x9E3779B9u) >> 4) & (P - 1)) == pidx);
+                        const bool live = b != a && (P == 1 || (((hb * 0x9E3779B1u) >> 12) & (P - 1)) == pidx);
                         key_[u] = live ? (((unsigned long long)b << 32) | ((unsigned long long)dd_[u] << 24)) : 0ull;
                         bk_[u] = (uint32_t)(((unsigned long long)hb * (unsigned long long)n_buckets) >> 32);
                         lo_[u] = *(const cf_u64x2*)&tab[4 * bk_[u]];
@@ -315,11 +324,13 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                             bk = bk + 1 == n_buckets ? 0u : bk + 1;
                         }
                         sel = ((double)cnt / (double)total) >= A.thr;
-                        if (sel) tab[s] = v | DIST_SEL_BIT;
+                        if (sel) {
+                            tab[s] = v | DIST_SEL_BIT;
+                            const uint32_t pos = atomicAdd(&sh[8], 1u);
+                            if (pos < A.stage_cap) stage[pos] = (uint16_t)s;
+                        }
                     }
                 }
-                const unsigned long long m = __ballot(sel);
-                if (m && lane == 0) atomicAdd(&sh[8], (uint32_t)__popcll(m));
             }
             __syncthreads();
             const uint32_t n_sel = sh[8];
@@ -335,7 +346,20 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                 sh[8] = 0;
             }
             __syncthreads();
-            if (n_sel) {
+            if (n_sel && n_sel <= A.stage_cap) {
+                const unsigned long long base = ((unsigned long long)sh[10] << 32) | sh[9];
+                for (uint32_t i = t; i < n_sel; i += nt) {
+                    const unsigned long long v = tab[stage[i]];
+                    const unsigned long long o = base + i;
+                    const uint32_t b = (uint32_t)(v >> 32);
+                    if (o < A.edge_cap) {
+                        uint32_t* E = A.edges + 4 * o;
+                        E[0] = (uint32_t)(v >> 24) & 0xFFu; E[1] = a; E[2] = b; E[3] = (uint32_t)v & DIST_CNT_MASK;
+                    }
+                    const uint32_t bit = 1u << (b & 31);
+                    if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
+                }
+            } else if (n_sel) {   // more selected edges than the stage holds: sweep the table for the marked slots
                 const unsigned long long base = ((unsigned long long)sh[10] << 32) | sh[9];
                 for (uint32_t rd = 0; rd < rounds; ++rd) {
                     const uint32_t s = rd * nt + t;
@@ -451,9 +475,9 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         cf_dist_args A;
         A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = ctx->d_cloud_ptr; A.entries = ctx->d_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.entry_i = d_entry_i;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
-        A.slots = ctx->dist_slots & ~3; A.fill_limit = (uint32_t)((int64_t)ctx->dist_slots * 3 / 4);
+        A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP); A.slots = ctx->dist_slots & ~3; A.fill_limit = (uint32_t)((int64_t)ctx->dist_slots * 3 / 4);
         A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
-        const size_t lds = (size_t)A.slots * 8 + (size_t)(4 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 16) * 4 + 16;
+        const size_t lds = (size_t)A.slots * 8 + (size_t)(4 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 16) * 4 + DIST_STAGE_CAP * 2 + 16;
         if (lds > 160 * 1024) { rc = cf_fail(ctx, -22, "cf_dist_edges: LDS request exceeds 160 KiB"); break; }
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / ctx->dist_block));
         // locality order of the first k-mers: sort (first posting unit, a); k-mers without postings drop out

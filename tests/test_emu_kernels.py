@@ -45,8 +45,10 @@ def test_stage2_spill_and_partition(engine, report, oracle_stage2):
     tup = oracle_stage2("lowcov", max_distance=2)
     engine.set_param("dist_slots", 256)   # forces the (b, d) table to be split by a second hash of b
     engine.set_param("dist_block", 64)
+    engine.set_param("dist_stage", 3)     # forces the marked-slot sweep instead of the staged edge list
     pathcheck.check_stage2(engine, report("lowcov"), tup, n_parts=3, check_table=False)
     assert engine.stats()["n_spilled"] > 0
+    engine.set_param("dist_stage", 2048)
 
 
 def test_stage3_against_reference_golden(engine, report, golden):

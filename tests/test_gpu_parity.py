@@ -57,11 +57,13 @@ def test_stage3_fixture_against_reference_golden(engine, name, report, golden):
 def test_partitions_spill_and_slices(engine, report, oracle_stage2):
     # first k-mers split 3 ways (the multi-GPU partition), tiny LDS table (forces the spill path)
     engine.set_param("dist_slots", 1024)
+    engine.set_param("dist_stage", 5)
     try:
         pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov"), n_parts=3, check_table=False)
         assert engine.stats()["n_spilled"] > 0
     finally:
         engine.set_param("dist_slots", 19200)
+        engine.set_param("dist_stage", 2048)
     # --min-nreads / --max-nreads slice and --min-distance 0 (kmer_clouds[:-0] is empty) and a narrow d window
     for ov in (dict(min_nreads=3, max_nreads=11), dict(min_distance=0, max_distance=4), dict(min_distance=2, max_distance=3)):
         pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov", **ov), check_table=False)
