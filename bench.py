@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--edge-cap", type=int, default=1 << 26, help="edges stored per GPU (all are counted)")
     ap.add_argument("--cpu-sample-reads", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--place", action="store_true", help="also run stage 3 (A4 + A8/A9 placement) once and report it (N = 1)")
     ap.add_argument("--param", action="append", default=[], help="library knob name=value (cf_set_param)")
     a = ap.parse_args()
 
@@ -149,12 +150,29 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms": mean_k_ms, "pair_emissions_per_s": out["local_emissions"] / (mean_k_ms * 1e-3) if mean_k_ms else 0.0},
             "counters": {k: out[k] for k in ("n_bases", "n_windows", "n_read_kmers", "n_distinct", "n_kept", "n_rare", "n_cloud_entries",
-                                             "n_emissions", "n_edges", "n_unique", "n_spilled")},
+                                             "n_emissions", "n_edges", "n_unique", "n_spilled", "n_dist_passes")},
             "stage_ms_per_step": {k: v / max(a.steps, 1) for k, v in stage_ms.items()},
             "setup_s": {"synth": round(t_synth, 2), "load_h2d": round(t_load, 3)},
             "steps_identical": bool(same),
             "device": sr.local.device_info()["name"].strip(),
         }
+        if world == 1 and a.place:
+            # BASELINE configs[2]: cloud_contig extension on the same reads with the k-mers selected above
+            e = sr.local
+            t1 = time.perf_counter()
+            gk = sr.rare[sr.unique_mask]
+            e.set_kmers(gk, K)
+            e.build_clouds()
+            e.filter_clouds(2)
+            cls = pk.classify(50000)
+            rank = np.argsort(np.argsort(np.array(pk.ids, dtype=object), kind="stable"), kind="stable").astype(np.int32)
+            t2 = time.perf_counter()
+            rd, pos, s0, s1 = e.place_reads(cls, rank, 2, 2, 10, 3)
+            t3 = time.perf_counter()
+            res["placement"] = {"reads": int(pk.n_reads), "placed": int((pos >= 0).sum()), "none": int((pos < 0).sum()),
+                                "classes": np.bincount(cls, minlength=3).tolist(), "clouds_filter_s": t2 - t1, "place_s": t3 - t2,
+                                "place_device_ms": e.times()["place_ms"],
+                                "end_to_end_bases_per_s": n_bases / (ms_per_step * 1e-3 + (t3 - t1))}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_sample_reads, a.seed)
         else:

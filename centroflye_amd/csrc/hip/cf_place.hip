@@ -20,6 +20,8 @@
 // events).  The host only polls a done flag every few hundred iterations.
 #include "cf_common.h"
 
+#include <cstdlib>
+
 #define PL_THREADS 256
 
 struct cf_cand {
@@ -137,9 +139,12 @@ cf_place_update_kernel(cf_place_state S) {
             const unsigned long long want = (((unsigned long long)r << 32) | off) | CF_OCC;
             uint64_t h = cf_mix64(want) & S.smask;
             bool ok = false;
-            for (uint64_t probe = 0; probe <= S.smask; ++probe) {
+            for (uint64_t probe = 0; probe <= S.smask && probe < 4096; ++probe) {   // a long probe = table too full: grow and restart
                 unsigned long long cur = S.skeys[h];
-                if (cur == 0ull) cur = atomicCAS(&S.skeys[h], 0ull, want);
+                if (cur == 0ull) {
+                    cur = atomicCAS(&S.skeys[h], 0ull, want);
+                    if (cur == 0ull && atomicAdd(&S.ctl[4], 1u) > (unsigned int)(S.smask >> 1)) atomicOr(&S.ctl[2], 2u);   // load > 0.5
+                }
                 if (cur == 0ull || cur == want) { ok = true; break; }
                 h = (h + 1) & S.smask;
             }
@@ -149,7 +154,7 @@ cf_place_update_kernel(cf_place_state S) {
             const unsigned long long sk = ((((unsigned long long)h) << 24) ^ ((unsigned long long)i)) | CF_OCC;  // slot < 2^38, i < 2^24
             uint64_t hs = cf_mix64(sk) & S.seen_mask;
             bool fresh = false, placed = false;
-            for (uint64_t probe = 0; probe <= S.seen_mask; ++probe) {
+            for (uint64_t probe = 0; probe <= S.seen_mask && probe < 4096; ++probe) {
                 unsigned long long cur = S.seen[hs];
                 if (cur == 0ull) { cur = atomicCAS(&S.seen[hs], 0ull, sk); if (cur == 0ull) { fresh = true; placed = true; break; } }
                 if (cur == sk) { placed = true; break; }
@@ -344,6 +349,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         CF_HIP(hipMemsetAsync(S.seen, 0, (size_t)seen_cap * 8, st));
         CF_HIP(hipMemsetAsync(S.n_events, 0, 16, st));
         CF_HIP(hipMemsetAsync(S.ctl, 0, 8, st));  // done = 0, n_out = 0 (error flags kept)
+        CF_HIP(hipMemsetAsync(S.ctl + 4, 0, 4, st));  // score-map entry count of this stage
         hipLaunchKernelGGL(cf_place_seed_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
         CF_KERNEL_CHECK("cf_place_seed_kernel");
         unsigned int h_ctl[4] = {0, 0, 0, 0};
@@ -357,6 +363,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
                 CF_KERNEL_CHECK("placement iteration");
                 CF_HIP(hipMemcpyAsync(h_ctl, S.ctl, 16, hipMemcpyDeviceToHost, st));
                 CF_HIP(hipStreamSynchronize(st));
+                if (std::getenv("CF_DEBUG") && ((it & 8191) == 8191 || h_ctl[2] || h_ctl[0])) std::fprintf(stderr, "[cf_place] stage %d iter %lld/%lld ctl=%u,%u,%u\n", stage_cls, (long long)it, (long long)n_iter, h_ctl[0], h_ctl[1], h_ctl[2]);
                 if (h_ctl[2]) return 1;
                 if (h_ctl[0]) break;
             }
@@ -399,13 +406,14 @@ int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int3
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     const int64_t R = ctx->n_reads;
     for (int64_t r = 0; r < R; ++r) if (cls[r] > 2) return cf_fail(ctx, -22, "cf_place_reads: class must be 0, 1 or 2");
-    uint64_t score_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(64 * R, 1 << 14));
-    uint64_t seen_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(4 * ctx->n_entries, 1 << 14));
+    uint64_t score_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(256 * R, 1 << 14));
+    uint64_t seen_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(8 * ctx->n_entries, 1 << 14));
     std::vector<int64_t> o_read, o_pos;
     std::vector<int32_t> o_s0, o_s1;
     int rc = 1;
     for (int attempt = 0; attempt < 6 && rc == 1; ++attempt) {
         rc = place_attempt(ctx, cls, id_rank, min_cloud_kmer_freq, min_unit, min_inters, min_prop, score_cap, seen_cap, o_read, o_pos, o_s0, o_s1);
+        if (std::getenv("CF_DEBUG")) std::fprintf(stderr, "[cf_place] attempt %d rc=%d score_cap=%llu seen_cap=%llu entries=%lld reads=%lld\n", attempt, rc, (unsigned long long)score_cap, (unsigned long long)seen_cap, (long long)ctx->n_entries, (long long)R);
         if (rc == 1) { score_cap *= 4; seen_cap *= 4; }
     }
     if (rc == 1) return cf_fail(ctx, -34, "cf_place_reads: score tables kept overflowing");

@@ -169,4 +169,4 @@ class ShardedRecruiter:
                     n_kept=c[6], n_cloud_entries=c[7], n_rare=n_rare, n_unique=int(self.unique_mask.sum()),
                     local_emissions=st_d["n_emissions"], local_edges=n_edges, local_bases=st_local["n_bases"],
                     local_cloud_entries=n_ce_local, dist_kernel_ms=D.times()["dist_kernel_ms"],
-                    n_spilled=st_d["n_spilled"])
+                    n_spilled=st_d["n_spilled"], n_dist_passes=st_d["n_dist_passes"])
