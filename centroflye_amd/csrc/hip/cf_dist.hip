@@ -159,6 +159,34 @@ __device__ __forceinline__ void cf_dist_insert(unsigned long long* tab, uint32_t
     sh[1] = 1;   // table full (cannot happen below the fill limit)
 }
 
+// Partner ranges of the postings [c0, c0 + np) of one first k-mer -> LDS (pE0, pig) and the exclusive prefix of
+// their lengths (pre[0..np]).  Called by all threads of the workgroup.
+__device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0, int np, int64_t* pE0, int32_t* pig, uint32_t* pre) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    for (int p = t; p < np; p += nt) {
+        const int32_t g = A.post[c0 + p];
+        const int32_t jlo = g + A.min_d;
+        const int32_t jhi = min(A.unit_rend[g] - 1, g + A.max_d);
+        int64_t E0 = 0, E1 = 0;
+        if (jhi >= jlo) { E0 = A.cloud_ptr[jlo]; E1 = A.cloud_ptr[jhi + 1]; }
+        pE0[p] = E0; pig[p] = g - A.unit_rbeg[g];
+        pre[p + 1] = (uint32_t)(E1 - E0);
+    }
+    __syncthreads();
+    if (t < 64) {   // wave 0: inclusive scan of np <= DIST_NP_CAP (= 4 x 64) lengths, 4 per lane
+        uint32_t v[DIST_NP_CAP / 64], sum = 0;
+#pragma unroll
+        for (int i = 0; i < DIST_NP_CAP / 64; ++i) { const int p = t * (DIST_NP_CAP / 64) + i; v[i] = p < np ? pre[p + 1] : 0u; sum += v[i]; v[i] = sum; }
+        uint32_t inc = sum;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, (unsigned)d); if (t >= d) inc += o; }
+        const uint32_t base = inc - sum;
+#pragma unroll
+        for (int i = 0; i < DIST_NP_CAP / 64; ++i) { const int p = t * (DIST_NP_CAP / 64) + i; if (p < np) pre[p + 1] = base + v[i]; }
+        if (t == 0) pre[0] = 0;
+    }
+    __syncthreads();
+}
+
 __global__ void cf_dist_kernel(cf_dist_args A) {
     unsigned long long* tab = (unsigned long long*)cf_lds;
     int64_t* pE0 = (int64_t*)(cf_lds + (size_t)A.slots * 8);  // first partner entry of each posting
@@ -193,10 +221,15 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
         const uint32_t a = (uint32_t)A.order[ai];
         const int64_t pp0 = A.post_ptr[a], pp1 = A.post_ptr[a + 1];
         if (pp1 == pp0) continue;
-        // upper bound of the emissions of a -> initial number of partitions of its (b, d) table
+        // upper bound of the emissions of a -> initial number of partitions of its (b, d) table.
+        // Usual case (<= DIST_NP_CAP postings): the partner ranges are set up ONCE and reused by every pass.
+        const bool one_chunk = (pp1 - pp0) <= DIST_NP_CAP;
         if (t == 0) sh[7] = 0;
         __syncthreads();
-        {
+        if (one_chunk) {
+            cf_dist_setup(A, pp0, (int)(pp1 - pp0), pE0, pig, pre);
+            if (t == 0) sh[7] = pre[pp1 - pp0];
+        } else {
             unsigned long long em = 0;
             for (int64_t p = pp0 + t; p < pp1; p += nt) {
                 const int32_t g = A.post[p];
@@ -220,7 +253,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             __syncthreads();  // everyone has read the stack pointer before thread 0 pops
             if (sp_now == 0) break;
             if (t == 0) { const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[1] = 0; sh[7] = 0; sh[8] = 0; }
-            for (uint32_t s = t; s < slots; s += nt) tab[s] = 0ull;
+            { const cf_u64x2 z{0ull, 0ull}; for (uint32_t s = t; s < (slots >> 1); s += nt) ((cf_u64x2*)tab)[s] = z; }
             __syncthreads();
             const uint32_t P = sh[3], pidx = sh[4];
             uint32_t my_e = 0;
@@ -231,18 +264,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             // loads in flight per lane.
             for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
                 const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
-                for (int p = t; p < np; p += nt) {
-                    const int32_t g = A.post[c0 + p];
-                    const int32_t jlo = g + A.min_d;
-                    const int32_t jhi = min(A.unit_rend[g] - 1, g + A.max_d);
-                    int64_t E0 = 0, E1 = 0;
-                    if (jhi >= jlo) { E0 = A.cloud_ptr[jlo]; E1 = A.cloud_ptr[jhi + 1]; }
-                    pE0[p] = E0; pig[p] = g - A.unit_rbeg[g];
-                    pre[p + 1] = (uint32_t)(E1 - E0);
-                }
-                __syncthreads();
-                if (t == 0) { pre[0] = 0; for (int p = 0; p < np; ++p) pre[p + 1] += pre[p]; }
-                __syncthreads();
+                if (!one_chunk) cf_dist_setup(A, c0, np, pE0, pig, pre);
                 const uint32_t total = pre[np];
                 int p_cur = 0;
                 uint32_t r_lo = 0, r_hi = pre[1];          // flat range of posting p_cur, cached in registers

@@ -76,3 +76,28 @@ def check_stage3(engine, pk, records, alns, lens, genomic_kmers, p3, expect_line
         none = sorted(ln for ln in lines if ln.endswith(" None"))
         assert placed == expect_lines["placed"] and none == expect_lines["none"], "A9 vs reference golden"
     return lines
+
+
+def check_synthetic_clouds(engine, n_reads=3, n_units=100, cloud=6, n_kmers=40, seed=0, min_d=1, max_d=150, min_cov=2):
+    """Distance stage on hand-made clouds (cf_set_clouds): k-mer 0 sits in EVERY unit, so its posting list
+    (n_reads * n_units entries) exceeds the kernel's per-chunk posting capacity and the multi-chunk path runs."""
+    rng = np.random.default_rng(seed)
+    unit_ptr = np.arange(n_reads + 1, dtype=np.int64) * n_units
+    U = n_reads * n_units
+    ent, cp = [], [0]
+    for _ in range(U):
+        c = np.unique(np.concatenate([[0], rng.integers(1, n_kmers, cloud - 1)])).astype(np.int32)
+        ent.append(c)
+        cp.append(cp[-1] + c.size)
+    entries, cloud_ptr = np.concatenate(ent), np.array(cp, np.int64)
+    a, b, d, cnt, E = recruit.dist_histogram(unit_ptr, cloud_ptr, entries, n_kmers, 0, n_reads, min_d, max_d)
+    edges, uniq = recruit.filter_edges(a, b, d, cnt, min_cov)
+    zeros = np.zeros(U, np.int64)
+    engine.load_arrays(np.zeros(0, np.uint8), np.zeros(n_reads + 1, np.int64), unit_ptr, zeros, zeros)
+    engine.set_kmers(np.arange(n_kmers, dtype=np.uint64), 19)
+    engine.set_clouds(cloud_ptr, entries)
+    engine.reset_unique()
+    ne = engine.dist_edges(0, n_reads, min_d, max_d, min_cov, 0.8, 0, 1, edge_cap=edges.shape[0] + 8)
+    assert engine.stats()["n_emissions"] == E
+    assert np.array_equal(sorted_edges(engine.edges(ne)), edges)
+    assert np.array_equal(np.flatnonzero(engine.unique_mask()), uniq)

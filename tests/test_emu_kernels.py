@@ -51,6 +51,13 @@ def test_stage2_spill_and_partition(engine, report, oracle_stage2):
     engine.set_param("dist_stage", 2048)
 
 
+def test_long_posting_lists_take_the_multi_chunk_path(engine):
+    engine.set_param("dist_slots", 4096)
+    engine.set_param("dist_block", 128)
+    pathcheck.check_synthetic_clouds(engine)                      # 300 postings of k-mer 0 > 256 per chunk
+    pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=40, max_d=7, min_d=3, seed=5)
+
+
 def test_stage3_against_reference_golden(engine, report, golden):
     from centroflye_amd import _host
     from oracle import ncrf

@@ -69,6 +69,11 @@ def test_partitions_spill_and_slices(engine, report, oracle_stage2):
         pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov", **ov), check_table=False)
 
 
+def test_long_posting_lists_take_the_multi_chunk_path(engine):
+    pathcheck.check_synthetic_clouds(engine, n_reads=4, n_units=150, cloud=8, n_kmers=60)   # 600 postings of k-mer 0
+    pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=40, max_d=7, min_d=3, seed=5)
+
+
 def test_against_c_oracle_on_bench_like_sample(engine):
     """Same generator and parameters as the benchmark workload, at a size the C oracle finishes in
     ~20 s: every counter and the order-independent checksums of rare set, clouds and edges."""
