@@ -18,6 +18,8 @@
 //   * first k-mers partition across GPUs (a % n_parts == part) with no reduction.
 #include "cf_common.h"
 
+#include <cstdlib>
+
 void cf_free_edges(cf_ctx* c);
 int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 
@@ -114,6 +116,7 @@ struct cf_dist_args {
     int32_t slots;
     uint32_t fill_limit;
     uint32_t stage_cap;            // <= DIST_STAGE_CAP
+    uint32_t debug_mode;           // diagnostic build only: 1 = bucket reads but no atomics, 2 = no LDS work at all
     uint32_t* edges;
     unsigned long long edge_cap;
     const int32_t* order;          // first k-mers of this partition, sorted by their first posting (locality)
@@ -129,34 +132,42 @@ struct cf_dist_args {
 // home(b) and the first bucket that still has an empty slot.
 struct alignas(16) cf_u64x2 { unsigned long long x, y; };
 
+// b is a dense rank: one odd multiplier spreads it; the home bucket is the high product (two integer
+// multiplies per entry in all; the partition id is taken from other bits of the same hash)
+__device__ __forceinline__ uint32_t cf_dist_hash(uint32_t b) { return b * 0x9E3779B1u; }
 __device__ __forceinline__ uint32_t cf_dist_home(uint32_t b, uint32_t n_buckets) {
-    return (uint32_t)(((unsigned long long)cf_mix32(b) * (unsigned long long)n_buckets) >> 32);
+    return (uint32_t)(((unsigned long long)cf_dist_hash(b) * (unsigned long long)n_buckets) >> 32);
 }
 // index (0..3) of the slot of bucket v that holds key (ignoring count and flag bits), or -1
+__device__ __forceinline__ bool cf_slot_is(unsigned long long v, uint32_t b, uint32_t dd) {
+    return (uint32_t)(v >> 32) == b && ((uint32_t)v >> 24) == dd;   // two 32-bit compares (dd >= 1, so an empty slot never matches)
+}
 __device__ __forceinline__ int cf_bucket_match(const cf_u64x2& lo, const cf_u64x2& hi, unsigned long long key24) {
-    return (lo.x >> 24) == key24 ? 0 : (lo.y >> 24) == key24 ? 1 : (hi.x >> 24) == key24 ? 2 : (hi.y >> 24) == key24 ? 3 : -1;
+    const uint32_t b = (uint32_t)(key24 >> 8), dd = (uint32_t)key24 & 0xFFu;
+    return cf_slot_is(lo.x, b, dd) ? 0 : cf_slot_is(lo.y, b, dd) ? 1 : cf_slot_is(hi.x, b, dd) ? 2 : cf_slot_is(hi.y, b, dd) ? 3 : -1;
 }
 __device__ __forceinline__ int cf_bucket_empty(const cf_u64x2& lo, const cf_u64x2& hi) {
     return lo.x == 0ull ? 0 : lo.y == 0ull ? 1 : hi.x == 0ull ? 2 : hi.y == 0ull ? 3 : -1;
 }
 // general insert: walk buckets from bk; claims an empty slot with a CAS when the key is absent
-__device__ __forceinline__ void cf_dist_insert(unsigned long long* tab, uint32_t n_buckets, uint32_t bk, unsigned long long key,
-                                               uint32_t* sh, uint32_t fill_limit) {
+__device__ __forceinline__ uint32_t cf_dist_insert(unsigned long long* tab, uint32_t n_buckets, uint32_t bk, unsigned long long key,
+                                                   uint32_t* sh) {
     const unsigned long long key24 = key >> 24;
     for (uint32_t tries = 0; tries < 5 * n_buckets; ++tries) {
         const cf_u64x2 lo = *(const cf_u64x2*)&tab[4 * bk], hi = *(const cf_u64x2*)&tab[4 * bk + 2];
         const int m = cf_bucket_match(lo, hi, key24);
-        if (m >= 0) { atomicAdd(&tab[4 * bk + m], 1ull); return; }
+        if (m >= 0) { atomicAdd(&tab[4 * bk + m], 1ull); return 0u; }
         const int e = cf_bucket_empty(lo, hi);
         if (e >= 0) {
             const unsigned long long old = atomicCAS(&tab[4 * bk + e], 0ull, key | 1ull);
-            if (old == 0ull) { if (atomicAdd(&sh[0], 1u) >= fill_limit) sh[1] = 1; return; }
-            if ((old >> 24) == key24) { atomicAdd(&tab[4 * bk + e], 1ull); return; }
+            if (old == 0ull) return 1u;
+            if ((old >> 24) == key24) { atomicAdd(&tab[4 * bk + e], 1ull); return 0u; }
             continue;   // another key took the slot: look at the same bucket again
         }
         bk = bk + 1 == n_buckets ? 0u : bk + 1;
     }
-    sh[1] = 1;   // table full (cannot happen below the fill limit)
+    sh[1] = 1;   // table physically full: the pass is void and will be split
+    return 0u;
 }
 
 // Partner ranges of the postings [c0, c0 + np) of one first k-mer -> LDS (pE0, pig) and the exclusive prefix of
@@ -187,6 +198,19 @@ __device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0,
     __syncthreads();
 }
 
+// Diagnostic build only (-DCF_DIST_STAMPS, tools/dist_stamps.py): per-phase shader-clock sums of thread 0 of every
+// workgroup into counters[8..15]; the shipped library compiles these to nothing.
+#if defined(CF_DIST_STAMPS)
+#define CF_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_t; stamp_t = now_; } } while (0)
+#else
+#define CF_STAMP(i) do { } while (0)
+#endif
+#if defined(CF_DIST_STAMPS)
+#define CF_SUB(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sub_acc[i] += now_ - sub_t; sub_t = now_; } } while (0)
+#else
+#define CF_SUB(i) do { } while (0)
+#endif
+
 __global__ void cf_dist_kernel(cf_dist_args A) {
     unsigned long long* tab = (unsigned long long*)cf_lds;
     int64_t* pE0 = (int64_t*)(cf_lds + (size_t)A.slots * 8);  // first partner entry of each posting
@@ -198,6 +222,10 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots >> 2;   // slots is a multiple of 4
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
+#if defined(CF_DIST_STAMPS)
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_amdgcn_s_memtime();
+    unsigned long long sub_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sub_t = stamp_t;
+#endif
 
     while (true) {
         __syncthreads();
@@ -218,6 +246,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
         __syncthreads();
         const int64_t ai = (int64_t)(((unsigned long long)sh[6] << 32) | sh[5]);
         if (ai < 0) break;
+        CF_STAMP(0);   // queue pop
         const uint32_t a = (uint32_t)A.order[ai];
         const int64_t pp0 = A.post_ptr[a], pp1 = A.post_ptr[a + 1];
         if (pp1 == pp0) continue;
@@ -246,8 +275,10 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             for (uint32_t i = 0; i < P0; ++i) { stack[2 * i] = P0; stack[2 * i + 1] = i; }
             sh[2] = P0;
         }
+        CF_STAMP(1);   // prologue: posting ranges, estimate
         bool spilled = false;
         while (true) {
+            CF_STAMP(5);   // reserve + write edges of the previous pass
             __syncthreads();
             const uint32_t sp_now = sh[2];
             __syncthreads();  // everyone has read the stack pointer before thread 0 pops
@@ -257,6 +288,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             __syncthreads();
             const uint32_t P = sh[3], pidx = sh[4];
             uint32_t my_e = 0;
+            CF_STAMP(2);   // pop partition + clear table
             // ---- stream the partner clouds of every posting of a, in chunks of DIST_NP_CAP postings.
             // The units g+min_d .. min(read end, g+max_d) of a posting are ONE contiguous range of the
             // CSR; the ranges of all postings are concatenated into a flat index space that all threads
@@ -265,28 +297,46 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
                 const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
                 if (!one_chunk) cf_dist_setup(A, c0, np, pE0, pig, pre);
+                if (t == 0) sh[11] = 0;   // shared cursor over the flat entry range of this chunk
+                __syncthreads();
                 const uint32_t total = pre[np];
                 int p_cur = 0;
                 uint32_t r_lo = 0, r_hi = pre[1];          // flat range of posting p_cur, cached in registers
                 int64_t r_e0 = pE0[0];
                 int32_t r_ig = pig[0];
-                for (uint32_t f0 = 0; f0 < total; f0 += (uint32_t)nt * DIST_UNROLL) {
-                    if (sh[1]) break;
+                // software pipeline: the global loads of step i+1 are issued before the LDS work of step i, so
+                // the 16 waves of the workgroup do not alternate between "all waiting on HBM/L2" and "all on LDS"
+                uint32_t nb_[DIST_UNROLL], nd_[DIST_UNROLL];
+#define CF_DIST_FETCH(F0)                                                                                     \
+                _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) {                                     \
+                    const uint32_t f = (F0) + (uint32_t)u * 64u + (uint32_t)lane;                             \
+                    nb_[u] = a; nd_[u] = 0;              /* a itself is never counted: skip marker */         \
+                    if (f < total) {                                                                          \
+                        if (f >= r_hi) {                 /* monotone: f only grows */                         \
+                            while (pre[p_cur + 1] <= f) ++p_cur;                                              \
+                            r_lo = pre[p_cur]; r_hi = pre[p_cur + 1]; r_e0 = pE0[p_cur]; r_ig = pig[p_cur];   \
+                        }                                                                                     \
+                        const int64_t e = r_e0 + (int64_t)(f - r_lo);                                         \
+                        nb_[u] = (uint32_t)A.entries[e];                                                      \
+                        nd_[u] = (uint32_t)((int32_t)A.entry_i[e] - r_ig);                                    \
+                    }                                                                                         \
+                }
+                // waves pull 64 x DIST_UNROLL consecutive flat entries at a time from a shared cursor: the cost of
+                // an entry varies (new key, full bucket), a static split leaves waves idle at the closing barrier
+#define CF_DIST_GRAB(VAR) { uint32_t g_ = 0; if (lane == 0) g_ = atomicAdd(&sh[11], 64u * DIST_UNROLL); VAR = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_); }
+                uint32_t f0, f1;
+                CF_DIST_GRAB(f0)
+                if (f0 < total) { CF_DIST_FETCH(f0) }
+                while (f0 < total) {
+                    if (sh[1] || sh[0] > A.fill_limit) break;
+                    CF_SUB(0);   // (outside the step) / loop top
                     uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) {
-                        const uint32_t f = f0 + (uint32_t)u * nt + t;
-                        bb[u] = a; dd_[u] = 0;                     // a itself is never counted: skip marker
-                        if (f < total) {
-                            if (f >= r_hi) {                       // monotone: f only grows
-                                while (pre[p_cur + 1] <= f) ++p_cur;
-                                r_lo = pre[p_cur]; r_hi = pre[p_cur + 1]; r_e0 = pE0[p_cur]; r_ig = pig[p_cur];
-                            }
-                            const int64_t e = r_e0 + (int64_t)(f - r_lo);
-                            bb[u] = (uint32_t)A.entries[e];
-                            dd_[u] = (uint32_t)((int32_t)A.entry_i[e] - r_ig);
-                        }
-                    }
+                    for (int u = 0; u < DIST_UNROLL; ++u) { bb[u] = nb_[u]; dd_[u] = nd_[u]; }
+                    CF_DIST_GRAB(f1)
+                    if (f1 < total) { CF_DIST_FETCH(f1) }
+                    f0 = f1;
+                    CF_SUB(1);   // take the prefetched entries, issue the next loads
                     // bucket reads of all unrolled emissions first (independent LDS reads in flight), then resolve
                     unsigned long long key_[DIST_UNROLL];
                     uint32_t bk_[DIST_UNROLL];
@@ -294,25 +344,61 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         const uint32_t b = bb[u];
-                        const uint32_t hb = cf_mix32(b);
-                        const bool live = b != a && (P == 1 || (((hb * 0x9E3779B1u) >> 12) & (P - 1)) == pidx);
+                        const uint32_t hb = cf_dist_hash(b);
+                        const bool live = b != a && (P == 1 || (((hb ^ (hb >> 15)) >> 3) & (P - 1)) == pidx);
                         key_[u] = live ? (((unsigned long long)b << 32) | ((unsigned long long)dd_[u] << 24)) : 0ull;
                         bk_[u] = (uint32_t)(((unsigned long long)hb * (unsigned long long)n_buckets) >> 32);
+#if defined(CF_DIST_STAMPS)
+                        if (A.debug_mode == 2) { lo_[u].x = lo_[u].y = hi_[u].x = key_[u]; hi_[u].y = bk_[u]; continue; }
+#endif
                         lo_[u] = *(const cf_u64x2*)&tab[4 * bk_[u]];
                         hi_[u] = *(const cf_u64x2*)&tab[4 * bk_[u] + 2];
                     }
+                    // resolve in three straight-line rounds so that one wave exposes ONE LDS round trip per round
+                    // instead of one per emission: (1) matches -> fire-and-forget adds, new keys -> pick the first
+                    // empty slot of the bucket already in registers; (2) all CASes of the step issued back to back;
+                    // (3) the rare leftovers (bucket full, slot lost to another key) take the general path.
+                    uint32_t fresh = 0;   // bit u: emission u created a new key
+                    int cand_[DIST_UNROLL];   // -1 done / not live, 0..3 slot to claim, 4 bucket full
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
+                        cand_[u] = -1;
                         if (key_[u] == 0ull) continue;
                         ++my_e;
                         const int m = cf_bucket_match(lo_[u], hi_[u], key_[u] >> 24);
+#if defined(CF_DIST_STAMPS)
+                        if (A.debug_mode) { my_e += (uint32_t)m & 1u; continue; }   // timing experiments: results are wrong on purpose
+#endif
                         if (m >= 0) atomicAdd(&tab[4 * bk_[u] + m], 1ull);          // common case: the pair was seen before
-                        else cf_dist_insert(tab, n_buckets, bk_[u], key_[u], sh, A.fill_limit);
+                        else { const int e = cf_bucket_empty(lo_[u], hi_[u]); cand_[u] = e >= 0 ? e : 4; }
                     }
+                    CF_SUB(2);   // bucket reads + match + fire-and-forget adds
+                    unsigned long long old_[DIST_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < DIST_UNROLL; ++u) {
+                        old_[u] = 1ull;
+                        if (cand_[u] >= 0 && cand_[u] < 4) old_[u] = atomicCAS(&tab[4 * bk_[u] + cand_[u]], 0ull, key_[u] | 1ull);
+                    }
+                    CF_SUB(3);   // CAS round issued
+#pragma unroll
+                    for (int u = 0; u < DIST_UNROLL; ++u) {
+                        if (cand_[u] < 0) continue;
+                        if (cand_[u] < 4 && old_[u] == 0ull) fresh |= 1u << u;                                   // claimed
+                        else if (cand_[u] < 4 && (old_[u] >> 24) == (key_[u] >> 24)) atomicAdd(&tab[4 * bk_[u] + cand_[u]], 1ull);  // lost the race to the same key
+                        else fresh |= cf_dist_insert(tab, n_buckets, cand_[u] < 4 ? bk_[u] : (bk_[u] + 1 == n_buckets ? 0u : bk_[u] + 1), key_[u], sh) << u;
+                    }
+                    CF_SUB(4);   // CAS results + general path
+                    // fill level: one fire-and-forget LDS atomic per wave and step; read back at the next step
+                    uint32_t wave_new = 0;
+#pragma unroll
+                    for (int u = 0; u < DIST_UNROLL; ++u) wave_new += (uint32_t)__popcll(__ballot((fresh >> u) & 1u));
+                    if (wave_new && lane == 0) atomicAdd(&sh[0], wave_new);
+                    CF_SUB(5);   // ballots
                 }
                 __syncthreads();
             }
-            if (sh[1]) {  // overflow: split this partition in two
+            CF_STAMP(3);   // stream + insert
+            if (sh[1] || sh[0] > A.fill_limit) {  // overflow: split this partition in two
                 if (t == 0) {
                     uint32_t sp = sh[2];
                     if (P >= (1u << 20) || sp + 2 > DIST_STACK) { atomicOr(&A.counters[4], 1ull); }
@@ -355,6 +441,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                 }
             }
             __syncthreads();
+            CF_STAMP(4);   // filter pass 1
             const uint32_t n_sel = sh[8];
             __syncthreads();  // everyone has read the count before thread 0 reuses the word as a cursor
             if (t == 0) {
@@ -413,6 +500,10 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
         if (acc_E) atomicAdd(&A.counters[1], acc_E);
         if (acc_spill) atomicAdd(&A.counters[2], acc_spill);
         if (acc_pass) atomicAdd(&A.counters[5], acc_pass);
+#if defined(CF_DIST_STAMPS)
+        for (int i = 0; i < 8; ++i) atomicAdd(&A.counters[8 + i], stamp_acc[i]);
+        for (int i = 0; i < 6; ++i) atomicAdd(&A.counters[152 - 8 + i], sub_acc[i]);
+#endif
     }
 }
 
@@ -497,7 +588,11 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         cf_dist_args A;
         A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = ctx->d_cloud_ptr; A.entries = ctx->d_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.entry_i = d_entry_i;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
-        A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP); A.slots = ctx->dist_slots & ~3; A.fill_limit = (uint32_t)((int64_t)ctx->dist_slots * 3 / 4);
+        A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP); A.debug_mode = 0;
+#if defined(CF_DIST_STAMPS)
+        if (std::getenv("CF_DIST_DEBUG")) A.debug_mode = (uint32_t)std::atoi(std::getenv("CF_DIST_DEBUG"));
+#endif
+        A.slots = ctx->dist_slots & ~3; A.fill_limit = (uint32_t)((int64_t)ctx->dist_slots * ctx->dist_fill_pct / 100);   // checked once per wave step: leave slack below the physical size
         A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
         const size_t lds = (size_t)A.slots * 8 + (size_t)(4 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 16) * 4 + DIST_STAGE_CAP * 2 + 16;
         if (lds > 160 * 1024) { rc = cf_fail(ctx, -22, "cf_dist_edges: LDS request exceeds 160 KiB"); break; }
@@ -536,6 +631,16 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
         if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_dist_edges: ") + hipGetErrorString(e)); break; }
+#if defined(CF_DIST_STAMPS)
+        {
+            unsigned long long st[8], sb[6];
+            if (hipMemcpy(sb, d_cnt + 144, 48, hipMemcpyDeviceToHost) == hipSuccess)
+                std::fprintf(stderr, "[cf_dist substamps] outside=%llu take+prefetch=%llu read+match=%llu cas_issue=%llu cas_result+general=%llu ballots=%llu\n", sb[0], sb[1], sb[2], sb[3], sb[4], sb[5]);
+            if (hipMemcpy(st, d_cnt + 8, 64, hipMemcpyDeviceToHost) == hipSuccess)
+                std::fprintf(stderr, "[cf_dist stamps] pop=%llu prologue=%llu clear=%llu stream=%llu filter=%llu write=%llu (shader cycles summed over %d workgroups; passes=%llu)\n",
+                             st[0], st[1], st[2], st[3], st[4], st[5], grid, h_cnt[5]);
+        }
+#endif
         if (h_cnt[4]) { rc = cf_fail(ctx, -34, "cf_dist_edges: (b,d) table could not be partitioned far enough"); break; }
         (void)hipEventElapsedTime(&ctx->times.dist_ms, ctx->ev0, ctx->ev1);
         (void)hipEventElapsedTime(&ctx->times.postings_ms, ctx->ev0, ctx->ev2);
