@@ -380,12 +380,25 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                         if (cand_[u] >= 0 && cand_[u] < 4) old_[u] = atomicCAS(&tab[4 * bk_[u] + cand_[u]], 0ull, key_[u] | 1ull);
                     }
                     CF_SUB(3);   // CAS round issued
+                    uint32_t failm = 0;   // bit u: bucket full or slot lost to another key -> general path
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         if (cand_[u] < 0) continue;
                         if (cand_[u] < 4 && old_[u] == 0ull) fresh |= 1u << u;                                   // claimed
                         else if (cand_[u] < 4 && (old_[u] >> 24) == (key_[u] >> 24)) atomicAdd(&tab[4 * bk_[u] + cand_[u]], 1ull);  // lost the race to the same key
-                        else fresh |= cf_dist_insert(tab, n_buckets, cand_[u] < 4 ? bk_[u] : (bk_[u] + 1 == n_buckets ? 0u : bk_[u] + 1), key_[u], sh) << u;
+                        else { failm |= 1u << u; if (cand_[u] == 4) bk_[u] = bk_[u] + 1 == n_buckets ? 0u : bk_[u] + 1; }
+                    }
+                    // leftovers: every lane works on ONE of its own leftovers per round, so the wave runs the general
+                    // probe loop max-over-lanes(#leftovers) times instead of once per unroll slot
+                    while (__any(failm != 0u)) {
+                        if (failm != 0u) {
+                            const int u = __ffs((int)failm) - 1;
+                            failm &= failm - 1u;
+                            unsigned long long kk = key_[0]; uint32_t kb = bk_[0];
+#pragma unroll
+                            for (int v = 1; v < DIST_UNROLL; ++v) if (u == v) { kk = key_[v]; kb = bk_[v]; }
+                            fresh |= cf_dist_insert(tab, n_buckets, kb, kk, sh) << u;
+                        }
                     }
                     CF_SUB(4);   // CAS results + general path
                     // fill level: one fire-and-forget LDS atomic per wave and step; read back at the next step
