@@ -63,7 +63,7 @@ def cpu_baseline(sample_reads, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=50000, help="reads per GPU")
     ap.add_argument("--seed", type=int, default=2)

@@ -254,6 +254,8 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "dist_slots") {
         if (value < 256 || value > 19200) return cf_fail(ctx, -22, "dist_slots out of range (256 .. 19200: table + work lists must fit the 160 KiB LDS)");
         ctx->dist_slots = (int)value;
+    } else if (n == "dist_wide") {
+        ctx->dist_wide = value != 0;
     } else if (n == "dist_fill_pct") {
         if (value < 10 || value > 90) return cf_fail(ctx, -22, "dist_fill_pct out of range (10 .. 90)");
         ctx->dist_fill_pct = (int)value;

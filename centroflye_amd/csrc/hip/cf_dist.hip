@@ -116,7 +116,6 @@ struct cf_dist_args {
     int32_t slots;
     uint32_t fill_limit;
     uint32_t stage_cap;            // <= DIST_STAGE_CAP
-    uint32_t debug_mode;           // diagnostic build only: 1 = bucket reads but no atomics, 2 = no LDS work at all
     uint32_t* edges;
     unsigned long long edge_cap;
     const int32_t* order;          // first k-mers of this partition, sorted by their first posting (locality)
@@ -125,43 +124,145 @@ struct cf_dist_args {
     uint32_t* unique_bits;
 };
 
-// The (b, d) table is organised in buckets of 4 x 64-bit slots (32 B, two ds_read_b128): a probe
-// inspects a whole bucket with straight-line code, so a wave does not iterate a per-lane probe loop
-// in the common case.  A key lives in the first bucket, starting at home(b), that held a match or an
-// empty slot when it was inserted; buckets never lose entries, so every (b, .) key sits between
-// home(b) and the first bucket that still has an empty slot.
+// ---------------------------------------------------------------------------------------------------
+// The (b, d) table lives in LDS and is organised in 32-byte buckets read with two ds_read_b128: a probe
+// inspects a whole bucket with straight-line code, so a wave does not run a per-lane probe loop in the
+// common case.  A key lives in the first bucket, starting at home(b), that held a match or an empty slot
+// when it was inserted; slots of a bucket fill in ascending order and never empty, so every (b, .) key sits
+// between home(b) and the first bucket that still has an empty slot, and a key is never inserted twice.
+// Two layouts with one interface:
+//   cf_tab_wide    4 slots of 64 bits  [b:32 | d:8 | sel:1 | cnt:23]            any k-mer set size
+//   cf_tab_narrow  8 keys of 32 bits   [d:8 | b:24] + 8 x 16-bit [sel:1 | cnt:15]  (6 bytes per slot: a third
+//                  more slots in the same LDS, half as many full buckets, 32-bit compares) when the set has
+//                  < 2^24 - 1 k-mers and no k-mer has more than 32767 postings
+// b is a dense rank, so one odd multiplier spreads it; the home bucket is the high product.
 struct alignas(16) cf_u64x2 { unsigned long long x, y; };
+struct alignas(16) cf_u32x4 { uint32_t x, y, z, w; };
 
-// b is a dense rank: one odd multiplier spreads it; the home bucket is the high product (two integer
-// multiplies per entry in all; the partition id is taken from other bits of the same hash)
 __device__ __forceinline__ uint32_t cf_dist_hash(uint32_t b) { return b * 0x9E3779B1u; }
 __device__ __forceinline__ uint32_t cf_dist_home(uint32_t b, uint32_t n_buckets) {
     return (uint32_t)(((unsigned long long)cf_dist_hash(b) * (unsigned long long)n_buckets) >> 32);
 }
-// index (0..3) of the slot of bucket v that holds key (ignoring count and flag bits), or -1
-__device__ __forceinline__ bool cf_slot_is(unsigned long long v, uint32_t b, uint32_t dd) {
-    return (uint32_t)(v >> 32) == b && ((uint32_t)v >> 24) == dd;   // two 32-bit compares (dd >= 1, so an empty slot never matches)
-}
-__device__ __forceinline__ int cf_bucket_match(const cf_u64x2& lo, const cf_u64x2& hi, unsigned long long key24) {
-    const uint32_t b = (uint32_t)(key24 >> 8), dd = (uint32_t)key24 & 0xFFu;
-    return cf_slot_is(lo.x, b, dd) ? 0 : cf_slot_is(lo.y, b, dd) ? 1 : cf_slot_is(hi.x, b, dd) ? 2 : cf_slot_is(hi.y, b, dd) ? 3 : -1;
-}
-__device__ __forceinline__ int cf_bucket_empty(const cf_u64x2& lo, const cf_u64x2& hi) {
-    return lo.x == 0ull ? 0 : lo.y == 0ull ? 1 : hi.x == 0ull ? 2 : hi.y == 0ull ? 3 : -1;
-}
-// general insert: walk buckets from bk; claims an empty slot with a CAS when the key is absent
-__device__ __forceinline__ uint32_t cf_dist_insert(unsigned long long* tab, uint32_t n_buckets, uint32_t bk, unsigned long long key,
-                                                   uint32_t* sh) {
-    const unsigned long long key24 = key >> 24;
-    for (uint32_t tries = 0; tries < 5 * n_buckets; ++tries) {
-        const cf_u64x2 lo = *(const cf_u64x2*)&tab[4 * bk], hi = *(const cf_u64x2*)&tab[4 * bk + 2];
-        const int m = cf_bucket_match(lo, hi, key24);
-        if (m >= 0) { atomicAdd(&tab[4 * bk + m], 1ull); return 0u; }
-        const int e = cf_bucket_empty(lo, hi);
+
+struct cf_tab_wide {
+    static constexpr uint32_t kSlotBytes = 8, kPerBucket = 4;
+    struct bucket { cf_u64x2 lo, hi; };
+    unsigned long long* tab;
+    __device__ __forceinline__ void init(unsigned char* lds, uint32_t) { tab = (unsigned long long*)lds; }
+    __device__ __forceinline__ void clear(uint32_t slots, uint32_t t, uint32_t nt) const {
+        const cf_u64x2 z{0ull, 0ull};
+        for (uint32_t s = t; s < (slots >> 1); s += nt) ((cf_u64x2*)tab)[s] = z;
+    }
+    __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u64x2*)&tab[4 * bk], *(const cf_u64x2*)&tab[4 * bk + 2]}; }
+    static __device__ __forceinline__ bool is(unsigned long long v, uint32_t b, uint32_t dd) { return (uint32_t)(v >> 32) == b && ((uint32_t)v >> 24) == dd; }
+    static __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) {   // dd >= 1: an empty slot never matches
+        return is(k.lo.x, b, dd) ? 0 : is(k.lo.y, b, dd) ? 1 : is(k.hi.x, b, dd) ? 2 : is(k.hi.y, b, dd) ? 3 : -1;
+    }
+    static __device__ __forceinline__ int empty(const bucket& k) { return k.lo.x == 0ull ? 0 : k.lo.y == 0ull ? 1 : k.hi.x == 0ull ? 2 : k.hi.y == 0ull ? 3 : -1; }
+    __device__ __forceinline__ void add(uint32_t bk, int i) const { atomicAdd(&tab[4 * bk + i], 1ull); }
+    // claim slot i of bucket bk for (b, dd): 0 = claimed (count 1), 1 = the same key got there first (counted), 2 = another key
+    __device__ __forceinline__ unsigned long long claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const {
+        return atomicCAS(&tab[4 * bk + i], 0ull, ((unsigned long long)b << 32) | ((unsigned long long)dd << 24) | 1ull);
+    }
+    __device__ __forceinline__ int claim_finish(unsigned long long old, uint32_t bk, int i, uint32_t b, uint32_t dd) const {
+        if (old == 0ull) return 0;
+        if (is(old, b, dd)) { add(bk, i); return 1; }
+        return 2;
+    }
+    // filter side: slot s -> (b, dd, cnt) or false when empty
+    __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
+        const unsigned long long v = tab[s];
+        b = (uint32_t)(v >> 32); dd = ((uint32_t)v >> 24) & 0xFFu; cnt = (uint32_t)v & 0x7FFFFFu;
+        return v != 0ull;
+    }
+    __device__ __forceinline__ unsigned long long total_of(uint32_t b, uint32_t n_buckets) const {
+        unsigned long long total = 0;
+        uint32_t bk = cf_dist_home(b, n_buckets);
+        for (uint32_t probe = 0; probe < n_buckets; ++probe) {
+            const bucket k = read(bk);
+            if ((uint32_t)(k.lo.x >> 32) == b && k.lo.x) total += k.lo.x & 0x7FFFFFull;
+            if ((uint32_t)(k.lo.y >> 32) == b && k.lo.y) total += k.lo.y & 0x7FFFFFull;
+            if ((uint32_t)(k.hi.x >> 32) == b && k.hi.x) total += k.hi.x & 0x7FFFFFull;
+            if ((uint32_t)(k.hi.y >> 32) == b && k.hi.y) total += k.hi.y & 0x7FFFFFull;
+            if (empty(k) >= 0) break;
+            bk = bk + 1 == n_buckets ? 0u : bk + 1;
+        }
+        return total;
+    }
+    __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&tab[s], 1ull << 23); }
+    __device__ __forceinline__ bool marked(uint32_t s) const { return (tab[s] >> 23) & 1ull; }
+};
+
+struct cf_tab_narrow {
+    static constexpr uint32_t kSlotBytes = 6, kPerBucket = 8;
+    static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+    struct bucket { cf_u32x4 lo, hi; };
+    uint32_t* keys;     // slots x 32-bit [d:8 | b:24]
+    uint32_t* cnt32;    // slots x 16-bit counts, two per word
+    __device__ __forceinline__ void init(unsigned char* lds, uint32_t slots) { keys = (uint32_t*)lds; cnt32 = keys + slots; }
+    __device__ __forceinline__ void clear(uint32_t slots, uint32_t t, uint32_t nt) const {
+        const cf_u32x4 e{kEmpty, kEmpty, kEmpty, kEmpty}, z{0u, 0u, 0u, 0u};
+        for (uint32_t s = t; s < (slots >> 2); s += nt) ((cf_u32x4*)keys)[s] = e;
+        for (uint32_t s = t; s < (slots >> 3); s += nt) ((cf_u32x4*)cnt32)[s] = z;
+    }
+    __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u32x4*)&keys[8 * bk], *(const cf_u32x4*)&keys[8 * bk + 4]}; }
+    static __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) { return (dd << 24) | b; }
+    static __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) {
+        const uint32_t q = key_of(b, dd);
+        return k.lo.x == q ? 0 : k.lo.y == q ? 1 : k.lo.z == q ? 2 : k.lo.w == q ? 3 : k.hi.x == q ? 4 : k.hi.y == q ? 5 : k.hi.z == q ? 6 : k.hi.w == q ? 7 : -1;
+    }
+    static __device__ __forceinline__ int empty(const bucket& k) {
+        return k.lo.x == kEmpty ? 0 : k.lo.y == kEmpty ? 1 : k.lo.z == kEmpty ? 2 : k.lo.w == kEmpty ? 3
+             : k.hi.x == kEmpty ? 4 : k.hi.y == kEmpty ? 5 : k.hi.z == kEmpty ? 6 : k.hi.w == kEmpty ? 7 : -1;
+    }
+    __device__ __forceinline__ void add(uint32_t bk, int i) const { const uint32_t s = 8 * bk + (uint32_t)i; atomicAdd(&cnt32[s >> 1], 1u << ((s & 1u) * 16u)); }
+    __device__ __forceinline__ uint32_t claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const { return atomicCAS(&keys[8 * bk + i], kEmpty, key_of(b, dd)); }
+    __device__ __forceinline__ int claim_finish(uint32_t old, uint32_t bk, int i, uint32_t b, uint32_t dd) const {
+        if (old == kEmpty) { add(bk, i); return 0; }
+        if (old == key_of(b, dd)) { add(bk, i); return 1; }
+        return 2;
+    }
+    __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
+        const uint32_t q = keys[s];
+        b = q & 0xFFFFFFu; dd = q >> 24; cnt = (cnt32[s >> 1] >> ((s & 1u) * 16u)) & 0x7FFFu;
+        return q != kEmpty;
+    }
+    __device__ __forceinline__ unsigned long long total_of(uint32_t b, uint32_t n_buckets) const {
+        unsigned long long total = 0;
+        uint32_t bk = cf_dist_home(b, n_buckets);
+        for (uint32_t probe = 0; probe < n_buckets; ++probe) {
+            const bucket k = read(bk);
+            const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];   // the 8 counts of the bucket
+            if ((k.lo.x & 0xFFFFFFu) == b && k.lo.x != kEmpty) total += c.x & 0x7FFFu;
+            if ((k.lo.y & 0xFFFFFFu) == b && k.lo.y != kEmpty) total += (c.x >> 16) & 0x7FFFu;
+            if ((k.lo.z & 0xFFFFFFu) == b && k.lo.z != kEmpty) total += c.y & 0x7FFFu;
+            if ((k.lo.w & 0xFFFFFFu) == b && k.lo.w != kEmpty) total += (c.y >> 16) & 0x7FFFu;
+            if ((k.hi.x & 0xFFFFFFu) == b && k.hi.x != kEmpty) total += c.z & 0x7FFFu;
+            if ((k.hi.y & 0xFFFFFFu) == b && k.hi.y != kEmpty) total += (c.z >> 16) & 0x7FFFu;
+            if ((k.hi.z & 0xFFFFFFu) == b && k.hi.z != kEmpty) total += c.w & 0x7FFFu;
+            if ((k.hi.w & 0xFFFFFFu) == b && k.hi.w != kEmpty) total += (c.w >> 16) & 0x7FFFu;
+            if (empty(k) >= 0) break;
+            bk = bk + 1 == n_buckets ? 0u : bk + 1;
+        }
+        return total;
+    }
+    __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&cnt32[s >> 1], 0x8000u << ((s & 1u) * 16u)); }
+    __device__ __forceinline__ bool marked(uint32_t s) const { return (cnt32[s >> 1] >> ((s & 1u) * 16u + 15u)) & 1u; }
+};
+
+// general insert: walk buckets from bk; claims the first empty slot with a CAS when the key is absent.
+// Returns 1 when a new key was created.
+template <class Tab>
+__device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buckets, uint32_t bk, uint32_t b, uint32_t dd, uint32_t* sh) {
+    for (uint32_t tries = 0; tries < 9 * n_buckets; ++tries) {
+        const typename Tab::bucket k = T.read(bk);
+        const int m = Tab::match(k, b, dd);
+        if (m >= 0) { T.add(bk, m); return 0u; }
+        const int e = Tab::empty(k);
         if (e >= 0) {
-            const unsigned long long old = atomicCAS(&tab[4 * bk + e], 0ull, key | 1ull);
-            if (old == 0ull) return 1u;
-            if ((old >> 24) == key24) { atomicAdd(&tab[4 * bk + e], 1ull); return 0u; }
+            const int st = T.claim_finish(T.claim_issue(bk, e, b, dd), bk, e, b, dd);
+            if (st == 0) return 1u;
+            if (st == 1) return 0u;
             continue;   // another key took the slot: look at the same bucket again
         }
         bk = bk + 1 == n_buckets ? 0u : bk + 1;
@@ -205,26 +306,22 @@ __device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0,
 #else
 #define CF_STAMP(i) do { } while (0)
 #endif
-#if defined(CF_DIST_STAMPS)
-#define CF_SUB(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sub_acc[i] += now_ - sub_t; sub_t = now_; } } while (0)
-#else
-#define CF_SUB(i) do { } while (0)
-#endif
 
+template <class Tab>
 __global__ void cf_dist_kernel(cf_dist_args A) {
-    unsigned long long* tab = (unsigned long long*)cf_lds;
-    int64_t* pE0 = (int64_t*)(cf_lds + (size_t)A.slots * 8);  // first partner entry of each posting
+    Tab T;
+    T.init(cf_lds, (uint32_t)A.slots);
+    int64_t* pE0 = (int64_t*)(cf_lds + (size_t)A.slots * Tab::kSlotBytes);  // first partner entry of each posting
     int32_t* pig = (int32_t*)(pE0 + DIST_NP_CAP);              // unit index of the posting inside its read
     uint32_t* pre = (uint32_t*)(pig + DIST_NP_CAP);            // prefix of partner-entry counts (NP_CAP + 1)
     uint32_t* stack = pre + DIST_NP_CAP + 1;                   // (P, idx) pairs
-    uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] n_used [1] overflow [2] sp [3] P [4] idx [5] a_idx lo [6] a_idx hi [7] E of leaf
+    uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] keys in table [1] overflow [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] stream cursor
     uint16_t* stage = (uint16_t*)(sh + 16);                    // slot indices of the selected edges of a pass
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
-    const uint32_t slots = (uint32_t)A.slots, n_buckets = slots >> 2;   // slots is a multiple of 4
+    const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
 #if defined(CF_DIST_STAMPS)
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_amdgcn_s_memtime();
-    unsigned long long sub_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sub_t = stamp_t;
 #endif
 
     while (true) {
@@ -284,16 +381,15 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             __syncthreads();  // everyone has read the stack pointer before thread 0 pops
             if (sp_now == 0) break;
             if (t == 0) { const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[1] = 0; sh[7] = 0; sh[8] = 0; }
-            { const cf_u64x2 z{0ull, 0ull}; for (uint32_t s = t; s < (slots >> 1); s += nt) ((cf_u64x2*)tab)[s] = z; }
+            T.clear(slots, (uint32_t)t, (uint32_t)nt);
             __syncthreads();
             const uint32_t P = sh[3], pidx = sh[4];
             uint32_t my_e = 0;
             CF_STAMP(2);   // pop partition + clear table
             // ---- stream the partner clouds of every posting of a, in chunks of DIST_NP_CAP postings.
             // The units g+min_d .. min(read end, g+max_d) of a posting are ONE contiguous range of the
-            // CSR; the ranges of all postings are concatenated into a flat index space that all threads
-            // sweep with coalesced loads (entry rank + the entry's unit index inside its read), several
-            // loads in flight per lane.
+            // CSR; the ranges of all postings are concatenated into a flat index space that the waves
+            // sweep with coalesced loads (entry rank + the entry's unit index inside its read).
             for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
                 const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
                 if (!one_chunk) cf_dist_setup(A, c0, np, pE0, pig, pre);
@@ -304,8 +400,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                 uint32_t r_lo = 0, r_hi = pre[1];          // flat range of posting p_cur, cached in registers
                 int64_t r_e0 = pE0[0];
                 int32_t r_ig = pig[0];
-                // software pipeline: the global loads of step i+1 are issued before the LDS work of step i, so
-                // the 16 waves of the workgroup do not alternate between "all waiting on HBM/L2" and "all on LDS"
+                // software pipeline: the global loads of step i+1 are issued before the LDS work of step i
                 uint32_t nb_[DIST_UNROLL], nd_[DIST_UNROLL];
 #define CF_DIST_FETCH(F0)                                                                                     \
                 _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) {                                     \
@@ -329,84 +424,67 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                 if (f0 < total) { CF_DIST_FETCH(f0) }
                 while (f0 < total) {
                     if (sh[1] || sh[0] > A.fill_limit) break;
-                    CF_SUB(0);   // (outside the step) / loop top
                     uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) { bb[u] = nb_[u]; dd_[u] = nd_[u]; }
                     CF_DIST_GRAB(f1)
                     if (f1 < total) { CF_DIST_FETCH(f1) }
                     f0 = f1;
-                    CF_SUB(1);   // take the prefetched entries, issue the next loads
                     // bucket reads of all unrolled emissions first (independent LDS reads in flight), then resolve
-                    unsigned long long key_[DIST_UNROLL];
-                    uint32_t bk_[DIST_UNROLL];
-                    cf_u64x2 lo_[DIST_UNROLL], hi_[DIST_UNROLL];
+                    uint32_t bk_[DIST_UNROLL], live = 0;
+                    typename Tab::bucket kb_[DIST_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         const uint32_t b = bb[u];
                         const uint32_t hb = cf_dist_hash(b);
-                        const bool live = b != a && (P == 1 || (((hb ^ (hb >> 15)) >> 3) & (P - 1)) == pidx);
-                        key_[u] = live ? (((unsigned long long)b << 32) | ((unsigned long long)dd_[u] << 24)) : 0ull;
+                        if (b != a && (P == 1 || (((hb ^ (hb >> 15)) >> 3) & (P - 1)) == pidx)) live |= 1u << u;
                         bk_[u] = (uint32_t)(((unsigned long long)hb * (unsigned long long)n_buckets) >> 32);
-#if defined(CF_DIST_STAMPS)
-                        if (A.debug_mode == 2) { lo_[u].x = lo_[u].y = hi_[u].x = key_[u]; hi_[u].y = bk_[u]; continue; }
-#endif
-                        lo_[u] = *(const cf_u64x2*)&tab[4 * bk_[u]];
-                        hi_[u] = *(const cf_u64x2*)&tab[4 * bk_[u] + 2];
+                        kb_[u] = T.read(bk_[u]);
                     }
-                    // resolve in three straight-line rounds so that one wave exposes ONE LDS round trip per round
-                    // instead of one per emission: (1) matches -> fire-and-forget adds, new keys -> pick the first
-                    // empty slot of the bucket already in registers; (2) all CASes of the step issued back to back;
-                    // (3) the rare leftovers (bucket full, slot lost to another key) take the general path.
-                    uint32_t fresh = 0;   // bit u: emission u created a new key
-                    int cand_[DIST_UNROLL];   // -1 done / not live, 0..3 slot to claim, 4 bucket full
+                    // (1) matches -> fire-and-forget adds, new keys -> first empty slot of the bucket already in
+                    // registers; (2) all CASes of the step issued back to back; (3) leftovers (bucket full, slot
+                    // lost to another key) take the general probe loop, one leftover per lane and round.
+                    uint32_t fresh = 0, failm = 0;   // bit u: created a new key / needs the general path
+                    int cand_[DIST_UNROLL];          // slot to claim, or -1
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         cand_[u] = -1;
-                        if (key_[u] == 0ull) continue;
+                        if (!((live >> u) & 1u)) continue;
                         ++my_e;
-                        const int m = cf_bucket_match(lo_[u], hi_[u], key_[u] >> 24);
-#if defined(CF_DIST_STAMPS)
-                        if (A.debug_mode) { my_e += (uint32_t)m & 1u; continue; }   // timing experiments: results are wrong on purpose
-#endif
-                        if (m >= 0) atomicAdd(&tab[4 * bk_[u] + m], 1ull);          // common case: the pair was seen before
-                        else { const int e = cf_bucket_empty(lo_[u], hi_[u]); cand_[u] = e >= 0 ? e : 4; }
+                        const int m = Tab::match(kb_[u], bb[u], dd_[u]);
+                        if (m >= 0) { T.add(bk_[u], m); continue; }              // common case: the pair was seen before
+                        const int e = Tab::empty(kb_[u]);
+                        if (e >= 0) cand_[u] = e;
+                        else { failm |= 1u << u; bk_[u] = bk_[u] + 1 == n_buckets ? 0u : bk_[u] + 1; }
                     }
-                    CF_SUB(2);   // bucket reads + match + fire-and-forget adds
-                    unsigned long long old_[DIST_UNROLL];
+                    decltype(T.claim_issue(0u, 0, 0u, 0u)) old_[DIST_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
-                        old_[u] = 1ull;
-                        if (cand_[u] >= 0 && cand_[u] < 4) old_[u] = atomicCAS(&tab[4 * bk_[u] + cand_[u]], 0ull, key_[u] | 1ull);
+                        old_[u] = 0;
+                        if (cand_[u] >= 0) old_[u] = T.claim_issue(bk_[u], cand_[u], bb[u], dd_[u]);
                     }
-                    CF_SUB(3);   // CAS round issued
-                    uint32_t failm = 0;   // bit u: bucket full or slot lost to another key -> general path
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         if (cand_[u] < 0) continue;
-                        if (cand_[u] < 4 && old_[u] == 0ull) fresh |= 1u << u;                                   // claimed
-                        else if (cand_[u] < 4 && (old_[u] >> 24) == (key_[u] >> 24)) atomicAdd(&tab[4 * bk_[u] + cand_[u]], 1ull);  // lost the race to the same key
-                        else { failm |= 1u << u; if (cand_[u] == 4) bk_[u] = bk_[u] + 1 == n_buckets ? 0u : bk_[u] + 1; }
+                        const int st = T.claim_finish(old_[u], bk_[u], cand_[u], bb[u], dd_[u]);
+                        if (st == 0) fresh |= 1u << u;
+                        else if (st == 2) failm |= 1u << u;
                     }
-                    // leftovers: every lane works on ONE of its own leftovers per round, so the wave runs the general
-                    // probe loop max-over-lanes(#leftovers) times instead of once per unroll slot
                     while (__any(failm != 0u)) {
                         if (failm != 0u) {
                             const int u = __ffs((int)failm) - 1;
                             failm &= failm - 1u;
-                            unsigned long long kk = key_[0]; uint32_t kb = bk_[0];
+                            uint32_t xb = bb[0], xd = dd_[0], xk = bk_[0];
 #pragma unroll
-                            for (int v = 1; v < DIST_UNROLL; ++v) if (u == v) { kk = key_[v]; kb = bk_[v]; }
-                            fresh |= cf_dist_insert(tab, n_buckets, kb, kk, sh) << u;
+                            for (int v = 1; v < DIST_UNROLL; ++v) if (u == v) { xb = bb[v]; xd = dd_[v]; xk = bk_[v]; }
+                            fresh |= cf_dist_insert(T, n_buckets, xk, xb, xd, sh) << u;
                         }
                     }
-                    CF_SUB(4);   // CAS results + general path
                     // fill level: one fire-and-forget LDS atomic per wave and step; read back at the next step
                     uint32_t wave_new = 0;
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) wave_new += (uint32_t)__popcll(__ballot((fresh >> u) & 1u));
                     if (wave_new && lane == 0) atomicAdd(&sh[0], wave_new);
-                    CF_SUB(5);   // ballots
                 }
                 __syncthreads();
             }
@@ -420,41 +498,25 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                 spilled = true;
                 continue;
             }
-            // ---- leaf done: count emissions, filter in LDS (pass 1 marks the selected slots with bit 23
-            // of the count field), reserve the edge range with ONE global atomic, then write (pass 2)
+            // ---- table of the pass complete: count emissions, filter in LDS (selected slots are marked and
+            // staged), reserve the edge range with ONE global atomic, then write
             for (int d = 32; d >= 1; d >>= 1) my_e += __shfl_down(my_e, (unsigned)d);
             if (lane == 0 && my_e) atomicAdd(&sh[7], my_e);
             const uint32_t rounds = (slots + nt - 1) / nt;
             for (uint32_t rd = 0; rd < rounds; ++rd) {
                 const uint32_t s = rd * nt + t;
-                bool sel = false;
-                if (s < slots) {
-                    const unsigned long long v = tab[s];
-                    const uint32_t cnt = (uint32_t)v & DIST_CNT_MASK;
-                    if (v != 0ull && cnt >= A.min_cov) {
-                        const uint32_t b = (uint32_t)(v >> 32);
-                        unsigned long long total = 0;
-                        uint32_t bk = cf_dist_home(b, n_buckets);
-                        for (uint32_t probe = 0; probe < n_buckets; ++probe) {
-                            const cf_u64x2 lo = *(const cf_u64x2*)&tab[4 * bk], hi = *(const cf_u64x2*)&tab[4 * bk + 2];
-                            if ((uint32_t)(lo.x >> 32) == b && lo.x) total += lo.x & DIST_CNT_MASK;
-                            if ((uint32_t)(lo.y >> 32) == b && lo.y) total += lo.y & DIST_CNT_MASK;
-                            if ((uint32_t)(hi.x >> 32) == b && hi.x) total += hi.x & DIST_CNT_MASK;
-                            if ((uint32_t)(hi.y >> 32) == b && hi.y) total += hi.y & DIST_CNT_MASK;
-                            if (cf_bucket_empty(lo, hi) >= 0) break;
-                            bk = bk + 1 == n_buckets ? 0u : bk + 1;
-                        }
-                        sel = ((double)cnt / (double)total) >= A.thr;
-                        if (sel) {
-                            tab[s] = v | DIST_SEL_BIT;
-                            const uint32_t pos = atomicAdd(&sh[8], 1u);
-                            if (pos < A.stage_cap) stage[pos] = (uint16_t)s;
-                        }
+                uint32_t b, dd, cnt;
+                if (s < slots && T.get(s, b, dd, cnt) && cnt >= A.min_cov) {
+                    const unsigned long long total = T.total_of(b, n_buckets);
+                    if (((double)cnt / (double)total) >= A.thr) {
+                        T.mark(s);
+                        const uint32_t pos = atomicAdd(&sh[8], 1u);
+                        if (pos < A.stage_cap) stage[pos] = (uint16_t)s;
                     }
                 }
             }
             __syncthreads();
-            CF_STAMP(4);   // filter pass 1
+            CF_STAMP(4);   // filter
             const uint32_t n_sel = sh[8];
             __syncthreads();  // everyone has read the count before thread 0 reuses the word as a cursor
             if (t == 0) {
@@ -468,41 +530,27 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                 sh[8] = 0;
             }
             __syncthreads();
-            if (n_sel && n_sel <= A.stage_cap) {
+            if (n_sel) {
                 const unsigned long long base = ((unsigned long long)sh[10] << 32) | sh[9];
-                for (uint32_t i = t; i < n_sel; i += nt) {
-                    const unsigned long long v = tab[stage[i]];
-                    const unsigned long long o = base + i;
-                    const uint32_t b = (uint32_t)(v >> 32);
-                    if (o < A.edge_cap) {
-                        uint32_t* E = A.edges + 4 * o;
-                        E[0] = (uint32_t)(v >> 24) & 0xFFu; E[1] = a; E[2] = b; E[3] = (uint32_t)v & DIST_CNT_MASK;
-                    }
-                    const uint32_t bit = 1u << (b & 31);
-                    if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
-                }
-            } else if (n_sel) {   // more selected edges than the stage holds: sweep the table for the marked slots
-                const unsigned long long base = ((unsigned long long)sh[10] << 32) | sh[9];
-                for (uint32_t rd = 0; rd < rounds; ++rd) {
-                    const uint32_t s = rd * nt + t;
-                    const unsigned long long v = s < slots ? tab[s] : 0ull;
-                    const bool sel = (v & DIST_SEL_BIT) != 0ull;
-                    const unsigned long long m = __ballot(sel);
-                    if (m) {
+                const bool staged = n_sel <= A.stage_cap;   // else: sweep the table for the marked slots
+                const uint32_t n_iter = staged ? n_sel : rounds * (uint32_t)nt;
+                for (uint32_t i0 = 0; i0 < n_iter; i0 += nt) {
+                    const uint32_t i = i0 + t;
+                    uint32_t b = 0, dd = 0, cnt = 0, s = 0;
+                    bool sel = false;
+                    if (staged) { if (i < n_sel) { s = stage[i]; sel = T.get(s, b, dd, cnt); } }
+                    else if (i < slots) { s = i; sel = T.marked(s) && T.get(s, b, dd, cnt); }
+                    unsigned long long o = base + i;
+                    if (!staged) {   // order of the sweep: wave-aggregated cursor
+                        const unsigned long long m = __ballot(sel);
                         uint32_t off = 0;
-                        const int leader = __ffsll((long long)m) - 1;
-                        if (lane == leader) off = atomicAdd(&sh[8], (uint32_t)__popcll(m));
-                        off = __shfl(off, leader);
-                        if (sel) {
-                            const unsigned long long o = base + off + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-                            const uint32_t b = (uint32_t)(v >> 32);
-                            if (o < A.edge_cap) {
-                                uint32_t* E = A.edges + 4 * o;
-                                E[0] = (uint32_t)(v >> 24) & 0xFFu; E[1] = a; E[2] = b; E[3] = (uint32_t)v & DIST_CNT_MASK;
-                            }
-                            const uint32_t bit = 1u << (b & 31);
-                            if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
-                        }
+                        if (m) { const int leader = __ffsll((long long)m) - 1; if (lane == leader) off = atomicAdd(&sh[8], (uint32_t)__popcll(m)); off = __shfl(off, leader); }
+                        o = base + off + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                    }
+                    if (sel) {
+                        if (o < A.edge_cap) { uint32_t* E = A.edges + 4 * o; E[0] = dd; E[1] = a; E[2] = b; E[3] = cnt; }
+                        const uint32_t bit = 1u << (b & 31);
+                        if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
                     }
                 }
             }
@@ -515,9 +563,17 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
         if (acc_pass) atomicAdd(&A.counters[5], acc_pass);
 #if defined(CF_DIST_STAMPS)
         for (int i = 0; i < 8; ++i) atomicAdd(&A.counters[8 + i], stamp_acc[i]);
-        for (int i = 0; i < 6; ++i) atomicAdd(&A.counters[152 - 8 + i], sub_acc[i]);
 #endif
     }
+}
+
+__global__ void __launch_bounds__(256)
+cf_max_u32_kernel(const uint32_t* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
+    uint32_t m = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = max(m, v[i]);
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_down(m, (unsigned)d));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 extern "C" {
@@ -601,13 +657,21 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         cf_dist_args A;
         A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = ctx->d_cloud_ptr; A.entries = ctx->d_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.entry_i = d_entry_i;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
-        A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP); A.debug_mode = 0;
-#if defined(CF_DIST_STAMPS)
-        if (std::getenv("CF_DIST_DEBUG")) A.debug_mode = (uint32_t)std::atoi(std::getenv("CF_DIST_DEBUG"));
-#endif
-        A.slots = ctx->dist_slots & ~3; A.fill_limit = (uint32_t)((int64_t)ctx->dist_slots * ctx->dist_fill_pct / 100);   // checked once per wave step: leave slack below the physical size
+        A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
+        // table layout: 6-byte slots (32-bit keys, 16-bit counts) whenever ranks fit 24 bits and counts 15 bits
+        uint32_t max_post = 0;
+        if (K) {
+            hipLaunchKernelGGL(cf_max_u32_kernel, dim3((unsigned)cf_grid_for(K, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                               (const uint32_t*)d_pcnt, K, (uint32_t*)(d_cnt + 7));
+            if (hipMemcpy(&max_post, d_cnt + 7, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "max postings"); break; }
+        }
+        const bool narrow = !ctx->dist_wide && K < ((int64_t)1 << 24) - 1 && max_post <= 32767u;
+        if (max_post >= (1u << 23)) { rc = cf_fail(ctx, -34, "cf_dist_edges: a k-mer has more than 2^23 postings"); break; }
+        const uint32_t slot_bytes = narrow ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
+        A.slots = (int32_t)(((int64_t)ctx->dist_slots * 8 / slot_bytes) & ~7ll);   // dist_slots is the LDS budget in 8-byte slots
+        A.fill_limit = (uint32_t)((int64_t)A.slots * ctx->dist_fill_pct / 100);   // checked once per wave step: leave slack below the physical size
         A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
-        const size_t lds = (size_t)A.slots * 8 + (size_t)(4 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 16) * 4 + DIST_STAGE_CAP * 2 + 16;
+        const size_t lds = (size_t)A.slots * slot_bytes + (size_t)(4 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 16) * 4 + DIST_STAGE_CAP * 2 + 16;
         if (lds > 160 * 1024) { rc = cf_fail(ctx, -22, "cf_dist_edges: LDS request exceeds 160 KiB"); break; }
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / ctx->dist_block));
         // locality order of the first k-mers: sort (first posting unit, a); k-mers without postings drop out
@@ -632,10 +696,12 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("order: ") + hipGetErrorString(e)); break; }
-        e = hipFuncSetAttribute((const void*)cf_dist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = narrow ? hipFuncSetAttribute((const void*)cf_dist_kernel<cf_tab_narrow>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                   : hipFuncSetAttribute((const void*)cf_dist_kernel<cf_tab_wide>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("dist LDS attribute: ") + hipGetErrorString(e)); break; }
         if (n_a > 0 && max_d >= min_d_eff && n_post > 0) {
-            hipLaunchKernelGGL(cf_dist_kernel, dim3((unsigned)grid), dim3((unsigned)ctx->dist_block), lds, ctx->stream, A);
+            if (narrow) hipLaunchKernelGGL((cf_dist_kernel<cf_tab_narrow>), dim3((unsigned)grid), dim3((unsigned)ctx->dist_block), lds, ctx->stream, A);
+            else hipLaunchKernelGGL((cf_dist_kernel<cf_tab_wide>), dim3((unsigned)grid), dim3((unsigned)ctx->dist_block), lds, ctx->stream, A);
             e = hipGetLastError();
             if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_dist_kernel: ") + hipGetErrorString(e)); break; }
         }
@@ -646,9 +712,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_dist_edges: ") + hipGetErrorString(e)); break; }
 #if defined(CF_DIST_STAMPS)
         {
-            unsigned long long st[8], sb[6];
-            if (hipMemcpy(sb, d_cnt + 144, 48, hipMemcpyDeviceToHost) == hipSuccess)
-                std::fprintf(stderr, "[cf_dist substamps] outside=%llu take+prefetch=%llu read+match=%llu cas_issue=%llu cas_result+general=%llu ballots=%llu\n", sb[0], sb[1], sb[2], sb[3], sb[4], sb[5]);
+            unsigned long long st[8];
             if (hipMemcpy(st, d_cnt + 8, 64, hipMemcpyDeviceToHost) == hipSuccess)
                 std::fprintf(stderr, "[cf_dist stamps] pop=%llu prologue=%llu clear=%llu stream=%llu filter=%llu write=%llu (shader cycles summed over %d workgroups; passes=%llu)\n",
                              st[0], st[1], st[2], st[3], st[4], st[5], grid, h_cnt[5]);

@@ -41,6 +41,22 @@ def test_stage2_small(engine, report, oracle_stage2):
     assert engine.stats()["n_spilled"] == 0
 
 
+def test_stage2_wide_table_layout(engine, report, oracle_stage2):
+    # 8-byte slots (any k-mer set size); the default above is the 6-byte layout (ranks < 2^24, counts < 2^15)
+    tup = oracle_stage2("lowcov", max_distance=2)
+    engine.set_param("dist_wide", 1)
+    try:
+        engine.set_param("dist_slots", 1024)
+        pathcheck.check_stage2(engine, report("lowcov"), tup, check_table=False)
+        engine.set_param("dist_slots", 256)   # spill path of the wide layout
+        engine.set_param("dist_stage", 2)
+        pathcheck.check_stage2(engine, report("lowcov"), tup, n_parts=2, check_table=False)
+        assert engine.stats()["n_spilled"] > 0
+    finally:
+        engine.set_param("dist_wide", 0)
+        engine.set_param("dist_stage", 2048)
+
+
 def test_stage2_spill_and_partition(engine, report, oracle_stage2):
     tup = oracle_stage2("lowcov", max_distance=2)
     engine.set_param("dist_slots", 256)   # forces the (b, d) table to be split by a second hash of b

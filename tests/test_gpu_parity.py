@@ -54,6 +54,20 @@ def test_stage3_fixture_against_reference_golden(engine, name, report, golden):
     pathcheck.check_stage3(engine, pk, records, alns, lens, gk, g["stage3"], expect_lines=g["read_positions"])
 
 
+def test_wide_table_layout(engine, report, oracle_stage2):
+    """The 8-byte-slot layout used for k-mer sets of 2^24 ranks or more (default: 6-byte slots)."""
+    engine.set_param("dist_wide", 1)
+    try:
+        pathcheck.check_stage2(engine, report("tiny"), oracle_stage2("tiny"), check_table=False)
+        engine.set_param("dist_slots", 512)
+        pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov"), n_parts=2, check_table=False)
+        assert engine.stats()["n_spilled"] > 0
+        pathcheck.check_synthetic_clouds(engine, n_reads=4, n_units=150, cloud=8, n_kmers=60)
+    finally:
+        engine.set_param("dist_wide", 0)
+        engine.set_param("dist_slots", 19200)
+
+
 def test_partitions_spill_and_slices(engine, report, oracle_stage2):
     # first k-mers split 3 ways (the multi-GPU partition), tiny LDS table (forces the spill path)
     engine.set_param("dist_slots", 1024)
