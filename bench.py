@@ -134,6 +134,16 @@ def main():
         # every cloud entry staged once, one 4-byte partner index per pair emission, 16 bytes per stored edge
         alg_bytes = 4 * out["n_cloud_entries"] + 4 * out["local_emissions"] + 16 * min(out["local_edges"], a.edge_cap)
         achieved = alg_bytes / (mean_k_ms * 1e-3) / 1e9 if mean_k_ms > 0 else 0.0
+        # HBM traffic of one launch cannot be read from inside this process: it comes from the committed PMC passes
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE with the guide's gfx950 correction) of the same workload, else null
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_dist_kernel.json")) as f:
+                pmc = json.load(f)
+            if world == 1 and pmc.get("workload_reads_per_gpu") == a.reads:
+                traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/r01_pmc_dist_kernel.json"
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "long-read bases/sec through rare-k-mer recruit+distance",
             "value": n_bases * a.steps / elapsed,
@@ -147,7 +157,8 @@ def main():
                                    f"max_distance {PARAMS['max_d']}: count + rare filter + clouds + distance/filter (BASELINE configs[1]+[2], stage 2)",
                        "reads_per_gpu": a.reads, "k": K, "parallelism": f"reads sharded x{world}, first k-mers partitioned x{world}"},
             "roofline": {"bound": "hbm", "kernel": "cf_dist_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, see traffic_source)",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms": mean_k_ms, "pair_emissions_per_s": out["local_emissions"] / (mean_k_ms * 1e-3) if mean_k_ms else 0.0},
             "counters": {k: out[k] for k in ("n_bases", "n_windows", "n_read_kmers", "n_distinct", "n_kept", "n_rare", "n_cloud_entries",
                                              "n_emissions", "n_edges", "n_unique", "n_spilled", "n_dist_passes")},
