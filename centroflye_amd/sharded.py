@@ -32,10 +32,13 @@ def _owner(keys_i64, world):
 
 
 class ShardedRecruiter:
-    def __init__(self, device_index=0, lib=None, torch_device=None, group=None):
+    def __init__(self, device_index=0, lib=None, torch_device=None, group=None, force_exchange=False):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.group = group
+        # force_exchange: run the exchange path (all-to-all, all-gathers, second engine) even with one rank — used by
+        # the tests to exercise the RCCL / device-pointer plumbing on a single GPU
+        self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
         self.dev = torch.device(torch_device) if torch_device is not None else torch.device("cuda", device_index)
         self.local = Engine(device_index, lib)   # owns the read shard, the table, the local clouds
         self.glob = Engine(device_index, lib)    # owns the all-gathered clouds for the distance stage
@@ -51,7 +54,7 @@ class ShardedRecruiter:
 
     def _all_gather_var(self, t):
         """All-gather 1-D tensors of different lengths; returns (concatenated tensor, sizes list)."""
-        if self.world == 1:
+        if not dist.is_initialized():
             return t, [int(t.numel())]
         n = torch.tensor([t.numel()], dtype=torch.int64, device=self.dev)
         sizes = [torch.zeros_like(n) for _ in range(self.world)]
@@ -75,7 +78,7 @@ class ShardedRecruiter:
         # 1. local counts
         L.count_kmers(k)
         st_local = L.stats()
-        if W > 1:
+        if self.exchange:
             # 2. all-to-all of (key, pres | multi << 32) bucketed by owner
             n = L.table_size()
             keys = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
@@ -104,7 +107,7 @@ class ShardedRecruiter:
         # 3. rare k-mers of the owned keys, gathered and sorted everywhere
         n_own = L.select_rare(max_nonuniq, lo, hi)
         st_owner = L.stats()
-        if W > 1:
+        if self.exchange:
             mine = torch.empty(max(n_own, 1), dtype=torch.int64, device=dev)
             self._sync()
             L.kmers_into(mine.data_ptr(), n_own)
@@ -117,7 +120,7 @@ class ShardedRecruiter:
             n_rare = n_own
         # 4. clouds of the local shard, gathered
         n_ce_local = L.build_clouds()
-        if W > 1:
+        if self.exchange:
             U = L.n_units
             cp = torch.empty(U + 1, dtype=torch.int64, device=dev)
             ent = torch.empty(max(n_ce_local, 1), dtype=torch.int32, device=dev)
@@ -145,7 +148,7 @@ class ShardedRecruiter:
         n_edges = D.dist_edges(0, 2 ** 62, min_d, max_d, min_cov, rel_threshold, self.rank, W, edge_cap)
         st_d = D.stats()
         # 6. combine
-        if W > 1:
+        if self.exchange:
             mask = torch.empty(max(n_rare, 1), dtype=torch.uint8, device=dev)
             self._sync()
             D.unique_mask_into(mask.data_ptr())

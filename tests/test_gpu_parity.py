@@ -161,3 +161,39 @@ def test_errors_and_degenerate_inputs(engine):
     assert engine.select_rare(0, 1, 1) == int((cnt == 1).sum())
     with pytest.raises(DeviceError, match="max_d"):
         engine.select_rare(3, 1, 1); engine.build_clouds(); engine.dist_edges(0, 10, 1, 300, 1, 0.8)
+
+
+def test_exchange_path_on_one_rank_rccl(tmp_path):
+    """The multi-GPU exchange path (all-to-all of table triples, all-gathers of rare lists and clouds, second
+    engine for the distance stage, device buffers handed to the library as raw pointers) executed for real with
+    RCCL on a single rank, against the plain single-engine path.  (N > 1 itself is covered on CPU by
+    tests/test_sharded_gloo.py; an N-GPU node is only available to the driver.)"""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from centroflye_amd import _host
+from centroflye_amd.sharded import ShardedRecruiter
+pk = _host.synth(seed=31, n_units=60, n_reads=200, var_len=8)
+P = dict(k=19, max_nonuniq=3, lo=10, hi=32, min_d=1, max_d=150, min_cov=4, rel_threshold=0.8)
+a = ShardedRecruiter(0, force_exchange=True); a.load(pk, 1); ra = a.run(edge_cap=1 << 22, **P)
+ea = a.dist_engine.edges(ra["local_edges"]); ua = a.unique_mask.copy(); ka = a.rare.copy(); a.close()
+b = ShardedRecruiter(0); b.load(pk, 1); rb = b.run(edge_cap=1 << 22, **P)
+eb = b.dist_engine.edges(rb["local_edges"]); ub = b.unique_mask.copy(); kb = b.rare.copy(); b.close()
+srt = lambda e: e[np.lexsort((e[:, 2], e[:, 1], e[:, 0]))]
+keys = ("n_edges", "n_emissions", "n_bases", "n_windows", "n_read_kmers", "n_distinct", "n_kept", "n_cloud_entries", "n_rare", "n_unique")
+print("RESULT " + json.dumps(dict(counters=all(ra[k] == rb[k] for k in keys), rare=bool(np.array_equal(ka, kb)), unique=bool(np.array_equal(ua, ub)),
+                                  edges=bool(np.array_equal(srt(ea), srt(eb))), n_edges=int(ra["n_edges"]), exchanged=bool(a.exchange and not b.exchange))))
+dist.destroy_process_group()
+''' % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    import json
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    assert res["exchanged"] and res["n_edges"] > 1000
+    assert res["counters"] and res["rare"] and res["unique"] and res["edges"], res
