@@ -181,9 +181,9 @@ from centroflye_amd import _host
 from centroflye_amd.sharded import ShardedRecruiter
 pk = _host.synth(seed=31, n_units=60, n_reads=200, var_len=8)
 P = dict(k=19, max_nonuniq=3, lo=10, hi=32, min_d=1, max_d=150, min_cov=4, rel_threshold=0.8)
-a = ShardedRecruiter(0, force_exchange=True); a.load(pk, 1); ra = a.run(edge_cap=1 << 22, **P)
+a = ShardedRecruiter(0, force_exchange=True); a.load(pk, 1); ra = a.run(edge_cap=1 << 24, **P)
 ea = a.dist_engine.edges(ra["local_edges"]); ua = a.unique_mask.copy(); ka = a.rare.copy(); a.close()
-b = ShardedRecruiter(0); b.load(pk, 1); rb = b.run(edge_cap=1 << 22, **P)
+b = ShardedRecruiter(0); b.load(pk, 1); rb = b.run(edge_cap=1 << 24, **P)
 eb = b.dist_engine.edges(rb["local_edges"]); ub = b.unique_mask.copy(); kb = b.rare.copy(); b.close()
 srt = lambda e: e[np.lexsort((e[:, 2], e[:, 1], e[:, 0]))]
 keys = ("n_edges", "n_emissions", "n_bases", "n_windows", "n_read_kmers", "n_distinct", "n_kept", "n_cloud_entries", "n_rare", "n_unique")
