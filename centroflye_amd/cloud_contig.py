@@ -1,114 +1,120 @@
-"""Drop-in counterpart of the reference's ``scripts/cloud_contig.py``.
+"""Host-side small-object counterpart of the reference's ``scripts/cloud_contig.py``.
 
-The pipeline's live use of this module — ``CloudContig.add_read`` and ``update_mapping_scores``
-inside ``ReadPlacer.add_reads`` — runs on the GPU (cf_place_reads, centroflye_amd/read_placer.py).
-This file keeps the reference's small-object API for interactive use and API parity (SURVEY.md §8
-row A10: these helpers are not reachable from either CLI): plain-Python data structures with the
-same attribute names and return values.  Reference: cloud_contig.py:8-41, :43-84, :87-156.
+Not on the pipeline's path: the live use of the cloud contig (adding reads and updating mapping scores inside
+``ReadPlacer.add_reads``) runs on the GPU (``cf_place_reads``, see ``centroflye_amd/read_placer.py``).  This module
+exists for interactive use and API parity: the same public names, attributes and return
+values as the reference (cloud_contig.py:8-41 CloudContig, :43-84 scoring helpers, :87-95 update_mapping_scores,
+:98-156 map_reads / map_reads_fast), written on plain dict / Counter containers.
 """
 from collections import Counter, defaultdict
+from itertools import chain
+
+
+def _score_of(per_unit_hits):
+    """(number of read units with at least one hit, total hits)."""
+    return (sum(1 for h in per_unit_hits if h > 0), sum(per_unit_hits))
 
 
 class CloudContig:
+    """Per contig position a multiset of k-mers; a k-mer becomes *frequent* at a position when its multiplicity
+    there reaches ``min_cloud_kmer_freq`` (at least 1)."""
+
     def __init__(self, min_cloud_kmer_freq):
-        self.min_cloud_kmer_freq = max(1, min_cloud_kmer_freq)
-        self.max_pos = 0
-        self.clouds = defaultdict(Counter)       # position -> multiset of k-mers
-        self.freq_clouds = defaultdict(set)      # position -> k-mers seen >= min_cloud_kmer_freq times there
-        self.freq_kmers = set()
-        self.kmer_positions = defaultdict(set)   # k-mer -> every position it was added at
-        self.read_positions = {}
+        self.min_cloud_kmer_freq = min_cloud_kmer_freq if min_cloud_kmer_freq > 1 else 1
+        self.clouds = defaultdict(Counter)
+        self.freq_clouds = defaultdict(set)
+        self.kmer_positions = defaultdict(set)
         self.coverage = defaultdict(int)
+        self.freq_kmers = set()
+        self.read_positions = {}
+        self.max_pos = 0
 
     def update_max_pos(self):
-        self.max_pos = max(self.clouds) if self.clouds else 0
+        self.max_pos = max(self.clouds, default=0)
 
     def add_read(self, read_kmer_clouds, position):
-        """Returns the (k-mer, position) pairs whose multiplicity just reached the threshold."""
+        """Lay the read's unit clouds onto positions position, position+1, ...; returns the (k-mer, position) pairs
+        that turned frequent through this read (each at most once)."""
+        turned = []
+        threshold = self.min_cloud_kmer_freq
         self.read_positions[read_kmer_clouds.r_id] = position
-        fresh = []
-        for pos, cloud in enumerate(read_kmer_clouds.kmers, start=position):
-            self.coverage[pos] += 1
-            counts = self.clouds[pos]
+        for offset, cloud in enumerate(read_kmer_clouds.kmers):
+            where = position + offset
+            self.coverage[where] += 1
+            column = self.clouds[where]
+            column.update(cloud)
             for kmer in cloud:
-                self.kmer_positions[kmer].add(pos)
-                counts[kmer] += 1
-                if counts[kmer] == self.min_cloud_kmer_freq:
-                    self.freq_clouds[pos].add(kmer)
-                    self.freq_kmers.add(kmer)
-                    fresh.append((kmer, pos))
+                self.kmer_positions[kmer].add(where)
+                if column[kmer] == threshold:     # a set contributes each k-mer once, so equality fires exactly once
+                    turned.append((kmer, where))
+        for kmer, where in turned:
+            self.freq_clouds[where].add(kmer)
+            self.freq_kmers.add(kmer)
         self.update_max_pos()
-        return fresh
+        return turned
 
     def calc_rough_inters_score(self, read_kmer_cloud):
-        return len(set(read_kmer_cloud.all_kmers) & self.freq_kmers)
+        return sum(1 for kmer in set(read_kmer_cloud.all_kmers) if kmer in self.freq_kmers)
 
     def calc_inters_score(self, read_kmer_cloud, min_position=0, max_position=None, min_unit=2, min_inters=10, verbose=False):
-        """Direct scoring: for every start position (units hit, shared k-mers); rightmost best wins."""
-        if max_position is None:
-            max_position = self.max_pos
-        units = [set(c) for c in read_kmer_cloud.kmers]
-        best_score, best_pos = (0, 0), None
-        for pos in range(min_position, max_position + 1):
-            hit = total = 0
-            for i in range(min(self.max_pos - pos + 1, len(units))):
-                shared = len(self.freq_clouds[pos + i] & units[i])
-                hit += shared >= 1
-                total += shared
-            score = (hit, total)
-            if hit >= min_unit and total >= min_inters and score >= best_score:
-                best_score, best_pos = score, pos
-        return best_score, best_pos
+        """Brute-force placement score of one read: for each start position the pair (units hit, shared frequent
+        k-mers); among positions passing both thresholds the best pair wins, the rightmost on ties."""
+        last = self.max_pos if max_position is None else max_position
+        unit_sets = [frozenset(c) for c in read_kmer_cloud.kmers]
+        winner, winner_pos = (0, 0), None
+        for start in range(min_position, last + 1):
+            span = min(len(unit_sets), self.max_pos - start + 1)
+            candidate = _score_of([len(unit_sets[i] & self.freq_clouds[start + i]) for i in range(span)])
+            if candidate[0] >= min_unit and candidate[1] >= min_inters and candidate >= winner:
+                winner, winner_pos = candidate, start
+        return winner, winner_pos
 
     def get_spread_kmers(self, max_npos=5):
-        return {kmer for kmer in self.freq_kmers if len(self.kmer_positions[kmer]) > max_npos}
+        return set(k for k in self.freq_kmers if len(self.kmer_positions[k]) > max_npos)
 
 
 def update_mapping_scores(cloud_contig, kmers2pos, freq_kmers, scores=None):
-    """scores[r_id][offset][unit] += 1 for every posting (r_id, unit) of every reported k-mer."""
-    if scores is None:
-        scores = defaultdict(lambda: defaultdict(Counter))
-    for kmer, contig_pos in freq_kmers:
+    """Posting-list join: a frequent k-mer at contig position q supports, for each (read, unit) holding it, the
+    hypothesis that the read starts at q - unit.  ``scores[read][start][unit]`` counts the support."""
+    scores = defaultdict(lambda: defaultdict(Counter)) if scores is None else scores
+    for kmer, q in freq_kmers:
         for r_id, unit in kmers2pos.get(kmer, ()):
-            if contig_pos >= unit:
-                scores[r_id][contig_pos - unit][unit] += 1
+            start = q - unit
+            if start >= 0:
+                scores[r_id][start][unit] += 1
     return scores
 
 
-def _postings(reads_kmer_clouds):
-    kmers2pos = defaultdict(list)
+def _inverted_index(reads_kmer_clouds):
+    index = defaultdict(list)
     for r_id in reads_kmer_clouds:
         for unit, cloud in enumerate(reads_kmer_clouds[r_id].kmers):
             for kmer in cloud:
-                kmers2pos[kmer].append((r_id, unit))
-    return kmers2pos
+                index[kmer].append((r_id, unit))
+    return index
 
 
 def map_reads(cloud_contig, reads_kmer_clouds, threshold=(5, 10), verbose=False):
-    scores, pos = {}, {}
+    """Place every read with calc_inters_score; keeps reads that land at 0 or beat the threshold pair."""
+    pos, scores = {}, {}
     for r_id in reads_kmer_clouds:
-        cloud = reads_kmer_clouds[r_id]
-        best_score, best_pos = cloud_contig.calc_inters_score(cloud, max_position=cloud_contig.max_pos - len(cloud.kmers) + 1)
-        if best_pos == 0 or best_score > threshold:
-            scores[r_id], pos[r_id] = best_score, best_pos
+        read = reads_kmer_clouds[r_id]
+        score, where = cloud_contig.calc_inters_score(read, max_position=cloud_contig.max_pos - len(read.kmers) + 1)
+        if where == 0 or score > threshold:
+            pos[r_id], scores[r_id] = where, score
     return pos, scores
 
 
 def map_reads_fast(cloud_contig, reads_kmer_clouds, threshold=(5, 10), verbose=False, debug=False):
-    seed = [(kmer, p) for kmer in cloud_contig.freq_kmers for p in cloud_contig.kmer_positions[kmer]]
-    scores = update_mapping_scores(cloud_contig, _postings(reads_kmer_clouds), seed)
+    """Same placement through the posting-list scores (the contig's current frequent k-mers at all their positions)."""
+    seed = list(chain.from_iterable(((kmer, q) for q in cloud_contig.kmer_positions[kmer]) for kmer in cloud_contig.freq_kmers))
+    scores = update_mapping_scores(cloud_contig, _inverted_index(reads_kmer_clouds), seed)
+    n_positions = len(cloud_contig.clouds)
     positions = {}
     for r_id in reads_kmer_clouds:
-        n_units = len(reads_kmer_clouds[r_id].kmers)
-        best = None
-        for pos, per_unit in scores[r_id].items():
-            if pos + n_units > len(cloud_contig.clouds):
-                continue
-            score = (len(per_unit), sum(per_unit.values()))
-            if score[0] < threshold[0] or score[1] < threshold[1]:
-                continue
-            if best is None or (score, pos) > best:
-                best = (score, pos)
-        if best is not None:
-            positions[r_id] = best[1]
+        length = len(reads_kmer_clouds[r_id].kmers)
+        ranked = [((len(units), sum(units.values())), start) for start, units in scores[r_id].items() if start + length <= n_positions]
+        ranked = [x for x in ranked if x[0][0] >= threshold[0] and x[0][1] >= threshold[1]]
+        if ranked:
+            positions[r_id] = max(ranked)[1]
     return positions, scores
