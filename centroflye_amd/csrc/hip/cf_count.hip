@@ -116,37 +116,49 @@ cf_count_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ r
     }
 }
 
-// mode 0: count {occupied, kept, selected}; mode 1: write selected keys (wave-ballot compaction)
+// Table scan with compaction.  Every workgroup owns one contiguous chunk of the table.
+// mode 0: count {occupied, kept, selected} and write the workgroup's selected count to block_io[blockIdx];
+// mode 1: block_io holds the exclusive scan of those counts; selected entries are written at
+//         block_io[blockIdx] + (LDS cursor), wave-ballot aggregated — no global atomics at all.
 __global__ void __launch_bounds__(256)
 cf_select_kernel(const cf_slot* __restrict__ table, uint64_t cap, uint32_t max_nonuniq, uint32_t lo, uint32_t hi,
-                 int mode, unsigned long long* __restrict__ counts, unsigned long long* __restrict__ out) {
+                 int mode, unsigned long long* __restrict__ counts, int64_t* __restrict__ block_io,
+                 unsigned long long* __restrict__ out, uint32_t* __restrict__ out_pres, uint32_t* __restrict__ out_multi) {
+    unsigned int* cursor = (unsigned int*)cf_lds;
     const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) cursor[0] = 0;
+    __syncthreads();
     unsigned long long occ = 0, kept = 0, sel = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint64_t rounds = (cap + stride - 1) / stride;
-    for (uint64_t rd = 0; rd < rounds; ++rd) {
-        const uint64_t i = rd * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t chunk = ((cap + gridDim.x - 1) / gridDim.x + 255) & ~255ull;
+    const uint64_t c0 = (uint64_t)blockIdx.x * chunk, c1 = min(cap, c0 + chunk);
+    const unsigned long long base = mode == 1 ? (unsigned long long)block_io[blockIdx.x] : 0ull;
+    for (uint64_t i0 = c0; i0 < c1; i0 += 256) {
+        const uint64_t i = i0 + threadIdx.x;
         bool s = false;
-        unsigned long long key = 0;
-        if (i < cap) {
-            const cf_slot sl = table[i];
+        cf_slot sl; sl.key = 0; sl.val = 0;
+        if (i < c1) {
+            sl = table[i];
             if (sl.key) {
                 const uint32_t pres = (uint32_t)sl.val, multi = (uint32_t)(sl.val >> 32);
                 ++occ;
                 if (multi <= max_nonuniq) {
                     ++kept;
-                    if (pres >= lo && pres <= hi) { s = true; key = sl.key & ~CF_OCC; ++sel; }
+                    if (pres >= lo && pres <= hi) { s = true; ++sel; }
                 }
             }
         }
         if (mode == 1) {
             const unsigned long long m = __ballot(s);
             if (m) {
-                unsigned long long base = 0;
+                unsigned int off = 0;
                 const int leader = __ffsll((long long)m) - 1;
-                if (lane == leader) base = atomicAdd(&counts[3], (unsigned long long)__popcll(m));
-                base = __shfl(base, leader);
-                if (s) out[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = key;
+                if (lane == leader) off = atomicAdd(&cursor[0], (unsigned int)__popcll(m));
+                off = __shfl(off, leader);
+                if (s) {
+                    const unsigned long long o = base + off + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                    out[o] = sl.key & ~CF_OCC;
+                    if (out_pres) { out_pres[o] = (uint32_t)sl.val; out_multi[o] = (uint32_t)(sl.val >> 32); }
+                }
             }
         }
     }
@@ -159,22 +171,10 @@ cf_select_kernel(const cf_slot* __restrict__ table, uint64_t cap, uint32_t max_n
         if (lane == 0) {
             if (occ) atomicAdd(&counts[0], occ);
             if (kept) atomicAdd(&counts[1], kept);
-            if (sel) atomicAdd(&counts[2], sel);
+            if (sel) { atomicAdd(&counts[2], sel); atomicAdd(&cursor[0], (unsigned int)sel); }
         }
-    }
-}
-
-__global__ void __launch_bounds__(256)
-cf_table_dump_kernel(const cf_slot* __restrict__ table, uint64_t cap, unsigned long long* __restrict__ counter,
-                     unsigned long long* __restrict__ keys, uint32_t* __restrict__ pres, uint32_t* __restrict__ multi,
-                     unsigned long long out_cap) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) {
-        const cf_slot sl = table[i];
-        if (sl.key) {
-            const unsigned long long p = atomicAdd(counter, 1ull);
-            if (p < out_cap) { keys[p] = sl.key & ~CF_OCC; pres[p] = (uint32_t)sl.val; multi[p] = (uint32_t)(sl.val >> 32); }
-        }
+        __syncthreads();
+        if (threadIdx.x == 0) block_io[blockIdx.x] = (int64_t)cursor[0];
     }
 }
 
@@ -185,6 +185,39 @@ cf_table_merge_kernel(cf_slot* __restrict__ table, uint64_t tmask, const unsigne
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         cf_table_add(table, tmask, keys[i], (unsigned long long)pres[i] | ((unsigned long long)multi[i] << 32), flags);
+}
+
+// Count, then compact the table entries passing (multi <= max_nonuniq, lo <= pres <= hi) into d_keys (and
+// d_pres / d_multi when given).  counts_out: {occupied, kept, selected}.  Buffers are allocated by the caller
+// through `alloc(n_selected)` once the count is known.
+template <class Alloc>
+static int table_compact(cf_ctx* ctx, uint32_t max_nonuniq, uint32_t lo, uint32_t hi, unsigned long long counts_out[3], Alloc alloc,
+                         unsigned long long** d_keys, uint32_t** d_pres, uint32_t** d_multi) {
+    const int grid = std::max(1, ctx->n_cu) * 8;
+    unsigned long long* d_cnt = nullptr;
+    int64_t* d_blk = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &d_cnt, 4, "select counters"));
+    int rc = cf_alloc_t(ctx, &d_blk, (size_t)grid + 1, "select block counts");
+    unsigned long long h[4] = {0, 0, 0, 0};
+    do {
+        if (rc) break;
+        if (hipMemsetAsync(d_cnt, 0, 32, ctx->stream) != hipSuccess || hipMemsetAsync(d_blk, 0, (size_t)(grid + 1) * 8, ctx->stream) != hipSuccess) { rc = cf_fail(ctx, -5, "select memset"); break; }
+        hipLaunchKernelGGL(cf_select_kernel, dim3((unsigned)grid), dim3(256), 16, ctx->stream, (const cf_slot*)ctx->d_table, (uint64_t)ctx->table_cap,
+                           max_nonuniq, lo, hi, 0, d_cnt, d_blk, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+        if (hipMemcpy(h, d_cnt, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "select count"); break; }
+        counts_out[0] = h[0]; counts_out[1] = h[1]; counts_out[2] = h[2];
+        if ((rc = alloc((int64_t)h[2]))) break;
+        if (h[2] == 0 || !*d_keys) break;
+        if ((rc = cf_scan_exclusive_i64(ctx, d_blk, d_blk, grid + 1, nullptr))) break;
+        hipLaunchKernelGGL(cf_select_kernel, dim3((unsigned)grid), dim3(256), 16, ctx->stream, (const cf_slot*)ctx->d_table, (uint64_t)ctx->table_cap,
+                           max_nonuniq, lo, hi, 1, d_cnt, d_blk, *d_keys, d_pres ? *d_pres : (uint32_t*)nullptr, d_multi ? *d_multi : (uint32_t*)nullptr);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_select_kernel: ") + hipGetErrorString(e)); break; }
+    } while (0);
+    if (d_blk) cf_release_t(ctx, d_blk, (size_t)grid + 1);
+    cf_release_t(ctx, d_cnt, 4);
+    return rc;
 }
 
 static int ensure_table(cf_ctx* ctx, uint64_t want_cap) {
@@ -289,40 +322,29 @@ int cf_get_table(cf_ctx* ctx, uint64_t* keys, uint32_t* pres, uint32_t* multi, i
     if (!ctx || !n_out) return -22;
     if (!ctx->d_table) return cf_fail(ctx, -22, "cf_get_table: no table");
     CF_HIP(hipSetDevice(ctx->device));
-    unsigned long long* d_cnt = nullptr;
-    CF_TRY(cf_alloc_t(ctx, &d_cnt, 4, "dump counters"));
-    int rc = 0;
-    unsigned long long h[4] = {0, 0, 0, 0};
-    unsigned long long* d_keys = nullptr; uint32_t *d_pres = nullptr, *d_multi = nullptr;
-    const int grid = std::max(1, ctx->n_cu) * 8;
-    do {
-        if (hipMemsetAsync(d_cnt, 0, 32, ctx->stream) != hipSuccess) { rc = cf_fail(ctx, -5, "memset"); break; }
-        if (!keys) {
-            hipLaunchKernelGGL(cf_select_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const cf_slot*)ctx->d_table,
-                               (uint64_t)ctx->table_cap, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0, d_cnt, (unsigned long long*)nullptr);
-            if (hipMemcpy(h, d_cnt, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "copy"); break; }
-            *n_out = (int64_t)h[0];
-            break;
-        }
-        if ((rc = cf_alloc_t(ctx, &d_keys, (size_t)cap, "dump keys"))) break;
-        if ((rc = cf_alloc_t(ctx, &d_pres, (size_t)cap, "dump pres"))) break;
-        if ((rc = cf_alloc_t(ctx, &d_multi, (size_t)cap, "dump multi"))) break;
-        hipLaunchKernelGGL(cf_table_dump_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const cf_slot*)ctx->d_table,
-                           (uint64_t)ctx->table_cap, d_cnt, d_keys, d_pres, d_multi, (unsigned long long)cap);
-        if (hipMemcpy(h, d_cnt, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "copy"); break; }
-        *n_out = (int64_t)h[0];
-        if ((int64_t)h[0] > cap) { rc = cf_fail(ctx, -22, "cf_get_table: buffer too small"); break; }
-        if (h[0]) {
-            hipError_t e = hipMemcpy(keys, d_keys, (size_t)h[0] * 8, hipMemcpyDefault);
-            if (e == hipSuccess) e = hipMemcpy(pres, d_pres, (size_t)h[0] * 4, hipMemcpyDefault);
-            if (e == hipSuccess) e = hipMemcpy(multi, d_multi, (size_t)h[0] * 4, hipMemcpyDefault);
-            if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_get_table copy: ") + hipGetErrorString(e)); break; }
-        }
-    } while (0);
-    if (d_multi) cf_release_t(ctx, d_multi, (size_t)cap);
-    if (d_pres) cf_release_t(ctx, d_pres, (size_t)cap);
-    if (d_keys) cf_release_t(ctx, d_keys, (size_t)cap);
-    cf_release_t(ctx, d_cnt, 4);
+    unsigned long long *d_keys = nullptr;
+    uint32_t *d_pres = nullptr, *d_multi = nullptr;
+    unsigned long long counts[3] = {0, 0, 0};
+    int64_t n_alloc = 0;
+    auto alloc = [&](int64_t n) -> int {
+        *n_out = n;
+        if (!keys) return 0;   // size query
+        if (n > cap) return cf_fail(ctx, -22, "cf_get_table: buffer too small");
+        n_alloc = n;
+        CF_TRY(cf_alloc_t(ctx, &d_keys, (size_t)n, "dump keys"));
+        CF_TRY(cf_alloc_t(ctx, &d_pres, (size_t)n, "dump pres"));
+        return cf_alloc_t(ctx, &d_multi, (size_t)n, "dump multi");
+    };
+    int rc = table_compact(ctx, 0xFFFFFFFFu, 0u, 0xFFFFFFFFu, counts, alloc, &d_keys, &d_pres, &d_multi);
+    if (rc == 0 && keys && n_alloc) {
+        hipError_t e = hipMemcpy(keys, d_keys, (size_t)n_alloc * 8, hipMemcpyDefault);
+        if (e == hipSuccess) e = hipMemcpy(pres, d_pres, (size_t)n_alloc * 4, hipMemcpyDefault);
+        if (e == hipSuccess) e = hipMemcpy(multi, d_multi, (size_t)n_alloc * 4, hipMemcpyDefault);
+        if (e != hipSuccess) rc = cf_fail(ctx, -5, std::string("cf_get_table copy: ") + hipGetErrorString(e));
+    }
+    if (d_multi) cf_release_t(ctx, d_multi, (size_t)n_alloc);
+    if (d_pres) cf_release_t(ctx, d_pres, (size_t)n_alloc);
+    if (d_keys) cf_release_t(ctx, d_keys, (size_t)n_alloc);
     return rc;
 }
 
@@ -365,34 +387,22 @@ int cf_select_rare(cf_ctx* ctx, int32_t max_nonuniq, uint32_t lo, uint32_t hi, i
     const uint32_t mn = max_nonuniq < 0 ? 0u : (uint32_t)max_nonuniq;
     if (max_nonuniq < 0) hi = 0, lo = 1;  // multi <= negative is never true: empty set
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    unsigned long long* d_cnt = nullptr;
-    CF_TRY(cf_alloc_t(ctx, &d_cnt, 4, "select counters"));
-    unsigned long long h[4] = {0, 0, 0, 0};
-    const int grid = std::max(1, ctx->n_cu) * 8;
-    int rc = 0;
     unsigned long long *d_keys = nullptr, *d_tmp = nullptr;
+    unsigned long long counts[3] = {0, 0, 0};
     int64_t n_sel = 0;
-    do {
-        if (hipMemsetAsync(d_cnt, 0, 32, ctx->stream) != hipSuccess) { rc = cf_fail(ctx, -5, "memset"); break; }
-        hipLaunchKernelGGL(cf_select_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const cf_slot*)ctx->d_table,
-                           (uint64_t)ctx->table_cap, mn, lo, hi, 0, d_cnt, (unsigned long long*)nullptr);
-        if (hipMemcpy(h, d_cnt, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "cf_select_rare count"); break; }
-        ctx->stats.n_distinct = (int64_t)h[0];
-        ctx->stats.n_kept = (int64_t)h[1];
-        n_sel = (int64_t)h[2];
-        if (n_sel >= (int64_t)1 << 31) { rc = cf_fail(ctx, -34, "more than 2^31 selected k-mers"); break; }
-        if ((rc = cf_alloc_t(ctx, &d_keys, (size_t)n_sel, "selected k-mers"))) break;
-        if ((rc = cf_alloc_t(ctx, &d_tmp, (size_t)n_sel, "sort scratch"))) break;
-        if (n_sel) {
-            hipLaunchKernelGGL(cf_select_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const cf_slot*)ctx->d_table,
-                               (uint64_t)ctx->table_cap, mn, lo, hi, 1, d_cnt, d_keys);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_select_kernel: ") + hipGetErrorString(e)); break; }
-            if ((rc = cf_radix_sort_u64(ctx, d_keys, d_tmp, n_sel, 2 * ctx->k))) break;
-        }
-    } while (0);
+    auto alloc = [&](int64_t n) -> int {
+        if (n >= (int64_t)1 << 31) return cf_fail(ctx, -34, "more than 2^31 selected k-mers");
+        n_sel = n;
+        CF_TRY(cf_alloc_t(ctx, &d_keys, (size_t)n, "selected k-mers"));
+        return cf_alloc_t(ctx, &d_tmp, (size_t)n, "sort scratch");
+    };
+    int rc = table_compact(ctx, mn, lo, hi, counts, alloc, &d_keys, nullptr, nullptr);
+    if (rc == 0) {
+        ctx->stats.n_distinct = (int64_t)counts[0];
+        ctx->stats.n_kept = (int64_t)counts[1];
+        if (n_sel) rc = cf_radix_sort_u64(ctx, d_keys, d_tmp, n_sel, 2 * ctx->k);
+    }
     if (d_tmp) cf_release_t(ctx, d_tmp, (size_t)n_sel);
-    cf_release_t(ctx, d_cnt, 4);
     if (rc) { if (d_keys) cf_release_t(ctx, d_keys, (size_t)n_sel); return rc; }
     cf_free_kmers(ctx);
     ctx->d_kmers = d_keys;
