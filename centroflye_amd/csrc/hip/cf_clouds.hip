@@ -16,7 +16,6 @@ void cf_free_clouds(cf_ctx* c);
 
 #define CL_THREADS 256
 #define CL_TILE_W 8
-#define CL_SET 8192
 #define CL_EMPTY 0xFFFFFFFFu
 
 __global__ void __launch_bounds__(256)
@@ -54,7 +53,7 @@ __device__ __forceinline__ uint32_t cf_lut_find(const unsigned long long* __rest
 // mode 0: sizes[u] = |cloud(u)|; mode 1: entries[cloud_ptr[u] ...] = sorted cloud
 __global__ void __launch_bounds__(CL_THREADS)
 cf_cloud_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ unit_start, const int64_t* __restrict__ unit_end,
-                int64_t n_units, int k, const unsigned long long* __restrict__ lut_keys, const uint32_t* __restrict__ lut_vals,
+                int64_t n_units, int k, int CL_SET /* LDS set slots, power of two */, const unsigned long long* __restrict__ lut_keys, const uint32_t* __restrict__ lut_vals,
                 uint64_t lut_mask, int mode, uint32_t* __restrict__ sizes, const int64_t* __restrict__ cloud_ptr,
                 int32_t* __restrict__ entries, unsigned int* __restrict__ flags) {
     uint32_t* set = (uint32_t*)cf_lds;                         // CL_SET
@@ -254,12 +253,8 @@ int cf_set_kmers(cf_ctx* ctx, const uint64_t* kmers, int64_t n, int32_t k) {
     return cf_install_kmers(ctx, k);
 }
 
-int cf_build_clouds(cf_ctx* ctx, int64_t* n_entries) {
-    if (!ctx) return -22;
-    if (!ctx->d_unit_ptr) return cf_fail(ctx, -22, "cf_build_clouds: no reads loaded");
-    if (!ctx->d_lut_keys) return cf_fail(ctx, -22, "cf_build_clouds: no k-mer set installed");
-    CF_HIP(hipSetDevice(ctx->device));
-    CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+// One attempt with an LDS set of set_slots entries per unit; returns 1 when some unit's cloud did not fit.
+static int build_clouds_attempt(cf_ctx* ctx, int set_slots, int64_t* n_entries) {
     cf_free_clouds(ctx);
     const int64_t U = ctx->n_units;
     uint32_t* d_sizes = nullptr;
@@ -267,8 +262,8 @@ int cf_build_clouds(cf_ctx* ctx, int64_t* n_entries) {
     CF_TRY(cf_alloc_t(ctx, &ctx->d_cloud_ptr, (size_t)U + 1, "cloud_ptr"));
     CF_TRY(cf_alloc_t(ctx, &d_sizes, (size_t)U + 1, "cloud sizes"));
     int rc = cf_alloc_t(ctx, &d_flags, 4, "cloud flags");
-    const size_t lds = (size_t)CL_SET * 8 + CL_THREADS * CL_TILE_W + 64 + 16;
-    const int grid = (int)std::min<int64_t>(std::max<int64_t>(U, 1), (int64_t)std::max(1, ctx->n_cu) * 16);
+    const size_t lds = (size_t)set_slots * 8 + CL_THREADS * CL_TILE_W + 64 + 16;
+    const int grid = (int)std::min<int64_t>(std::max<int64_t>(U, 1), (int64_t)std::max(1, ctx->n_cu) * 32);
     int64_t total = 0;
     unsigned int flags = 0;
     do {
@@ -279,7 +274,7 @@ int cf_build_clouds(cf_ctx* ctx, int64_t* n_entries) {
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_build_clouds setup: ") + hipGetErrorString(e)); break; }
         if (U) {
             hipLaunchKernelGGL(cf_cloud_kernel, dim3((unsigned)grid), dim3(CL_THREADS), lds, ctx->stream, (const uint8_t*)ctx->d_bases,
-                               (const int64_t*)ctx->d_unit_start, (const int64_t*)ctx->d_unit_end, U, ctx->set_k,
+                               (const int64_t*)ctx->d_unit_start, (const int64_t*)ctx->d_unit_end, U, ctx->set_k, set_slots,
                                (const unsigned long long*)ctx->d_lut_keys, (const uint32_t*)ctx->d_lut_vals, (uint64_t)(ctx->lut_cap - 1),
                                0, d_sizes, (const int64_t*)nullptr, (int32_t*)nullptr, d_flags);
             e = hipGetLastError();
@@ -287,12 +282,12 @@ int cf_build_clouds(cf_ctx* ctx, int64_t* n_entries) {
         }
         if ((rc = cf_scan_exclusive_u32_to_i64(ctx, d_sizes, ctx->d_cloud_ptr, U + 1, &total))) break;
         if (hipMemcpy(&flags, d_flags, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "cloud flags copy"); break; }
-        if (flags & 1u) { rc = cf_fail(ctx, -34, "a unit holds more distinct set k-mers than the LDS cloud set (6144)"); break; }
+        if (flags & 1u) { rc = 1; break; }
         ctx->n_entries = total;
         if ((rc = cf_alloc_t(ctx, &ctx->d_entries, (size_t)total, "cloud entries"))) break;
         if (U && total) {
             hipLaunchKernelGGL(cf_cloud_kernel, dim3((unsigned)grid), dim3(CL_THREADS), lds, ctx->stream, (const uint8_t*)ctx->d_bases,
-                               (const int64_t*)ctx->d_unit_start, (const int64_t*)ctx->d_unit_end, U, ctx->set_k,
+                               (const int64_t*)ctx->d_unit_start, (const int64_t*)ctx->d_unit_end, U, ctx->set_k, set_slots,
                                (const unsigned long long*)ctx->d_lut_keys, (const uint32_t*)ctx->d_lut_vals, (uint64_t)(ctx->lut_cap - 1),
                                1, d_sizes, (const int64_t*)ctx->d_cloud_ptr, ctx->d_entries, d_flags);
             e = hipGetLastError();
@@ -309,6 +304,23 @@ int cf_build_clouds(cf_ctx* ctx, int64_t* n_entries) {
     ctx->have_clouds = true;
     ctx->stats.n_cloud_entries = total;
     if (n_entries) *n_entries = total;
+    return 0;
+}
+
+int cf_build_clouds(cf_ctx* ctx, int64_t* n_entries) {
+    if (!ctx) return -22;
+    if (!ctx->d_unit_ptr) return cf_fail(ctx, -22, "cf_build_clouds: no reads loaded");
+    if (!ctx->d_lut_keys) return cf_fail(ctx, -22, "cf_build_clouds: no k-mer set installed");
+    CF_HIP(hipSetDevice(ctx->device));
+    CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    // small LDS set first (16 KiB: many workgroups per CU); clouds of > 1536 k-mers get the 64 KiB set
+    int rc = build_clouds_attempt(ctx, 2048, n_entries);
+    if (rc == 1) rc = build_clouds_attempt(ctx, 8192, n_entries);
+    if (rc == 1) return cf_fail(ctx, -34, "a unit holds more distinct set k-mers than the LDS cloud set (6144)");
+    if (rc) return rc;
+    CF_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    CF_HIP(hipEventSynchronize(ctx->ev1));
+    CF_HIP(hipEventElapsedTime(&ctx->times.clouds_ms, ctx->ev0, ctx->ev1));
     return 0;
 }
 

@@ -99,7 +99,7 @@ struct cf_ctx {
     int dist_wide = 0;       // 1 forces the 8-byte-slot table layout (tests)
     int dist_fill_pct = 70;  // a (b,d) table pass is split when more than this share of the slots is in use
     int dist_stage = 2048;   // selected edges staged in LDS per table pass (0 forces the table sweep)
-    int count_slots = 8192;
+    int count_slots = 4096;
     int count_tile = 16;
 };
 
