@@ -155,10 +155,15 @@ struct cf_tab_wide {
     }
     __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u64x2*)&tab[4 * bk], *(const cf_u64x2*)&tab[4 * bk + 2]}; }
     static __device__ __forceinline__ bool is(unsigned long long v, uint32_t b, uint32_t dd) { return (uint32_t)(v >> 32) == b && ((uint32_t)v >> 24) == dd; }
+    // branch-free: one bit per slot, then find-first-set (nested ?: chains compile to a cascade of exec-mask branches)
     static __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) {   // dd >= 1: an empty slot never matches
-        return is(k.lo.x, b, dd) ? 0 : is(k.lo.y, b, dd) ? 1 : is(k.hi.x, b, dd) ? 2 : is(k.hi.y, b, dd) ? 3 : -1;
+        const uint32_t m = (uint32_t)is(k.lo.x, b, dd) | ((uint32_t)is(k.lo.y, b, dd) << 1) | ((uint32_t)is(k.hi.x, b, dd) << 2) | ((uint32_t)is(k.hi.y, b, dd) << 3);
+        return __ffs((int)m) - 1;
     }
-    static __device__ __forceinline__ int empty(const bucket& k) { return k.lo.x == 0ull ? 0 : k.lo.y == 0ull ? 1 : k.hi.x == 0ull ? 2 : k.hi.y == 0ull ? 3 : -1; }
+    static __device__ __forceinline__ int empty(const bucket& k) {
+        const uint32_t m = (uint32_t)(k.lo.x == 0ull) | ((uint32_t)(k.lo.y == 0ull) << 1) | ((uint32_t)(k.hi.x == 0ull) << 2) | ((uint32_t)(k.hi.y == 0ull) << 3);
+        return __ffs((int)m) - 1;
+    }
     __device__ __forceinline__ void add(uint32_t bk, int i) const { atomicAdd(&tab[4 * bk + i], 1ull); }
     // claim slot i of bucket bk for (b, dd): 0 = claimed (count 1), 1 = the same key got there first (counted), 2 = another key
     __device__ __forceinline__ unsigned long long claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const {
@@ -207,20 +212,22 @@ struct cf_tab_narrow {
     }
     __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u32x4*)&keys[8 * bk], *(const cf_u32x4*)&keys[8 * bk + 4]}; }
     static __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) { return (dd << 24) | b; }
-    static __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) {
-        const uint32_t q = key_of(b, dd);
-        return k.lo.x == q ? 0 : k.lo.y == q ? 1 : k.lo.z == q ? 2 : k.lo.w == q ? 3 : k.hi.x == q ? 4 : k.hi.y == q ? 5 : k.hi.z == q ? 6 : k.hi.w == q ? 7 : -1;
+    // branch-free: one bit per slot, then find-first-set (nested ?: chains compile to a cascade of exec-mask branches)
+    // bit i set <=> slot i differs from q: min(k ^ q, 1) stays in vector registers (no compare -> SGPR -> select hazard)
+    static __device__ __forceinline__ uint32_t ne_bit(uint32_t k, uint32_t q) { return min(k ^ q, 1u); }
+    static __device__ __forceinline__ uint32_t eq_mask(const bucket& k, uint32_t q) {
+        const uint32_t ne = ne_bit(k.lo.x, q) | (ne_bit(k.lo.y, q) << 1) | (ne_bit(k.lo.z, q) << 2) | (ne_bit(k.lo.w, q) << 3)
+                          | (ne_bit(k.hi.x, q) << 4) | (ne_bit(k.hi.y, q) << 5) | (ne_bit(k.hi.z, q) << 6) | (ne_bit(k.hi.w, q) << 7);
+        return ne ^ 0xFFu;
     }
-    static __device__ __forceinline__ int empty(const bucket& k) {
-        return k.lo.x == kEmpty ? 0 : k.lo.y == kEmpty ? 1 : k.lo.z == kEmpty ? 2 : k.lo.w == kEmpty ? 3
-             : k.hi.x == kEmpty ? 4 : k.hi.y == kEmpty ? 5 : k.hi.z == kEmpty ? 6 : k.hi.w == kEmpty ? 7 : -1;
-    }
+    static __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) { return __ffs((int)eq_mask(k, key_of(b, dd))) - 1; }
+    static __device__ __forceinline__ int empty(const bucket& k) { return __ffs((int)eq_mask(k, kEmpty)) - 1; }
     __device__ __forceinline__ void add(uint32_t bk, int i) const { const uint32_t s = 8 * bk + (uint32_t)i; atomicAdd(&cnt32[s >> 1], 1u << ((s & 1u) * 16u)); }
     __device__ __forceinline__ uint32_t claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const { return atomicCAS(&keys[8 * bk + i], kEmpty, key_of(b, dd)); }
     __device__ __forceinline__ int claim_finish(uint32_t old, uint32_t bk, int i, uint32_t b, uint32_t dd) const {
-        if (old == kEmpty) { add(bk, i); return 0; }
-        if (old == key_of(b, dd)) { add(bk, i); return 1; }
-        return 2;
+        const bool mine = old == kEmpty, same = old == key_of(b, dd);
+        if (mine | same) add(bk, i);          // the claimed key, or the same key claimed by someone else: count it
+        return mine ? 0 : same ? 1 : 2;
     }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
         const uint32_t q = keys[s];
