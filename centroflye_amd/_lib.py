@@ -44,6 +44,8 @@ PROTOTYPES = {
     "cf_load_reads": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "cf_load_units": (C.c_int, [_P, _P, _P, _P]),
     "cf_count_kmers": (C.c_int, [_P, _I32, _I64, _I64]),
+    "cf_count_occurrences": (C.c_int, [_P, _I32, _I64, _I64]),
+    "cf_top_kmers": (C.c_int, [_P, _I64, _P, _P, _PI64]),
     "cf_reset_table": (C.c_int, [_P, _I32, _I64]),
     "cf_get_table": (C.c_int, [_P, _P, _P, _P, _I64, _PI64]),
     "cf_merge_table": (C.c_int, [_P, _P, _P, _P, _I64]),

@@ -116,6 +116,66 @@ cf_count_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ r
     }
 }
 
+// Occurrence counting (reference scripts/better_consensus_unit_reconstruction.py:127-135:
+// kmer_counts_reads[kmer] += 1 for every window of every read).  Same work items as A1; the LDS set carries a count
+// per key, so a k-mer that occurs thousands of times in a read (HOR k-mers) costs ONE 64-bit HBM atomic per item.
+__global__ void __launch_bounds__(CNT_THREADS)
+cf_occ_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ read_off, const cf_count_item* __restrict__ items,
+              int n_items, int k, int slots, int tile_w, cf_slot* __restrict__ table, uint64_t tmask, unsigned int* __restrict__ flags) {
+    unsigned long long* set = (unsigned long long*)cf_lds;            // slots x 8 B keys
+    unsigned int* cnt = (unsigned int*)(cf_lds + (size_t)slots * 8);   // slots x 4 B occurrence counts
+    uint8_t* stage = cf_lds + (size_t)slots * 12;
+    unsigned int* counters = (unsigned int*)(stage + ((CNT_THREADS * tile_w + 64 + 15) & ~15));
+    const int t = threadIdx.x;
+    const uint32_t smask = (uint32_t)slots - 1u;
+    const unsigned long long kmask = (1ull << (2 * k)) - 1ull;
+    const int tile = CNT_THREADS * tile_w;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const cf_count_item item = items[it];
+        const int64_t r0 = read_off[item.read], r1 = read_off[item.read + 1];
+        const int64_t n_win = r1 - r0 - k + 1;
+        for (int s = t; s < slots; s += CNT_THREADS) { set[s] = 0ull; cnt[s] = 0u; }
+        if (t == 0) counters[1] = 0;
+        __syncthreads();
+        for (int64_t w0 = 0; w0 < n_win; w0 += tile) {
+            const int64_t nb = min((int64_t)tile + k - 1, r1 - r0 - w0);
+            for (int64_t i = t; i < nb; i += CNT_THREADS) stage[i] = bases[r0 + w0 + i];
+            __syncthreads();
+            const int64_t my0 = (int64_t)t * tile_w;
+            const int64_t my_n = min((int64_t)tile_w, n_win - w0 - my0);
+            if (my_n > 0) {
+                unsigned long long code = 0;
+                for (int j = 0; j < k - 1; ++j) code = (code << 2) | cf_base2(stage[my0 + j]);
+                for (int64_t i = 0; i < my_n; ++i) {
+                    code = ((code << 2) | cf_base2(stage[my0 + i + k - 1])) & kmask;
+                    const uint64_t hh = cf_mix64(code);
+                    if ((int)((hh >> 40) % (uint64_t)item.n_cls) != item.cls) continue;
+                    const unsigned long long want = code | CF_OCC;
+                    uint32_t h = (uint32_t)hh & smask;
+                    bool done = false;
+                    for (int probe = 0; probe < slots; ++probe) {
+                        unsigned long long cur = set[h];
+                        if (cur == 0ull) cur = atomicCAS(&set[h], 0ull, want);
+                        if (cur == 0ull || cur == want) { atomicAdd(&cnt[h], 1u); done = true; break; }
+                        h = (h + 1) & smask;
+                    }
+                    if (!done) counters[1] = 1;  // LDS set full
+                }
+            }
+            __syncthreads();
+        }
+        if (counters[1]) {
+            if (t == 0) atomicOr(flags, 2u);
+        } else {
+            for (int s = t; s < slots; s += CNT_THREADS) {
+                const unsigned long long v = set[s];
+                if (v) cf_table_add(table, tmask, v & ~CF_OCC, (unsigned long long)cnt[s], flags);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Table scan with compaction.  Every workgroup owns one contiguous chunk of the table.
 // mode 0: count {occupied, kept, selected} and write the workgroup's selected count to block_io[blockIdx];
 // mode 1: block_io holds the exclusive scan of those counts; selected entries are written at
@@ -123,7 +183,10 @@ cf_count_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ r
 __global__ void __launch_bounds__(256)
 cf_select_kernel(const cf_slot* __restrict__ table, uint64_t cap, uint32_t max_nonuniq, uint32_t lo, uint32_t hi,
                  int mode, unsigned long long* __restrict__ counts, int64_t* __restrict__ block_io,
-                 unsigned long long* __restrict__ out, uint32_t* __restrict__ out_pres, uint32_t* __restrict__ out_multi) {
+                 unsigned long long* __restrict__ out, uint32_t* __restrict__ out_pres, uint32_t* __restrict__ out_multi,
+                 int pred, unsigned long long t_val, unsigned long long t_key) {
+    // pred 0: multi <= max_nonuniq && lo <= pres <= hi (A2).  pred 1 (occurrence table, val = 64-bit count):
+    // val > t_val || (val == t_val && key >= t_key); counts[1] then accumulates the maximum count instead of "kept".
     unsigned int* cursor = (unsigned int*)cf_lds;
     const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0) cursor[0] = 0;
@@ -141,7 +204,10 @@ cf_select_kernel(const cf_slot* __restrict__ table, uint64_t cap, uint32_t max_n
             if (sl.key) {
                 const uint32_t pres = (uint32_t)sl.val, multi = (uint32_t)(sl.val >> 32);
                 ++occ;
-                if (multi <= max_nonuniq) {
+                if (pred == 1) {
+                    kept = max(kept, sl.val);
+                    if (sl.val > t_val || (sl.val == t_val && (sl.key & ~CF_OCC) >= t_key)) { s = true; ++sel; }
+                } else if (multi <= max_nonuniq) {
                     ++kept;
                     if (pres >= lo && pres <= hi) { s = true; ++sel; }
                 }
@@ -165,12 +231,12 @@ cf_select_kernel(const cf_slot* __restrict__ table, uint64_t cap, uint32_t max_n
     if (mode == 0) {
         for (int d = 32; d >= 1; d >>= 1) {
             occ += __shfl_down(occ, (unsigned)d);
-            kept += __shfl_down(kept, (unsigned)d);
+            { const unsigned long long o = __shfl_down(kept, (unsigned)d); kept = pred == 1 ? max(kept, o) : kept + o; }
             sel += __shfl_down(sel, (unsigned)d);
         }
         if (lane == 0) {
             if (occ) atomicAdd(&counts[0], occ);
-            if (kept) atomicAdd(&counts[1], kept);
+            if (kept) { if (pred == 1) atomicMax(&counts[1], kept); else atomicAdd(&counts[1], kept); }
             if (sel) { atomicAdd(&counts[2], sel); atomicAdd(&cursor[0], (unsigned int)sel); }
         }
         __syncthreads();
@@ -192,7 +258,8 @@ cf_table_merge_kernel(cf_slot* __restrict__ table, uint64_t tmask, const unsigne
 // through `alloc(n_selected)` once the count is known.
 template <class Alloc>
 static int table_compact(cf_ctx* ctx, uint32_t max_nonuniq, uint32_t lo, uint32_t hi, unsigned long long counts_out[3], Alloc alloc,
-                         unsigned long long** d_keys, uint32_t** d_pres, uint32_t** d_multi) {
+                         unsigned long long** d_keys, uint32_t** d_pres, uint32_t** d_multi, int pred = 0,
+                         unsigned long long t_val = 0, unsigned long long t_key = 0) {
     const int grid = std::max(1, ctx->n_cu) * 8;
     unsigned long long* d_cnt = nullptr;
     int64_t* d_blk = nullptr;
@@ -203,14 +270,14 @@ static int table_compact(cf_ctx* ctx, uint32_t max_nonuniq, uint32_t lo, uint32_
         if (rc) break;
         if (hipMemsetAsync(d_cnt, 0, 32, ctx->stream) != hipSuccess || hipMemsetAsync(d_blk, 0, (size_t)(grid + 1) * 8, ctx->stream) != hipSuccess) { rc = cf_fail(ctx, -5, "select memset"); break; }
         hipLaunchKernelGGL(cf_select_kernel, dim3((unsigned)grid), dim3(256), 16, ctx->stream, (const cf_slot*)ctx->d_table, (uint64_t)ctx->table_cap,
-                           max_nonuniq, lo, hi, 0, d_cnt, d_blk, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                           max_nonuniq, lo, hi, 0, d_cnt, d_blk, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, pred, t_val, t_key);
         if (hipMemcpy(h, d_cnt, 32, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "select count"); break; }
         counts_out[0] = h[0]; counts_out[1] = h[1]; counts_out[2] = h[2];
         if ((rc = alloc((int64_t)h[2]))) break;
         if (h[2] == 0 || !*d_keys) break;
         if ((rc = cf_scan_exclusive_i64(ctx, d_blk, d_blk, grid + 1, nullptr))) break;
         hipLaunchKernelGGL(cf_select_kernel, dim3((unsigned)grid), dim3(256), 16, ctx->stream, (const cf_slot*)ctx->d_table, (uint64_t)ctx->table_cap,
-                           max_nonuniq, lo, hi, 1, d_cnt, d_blk, *d_keys, d_pres ? *d_pres : (uint32_t*)nullptr, d_multi ? *d_multi : (uint32_t*)nullptr);
+                           max_nonuniq, lo, hi, 1, d_cnt, d_blk, *d_keys, d_pres ? *d_pres : (uint32_t*)nullptr, d_multi ? *d_multi : (uint32_t*)nullptr, pred, t_val, t_key);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_select_kernel: ") + hipGetErrorString(e)); break; }
@@ -230,7 +297,10 @@ static int ensure_table(cf_ctx* ctx, uint64_t want_cap) {
 
 extern "C" {
 
-int cf_count_kmers(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi) {
+}  // extern "C" (reopened below)
+
+// mode 0: presence / multi-occurrence table (A1); mode 1: occurrence counts
+static int count_impl(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, int mode) {
     if (!ctx) return -22;
     if (!ctx->d_read_off) return cf_fail(ctx, -22, "cf_count_kmers: no reads loaded");
     if (k < 1 || k > 31) return cf_fail(ctx, -22, "k must be in [1, 31]");
@@ -273,16 +343,22 @@ int cf_count_kmers(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi) {
                 e = hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(cf_count_item), hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess && !items.empty()) {
                 const int tile_w = ctx->count_tile;
-                const size_t lds = (size_t)slots * 8 + (size_t)((CNT_THREADS * tile_w + 64 + 15) & ~15) + 16;
+                const size_t lds = (size_t)slots * (mode == 1 ? 12 : 8) + (size_t)((CNT_THREADS * tile_w + 64 + 15) & ~15) + 16;
                 const int grid = (int)std::min<int64_t>((int64_t)items.size(), (int64_t)std::max(1, ctx->n_cu) * 8);
                 if (lds > 64 * 1024)
-                    e = hipFuncSetAttribute((const void*)cf_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    e = mode == 1 ? hipFuncSetAttribute((const void*)cf_occ_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                  : hipFuncSetAttribute((const void*)cf_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e == hipSuccess) {
                     (void)hipEventRecord(ctx->ev2, ctx->stream);
-                    hipLaunchKernelGGL(cf_count_kernel, dim3((unsigned)grid), dim3(CNT_THREADS), lds, ctx->stream,
-                                       (const uint8_t*)ctx->d_bases, (const int64_t*)ctx->d_read_off, (const cf_count_item*)d_items,
-                                       (int)items.size(), (int)k, slots, tile_w, ctx->d_table, (uint64_t)(cap - 1), d_cnt,
-                                       (unsigned int*)(d_cnt + 1));
+                    if (mode == 1)
+                        hipLaunchKernelGGL(cf_occ_kernel, dim3((unsigned)grid), dim3(CNT_THREADS), lds, ctx->stream,
+                                           (const uint8_t*)ctx->d_bases, (const int64_t*)ctx->d_read_off, (const cf_count_item*)d_items,
+                                           (int)items.size(), (int)k, slots, tile_w, ctx->d_table, (uint64_t)(cap - 1), (unsigned int*)(d_cnt + 1));
+                    else
+                        hipLaunchKernelGGL(cf_count_kernel, dim3((unsigned)grid), dim3(CNT_THREADS), lds, ctx->stream,
+                                           (const uint8_t*)ctx->d_bases, (const int64_t*)ctx->d_read_off, (const cf_count_item*)d_items,
+                                           (int)items.size(), (int)k, slots, tile_w, ctx->d_table, (uint64_t)(cap - 1), d_cnt,
+                                           (unsigned int*)(d_cnt + 1));
                     e = hipGetLastError();
                     (void)hipEventRecord(ctx->ev3, ctx->stream);
                 }
@@ -304,6 +380,84 @@ int cf_count_kmers(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi) {
         return 0;
     }
     return cf_fail(ctx, -34, "cf_count_kmers: k-mer table kept overflowing");
+}
+
+// the n k-mers with the largest (count, k-mer) of an occurrence table, sorted descending
+// (reference better_consensus_unit_reconstruction.py:156-167: heapq.nlargest(n, counts, key=lambda kmer: (counts[kmer], kmer)))
+static int top_impl(cf_ctx* ctx, int64_t n, uint64_t* keys_out, uint64_t* counts_out, int64_t* n_out) {
+    unsigned long long c[3] = {0, 0, 0};
+    auto none = [&](int64_t) -> int { return 0; };
+    unsigned long long* nokeys = nullptr;
+    // pred 1 with (t_val, t_key): val > t_val || (val == t_val && key >= t_key)
+    auto count_ge = [&](unsigned long long t, unsigned long long kt, unsigned long long* cnt, unsigned long long* mx) -> int {
+        int rc = table_compact(ctx, 0, 0, 0, c, none, &nokeys, nullptr, nullptr, 1, t, kt);
+        *cnt = c[2]; if (mx) *mx = c[1];
+        return rc;
+    };
+    unsigned long long total = 0, vmax = 0, cnt = 0;
+    CF_TRY(count_ge(0, ~0ull, &total, &vmax));              // val > 0: every occupied slot
+    if (n > (int64_t)total) n = (int64_t)total;
+    *n_out = n;
+    if (n == 0 || !keys_out) return 0;
+    // largest T with #(val >= T) >= n   (#(val >= T) = #(val > T - 1))
+    unsigned long long lo = 1, hi = vmax;
+    while (lo < hi) {
+        const unsigned long long mid = lo + (hi - lo + 1) / 2;
+        CF_TRY(count_ge(mid - 1, ~0ull, &cnt, nullptr));
+        if ((int64_t)cnt >= n) lo = mid; else hi = mid - 1;
+    }
+    const unsigned long long T = lo;
+    unsigned long long above = 0;
+    CF_TRY(count_ge(T, ~0ull, &above, nullptr));             // val > T
+    const int64_t need = n - (int64_t)above;                // ties at val == T: the `need` largest k-mers
+    unsigned long long klo = 0, khi = (ctx->k >= 32) ? ~0ull : ((1ull << (2 * ctx->k)) - 1ull);
+    while (klo < khi) {                                      // largest kt with #(val == T && key >= kt) >= need
+        const unsigned long long mid = klo + (khi - klo + 1) / 2;
+        CF_TRY(count_ge(T, mid, &cnt, nullptr));
+        if ((int64_t)cnt - (int64_t)above >= need) klo = mid; else khi = mid - 1;
+    }
+    unsigned long long* d_keys = nullptr; uint32_t *d_lo = nullptr, *d_hi = nullptr;
+    int64_t n_sel = 0;
+    auto alloc = [&](int64_t m) -> int {
+        n_sel = m;
+        CF_TRY(cf_alloc_t(ctx, &d_keys, (size_t)m, "top keys"));
+        CF_TRY(cf_alloc_t(ctx, &d_lo, (size_t)m, "top counts lo"));
+        return cf_alloc_t(ctx, &d_hi, (size_t)m, "top counts hi");
+    };
+    int rc = table_compact(ctx, 0, 0, 0, c, alloc, &d_keys, &d_lo, &d_hi, 1, T, klo);
+    std::vector<unsigned long long> hk((size_t)n_sel);
+    std::vector<uint32_t> hl((size_t)n_sel), hh((size_t)n_sel);
+    if (rc == 0 && n_sel != n) rc = cf_fail(ctx, -5, "cf_top_kmers: internal error, selection size mismatch");
+    if (rc == 0) {
+        hipError_t e = hipMemcpy(hk.data(), d_keys, (size_t)n_sel * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hl.data(), d_lo, (size_t)n_sel * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hh.data(), d_hi, (size_t)n_sel * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = cf_fail(ctx, -5, std::string("cf_top_kmers copy: ") + hipGetErrorString(e));
+    }
+    if (d_hi) cf_release_t(ctx, d_hi, (size_t)n_sel);
+    if (d_lo) cf_release_t(ctx, d_lo, (size_t)n_sel);
+    if (d_keys) cf_release_t(ctx, d_keys, (size_t)n_sel);
+    if (rc) return rc;
+    std::vector<int64_t> idx((size_t)n);
+    for (int64_t i = 0; i < n; ++i) idx[(size_t)i] = i;
+    auto val = [&](int64_t i) { return (unsigned long long)hl[(size_t)i] | ((unsigned long long)hh[(size_t)i] << 32); };
+    std::sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return val(a) != val(b) ? val(a) > val(b) : hk[(size_t)a] > hk[(size_t)b]; });
+    for (int64_t i = 0; i < n; ++i) { keys_out[i] = hk[(size_t)idx[(size_t)i]]; counts_out[i] = val(idx[(size_t)i]); }
+    return 0;
+}
+
+extern "C" {
+
+int cf_count_kmers(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi) { return count_impl(ctx, k, read_lo, read_hi, 0); }
+
+int cf_count_occurrences(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi) { return count_impl(ctx, k, read_lo, read_hi, 1); }
+
+int cf_top_kmers(cf_ctx* ctx, int64_t n, uint64_t* keys_out, uint64_t* counts_out, int64_t* n_out) {
+    if (!ctx || !n_out) return -22;
+    if (!ctx->d_table) return cf_fail(ctx, -22, "cf_top_kmers: no table (call cf_count_occurrences first)");
+    if (n < 0) return cf_fail(ctx, -22, "cf_top_kmers: n < 0");
+    CF_HIP(hipSetDevice(ctx->device));
+    return top_impl(ctx, n, keys_out, counts_out, n_out);
 }
 
 int cf_reset_table(cf_ctx* ctx, int32_t k, int64_t expected_keys) {

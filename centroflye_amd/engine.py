@@ -117,6 +117,22 @@ class Engine:
             keys, pres, multi = keys[o], pres[o], multi[o]
         return keys, pres, multi
 
+    def count_occurrences(self, k, read_lo=0, read_hi=None):
+        """Total occurrence counts of every k-mer; table() then returns count = pres | multi << 32."""
+        self._check(self._lib.cf_count_occurrences(self._ctx, int(k), int(read_lo),
+                                                   int(self.n_reads if read_hi is None else read_hi)), "cf_count_occurrences")
+        self.k = int(k)
+
+    def top_kmers(self, n):
+        """(keys uint64, counts uint64) of the n k-mers with the largest (count, k-mer), descending."""
+        m = C.c_int64()
+        self._check(self._lib.cf_top_kmers(self._ctx, int(n), None, None, C.byref(m)), "cf_top_kmers")
+        keys = np.zeros(m.value, np.uint64)
+        counts = np.zeros(m.value, np.uint64)
+        if m.value:
+            self._check(self._lib.cf_top_kmers(self._ctx, int(n), _ptr(keys), _ptr(counts), C.byref(m)), "cf_top_kmers")
+        return keys, counts
+
     def reset_table(self, k, expected_keys):
         self._check(self._lib.cf_reset_table(self._ctx, int(k), int(expected_keys)), "cf_reset_table")
         self.k = int(k)

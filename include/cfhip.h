@@ -76,6 +76,12 @@ int cf_load_units(cf_ctx* ctx, const int64_t* unit_ptr, const int64_t* unit_star
 /* A1: presence / multi-occurrence table over the reads [read_lo, read_hi) (the whole set when
  * read_lo = 0, read_hi >= R). */
 int cf_count_kmers(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi);
+/* SURVEY §8(f) rank 2 (scripts/better_consensus_unit_reconstruction.py:127-135, :156-167): table of total
+ * OCCURRENCE counts (every window of every read counts; val is one 64-bit count, cf_get_table returns its low /
+ * high halves in pres / multi), and the n k-mers with the largest (count, k-mer), sorted descending
+ * (size-query with keys_out == NULL: n_out = min(n, distinct)). */
+int cf_count_occurrences(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi);
+int cf_top_kmers(cf_ctx* ctx, int64_t n, uint64_t* keys_out, uint64_t* counts_out, int64_t* n_out);
 /* Start an empty table for keys of length k sized for about expected_keys distinct k-mers (owner side of
  * the multi-GPU exchange, followed by cf_merge_table). */
 int cf_reset_table(cf_ctx* ctx, int32_t k, int64_t expected_keys);

@@ -101,3 +101,33 @@ def check_synthetic_clouds(engine, n_reads=3, n_units=100, cloud=6, n_kmers=40, 
     assert engine.stats()["n_emissions"] == E
     assert np.array_equal(sorted_edges(engine.edges(ne)), edges)
     assert np.array_equal(np.flatnonzero(engine.unique_mask()), uniq)
+
+
+def check_unit_kmers(engine, report_path, golden_entry, k):
+    """occurrence table and top-n k-mers against the oracle and the reference golden."""
+    import canon
+    from oracle import ncrf, unit_kmers
+    records, _, _ = ncrf.parse_report(report_path)
+    recs = list(records.values())
+    seqs = [r.r_al.replace("-", "").encode() for r in recs]
+    okeys, ocnt = unit_kmers.kmer_occurrences(seqs, k)
+    pk = _host.parse_report(report_path)
+    engine.load(pk, 1)
+    engine.count_occurrences(k)
+    keys, lo, hi = engine.table()
+    cnt = lo.astype(np.int64) | (hi.astype(np.int64) << 32)
+    assert np.array_equal(keys, okeys) and np.array_equal(cnt, ocnt), "occurrence counts"
+    g = golden_entry["k"][str(k)]
+    assert keys.size == g["n_distinct"] and int(cnt.sum()) == g["total"]
+    n = 3 * unit_kmers.n_circular_unit_kmers(recs[0].motif, k)
+    tk, tc = engine.top_kmers(n)
+    want = unit_kmers.most_frequent(okeys, ocnt, n)
+    assert np.array_equal(tk, okeys[want]) and np.array_equal(tc.astype(np.int64), ocnt[want]), "top-n k-mers"
+    strs = [recruit.decode_kmer(c, k) for c in tk]
+    assert len(strs) == g["n_top"] and canon.set_digest(strs) == g["top_digest"], "top-n vs reference golden"
+    assert [[s_, int(c_)] for s_, c_ in zip(strs[:20], tc[:20])] == g["top_head"]
+    assert [[s_, int(c_)] for s_, c_ in zip(strs[-5:], tc[-5:])] == g["top_tail"]
+    # degenerate requests
+    assert engine.top_kmers(0)[0].size == 0
+    allk, allc = engine.top_kmers(10 ** 9)
+    assert allk.size == okeys.size and int(allc.astype(np.int64).sum()) == g["total"]

@@ -136,3 +136,17 @@ def test_cli_scripts_reproduce_the_reference_files(name, report, golden, tmp_pat
     subprocess.check_call([sys.executable, "-u", os.path.join(ROOT, "scripts", "read_placer.py")] + _placer_argv(name, report(name), kfile, out3, g),
                           stdout=subprocess.DEVNULL)
     _check_positions(os.path.join(out3, "read_positions.csv"), g)
+
+
+def test_unit_kmer_front_end_mirror(emu_session, report):
+    """§8(f) rank 2 through the module with the reference's name and function signatures."""
+    import json
+    from centroflye_amd import better_consensus_unit_reconstruction as B
+    with open(os.path.join(ROOT, "tests", "golden", "lowcov.unit_kmers.json")) as f:
+        g = json.load(f)["k"]["30"]
+    rep = NCRF_Report(report("lowcov"))
+    unit = next(iter(rep.records.values())).motif
+    counts, top = B.get_most_frequent_kmers(rep, 30, unit)
+    assert len(counts) == g["n_distinct"] and len(top) == g["n_top"] and canon.set_digest(top) == g["top_digest"]
+    first = g["top_head"][0]
+    assert counts[first[0]] == first[1] and first[0] in top

@@ -87,6 +87,13 @@ def test_stage3_against_reference_golden(engine, report, golden):
     assert any(ln.endswith(" None") for ln in lines)
 
 
+def test_unit_kmer_occurrences_and_top_n(engine, report):
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "lowcov.unit_kmers.json")) as f:
+        g = json.load(f)
+    pathcheck.check_unit_kmers(engine, report("lowcov"), g, 30)
+
+
 def test_errors(engine):
     bases = np.frombuffer(b"ACGTNACGT", np.uint8)
     with pytest.raises(DeviceError, match="ACGT"):

@@ -83,6 +83,14 @@ def test_partitions_spill_and_slices(engine, report, oracle_stage2):
         pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov", **ov), check_table=False)
 
 
+@pytest.mark.parametrize("name,k", [("tiny", 30), ("hor2055", 30), ("lowcov", 19)])
+def test_unit_kmer_occurrences_and_top_n(engine, report, name, k):
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.unit_kmers.json")) as f:
+        g = json.load(f)
+    pathcheck.check_unit_kmers(engine, report(name), g, k)
+
+
 def test_long_posting_lists_take_the_multi_chunk_path(engine):
     pathcheck.check_synthetic_clouds(engine, n_reads=4, n_units=150, cloud=8, n_kmers=60)   # 600 postings of k-mer 0
     pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=40, max_d=7, min_d=3, seed=5)

@@ -120,3 +120,26 @@ def test_c_oracle_equals_numpy_oracle(name, report, oracle_stage2):
     assert c["edge_checksum"] == cport.edge_checksum(res["edges"])
     assert c["rare_checksum"] == cport.rare_checksum(res["rare"])
     assert c["cloud_checksum"] == cport.cloud_checksum(res["cloud_ptr"], res["entries"])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_unit_kmer_oracle_against_reference_golden(name, report):
+    """§8(f) rank 2: occurrence counts and top-n (k = 30 and 19) of oracle/unit_kmers.py vs the reference."""
+    import json
+    from oracle import unit_kmers
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.unit_kmers.json")) as f:
+        g = json.load(f)
+    assert fixtures.sha256_file(report(name)) == g["report_sha256"]
+    records, _, _ = ncrf.parse_report(report(name))
+    recs = list(records.values())
+    seqs = [r.r_al.replace("-", "").encode() for r in recs]
+    for k in (30, 19):
+        e = g["k"][str(k)]
+        keys, cnt = unit_kmers.kmer_occurrences(seqs, k)
+        assert keys.size == e["n_distinct"] and int(cnt.sum()) == e["total"]
+        assert canon.presence_digest((recruit.decode_kmer(c, k), int(v)) for c, v in zip(keys, cnt)) == e["counts_digest"]
+        n = 3 * unit_kmers.n_circular_unit_kmers(recs[0].motif, k)
+        top = unit_kmers.most_frequent(keys, cnt, n)
+        strs = [recruit.decode_kmer(keys[i], k) for i in top]
+        assert len(strs) == e["n_top"] and canon.set_digest(strs) == e["top_digest"]
+        assert [[s_, int(cnt[i])] for s_, i in zip(strs[:20], top[:20])] == e["top_head"]
