@@ -13,11 +13,12 @@
 //       smaller r_id) among entries with s0 >= min_unit, s0 * min_prop <= s1, s1 >= min_inters;
 //       if none qualifies all remaining reads of the stage are written as None.
 //
-// Device design: everything lives in HBM hash tables — contig (pos,kmer)->count, score
-// (read,offset)->(s0,s1), a seen-set of (score slot, unit) for s0.  One iteration = 4 small
-// kernels enqueued back to back with NO host round trip: apply events -> block arg-max ->
-// final arg-max (records the placement, device-side) -> add the chosen read (emits the next
-// events).  The host only polls a done flag every few hundred iterations.
+// Device design: everything lives in HBM hash tables — contig (pos,kmer)->count, per read a small
+// open-addressed table offset->(s0,s1), a seen-set of (score slot, unit) for s0.  One iteration = 4 small
+// kernels enqueued back to back with NO host round trip: apply events (marks the touched reads dirty) ->
+// recompute the best qualifying entry of the dirty reads -> single-block arg-max over the per-read bests
+// (records the placement device-side) -> add the chosen read (emits the next events).  The host only
+// polls a done flag every few hundred iterations.
 #include "cf_common.h"
 
 #include <cstdlib>
@@ -51,8 +52,10 @@ struct cf_place_state {
     uint8_t* freq_flag;
     // postings of the stage
     const int64_t* post_ptr; const int32_t* post;
-    // score map: key (read<<32|off)|OCC, s0, s1
-    unsigned long long* skeys; uint32_t* s0; uint32_t* s1; uint64_t smask;
+    // scores: one open-addressed mini-table of `rcap` slots per read (key = offset, 0xFFFFFFFF empty) with s0 / s1;
+    // a read whose table changed is put on the dirty list, its best qualifying entry is recomputed into rbest[read]
+    uint32_t* soff; uint32_t* s0; uint32_t* s1; uint32_t rcap;
+    uint32_t* rcount; uint32_t* dirty_flag; int32_t* dirty_list; cf_cand* rbest; int64_t n_reads;
     // seen set of (score slot << 32 | unit index)
     unsigned long long* seen; uint64_t seen_mask;
     // events (kmer << 32 | pos)
@@ -61,7 +64,7 @@ struct cf_place_state {
     unsigned int* ctl;
     const uint8_t* used_in; uint8_t* used;
     const int32_t* id_rank;
-    cf_cand* block_best; cf_cand* best;
+    cf_cand* best;
     int64_t* out_read; int64_t* out_pos; int32_t* out_s0; int32_t* out_s1;
     uint32_t thr, min_unit, min_inters, min_prop;
 };
@@ -136,19 +139,21 @@ cf_place_update_kernel(cf_place_state S) {
             const uint32_t i = (uint32_t)(g - S.unit_ptr[r]);
             if (q < i) continue;
             const uint32_t off = q - i;
-            const unsigned long long want = (((unsigned long long)r << 32) | off) | CF_OCC;
-            uint64_t h = cf_mix64(want) & S.smask;
+            const uint64_t base = (uint64_t)r * S.rcap;
+            uint32_t hh = cf_mix32(off) & (S.rcap - 1);
             bool ok = false;
-            for (uint64_t probe = 0; probe <= S.smask && probe < 4096; ++probe) {   // a long probe = table too full: grow and restart
-                unsigned long long cur = S.skeys[h];
-                if (cur == 0ull) {
-                    cur = atomicCAS(&S.skeys[h], 0ull, want);
-                    if (cur == 0ull && atomicAdd(&S.ctl[4], 1u) > (unsigned int)(S.smask >> 1)) atomicOr(&S.ctl[2], 2u);   // load > 0.5
+            for (uint32_t probe = 0; probe < S.rcap; ++probe) {
+                uint32_t cur = S.soff[base + hh];
+                if (cur == 0xFFFFFFFFu) {
+                    cur = atomicCAS(&S.soff[base + hh], 0xFFFFFFFFu, off);
+                    if (cur == 0xFFFFFFFFu && atomicAdd(&S.rcount[r], 1u) >= (S.rcap >> 2) * 3u) atomicOr(&S.ctl[2], 2u);   // mini-table 3/4 full: grow and restart
                 }
-                if (cur == 0ull || cur == want) { ok = true; break; }
-                h = (h + 1) & S.smask;
+                if (cur == 0xFFFFFFFFu || cur == off) { ok = true; break; }
+                hh = (hh + 1) & (S.rcap - 1);
             }
             if (!ok) { atomicOr(&S.ctl[2], 2u); continue; }
+            const uint64_t h = base + hh;
+            if (atomicExch(&S.dirty_flag[r], 1u) == 0u) S.dirty_list[atomicAdd(&S.ctl[5], 1u)] = (int32_t)r;
             atomicAdd(&S.s1[h], 1u);
             // first hit of unit i at this (read, offset)?
             const unsigned long long sk = ((((unsigned long long)h) << 24) ^ ((unsigned long long)i)) | CF_OCC;  // slot < 2^38, i < 2^24
@@ -188,37 +193,50 @@ __device__ __forceinline__ cf_cand cf_block_best(cf_cand mine) {
     return best;
 }
 
+// best qualifying entry of every dirty read (one wave per read, lanes over its mini-table)
 __global__ void __launch_bounds__(PL_THREADS)
-cf_place_argmax_kernel(cf_place_state S) {
-    cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
-    if (!S.ctl[0]) {
-        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= S.smask; i += stride) {
-            const unsigned long long k = S.skeys[i];
-            if (!k) continue;
-            const uint32_t r = (uint32_t)((k & ~CF_OCC) >> 32), off = (uint32_t)k;
-            if (S.used[r]) continue;
-            const uint32_t v0 = S.s0[i], v1 = S.s1[i];
+cf_place_best_kernel(cf_place_state S) {
+    if (S.ctl[0]) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t n_dirty = (int64_t)S.ctl[5];
+    for (int64_t di = wave; di < n_dirty; di += n_waves) {
+        const uint32_t r = (uint32_t)S.dirty_list[di];
+        const uint64_t base = (uint64_t)r * S.rcap;
+        cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = 0; mine.rank = (uint32_t)S.id_rank[r]; mine.read = r;
+        for (uint32_t i = (uint32_t)lane; i < S.rcap; i += 64) {
+            const uint32_t off = S.soff[base + i];
+            if (off == 0xFFFFFFFFu) continue;
+            const uint32_t v0 = S.s0[base + i], v1 = S.s1[base + i];
             if (v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters) {
-                cf_cand c; c.s0 = v0; c.s1 = v1; c.off = off; c.rank = (uint32_t)S.id_rank[r]; c.read = r; c.valid = 1;
+                cf_cand c = mine; c.s0 = v0; c.s1 = v1; c.off = off; c.valid = 1;
                 if (cf_cand_better(c, mine)) mine = c;
             }
         }
+        for (int d = 32; d >= 1; d >>= 1) {
+            cf_cand o = cf_cand_shfl_down(mine, (unsigned)d);
+            if (lane + d < 64 && cf_cand_better(o, mine)) mine = o;
+        }
+        if (lane == 0) { S.rbest[r] = mine; S.dirty_flag[r] = 0u; }
     }
-    const cf_cand b = cf_block_best(mine);
-    if (threadIdx.x == 0) S.block_best[blockIdx.x] = b;
 }
 
-// single block: reduce the block candidates, record the placement, reset the event list
-__global__ void __launch_bounds__(PL_THREADS)
-cf_place_final_kernel(cf_place_state S, int n_blocks) {
+// single block: arg-max over the per-read bests of the unused reads, record the placement, reset the event and dirty lists
+__global__ void __launch_bounds__(1024)
+cf_place_final_kernel(cf_place_state S) {
     if (S.ctl[0]) return;
     cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
-    for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) if (cf_cand_better(S.block_best[i], mine)) mine = S.block_best[i];
+    for (int64_t r = threadIdx.x; r < S.n_reads; r += blockDim.x) {
+        if (S.used[r]) continue;
+        const cf_cand c = S.rbest[r];
+        if (cf_cand_better(c, mine)) mine = c;
+    }
     const cf_cand b = cf_block_best(mine);
     if (threadIdx.x == 0) {
         *S.best = b;
         S.n_events[0] = 0ull;
+        S.ctl[5] = 0;
         if (!b.valid) S.ctl[0] = 1;
         else {
             const unsigned int o = S.ctl[1]++;
@@ -270,7 +288,7 @@ struct Bufs {
 
 // One attempt with given table sizes; returns 1 if a table overflowed (caller retries larger).
 static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int32_t min_freq, int32_t min_unit,
-                         int32_t min_inters, int32_t min_prop, uint64_t score_cap, uint64_t seen_cap,
+                         int32_t min_inters, int32_t min_prop, uint64_t rcap, uint64_t seen_cap,
                          std::vector<int64_t>& o_read, std::vector<int64_t>& o_pos, std::vector<int32_t>& o_s0, std::vector<int32_t>& o_s1) {
     const int64_t R = ctx->n_reads, U = ctx->n_units, N = ctx->n_entries, K = ctx->n_kmers;
     Bufs B{ctx, {}};
@@ -294,21 +312,25 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     CF_TRY(B.get(&d_pcnt, (size_t)K + 1, "stage posting counts"));
     CF_TRY(B.get(&d_post_ptr, (size_t)K + 1, "stage posting offsets"));
     CF_TRY(B.get(&d_post, (size_t)N + 1, "stage postings"));
-    CF_TRY(B.get(&S.skeys, (size_t)score_cap, "score keys"));
-    CF_TRY(B.get(&S.s0, (size_t)score_cap, "score s0"));
-    CF_TRY(B.get(&S.s1, (size_t)score_cap, "score s1"));
+    const size_t score_cap = (size_t)(R + 1) * rcap;
+    CF_TRY(B.get(&S.soff, score_cap, "score offsets"));
+    CF_TRY(B.get(&S.s0, score_cap, "score s0"));
+    CF_TRY(B.get(&S.s1, score_cap, "score s1"));
+    CF_TRY(B.get(&S.rcount, (size_t)R + 1, "score entries per read"));
+    CF_TRY(B.get(&S.dirty_flag, (size_t)R + 1, "dirty flags"));
+    CF_TRY(B.get(&S.dirty_list, (size_t)R + 1, "dirty list"));
+    CF_TRY(B.get(&S.rbest, (size_t)R + 1, "per-read best"));
     CF_TRY(B.get(&S.seen, (size_t)seen_cap, "seen set"));
     CF_TRY(B.get(&S.events, (size_t)N + 1, "events"));
     CF_TRY(B.get(&S.n_events, 2, "event count"));
     CF_TRY(B.get(&S.ctl, 8, "control"));
     const int n_blocks = std::max(1, ctx->n_cu) * 4;
-    CF_TRY(B.get(&S.block_best, (size_t)n_blocks, "block candidates"));
     CF_TRY(B.get(&S.best, 1, "best candidate"));
     CF_TRY(B.get(&S.out_read, (size_t)R + 1, "out_read"));
     CF_TRY(B.get(&S.out_pos, (size_t)R + 1, "out_pos"));
     CF_TRY(B.get(&S.out_s0, (size_t)R + 1, "out_s0"));
     CF_TRY(B.get(&S.out_s1, (size_t)R + 1, "out_s1"));
-    S.unit2read = d_u2r; S.cmask = ccap - 1; S.smask = score_cap - 1; S.seen_mask = seen_cap - 1;
+    S.unit2read = d_u2r; S.cmask = ccap - 1; S.rcap = (uint32_t)rcap; S.n_reads = R; S.seen_mask = seen_cap - 1;
     S.used = d_used; S.id_rank = d_rank; S.post_ptr = d_post_ptr; S.post = d_post;
     hipStream_t st = ctx->stream;
     CF_HIP(hipMemcpyAsync(d_cls, cls, (size_t)R, hipMemcpyHostToDevice, st));
@@ -343,21 +365,24 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         hipLaunchKernelGGL(cf_place_post_kernel, dim3((unsigned)g_units), dim3(256), 0, st, (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries,
                            (const int32_t*)d_u2r, (const uint8_t*)d_cls, stage_cls, U, 1, d_pcnt, (const int64_t*)d_post_ptr, d_post);
         // fresh scores, seed events
-        CF_HIP(hipMemsetAsync(S.skeys, 0, (size_t)score_cap * 8, st));
-        CF_HIP(hipMemsetAsync(S.s0, 0, (size_t)score_cap * 4, st));
-        CF_HIP(hipMemsetAsync(S.s1, 0, (size_t)score_cap * 4, st));
+        CF_HIP(hipMemsetAsync(S.soff, 0xFF, score_cap * 4, st));
+        CF_HIP(hipMemsetAsync(S.s0, 0, score_cap * 4, st));
+        CF_HIP(hipMemsetAsync(S.s1, 0, score_cap * 4, st));
+        CF_HIP(hipMemsetAsync(S.rcount, 0, (size_t)(R + 1) * 4, st));
+        CF_HIP(hipMemsetAsync(S.dirty_flag, 0, (size_t)(R + 1) * 4, st));
+        CF_HIP(hipMemsetAsync(S.rbest, 0, (size_t)(R + 1) * sizeof(cf_cand), st));   // valid = 0
         CF_HIP(hipMemsetAsync(S.seen, 0, (size_t)seen_cap * 8, st));
         CF_HIP(hipMemsetAsync(S.n_events, 0, 16, st));
         CF_HIP(hipMemsetAsync(S.ctl, 0, 8, st));  // done = 0, n_out = 0 (error flags kept)
-        CF_HIP(hipMemsetAsync(S.ctl + 4, 0, 4, st));  // score-map entry count of this stage
+        CF_HIP(hipMemsetAsync(S.ctl + 4, 0, 8, st));  // [5] = number of dirty reads
         hipLaunchKernelGGL(cf_place_seed_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
         CF_KERNEL_CHECK("cf_place_seed_kernel");
         unsigned int h_ctl[4] = {0, 0, 0, 0};
         const int64_t n_iter = (int64_t)stage_reads.size();
         for (int64_t it = 0; it < n_iter; ++it) {
             hipLaunchKernelGGL(cf_place_update_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
-            hipLaunchKernelGGL(cf_place_argmax_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S);
-            hipLaunchKernelGGL(cf_place_final_kernel, dim3(1), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S, n_blocks);
+            hipLaunchKernelGGL(cf_place_best_kernel, dim3(64), dim3(PL_THREADS), 0, st, S);
+            hipLaunchKernelGGL(cf_place_final_kernel, dim3(1), dim3(1024), 16 * sizeof(cf_cand), st, S);
             hipLaunchKernelGGL(cf_place_add_kernel, dim3(8), dim3(PL_THREADS), 0, st, S, 1, (int64_t)0);
             if ((it & 255) == 255 || it + 1 == n_iter) {
                 CF_KERNEL_CHECK("placement iteration");
@@ -406,7 +431,7 @@ int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int3
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     const int64_t R = ctx->n_reads;
     for (int64_t r = 0; r < R; ++r) if (cls[r] > 2) return cf_fail(ctx, -22, "cf_place_reads: class must be 0, 1 or 2");
-    uint64_t score_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(256 * R, 1 << 14));
+    uint64_t score_cap = 256;   // slots of the per-read score table (grown x4 when a read fills 3/4 of it)
     uint64_t seen_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(8 * ctx->n_entries, 1 << 14));
     std::vector<int64_t> o_read, o_pos;
     std::vector<int32_t> o_s0, o_s1;
