@@ -52,9 +52,9 @@ struct cf_place_state {
     uint8_t* freq_flag;
     // postings of the stage
     const int64_t* post_ptr; const int32_t* post;
-    // scores: one open-addressed mini-table of `rcap` slots per read (key = offset, 0xFFFFFFFF empty) with s0 / s1;
+    // scores: one open-addressed mini-table per read, sized from the read's cloud entries (key = offset, 0xFFFFFFFF empty) with s0 / s1;
     // a read whose table changed is put on the dirty list, its best qualifying entry is recomputed into rbest[read]
-    uint32_t* soff; uint32_t* s0; uint32_t* s1; uint32_t rcap;
+    uint32_t* soff; uint32_t* s0; uint32_t* s1; const int64_t* rbase; const uint32_t* rcapv;   // per read: first slot, slots (power of two)
     uint32_t* rcount; uint32_t* dirty_flag; int32_t* dirty_list; cf_cand* rbest; int64_t n_reads;
     // seen set of (score slot << 32 | unit index)
     unsigned long long* seen; uint64_t seen_mask;
@@ -139,17 +139,18 @@ cf_place_update_kernel(cf_place_state S) {
             const uint32_t i = (uint32_t)(g - S.unit_ptr[r]);
             if (q < i) continue;
             const uint32_t off = q - i;
-            const uint64_t base = (uint64_t)r * S.rcap;
-            uint32_t hh = cf_mix32(off) & (S.rcap - 1);
+            const uint64_t base = (uint64_t)S.rbase[r];
+            const uint32_t rcap = S.rcapv[r];
+            uint32_t hh = cf_mix32(off) & (rcap - 1);
             bool ok = false;
-            for (uint32_t probe = 0; probe < S.rcap; ++probe) {
+            for (uint32_t probe = 0; probe < rcap; ++probe) {
                 uint32_t cur = S.soff[base + hh];
                 if (cur == 0xFFFFFFFFu) {
                     cur = atomicCAS(&S.soff[base + hh], 0xFFFFFFFFu, off);
-                    if (cur == 0xFFFFFFFFu && atomicAdd(&S.rcount[r], 1u) >= (S.rcap >> 2) * 3u) atomicOr(&S.ctl[2], 2u);   // mini-table 3/4 full: grow and restart
+                    if (cur == 0xFFFFFFFFu && atomicAdd(&S.rcount[r], 1u) >= (rcap >> 2) * 3u) atomicOr(&S.ctl[2], 2u);   // mini-table 3/4 full: grow and restart
                 }
                 if (cur == 0xFFFFFFFFu || cur == off) { ok = true; break; }
-                hh = (hh + 1) & (S.rcap - 1);
+                hh = (hh + 1) & (rcap - 1);
             }
             if (!ok) { atomicOr(&S.ctl[2], 2u); continue; }
             const uint64_t h = base + hh;
@@ -203,9 +204,10 @@ cf_place_best_kernel(cf_place_state S) {
     const int64_t n_dirty = (int64_t)S.ctl[5];
     for (int64_t di = wave; di < n_dirty; di += n_waves) {
         const uint32_t r = (uint32_t)S.dirty_list[di];
-        const uint64_t base = (uint64_t)r * S.rcap;
+        const uint64_t base = (uint64_t)S.rbase[r];
+        const uint32_t rcap = S.rcapv[r];
         cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = 0; mine.rank = (uint32_t)S.id_rank[r]; mine.read = r;
-        for (uint32_t i = (uint32_t)lane; i < S.rcap; i += 64) {
+        for (uint32_t i = (uint32_t)lane; i < rcap; i += 64) {
             const uint32_t off = S.soff[base + i];
             if (off == 0xFFFFFFFFu) continue;
             const uint32_t v0 = S.s0[base + i], v1 = S.s1[base + i];
@@ -288,7 +290,7 @@ struct Bufs {
 
 // One attempt with given table sizes; returns 1 if a table overflowed (caller retries larger).
 static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int32_t min_freq, int32_t min_unit,
-                         int32_t min_inters, int32_t min_prop, uint64_t rcap, uint64_t seen_cap,
+                         int32_t min_inters, int32_t min_prop, uint64_t score_mult, uint64_t seen_cap,
                          std::vector<int64_t>& o_read, std::vector<int64_t>& o_pos, std::vector<int32_t>& o_s0, std::vector<int32_t>& o_s1) {
     const int64_t R = ctx->n_reads, U = ctx->n_units, N = ctx->n_entries, K = ctx->n_kmers;
     Bufs B{ctx, {}};
@@ -312,7 +314,29 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     CF_TRY(B.get(&d_pcnt, (size_t)K + 1, "stage posting counts"));
     CF_TRY(B.get(&d_post_ptr, (size_t)K + 1, "stage posting offsets"));
     CF_TRY(B.get(&d_post, (size_t)N + 1, "stage postings"));
-    const size_t score_cap = (size_t)(R + 1) * rcap;
+    // per-read score table: power of two >= score_mult x (cloud entries of the read) / 8, at least 64 slots
+    std::vector<int64_t> h_cp((size_t)R + 1), h_rbase((size_t)R + 1);
+    std::vector<uint32_t> h_rcap((size_t)R + 1, 64u);
+    {
+        std::vector<int64_t> h_cloud((size_t)U + 1);
+        CF_HIP(hipMemcpy(h_cloud.data(), ctx->d_cloud_ptr, (size_t)(U + 1) * 8, hipMemcpyDeviceToHost));
+        for (int64_t r = 0; r <= R; ++r) h_cp[(size_t)r] = h_cloud[(size_t)ctx->h_unit_ptr[(size_t)r]];
+    }
+    size_t score_cap = 0;
+    for (int64_t r = 0; r < R; ++r) {
+        const uint64_t want = (uint64_t)(h_cp[(size_t)r + 1] - h_cp[(size_t)r]) * score_mult / 8;
+        h_rcap[(size_t)r] = (uint32_t)std::min<uint64_t>(cf_pow2_ceil(std::max<uint64_t>(want, 64)), 1u << 30);
+        h_rbase[(size_t)r] = (int64_t)score_cap;
+        score_cap += h_rcap[(size_t)r];
+    }
+    h_rbase[(size_t)R] = (int64_t)score_cap;
+    int64_t* d_rbase = nullptr; uint32_t* d_rcapv = nullptr;
+    CF_TRY(B.get(&d_rbase, (size_t)R + 1, "score table bases"));
+    CF_TRY(B.get(&d_rcapv, (size_t)R + 1, "score table sizes"));
+    CF_HIP(hipMemcpyAsync(d_rbase, h_rbase.data(), (size_t)(R + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    CF_HIP(hipMemcpyAsync(d_rcapv, h_rcap.data(), (size_t)(R + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    CF_HIP(hipStreamSynchronize(ctx->stream));
+    S.rbase = d_rbase; S.rcapv = d_rcapv;
     CF_TRY(B.get(&S.soff, score_cap, "score offsets"));
     CF_TRY(B.get(&S.s0, score_cap, "score s0"));
     CF_TRY(B.get(&S.s1, score_cap, "score s1"));
@@ -330,7 +354,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     CF_TRY(B.get(&S.out_pos, (size_t)R + 1, "out_pos"));
     CF_TRY(B.get(&S.out_s0, (size_t)R + 1, "out_s0"));
     CF_TRY(B.get(&S.out_s1, (size_t)R + 1, "out_s1"));
-    S.unit2read = d_u2r; S.cmask = ccap - 1; S.rcap = (uint32_t)rcap; S.n_reads = R; S.seen_mask = seen_cap - 1;
+    S.unit2read = d_u2r; S.cmask = ccap - 1; S.n_reads = R; S.seen_mask = seen_cap - 1;
     S.used = d_used; S.id_rank = d_rank; S.post_ptr = d_post_ptr; S.post = d_post;
     hipStream_t st = ctx->stream;
     CF_HIP(hipMemcpyAsync(d_cls, cls, (size_t)R, hipMemcpyHostToDevice, st));
@@ -389,7 +413,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
                 CF_HIP(hipMemcpyAsync(h_ctl, S.ctl, 16, hipMemcpyDeviceToHost, st));
                 CF_HIP(hipStreamSynchronize(st));
                 if (std::getenv("CF_DEBUG") && ((it & 8191) == 8191 || h_ctl[2] || h_ctl[0])) std::fprintf(stderr, "[cf_place] stage %d iter %lld/%lld ctl=%u,%u,%u\n", stage_cls, (long long)it, (long long)n_iter, h_ctl[0], h_ctl[1], h_ctl[2]);
-                if (h_ctl[2]) return 1;
+                if (h_ctl[2]) { ctx->place_flags = h_ctl[2]; return 1; }
                 if (h_ctl[0]) break;
             }
         }
@@ -415,7 +439,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     }
     unsigned int h_ctl[4] = {0, 0, 0, 0};
     CF_HIP(hipMemcpy(h_ctl, S.ctl, 16, hipMemcpyDeviceToHost));
-    if (h_ctl[2]) return 1;
+    if (h_ctl[2]) { ctx->place_flags = h_ctl[2]; return 1; }
     return 0;
 }
 
@@ -431,7 +455,7 @@ int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int3
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     const int64_t R = ctx->n_reads;
     for (int64_t r = 0; r < R; ++r) if (cls[r] > 2) return cf_fail(ctx, -22, "cf_place_reads: class must be 0, 1 or 2");
-    uint64_t score_cap = 256;   // slots of the per-read score table (grown x4 when a read fills 3/4 of it)
+    uint64_t score_cap = 1;     // multiplier of the per-read score table size (x4 when a read fills 3/4 of its table)
     uint64_t seen_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(8 * ctx->n_entries, 1 << 14));
     std::vector<int64_t> o_read, o_pos;
     std::vector<int32_t> o_s0, o_s1;
@@ -439,7 +463,7 @@ int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int3
     for (int attempt = 0; attempt < 6 && rc == 1; ++attempt) {
         rc = place_attempt(ctx, cls, id_rank, min_cloud_kmer_freq, min_unit, min_inters, min_prop, score_cap, seen_cap, o_read, o_pos, o_s0, o_s1);
         if (std::getenv("CF_DEBUG")) std::fprintf(stderr, "[cf_place] attempt %d rc=%d score_cap=%llu seen_cap=%llu entries=%lld reads=%lld\n", attempt, rc, (unsigned long long)score_cap, (unsigned long long)seen_cap, (long long)ctx->n_entries, (long long)R);
-        if (rc == 1) { score_cap *= 4; seen_cap *= 4; }
+        if (rc == 1) { if (ctx->place_flags & 2u) score_cap *= 4; if (ctx->place_flags & 4u) seen_cap *= 4; if (!(ctx->place_flags & 6u)) { score_cap *= 4; seen_cap *= 4; } }
     }
     if (rc == 1) return cf_fail(ctx, -34, "cf_place_reads: score tables kept overflowing");
     if (rc) return rc;
