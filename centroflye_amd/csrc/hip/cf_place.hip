@@ -15,10 +15,11 @@
 //
 // Device design: everything lives in HBM hash tables — contig (pos,kmer)->count, per read a small
 // open-addressed table offset->(s0,s1), a seen-set of (score slot, unit) for s0.  One iteration = 4 small
-// kernels enqueued back to back with NO host round trip: apply events (marks the touched reads dirty) ->
-// recompute the best qualifying entry of the dirty reads -> single-block arg-max over the per-read bests
-// (records the placement device-side) -> add the chosen read (emits the next events).  The host only
-// polls a done flag every few hundred iterations.
+// open-addressed table offset->(s0,s1), a seen-set of (score slot, unit) for s0.  One iteration = 3 small
+// kernels enqueued back to back with NO host round trip: apply events (every touched entry publishes its
+// packed score to its read's running maximum with one atomicMax) -> single-block arg-max over the per-read
+// maxima, verified against the winner's table (records the placement device-side) -> add the chosen read
+// (emits the next events).  The host only polls a done flag every few hundred iterations.
 #include "cf_common.h"
 
 #include <cstdlib>
@@ -53,9 +54,8 @@ struct cf_place_state {
     // postings of the stage
     const int64_t* post_ptr; const int32_t* post;
     // scores: one open-addressed mini-table per read, sized from the read's cloud entries (key = offset, 0xFFFFFFFF empty) with s0 / s1;
-    // a read whose table changed is put on the dirty list, its best qualifying entry is recomputed into rbest[read]
     uint32_t* soff; uint32_t* s0; uint32_t* s1; const int64_t* rbase; const uint32_t* rcapv;   // per read: first slot, slots (power of two)
-    uint32_t* rcount; uint32_t* dirty_flag; int32_t* dirty_list; cf_cand* rbest; int64_t n_reads;
+    uint32_t* rcount; unsigned long long* rkey; int64_t n_reads;   // rkey[read]: upper bound of the read's best qualifying packed score (see cf_pack_score)
     // seen set of (score slot << 32 | unit index)
     unsigned long long* seen; uint64_t seen_mask;
     // events (kmer << 32 | pos)
@@ -68,6 +68,14 @@ struct cf_place_state {
     int64_t* out_read; int64_t* out_pos; int32_t* out_s0; int32_t* out_s1;
     uint32_t thr, min_unit, min_inters, min_prop;
 };
+
+// packed (s0:16 | s1:24 | offset:24): integer order = the reference's tuple order (s0, s1, offset)
+__device__ __forceinline__ unsigned long long cf_pack_score(uint32_t s0, uint32_t s1, uint32_t off) {
+    return ((unsigned long long)s0 << 48) | ((unsigned long long)s1 << 24) | (unsigned long long)off;
+}
+__device__ __forceinline__ bool cf_qualifies(const cf_place_state& S, uint32_t v0, uint32_t v1) {
+    return v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters;
+}
 
 // ---- add one read at a position: thread-block grid over units of the read
 __device__ __forceinline__ void cf_contig_add(const cf_place_state& S, uint32_t x, uint32_t q) {
@@ -154,8 +162,7 @@ cf_place_update_kernel(cf_place_state S) {
             }
             if (!ok) { atomicOr(&S.ctl[2], 2u); continue; }
             const uint64_t h = base + hh;
-            if (atomicExch(&S.dirty_flag[r], 1u) == 0u) S.dirty_list[atomicAdd(&S.ctl[5], 1u)] = (int32_t)r;
-            atomicAdd(&S.s1[h], 1u);
+            const uint32_t v1 = atomicAdd(&S.s1[h], 1u) + 1u;
             // first hit of unit i at this (read, offset)?
             const unsigned long long sk = ((((unsigned long long)h) << 24) ^ ((unsigned long long)i)) | CF_OCC;  // slot < 2^38, i < 2^24
             uint64_t hs = cf_mix64(sk) & S.seen_mask;
@@ -167,7 +174,11 @@ cf_place_update_kernel(cf_place_state S) {
                 hs = (hs + 1) & S.seen_mask;
             }
             if (!placed) atomicOr(&S.ctl[2], 4u);
-            if (fresh) atomicAdd(&S.s0[h], 1u);
+            const uint32_t v0 = fresh ? atomicAdd(&S.s0[h], 1u) + 1u : S.s0[h];
+            // publish this view of the entry if it qualifies.  Scores only grow, so after the kernel rkey[r] is >= the
+            // key of the read's best qualifying entry; it can be stale (an entry that no longer qualifies, or a mixed
+            // view of concurrent increments) — the arg-max kernel verifies the winner and rescans that read if needed.
+            if (cf_qualifies(S, v0, v1)) atomicMax(&S.rkey[r], cf_pack_score(v0, v1, off));
         }
     }
 }
@@ -194,51 +205,57 @@ __device__ __forceinline__ cf_cand cf_block_best(cf_cand mine) {
     return best;
 }
 
-// best qualifying entry of every dirty read (one wave per read, lanes over its mini-table)
-__global__ void __launch_bounds__(PL_THREADS)
-cf_place_best_kernel(cf_place_state S) {
-    if (S.ctl[0]) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t n_dirty = (int64_t)S.ctl[5];
-    for (int64_t di = wave; di < n_dirty; di += n_waves) {
-        const uint32_t r = (uint32_t)S.dirty_list[di];
-        const uint64_t base = (uint64_t)S.rbase[r];
-        const uint32_t rcap = S.rcapv[r];
-        cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = 0; mine.rank = (uint32_t)S.id_rank[r]; mine.read = r;
-        for (uint32_t i = (uint32_t)lane; i < rcap; i += 64) {
-            const uint32_t off = S.soff[base + i];
-            if (off == 0xFFFFFFFFu) continue;
-            const uint32_t v0 = S.s0[base + i], v1 = S.s1[base + i];
-            if (v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters) {
-                cf_cand c = mine; c.s0 = v0; c.s1 = v1; c.off = off; c.valid = 1;
-                if (cf_cand_better(c, mine)) mine = c;
-            }
-        }
-        for (int d = 32; d >= 1; d >>= 1) {
-            cf_cand o = cf_cand_shfl_down(mine, (unsigned)d);
-            if (lane + d < 64 && cf_cand_better(o, mine)) mine = o;
-        }
-        if (lane == 0) { S.rbest[r] = mine; S.dirty_flag[r] = 0u; }
-    }
-}
-
-// single block: arg-max over the per-read bests of the unused reads, record the placement, reset the event and dirty lists
+// single block: arg-max over rkey[] of the unused reads, verified against the winner's table (stale keys are
+// repaired by rescanning that one read), then the placement is recorded and the event list reset
 __global__ void __launch_bounds__(1024)
 cf_place_final_kernel(cf_place_state S) {
     if (S.ctl[0]) return;
-    cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
-    for (int64_t r = threadIdx.x; r < S.n_reads; r += blockDim.x) {
-        if (S.used[r]) continue;
-        const cf_cand c = S.rbest[r];
-        if (cf_cand_better(c, mine)) mine = c;
+    unsigned int* shw = (unsigned int*)(cf_lds + 16 * sizeof(cf_cand));   // [0] verdict
+    cf_cand b;
+    for (int guard = 0; guard < 1 << 20; ++guard) {
+        cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
+        for (int64_t r = threadIdx.x; r < S.n_reads; r += blockDim.x) {
+            const unsigned long long key = S.rkey[r];
+            if (!key || S.used[r]) continue;
+            cf_cand c; c.s0 = (uint32_t)(key >> 48); c.s1 = (uint32_t)(key >> 24) & 0xFFFFFFu; c.off = (uint32_t)key & 0xFFFFFFu;
+            c.rank = (uint32_t)S.id_rank[r]; c.read = (uint32_t)r; c.valid = 1;
+            if (cf_cand_better(c, mine)) mine = c;
+        }
+        b = cf_block_best(mine);
+        if (!b.valid) break;
+        // verify: the winner's entry must currently hold exactly this qualifying score
+        const uint64_t base = (uint64_t)S.rbase[b.read];
+        const uint32_t rcap = S.rcapv[b.read];
+        if (threadIdx.x == 0) {
+            uint32_t hh = cf_mix32(b.off) & (rcap - 1), ok = 0;
+            for (uint32_t probe = 0; probe < rcap; ++probe) {
+                const uint32_t cur = S.soff[base + hh];
+                if (cur == b.off) { ok = (S.s0[base + hh] == b.s0 && S.s1[base + hh] == b.s1 && cf_qualifies(S, b.s0, b.s1)); break; }
+                if (cur == 0xFFFFFFFFu) break;
+                hh = (hh + 1) & (rcap - 1);
+            }
+            shw[0] = ok;
+        }
+        __syncthreads();
+        const unsigned int ok = shw[0];
+        __syncthreads();
+        if (ok) break;
+        // stale: recompute the exact best qualifying entry of this read
+        cf_cand fix; fix.valid = 0; fix.s0 = fix.s1 = fix.off = 0; fix.rank = b.rank; fix.read = b.read;
+        for (uint32_t i = threadIdx.x; i < rcap; i += blockDim.x) {
+            const uint32_t off = S.soff[base + i];
+            if (off == 0xFFFFFFFFu) continue;
+            const uint32_t v0 = S.s0[base + i], v1 = S.s1[base + i];
+            if (cf_qualifies(S, v0, v1)) { cf_cand c = fix; c.s0 = v0; c.s1 = v1; c.off = off; c.valid = 1; if (cf_cand_better(c, fix)) fix = c; }
+        }
+        const cf_cand fb = cf_block_best(fix);
+        if (threadIdx.x == 0) S.rkey[b.read] = fb.valid ? cf_pack_score(fb.s0, fb.s1, fb.off) : 0ull;
+        __threadfence();
+        __syncthreads();
     }
-    const cf_cand b = cf_block_best(mine);
     if (threadIdx.x == 0) {
         *S.best = b;
         S.n_events[0] = 0ull;
-        S.ctl[5] = 0;
         if (!b.valid) S.ctl[0] = 1;
         else {
             const unsigned int o = S.ctl[1]++;
@@ -322,6 +339,12 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         CF_HIP(hipMemcpy(h_cloud.data(), ctx->d_cloud_ptr, (size_t)(U + 1) * 8, hipMemcpyDeviceToHost));
         for (int64_t r = 0; r <= R; ++r) h_cp[(size_t)r] = h_cloud[(size_t)ctx->h_unit_ptr[(size_t)r]];
     }
+    // limits of the packed per-read score key (s0:16 | s1:24 | offset:24)
+    if (U >= ((int64_t)1 << 24)) return cf_fail(ctx, -22, "cf_place_reads: more than 2^24 units");
+    for (int64_t r = 0; r < R; ++r) {
+        if (ctx->h_unit_ptr[(size_t)r + 1] - ctx->h_unit_ptr[(size_t)r] > 65535) return cf_fail(ctx, -22, "cf_place_reads: a read has more than 65535 units");
+        if (h_cp[(size_t)r + 1] - h_cp[(size_t)r] >= ((int64_t)1 << 24)) return cf_fail(ctx, -22, "cf_place_reads: a read has more than 2^24 cloud entries");
+    }
     size_t score_cap = 0;
     for (int64_t r = 0; r < R; ++r) {
         const uint64_t want = (uint64_t)(h_cp[(size_t)r + 1] - h_cp[(size_t)r]) * score_mult / 8;
@@ -341,9 +364,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     CF_TRY(B.get(&S.s0, score_cap, "score s0"));
     CF_TRY(B.get(&S.s1, score_cap, "score s1"));
     CF_TRY(B.get(&S.rcount, (size_t)R + 1, "score entries per read"));
-    CF_TRY(B.get(&S.dirty_flag, (size_t)R + 1, "dirty flags"));
-    CF_TRY(B.get(&S.dirty_list, (size_t)R + 1, "dirty list"));
-    CF_TRY(B.get(&S.rbest, (size_t)R + 1, "per-read best"));
+    CF_TRY(B.get(&S.rkey, (size_t)R + 1, "per-read best keys"));
     CF_TRY(B.get(&S.seen, (size_t)seen_cap, "seen set"));
     CF_TRY(B.get(&S.events, (size_t)N + 1, "events"));
     CF_TRY(B.get(&S.n_events, 2, "event count"));
@@ -393,20 +414,18 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         CF_HIP(hipMemsetAsync(S.s0, 0, score_cap * 4, st));
         CF_HIP(hipMemsetAsync(S.s1, 0, score_cap * 4, st));
         CF_HIP(hipMemsetAsync(S.rcount, 0, (size_t)(R + 1) * 4, st));
-        CF_HIP(hipMemsetAsync(S.dirty_flag, 0, (size_t)(R + 1) * 4, st));
-        CF_HIP(hipMemsetAsync(S.rbest, 0, (size_t)(R + 1) * sizeof(cf_cand), st));   // valid = 0
+        CF_HIP(hipMemsetAsync(S.rkey, 0, (size_t)(R + 1) * 8, st));
         CF_HIP(hipMemsetAsync(S.seen, 0, (size_t)seen_cap * 8, st));
         CF_HIP(hipMemsetAsync(S.n_events, 0, 16, st));
         CF_HIP(hipMemsetAsync(S.ctl, 0, 8, st));  // done = 0, n_out = 0 (error flags kept)
-        CF_HIP(hipMemsetAsync(S.ctl + 4, 0, 8, st));  // [5] = number of dirty reads
+        CF_HIP(hipMemsetAsync(S.ctl + 4, 0, 8, st));
         hipLaunchKernelGGL(cf_place_seed_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
         CF_KERNEL_CHECK("cf_place_seed_kernel");
         unsigned int h_ctl[4] = {0, 0, 0, 0};
         const int64_t n_iter = (int64_t)stage_reads.size();
         for (int64_t it = 0; it < n_iter; ++it) {
             hipLaunchKernelGGL(cf_place_update_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
-            hipLaunchKernelGGL(cf_place_best_kernel, dim3(64), dim3(PL_THREADS), 0, st, S);
-            hipLaunchKernelGGL(cf_place_final_kernel, dim3(1), dim3(1024), 16 * sizeof(cf_cand), st, S);
+            hipLaunchKernelGGL(cf_place_final_kernel, dim3(1), dim3(1024), 16 * sizeof(cf_cand) + 16, st, S);
             hipLaunchKernelGGL(cf_place_add_kernel, dim3(8), dim3(PL_THREADS), 0, st, S, 1, (int64_t)0);
             if ((it & 255) == 255 || it + 1 == n_iter) {
                 CF_KERNEL_CHECK("placement iteration");
@@ -455,7 +474,7 @@ int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int3
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     const int64_t R = ctx->n_reads;
     for (int64_t r = 0; r < R; ++r) if (cls[r] > 2) return cf_fail(ctx, -22, "cf_place_reads: class must be 0, 1 or 2");
-    uint64_t score_cap = 1;     // multiplier of the per-read score table size (x4 when a read fills 3/4 of its table)
+    uint64_t score_cap = 16;    // per-read score table = 2 x (cloud entries of the read), x4 when a read fills 3/4 of its table
     uint64_t seen_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(8 * ctx->n_entries, 1 << 14));
     std::vector<int64_t> o_read, o_pos;
     std::vector<int32_t> o_s0, o_s1;
