@@ -13,13 +13,11 @@
 //       smaller r_id) among entries with s0 >= min_unit, s0 * min_prop <= s1, s1 >= min_inters;
 //       if none qualifies all remaining reads of the stage are written as None.
 //
-// Device design: everything lives in HBM hash tables — contig (pos,kmer)->count, per read a small
-// open-addressed table offset->(s0,s1), a seen-set of (score slot, unit) for s0.  One iteration = 4 small
-// open-addressed table offset->(s0,s1), a seen-set of (score slot, unit) for s0.  One iteration = 3 small
-// kernels enqueued back to back with NO host round trip: apply events (every touched entry publishes its
-// packed score to its read's running maximum with one atomicMax) -> single-block arg-max over the per-read
-// maxima, verified against the winner's table (records the placement device-side) -> add the chosen read
-// (emits the next events).  The host only polls a done flag every few hundred iterations.
+// Device design: everything lives in HBM hash tables — contig (pos,kmer)->count, score
+// (read,offset)->(s0,s1), a seen-set of (score slot, unit) for s0.  One iteration = 4 small
+// kernels enqueued back to back with NO host round trip: apply events -> block arg-max ->
+// final arg-max (records the placement, device-side) -> add the chosen read (emits the next
+// events).  The host only polls a done flag every few hundred iterations.
 #include "cf_common.h"
 
 #include <cstdlib>
@@ -53,9 +51,8 @@ struct cf_place_state {
     uint8_t* freq_flag;
     // postings of the stage
     const int64_t* post_ptr; const int32_t* post;
-    // scores: one open-addressed mini-table per read, sized from the read's cloud entries (key = offset, 0xFFFFFFFF empty) with s0 / s1;
-    uint32_t* soff; uint32_t* s0; uint32_t* s1; const int64_t* rbase; const uint32_t* rcapv;   // per read: first slot, slots (power of two)
-    uint32_t* rcount; unsigned long long* rkey; int64_t n_reads;   // rkey[read]: upper bound of the read's best qualifying packed score (see cf_pack_score)
+    // score map: key (read<<32|off)|OCC, s0, s1
+    unsigned long long* skeys; uint32_t* s0; uint32_t* s1; uint64_t smask;
     // seen set of (score slot << 32 | unit index)
     unsigned long long* seen; uint64_t seen_mask;
     // events (kmer << 32 | pos)
@@ -64,18 +61,10 @@ struct cf_place_state {
     unsigned int* ctl;
     const uint8_t* used_in; uint8_t* used;
     const int32_t* id_rank;
-    cf_cand* best;
+    cf_cand* block_best; cf_cand* best;
     int64_t* out_read; int64_t* out_pos; int32_t* out_s0; int32_t* out_s1;
     uint32_t thr, min_unit, min_inters, min_prop;
 };
-
-// packed (s0:16 | s1:24 | offset:24): integer order = the reference's tuple order (s0, s1, offset)
-__device__ __forceinline__ unsigned long long cf_pack_score(uint32_t s0, uint32_t s1, uint32_t off) {
-    return ((unsigned long long)s0 << 48) | ((unsigned long long)s1 << 24) | (unsigned long long)off;
-}
-__device__ __forceinline__ bool cf_qualifies(const cf_place_state& S, uint32_t v0, uint32_t v1) {
-    return v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters;
-}
 
 // ---- add one read at a position: thread-block grid over units of the read
 __device__ __forceinline__ void cf_contig_add(const cf_place_state& S, uint32_t x, uint32_t q) {
@@ -147,22 +136,20 @@ cf_place_update_kernel(cf_place_state S) {
             const uint32_t i = (uint32_t)(g - S.unit_ptr[r]);
             if (q < i) continue;
             const uint32_t off = q - i;
-            const uint64_t base = (uint64_t)S.rbase[r];
-            const uint32_t rcap = S.rcapv[r];
-            uint32_t hh = cf_mix32(off) & (rcap - 1);
+            const unsigned long long want = (((unsigned long long)r << 32) | off) | CF_OCC;
+            uint64_t h = cf_mix64(want) & S.smask;
             bool ok = false;
-            for (uint32_t probe = 0; probe < rcap; ++probe) {
-                uint32_t cur = S.soff[base + hh];
-                if (cur == 0xFFFFFFFFu) {
-                    cur = atomicCAS(&S.soff[base + hh], 0xFFFFFFFFu, off);
-                    if (cur == 0xFFFFFFFFu && atomicAdd(&S.rcount[r], 1u) >= (rcap >> 2) * 3u) atomicOr(&S.ctl[2], 2u);   // mini-table 3/4 full: grow and restart
+            for (uint64_t probe = 0; probe <= S.smask && probe < 4096; ++probe) {   // a long probe = table too full: grow and restart
+                unsigned long long cur = S.skeys[h];
+                if (cur == 0ull) {
+                    cur = atomicCAS(&S.skeys[h], 0ull, want);
+                    if (cur == 0ull && atomicAdd(&S.ctl[4], 1u) > (unsigned int)(S.smask >> 1)) atomicOr(&S.ctl[2], 2u);   // load > 0.5
                 }
-                if (cur == 0xFFFFFFFFu || cur == off) { ok = true; break; }
-                hh = (hh + 1) & (rcap - 1);
+                if (cur == 0ull || cur == want) { ok = true; break; }
+                h = (h + 1) & S.smask;
             }
             if (!ok) { atomicOr(&S.ctl[2], 2u); continue; }
-            const uint64_t h = base + hh;
-            const uint32_t v1 = atomicAdd(&S.s1[h], 1u) + 1u;
+            atomicAdd(&S.s1[h], 1u);
             // first hit of unit i at this (read, offset)?
             const unsigned long long sk = ((((unsigned long long)h) << 24) ^ ((unsigned long long)i)) | CF_OCC;  // slot < 2^38, i < 2^24
             uint64_t hs = cf_mix64(sk) & S.seen_mask;
@@ -174,11 +161,7 @@ cf_place_update_kernel(cf_place_state S) {
                 hs = (hs + 1) & S.seen_mask;
             }
             if (!placed) atomicOr(&S.ctl[2], 4u);
-            const uint32_t v0 = fresh ? atomicAdd(&S.s0[h], 1u) + 1u : S.s0[h];
-            // publish this view of the entry if it qualifies.  Scores only grow, so after the kernel rkey[r] is >= the
-            // key of the read's best qualifying entry; it can be stale (an entry that no longer qualifies, or a mixed
-            // view of concurrent increments) — the arg-max kernel verifies the winner and rescans that read if needed.
-            if (cf_qualifies(S, v0, v1)) atomicMax(&S.rkey[r], cf_pack_score(v0, v1, off));
+            if (fresh) atomicAdd(&S.s0[h], 1u);
         }
     }
 }
@@ -205,54 +188,34 @@ __device__ __forceinline__ cf_cand cf_block_best(cf_cand mine) {
     return best;
 }
 
-// single block: arg-max over rkey[] of the unused reads, verified against the winner's table (stale keys are
-// repaired by rescanning that one read), then the placement is recorded and the event list reset
-__global__ void __launch_bounds__(1024)
-cf_place_final_kernel(cf_place_state S) {
-    if (S.ctl[0]) return;
-    unsigned int* shw = (unsigned int*)(cf_lds + 16 * sizeof(cf_cand));   // [0] verdict
-    cf_cand b;
-    for (int guard = 0; guard < 1 << 20; ++guard) {
-        cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
-        for (int64_t r = threadIdx.x; r < S.n_reads; r += blockDim.x) {
-            const unsigned long long key = S.rkey[r];
-            if (!key || S.used[r]) continue;
-            cf_cand c; c.s0 = (uint32_t)(key >> 48); c.s1 = (uint32_t)(key >> 24) & 0xFFFFFFu; c.off = (uint32_t)key & 0xFFFFFFu;
-            c.rank = (uint32_t)S.id_rank[r]; c.read = (uint32_t)r; c.valid = 1;
-            if (cf_cand_better(c, mine)) mine = c;
-        }
-        b = cf_block_best(mine);
-        if (!b.valid) break;
-        // verify: the winner's entry must currently hold exactly this qualifying score
-        const uint64_t base = (uint64_t)S.rbase[b.read];
-        const uint32_t rcap = S.rcapv[b.read];
-        if (threadIdx.x == 0) {
-            uint32_t hh = cf_mix32(b.off) & (rcap - 1), ok = 0;
-            for (uint32_t probe = 0; probe < rcap; ++probe) {
-                const uint32_t cur = S.soff[base + hh];
-                if (cur == b.off) { ok = (S.s0[base + hh] == b.s0 && S.s1[base + hh] == b.s1 && cf_qualifies(S, b.s0, b.s1)); break; }
-                if (cur == 0xFFFFFFFFu) break;
-                hh = (hh + 1) & (rcap - 1);
+__global__ void __launch_bounds__(PL_THREADS)
+cf_place_argmax_kernel(cf_place_state S) {
+    cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
+    if (!S.ctl[0]) {
+        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= S.smask; i += stride) {
+            const unsigned long long k = S.skeys[i];
+            if (!k) continue;
+            const uint32_t r = (uint32_t)((k & ~CF_OCC) >> 32), off = (uint32_t)k;
+            if (S.used[r]) continue;
+            const uint32_t v0 = S.s0[i], v1 = S.s1[i];
+            if (v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters) {
+                cf_cand c; c.s0 = v0; c.s1 = v1; c.off = off; c.rank = (uint32_t)S.id_rank[r]; c.read = r; c.valid = 1;
+                if (cf_cand_better(c, mine)) mine = c;
             }
-            shw[0] = ok;
         }
-        __syncthreads();
-        const unsigned int ok = shw[0];
-        __syncthreads();
-        if (ok) break;
-        // stale: recompute the exact best qualifying entry of this read
-        cf_cand fix; fix.valid = 0; fix.s0 = fix.s1 = fix.off = 0; fix.rank = b.rank; fix.read = b.read;
-        for (uint32_t i = threadIdx.x; i < rcap; i += blockDim.x) {
-            const uint32_t off = S.soff[base + i];
-            if (off == 0xFFFFFFFFu) continue;
-            const uint32_t v0 = S.s0[base + i], v1 = S.s1[base + i];
-            if (cf_qualifies(S, v0, v1)) { cf_cand c = fix; c.s0 = v0; c.s1 = v1; c.off = off; c.valid = 1; if (cf_cand_better(c, fix)) fix = c; }
-        }
-        const cf_cand fb = cf_block_best(fix);
-        if (threadIdx.x == 0) S.rkey[b.read] = fb.valid ? cf_pack_score(fb.s0, fb.s1, fb.off) : 0ull;
-        __threadfence();
-        __syncthreads();
     }
+    const cf_cand b = cf_block_best(mine);
+    if (threadIdx.x == 0) S.block_best[blockIdx.x] = b;
+}
+
+// single block: reduce the block candidates, record the placement, reset the event list
+__global__ void __launch_bounds__(PL_THREADS)
+cf_place_final_kernel(cf_place_state S, int n_blocks) {
+    if (S.ctl[0]) return;
+    cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
+    for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) if (cf_cand_better(S.block_best[i], mine)) mine = S.block_best[i];
+    const cf_cand b = cf_block_best(mine);
     if (threadIdx.x == 0) {
         *S.best = b;
         S.n_events[0] = 0ull;
@@ -307,7 +270,7 @@ struct Bufs {
 
 // One attempt with given table sizes; returns 1 if a table overflowed (caller retries larger).
 static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int32_t min_freq, int32_t min_unit,
-                         int32_t min_inters, int32_t min_prop, uint64_t score_mult, uint64_t seen_cap,
+                         int32_t min_inters, int32_t min_prop, uint64_t score_cap, uint64_t seen_cap,
                          std::vector<int64_t>& o_read, std::vector<int64_t>& o_pos, std::vector<int32_t>& o_s0, std::vector<int32_t>& o_s1) {
     const int64_t R = ctx->n_reads, U = ctx->n_units, N = ctx->n_entries, K = ctx->n_kmers;
     Bufs B{ctx, {}};
@@ -331,51 +294,21 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     CF_TRY(B.get(&d_pcnt, (size_t)K + 1, "stage posting counts"));
     CF_TRY(B.get(&d_post_ptr, (size_t)K + 1, "stage posting offsets"));
     CF_TRY(B.get(&d_post, (size_t)N + 1, "stage postings"));
-    // per-read score table: power of two >= score_mult x (cloud entries of the read) / 8, at least 64 slots
-    std::vector<int64_t> h_cp((size_t)R + 1), h_rbase((size_t)R + 1);
-    std::vector<uint32_t> h_rcap((size_t)R + 1, 64u);
-    {
-        std::vector<int64_t> h_cloud((size_t)U + 1);
-        CF_HIP(hipMemcpy(h_cloud.data(), ctx->d_cloud_ptr, (size_t)(U + 1) * 8, hipMemcpyDeviceToHost));
-        for (int64_t r = 0; r <= R; ++r) h_cp[(size_t)r] = h_cloud[(size_t)ctx->h_unit_ptr[(size_t)r]];
-    }
-    // limits of the packed per-read score key (s0:16 | s1:24 | offset:24)
-    if (U >= ((int64_t)1 << 24)) return cf_fail(ctx, -22, "cf_place_reads: more than 2^24 units");
-    for (int64_t r = 0; r < R; ++r) {
-        if (ctx->h_unit_ptr[(size_t)r + 1] - ctx->h_unit_ptr[(size_t)r] > 65535) return cf_fail(ctx, -22, "cf_place_reads: a read has more than 65535 units");
-        if (h_cp[(size_t)r + 1] - h_cp[(size_t)r] >= ((int64_t)1 << 24)) return cf_fail(ctx, -22, "cf_place_reads: a read has more than 2^24 cloud entries");
-    }
-    size_t score_cap = 0;
-    for (int64_t r = 0; r < R; ++r) {
-        const uint64_t want = (uint64_t)(h_cp[(size_t)r + 1] - h_cp[(size_t)r]) * score_mult / 8;
-        h_rcap[(size_t)r] = (uint32_t)std::min<uint64_t>(cf_pow2_ceil(std::max<uint64_t>(want, 64)), 1u << 30);
-        h_rbase[(size_t)r] = (int64_t)score_cap;
-        score_cap += h_rcap[(size_t)r];
-    }
-    h_rbase[(size_t)R] = (int64_t)score_cap;
-    int64_t* d_rbase = nullptr; uint32_t* d_rcapv = nullptr;
-    CF_TRY(B.get(&d_rbase, (size_t)R + 1, "score table bases"));
-    CF_TRY(B.get(&d_rcapv, (size_t)R + 1, "score table sizes"));
-    CF_HIP(hipMemcpyAsync(d_rbase, h_rbase.data(), (size_t)(R + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    CF_HIP(hipMemcpyAsync(d_rcapv, h_rcap.data(), (size_t)(R + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    CF_HIP(hipStreamSynchronize(ctx->stream));
-    S.rbase = d_rbase; S.rcapv = d_rcapv;
-    CF_TRY(B.get(&S.soff, score_cap, "score offsets"));
-    CF_TRY(B.get(&S.s0, score_cap, "score s0"));
-    CF_TRY(B.get(&S.s1, score_cap, "score s1"));
-    CF_TRY(B.get(&S.rcount, (size_t)R + 1, "score entries per read"));
-    CF_TRY(B.get(&S.rkey, (size_t)R + 1, "per-read best keys"));
+    CF_TRY(B.get(&S.skeys, (size_t)score_cap, "score keys"));
+    CF_TRY(B.get(&S.s0, (size_t)score_cap, "score s0"));
+    CF_TRY(B.get(&S.s1, (size_t)score_cap, "score s1"));
     CF_TRY(B.get(&S.seen, (size_t)seen_cap, "seen set"));
     CF_TRY(B.get(&S.events, (size_t)N + 1, "events"));
     CF_TRY(B.get(&S.n_events, 2, "event count"));
     CF_TRY(B.get(&S.ctl, 8, "control"));
     const int n_blocks = std::max(1, ctx->n_cu) * 4;
+    CF_TRY(B.get(&S.block_best, (size_t)n_blocks, "block candidates"));
     CF_TRY(B.get(&S.best, 1, "best candidate"));
     CF_TRY(B.get(&S.out_read, (size_t)R + 1, "out_read"));
     CF_TRY(B.get(&S.out_pos, (size_t)R + 1, "out_pos"));
     CF_TRY(B.get(&S.out_s0, (size_t)R + 1, "out_s0"));
     CF_TRY(B.get(&S.out_s1, (size_t)R + 1, "out_s1"));
-    S.unit2read = d_u2r; S.cmask = ccap - 1; S.n_reads = R; S.seen_mask = seen_cap - 1;
+    S.unit2read = d_u2r; S.cmask = ccap - 1; S.smask = score_cap - 1; S.seen_mask = seen_cap - 1;
     S.used = d_used; S.id_rank = d_rank; S.post_ptr = d_post_ptr; S.post = d_post;
     hipStream_t st = ctx->stream;
     CF_HIP(hipMemcpyAsync(d_cls, cls, (size_t)R, hipMemcpyHostToDevice, st));
@@ -410,29 +343,28 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         hipLaunchKernelGGL(cf_place_post_kernel, dim3((unsigned)g_units), dim3(256), 0, st, (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries,
                            (const int32_t*)d_u2r, (const uint8_t*)d_cls, stage_cls, U, 1, d_pcnt, (const int64_t*)d_post_ptr, d_post);
         // fresh scores, seed events
-        CF_HIP(hipMemsetAsync(S.soff, 0xFF, score_cap * 4, st));
-        CF_HIP(hipMemsetAsync(S.s0, 0, score_cap * 4, st));
-        CF_HIP(hipMemsetAsync(S.s1, 0, score_cap * 4, st));
-        CF_HIP(hipMemsetAsync(S.rcount, 0, (size_t)(R + 1) * 4, st));
-        CF_HIP(hipMemsetAsync(S.rkey, 0, (size_t)(R + 1) * 8, st));
+        CF_HIP(hipMemsetAsync(S.skeys, 0, (size_t)score_cap * 8, st));
+        CF_HIP(hipMemsetAsync(S.s0, 0, (size_t)score_cap * 4, st));
+        CF_HIP(hipMemsetAsync(S.s1, 0, (size_t)score_cap * 4, st));
         CF_HIP(hipMemsetAsync(S.seen, 0, (size_t)seen_cap * 8, st));
         CF_HIP(hipMemsetAsync(S.n_events, 0, 16, st));
         CF_HIP(hipMemsetAsync(S.ctl, 0, 8, st));  // done = 0, n_out = 0 (error flags kept)
-        CF_HIP(hipMemsetAsync(S.ctl + 4, 0, 8, st));
+        CF_HIP(hipMemsetAsync(S.ctl + 4, 0, 4, st));  // score-map entry count of this stage
         hipLaunchKernelGGL(cf_place_seed_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
         CF_KERNEL_CHECK("cf_place_seed_kernel");
         unsigned int h_ctl[4] = {0, 0, 0, 0};
         const int64_t n_iter = (int64_t)stage_reads.size();
         for (int64_t it = 0; it < n_iter; ++it) {
             hipLaunchKernelGGL(cf_place_update_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
-            hipLaunchKernelGGL(cf_place_final_kernel, dim3(1), dim3(1024), 16 * sizeof(cf_cand) + 16, st, S);
+            hipLaunchKernelGGL(cf_place_argmax_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S);
+            hipLaunchKernelGGL(cf_place_final_kernel, dim3(1), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S, n_blocks);
             hipLaunchKernelGGL(cf_place_add_kernel, dim3(8), dim3(PL_THREADS), 0, st, S, 1, (int64_t)0);
             if ((it & 255) == 255 || it + 1 == n_iter) {
                 CF_KERNEL_CHECK("placement iteration");
                 CF_HIP(hipMemcpyAsync(h_ctl, S.ctl, 16, hipMemcpyDeviceToHost, st));
                 CF_HIP(hipStreamSynchronize(st));
                 if (std::getenv("CF_DEBUG") && ((it & 8191) == 8191 || h_ctl[2] || h_ctl[0])) std::fprintf(stderr, "[cf_place] stage %d iter %lld/%lld ctl=%u,%u,%u\n", stage_cls, (long long)it, (long long)n_iter, h_ctl[0], h_ctl[1], h_ctl[2]);
-                if (h_ctl[2]) { ctx->place_flags = h_ctl[2]; return 1; }
+                if (h_ctl[2]) return 1;
                 if (h_ctl[0]) break;
             }
         }
@@ -458,7 +390,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     }
     unsigned int h_ctl[4] = {0, 0, 0, 0};
     CF_HIP(hipMemcpy(h_ctl, S.ctl, 16, hipMemcpyDeviceToHost));
-    if (h_ctl[2]) { ctx->place_flags = h_ctl[2]; return 1; }
+    if (h_ctl[2]) return 1;
     return 0;
 }
 
@@ -474,7 +406,7 @@ int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int3
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     const int64_t R = ctx->n_reads;
     for (int64_t r = 0; r < R; ++r) if (cls[r] > 2) return cf_fail(ctx, -22, "cf_place_reads: class must be 0, 1 or 2");
-    uint64_t score_cap = 16;    // per-read score table = 2 x (cloud entries of the read), x4 when a read fills 3/4 of its table
+    uint64_t score_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(256 * R, 1 << 14));
     uint64_t seen_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(8 * ctx->n_entries, 1 << 14));
     std::vector<int64_t> o_read, o_pos;
     std::vector<int32_t> o_s0, o_s1;
@@ -482,7 +414,7 @@ int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int3
     for (int attempt = 0; attempt < 6 && rc == 1; ++attempt) {
         rc = place_attempt(ctx, cls, id_rank, min_cloud_kmer_freq, min_unit, min_inters, min_prop, score_cap, seen_cap, o_read, o_pos, o_s0, o_s1);
         if (std::getenv("CF_DEBUG")) std::fprintf(stderr, "[cf_place] attempt %d rc=%d score_cap=%llu seen_cap=%llu entries=%lld reads=%lld\n", attempt, rc, (unsigned long long)score_cap, (unsigned long long)seen_cap, (long long)ctx->n_entries, (long long)R);
-        if (rc == 1) { if (ctx->place_flags & 2u) score_cap *= 4; if (ctx->place_flags & 4u) seen_cap *= 4; if (!(ctx->place_flags & 6u)) { score_cap *= 4; seen_cap *= 4; } }
+        if (rc == 1) { score_cap *= 4; seen_cap *= 4; }
     }
     if (rc == 1) return cf_fail(ctx, -34, "cf_place_reads: score tables kept overflowing");
     if (rc) return rc;
