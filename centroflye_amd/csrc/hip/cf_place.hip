@@ -53,6 +53,7 @@ struct cf_place_state {
     const int64_t* post_ptr; const int32_t* post;
     // score map: key (read<<32|off)|OCC, s0, s1
     unsigned long long* skeys; uint32_t* s0; uint32_t* s1; uint64_t smask;
+    uint32_t* qflag;   // one byte per score slot (4 per word): some view of the entry qualified; the arg-max scans these bytes only
     // seen set of (score slot << 32 | unit index)
     unsigned long long* seen; uint64_t seen_mask;
     // events (kmer << 32 | pos)
@@ -162,6 +163,11 @@ cf_place_update_kernel(cf_place_state S) {
             }
             if (!placed) atomicOr(&S.ctl[2], 4u);
             if (fresh) atomicAdd(&S.s0[h], 1u);
+            // flag the slot when the entry qualifies in this lane's view, read back at L2 AFTER its own increments: the
+            // lane whose increment is the last one on the entry sees its final state, so a finally-qualifying entry is
+            // always flagged; flags can be stale-true (the arg-max re-checks and clears them), never stale-false
+            const uint32_t v0 = atomicAdd(&S.s0[h], 0u), v1 = atomicAdd(&S.s1[h], 0u);
+            if (v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters) ((uint8_t*)S.qflag)[h] = 1;
         }
     }
 }
@@ -193,13 +199,18 @@ cf_place_argmax_kernel(cf_place_state S) {
     cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
     if (!S.ctl[0]) {
         const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= S.smask; i += stride) {
-            const unsigned long long k = S.skeys[i];
-            if (!k) continue;
-            const uint32_t r = (uint32_t)((k & ~CF_OCC) >> 32), off = (uint32_t)k;
-            if (S.used[r]) continue;
-            const uint32_t v0 = S.s0[i], v1 = S.s1[i];
-            if (v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters) {
+        const uint64_t n_words = (S.smask + 1) >> 2;   // 4 flag bytes per word
+        for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+            uint32_t f = S.qflag[w];
+            if (!f) continue;
+            for (int j = 0; j < 4; ++j) {
+                if (!((f >> (8 * j)) & 0xFFu)) continue;
+                const uint64_t i = 4 * w + (uint64_t)j;
+                const unsigned long long k = S.skeys[i];
+                const uint32_t r = (uint32_t)((k & ~CF_OCC) >> 32), off = (uint32_t)k;
+                const uint32_t v0 = S.s0[i], v1 = S.s1[i];
+                if (!(v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters)) { ((uint8_t*)S.qflag)[i] = 0; continue; }   // stale flag
+                if (S.used[r]) continue;
                 cf_cand c; c.s0 = v0; c.s1 = v1; c.off = off; c.rank = (uint32_t)S.id_rank[r]; c.read = r; c.valid = 1;
                 if (cf_cand_better(c, mine)) mine = c;
             }
@@ -297,6 +308,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     CF_TRY(B.get(&S.skeys, (size_t)score_cap, "score keys"));
     CF_TRY(B.get(&S.s0, (size_t)score_cap, "score s0"));
     CF_TRY(B.get(&S.s1, (size_t)score_cap, "score s1"));
+    CF_TRY(B.get(&S.qflag, (size_t)score_cap / 4 + 1, "score flags"));
     CF_TRY(B.get(&S.seen, (size_t)seen_cap, "seen set"));
     CF_TRY(B.get(&S.events, (size_t)N + 1, "events"));
     CF_TRY(B.get(&S.n_events, 2, "event count"));
@@ -346,6 +358,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         CF_HIP(hipMemsetAsync(S.skeys, 0, (size_t)score_cap * 8, st));
         CF_HIP(hipMemsetAsync(S.s0, 0, (size_t)score_cap * 4, st));
         CF_HIP(hipMemsetAsync(S.s1, 0, (size_t)score_cap * 4, st));
+        CF_HIP(hipMemsetAsync(S.qflag, 0, (size_t)score_cap + 4, st));
         CF_HIP(hipMemsetAsync(S.seen, 0, (size_t)seen_cap * 8, st));
         CF_HIP(hipMemsetAsync(S.n_events, 0, 16, st));
         CF_HIP(hipMemsetAsync(S.ctl, 0, 8, st));  // done = 0, n_out = 0 (error flags kept)
