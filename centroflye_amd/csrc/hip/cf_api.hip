@@ -252,13 +252,16 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
         if (value < 64 || value > 1024 || value % 64) return cf_fail(ctx, -22, "dist_block must be a multiple of 64 in [64, 1024]");
         ctx->dist_block = (int)value;
     } else if (n == "dist_slots") {
-        if (value < 256 || value > 19200) return cf_fail(ctx, -22, "dist_slots out of range (256 .. 19200: table + work lists must fit the 160 KiB LDS)");
+        if (value != 0 && (value < 256 || value > 19200)) return cf_fail(ctx, -22, "dist_slots out of range (0 = auto, 256 .. 19200: table + work lists must fit the 160 KiB LDS)");
         ctx->dist_slots = (int)value;
     } else if (n == "dist_wide") {
         ctx->dist_wide = value != 0;
     } else if (n == "dist_fill_pct") {
         if (value < 10 || value > 90) return cf_fail(ctx, -22, "dist_fill_pct out of range (10 .. 90)");
         ctx->dist_fill_pct = (int)value;
+    } else if (n == "dist_est_pct") {
+        if (value < 5 || value > 100) return cf_fail(ctx, -22, "dist_est_pct out of range (5 .. 100)");
+        ctx->dist_est_pct = (int)value;
     } else if (n == "dist_stage") {
         if (value < 0 || value > 2048) return cf_fail(ctx, -22, "dist_stage out of range (0 .. 2048)");
         ctx->dist_stage = (int)value;

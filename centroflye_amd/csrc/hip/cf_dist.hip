@@ -62,15 +62,18 @@ cf_unit_rend_kernel(const int64_t* __restrict__ unit_ptr, int64_t n_reads, int32
     }
 }
 
-// per cloud entry the index of its unit inside its read (one wave per unit)
+// per cloud entry the index of its unit inside its read (one wave per unit): as a 16-bit side array (wide table
+// layout) or, mod 256, packed above the 24-bit rank (narrow layout: one 4-byte load per pair emission)
 __global__ void __launch_bounds__(256)
-cf_entry_unit_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ rbeg, int64_t n_units, uint16_t* __restrict__ entry_i) {
+cf_entry_unit_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ rbeg, const int32_t* __restrict__ entries, int64_t n_units,
+                     uint16_t* __restrict__ entry_i, uint32_t* __restrict__ packed) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t u = wave; u < n_units; u += n_waves) {
-        const uint16_t i = (uint16_t)(u - rbeg[u]);
-        for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) entry_i[e] = i;
+        const uint32_t i = (uint32_t)(u - rbeg[u]);
+        if (packed) { for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) packed[e] = ((i & 0xFFu) << 24) | (uint32_t)entries[e]; }
+        else { for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) entry_i[e] = (uint16_t)i; }
     }
 }
 
@@ -107,7 +110,8 @@ struct cf_dist_args {
     const int32_t* entries;
     const int32_t* unit_rend;      // one past the last unit of the unit's read
     const int32_t* unit_rbeg;      // first unit of the unit's read
-    const uint16_t* entry_i;       // per cloud entry: index of its unit inside its read
+    const uint16_t* entry_i;       // wide layout: per cloud entry the index of its unit inside its read
+    const uint32_t* packed;        // narrow layout: per cloud entry [unit index inside its read mod 256 : 8 | rank : 24]
     int64_t n_kmers;
     int32_t part, n_parts;
     int32_t min_d, max_d;       // min_d already clamped to >= 1
@@ -115,6 +119,7 @@ struct cf_dist_args {
     double thr;
     int32_t slots;
     uint32_t fill_limit;
+    uint32_t est_limit;            // emissions one partition is expected to hold (fill_limit / expected distinct share)
     uint32_t stage_cap;            // <= DIST_STAGE_CAP
     uint32_t* edges;
     unsigned long long edge_cap;
@@ -132,27 +137,35 @@ struct cf_dist_args {
 // between home(b) and the first bucket that still has an empty slot, and a key is never inserted twice.
 // Two layouts with one interface:
 //   cf_tab_wide    4 slots of 64 bits  [b:32 | d:8 | sel:1 | cnt:23]            any k-mer set size
-//   cf_tab_narrow  8 keys of 32 bits   [d:8 | b:24] + 8 x 16-bit [sel:1 | cnt:15]  (6 bytes per slot: a third
+//   cf_tab_narrow  8 keys of 32 bits   [d:8 | b:24] + 8 x 16-bit [sel:1 | cnt-1:15]  (6 bytes per slot: a third
 //                  more slots in the same LDS, half as many full buckets, 32-bit compares) when the set has
-//                  < 2^24 - 1 k-mers and no k-mer has more than 32767 postings
-// b is a dense rank, so one odd multiplier spreads it; the home bucket is the high product.
+//                  < 2^24 - 1 k-mers and no k-mer has more than 32767 postings.  A claimed slot counts 1 with
+//                  its count field still 0 (most pairs are seen once: no second atomic for them); the cloud
+//                  entries are pre-packed [unit index mod 256 : 8 | b : 24], so ONE 4-byte load and one
+//                  subtraction give the key; hashing uses 24-bit multiplies (full rate, v_mul_u32_u24).
+// b is a dense rank, so one odd multiplier spreads it; the home bucket comes from the high bits of the product.
 struct alignas(16) cf_u64x2 { unsigned long long x, y; };
 struct alignas(16) cf_u32x4 { uint32_t x, y, z, w; };
-
-__device__ __forceinline__ uint32_t cf_dist_hash(uint32_t b) { return b * 0x9E3779B1u; }
-__device__ __forceinline__ uint32_t cf_dist_home(uint32_t b, uint32_t n_buckets) {
-    return (uint32_t)(((unsigned long long)cf_dist_hash(b) * (unsigned long long)n_buckets) >> 32);
-}
 
 struct cf_tab_wide {
     static constexpr uint32_t kSlotBytes = 8, kPerBucket = 4;
     struct bucket { cf_u64x2 lo, hi; };
+    struct raw { uint32_t b, i; };
+    typedef unsigned long long qitem;   // deferred insert: [b:32 | d:8 | bucket to look at next:24]
+    static __device__ __forceinline__ qitem q_make(uint32_t b, uint32_t dd, uint32_t bk) { return ((unsigned long long)b << 32) | ((unsigned long long)dd << 24) | bk; }
+    static __device__ __forceinline__ void q_take(qitem q, uint32_t n_buckets, uint32_t& b, uint32_t& dd, uint32_t& bk) { b = (uint32_t)(q >> 32); dd = ((uint32_t)q >> 24) & 0xFFu; bk = (uint32_t)q & 0xFFFFFFu; }
     unsigned long long* tab;
     __device__ __forceinline__ void init(unsigned char* lds, uint32_t) { tab = (unsigned long long*)lds; }
     __device__ __forceinline__ void clear(uint32_t slots, uint32_t t, uint32_t nt) const {
         const cf_u64x2 z{0ull, 0ull};
         for (uint32_t s = t; s < (slots >> 1); s += nt) ((cf_u64x2*)tab)[s] = z;
     }
+    // streaming side: one cloud entry -> (b, d)
+    static __device__ __forceinline__ raw load(const cf_dist_args& A, int64_t e) { return raw{(uint32_t)A.entries[e], (uint32_t)A.entry_i[e]}; }
+    static __device__ __forceinline__ raw skip(uint32_t a, uint32_t ig) { return raw{a, ig}; }     // decodes to b == a: never counted
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { b = r.b; dd = r.i - ig; }
+    static __device__ __forceinline__ uint32_t hash(uint32_t b) { return b * 0x9E3779B1u; }
+    static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return (uint32_t)(((unsigned long long)h * (unsigned long long)n_buckets) >> 32); }
     __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u64x2*)&tab[4 * bk], *(const cf_u64x2*)&tab[4 * bk + 2]}; }
     static __device__ __forceinline__ bool is(unsigned long long v, uint32_t b, uint32_t dd) { return (uint32_t)(v >> 32) == b && ((uint32_t)v >> 24) == dd; }
     // branch-free: one bit per slot, then find-first-set (nested ?: chains compile to a cascade of exec-mask branches)
@@ -182,7 +195,7 @@ struct cf_tab_wide {
     }
     __device__ __forceinline__ unsigned long long total_of(uint32_t b, uint32_t n_buckets) const {
         unsigned long long total = 0;
-        uint32_t bk = cf_dist_home(b, n_buckets);
+        uint32_t bk = home(hash(b), n_buckets);
         for (uint32_t probe = 0; probe < n_buckets; ++probe) {
             const bucket k = read(bk);
             if ((uint32_t)(k.lo.x >> 32) == b && k.lo.x) total += k.lo.x & 0x7FFFFFull;
@@ -202,52 +215,66 @@ struct cf_tab_narrow {
     static constexpr uint32_t kSlotBytes = 6, kPerBucket = 8;
     static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
     struct bucket { cf_u32x4 lo, hi; };
+    struct raw { uint32_t v; };
+    typedef uint32_t qitem;             // deferred insert: the key; probing restarts at the home bucket
+    static __device__ __forceinline__ qitem q_make(uint32_t b, uint32_t dd, uint32_t) { return key_of(b, dd); }
+    static __device__ __forceinline__ void q_take(qitem q, uint32_t n_buckets, uint32_t& b, uint32_t& dd, uint32_t& bk) { b = q & 0xFFFFFFu; dd = q >> 24; bk = home(hash(b), n_buckets); }
     uint32_t* keys;     // slots x 32-bit [d:8 | b:24]
-    uint32_t* cnt32;    // slots x 16-bit counts, two per word
+    uint32_t* cnt32;    // slots x 16-bit [sel:1 | count - 1 : 15], two per word
     __device__ __forceinline__ void init(unsigned char* lds, uint32_t slots) { keys = (uint32_t*)lds; cnt32 = keys + slots; }
     __device__ __forceinline__ void clear(uint32_t slots, uint32_t t, uint32_t nt) const {
         const cf_u32x4 e{kEmpty, kEmpty, kEmpty, kEmpty}, z{0u, 0u, 0u, 0u};
         for (uint32_t s = t; s < (slots >> 2); s += nt) ((cf_u32x4*)keys)[s] = e;
         for (uint32_t s = t; s < (slots >> 3); s += nt) ((cf_u32x4*)cnt32)[s] = z;
     }
+    static __device__ __forceinline__ raw load(const cf_dist_args& A, int64_t e) { return raw{A.packed[e]}; }
+    static __device__ __forceinline__ raw skip(uint32_t a, uint32_t ig) { return raw{(ig << 24) + a}; }   // decodes to b == a: never counted
+    // the unit index is kept mod 256 and 1 <= d <= max_d <= 255, so the 8-bit difference IS d; no borrow reaches b
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { const uint32_t q = r.v - (ig << 24); b = q & 0xFFFFFFu; dd = q >> 24; }
+    static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }               // 24 x 24 -> low 32 bits
+    static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return ((h >> 16) * (n_buckets & 0xFFFFu)) >> 16; }
     __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u32x4*)&keys[8 * bk], *(const cf_u32x4*)&keys[8 * bk + 4]}; }
     static __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) { return (dd << 24) | b; }
     // branch-free: one bit per slot, then find-first-set (nested ?: chains compile to a cascade of exec-mask branches)
-    // bit i set <=> slot i differs from q: min(k ^ q, 1) stays in vector registers (no compare -> SGPR -> select hazard)
     static __device__ __forceinline__ uint32_t ne_bit(uint32_t k, uint32_t q) { return min(k ^ q, 1u); }
-    static __device__ __forceinline__ uint32_t eq_mask(const bucket& k, uint32_t q) {
+    static __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) {
+        const uint32_t q = key_of(b, dd);
         const uint32_t ne = ne_bit(k.lo.x, q) | (ne_bit(k.lo.y, q) << 1) | (ne_bit(k.lo.z, q) << 2) | (ne_bit(k.lo.w, q) << 3)
                           | (ne_bit(k.hi.x, q) << 4) | (ne_bit(k.hi.y, q) << 5) | (ne_bit(k.hi.z, q) << 6) | (ne_bit(k.hi.w, q) << 7);
-        return ne ^ 0xFFu;
+        return __ffs((int)(ne ^ 0xFFu)) - 1;
     }
-    static __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) { return __ffs((int)eq_mask(k, key_of(b, dd))) - 1; }
-    static __device__ __forceinline__ int empty(const bucket& k) { return __ffs((int)eq_mask(k, kEmpty)) - 1; }
+    static __device__ __forceinline__ int empty(const bucket& k) {
+        const uint32_t q = kEmpty;
+        const uint32_t ne = ne_bit(k.lo.x, q) | (ne_bit(k.lo.y, q) << 1) | (ne_bit(k.lo.z, q) << 2) | (ne_bit(k.lo.w, q) << 3)
+                          | (ne_bit(k.hi.x, q) << 4) | (ne_bit(k.hi.y, q) << 5) | (ne_bit(k.hi.z, q) << 6) | (ne_bit(k.hi.w, q) << 7);
+        return __ffs((int)(ne ^ 0xFFu)) - 1;
+    }
     __device__ __forceinline__ void add(uint32_t bk, int i) const { const uint32_t s = 8 * bk + (uint32_t)i; atomicAdd(&cnt32[s >> 1], 1u << ((s & 1u) * 16u)); }
     __device__ __forceinline__ uint32_t claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const { return atomicCAS(&keys[8 * bk + i], kEmpty, key_of(b, dd)); }
     __device__ __forceinline__ int claim_finish(uint32_t old, uint32_t bk, int i, uint32_t b, uint32_t dd) const {
-        const bool mine = old == kEmpty, same = old == key_of(b, dd);
-        if (mine | same) add(bk, i);          // the claimed key, or the same key claimed by someone else: count it
-        return mine ? 0 : same ? 1 : 2;
+        if (old == kEmpty) return 0;                        // claimed: the zero count field already means "seen once"
+        if (old == key_of(b, dd)) { add(bk, i); return 1; }  // the same key was claimed by someone else: count it
+        return 2;
     }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
         const uint32_t q = keys[s];
-        b = q & 0xFFFFFFu; dd = q >> 24; cnt = (cnt32[s >> 1] >> ((s & 1u) * 16u)) & 0x7FFFu;
+        b = q & 0xFFFFFFu; dd = q >> 24; cnt = ((cnt32[s >> 1] >> ((s & 1u) * 16u)) & 0x7FFFu) + 1u;
         return q != kEmpty;
     }
     __device__ __forceinline__ unsigned long long total_of(uint32_t b, uint32_t n_buckets) const {
         unsigned long long total = 0;
-        uint32_t bk = cf_dist_home(b, n_buckets);
+        uint32_t bk = home(hash(b), n_buckets);
         for (uint32_t probe = 0; probe < n_buckets; ++probe) {
             const bucket k = read(bk);
-            const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];   // the 8 counts of the bucket
-            if ((k.lo.x & 0xFFFFFFu) == b && k.lo.x != kEmpty) total += c.x & 0x7FFFu;
-            if ((k.lo.y & 0xFFFFFFu) == b && k.lo.y != kEmpty) total += (c.x >> 16) & 0x7FFFu;
-            if ((k.lo.z & 0xFFFFFFu) == b && k.lo.z != kEmpty) total += c.y & 0x7FFFu;
-            if ((k.lo.w & 0xFFFFFFu) == b && k.lo.w != kEmpty) total += (c.y >> 16) & 0x7FFFu;
-            if ((k.hi.x & 0xFFFFFFu) == b && k.hi.x != kEmpty) total += c.z & 0x7FFFu;
-            if ((k.hi.y & 0xFFFFFFu) == b && k.hi.y != kEmpty) total += (c.z >> 16) & 0x7FFFu;
-            if ((k.hi.z & 0xFFFFFFu) == b && k.hi.z != kEmpty) total += c.w & 0x7FFFu;
-            if ((k.hi.w & 0xFFFFFFu) == b && k.hi.w != kEmpty) total += (c.w >> 16) & 0x7FFFu;
+            const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];   // the 8 count fields of the bucket
+            if ((k.lo.x & 0xFFFFFFu) == b && k.lo.x != kEmpty) total += (c.x & 0x7FFFu) + 1u;
+            if ((k.lo.y & 0xFFFFFFu) == b && k.lo.y != kEmpty) total += ((c.x >> 16) & 0x7FFFu) + 1u;
+            if ((k.lo.z & 0xFFFFFFu) == b && k.lo.z != kEmpty) total += (c.y & 0x7FFFu) + 1u;
+            if ((k.lo.w & 0xFFFFFFu) == b && k.lo.w != kEmpty) total += ((c.y >> 16) & 0x7FFFu) + 1u;
+            if ((k.hi.x & 0xFFFFFFu) == b && k.hi.x != kEmpty) total += (c.z & 0x7FFFu) + 1u;
+            if ((k.hi.y & 0xFFFFFFu) == b && k.hi.y != kEmpty) total += ((c.z >> 16) & 0x7FFFu) + 1u;
+            if ((k.hi.z & 0xFFFFFFu) == b && k.hi.z != kEmpty) total += (c.w & 0x7FFFu) + 1u;
+            if ((k.hi.w & 0xFFFFFFu) == b && k.hi.w != kEmpty) total += ((c.w >> 16) & 0x7FFFu) + 1u;
             if (empty(k) >= 0) break;
             bk = bk + 1 == n_buckets ? 0u : bk + 1;
         }
@@ -256,6 +283,9 @@ struct cf_tab_narrow {
     __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&cnt32[s >> 1], 0x8000u << ((s & 1u) * 16u)); }
     __device__ __forceinline__ bool marked(uint32_t s) const { return (cnt32[s >> 1] >> ((s & 1u) * 16u + 15u)) & 1u; }
 };
+
+#define DIST_QCAP 128                    /* deferred inserts per wave (pushes come in batches of <= 64, drains take 64) */
+#define DIST_FULL_BIT 0x80000000u        /* sh[0]: the table is physically full (the pass is void and will be split) */
 
 // general insert: walk buckets from bk; claims the first empty slot with a CAS when the key is absent.
 // Returns 1 when a new key was created.
@@ -274,34 +304,43 @@ __device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buck
         }
         bk = bk + 1 == n_buckets ? 0u : bk + 1;
     }
-    sh[1] = 1;   // table physically full: the pass is void and will be split
+    atomicOr(&sh[0], DIST_FULL_BIT);
     return 0u;
 }
 
-// Partner ranges of the postings [c0, c0 + np) of one first k-mer -> LDS (pE0, pig) and the exclusive prefix of
-// their lengths (pre[0..np]).  Called by all threads of the workgroup.
-__device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0, int np, int64_t* pE0, int32_t* pig, uint32_t* pre) {
+// One posting of the first k-mer: its partner entries are ONE contiguous CSR range [e0, e0 + len); ig is the unit
+// index of the posting inside its read.  The range is swept in items of 64 entries.
+struct alignas(16) cf_dist_rec { int64_t e0; uint32_t len; uint32_t ig; };
+
+// Partner ranges of the postings [c0, c0 + np) of one first k-mer -> LDS: rec[p], the inclusive prefix of their item
+// counts ipx[4 + p] (0xFFFFFFFF beyond np; ipx[0..3] = 0 so that ipx[3 + p] is the exclusive prefix) and the number
+// of partner entries in sh[12].  Called by all threads of the workgroup.
+__device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0, int np, cf_dist_rec* rec, uint32_t* ipx, uint32_t* sh) {
     const int t = threadIdx.x, nt = blockDim.x;
-    for (int p = t; p < np; p += nt) {
-        const int32_t g = A.post[c0 + p];
-        const int32_t jlo = g + A.min_d;
-        const int32_t jhi = min(A.unit_rend[g] - 1, g + A.max_d);
-        int64_t E0 = 0, E1 = 0;
-        if (jhi >= jlo) { E0 = A.cloud_ptr[jlo]; E1 = A.cloud_ptr[jhi + 1]; }
-        pE0[p] = E0; pig[p] = g - A.unit_rbeg[g];
-        pre[p + 1] = (uint32_t)(E1 - E0);
+    for (int p = t; p < DIST_NP_CAP; p += nt) {
+        cf_dist_rec r{0, 0u, 0u};
+        if (p < np) {
+            const int32_t g = A.post[c0 + p];
+            const int32_t jlo = g + A.min_d;
+            const int32_t jhi = min(A.unit_rend[g] - 1, g + A.max_d);
+            if (jhi >= jlo) { r.e0 = A.cloud_ptr[jlo]; r.len = (uint32_t)(A.cloud_ptr[jhi + 1] - r.e0); }
+            r.ig = (uint32_t)(g - A.unit_rbeg[g]);
+        }
+        rec[p] = r;
     }
     __syncthreads();
-    if (t < 64) {   // wave 0: inclusive scan of np <= DIST_NP_CAP (= 4 x 64) lengths, 4 per lane
+    if (t < 64) {   // wave 0: inclusive scan of DIST_NP_CAP (= 4 x 64) item counts, 4 per lane
         uint32_t v[DIST_NP_CAP / 64], sum = 0;
+        unsigned long long lens = 0;
 #pragma unroll
-        for (int i = 0; i < DIST_NP_CAP / 64; ++i) { const int p = t * (DIST_NP_CAP / 64) + i; v[i] = p < np ? pre[p + 1] : 0u; sum += v[i]; v[i] = sum; }
+        for (int i = 0; i < DIST_NP_CAP / 64; ++i) { const uint32_t len = rec[t * (DIST_NP_CAP / 64) + i].len; lens += len; sum += (len + 63u) >> 6; v[i] = sum; }
         uint32_t inc = sum;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, (unsigned)d); if (t >= d) inc += o; }
         const uint32_t base = inc - sum;
 #pragma unroll
-        for (int i = 0; i < DIST_NP_CAP / 64; ++i) { const int p = t * (DIST_NP_CAP / 64) + i; if (p < np) pre[p + 1] = base + v[i]; }
-        if (t == 0) pre[0] = 0;
+        for (int i = 0; i < DIST_NP_CAP / 64; ++i) { const int p = t * (DIST_NP_CAP / 64) + i; ipx[4 + p] = p < np ? base + v[i] : 0xFFFFFFFFu; }
+        for (int d = 32; d >= 1; d >>= 1) lens += __shfl_down(lens, (unsigned)d);
+        if (t == 0) { ipx[0] = 0; ipx[1] = 0; ipx[2] = 0; ipx[3] = 0; sh[12] = (uint32_t)min(lens, 0x3FFFFFFFull); }
     }
     __syncthreads();
 }
@@ -318,13 +357,16 @@ template <class Tab>
 __global__ void cf_dist_kernel(cf_dist_args A) {
     Tab T;
     T.init(cf_lds, (uint32_t)A.slots);
-    int64_t* pE0 = (int64_t*)(cf_lds + (size_t)A.slots * Tab::kSlotBytes);  // first partner entry of each posting
-    int32_t* pig = (int32_t*)(pE0 + DIST_NP_CAP);              // unit index of the posting inside its read
-    uint32_t* pre = (uint32_t*)(pig + DIST_NP_CAP);            // prefix of partner-entry counts (NP_CAP + 1)
-    uint32_t* stack = pre + DIST_NP_CAP + 1;                   // (P, idx) pairs
-    uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] keys in table [1] overflow [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] stream cursor
+    cf_dist_rec* rec = (cf_dist_rec*)(cf_lds + (size_t)A.slots * Tab::kSlotBytes);   // partner range of each posting of the chunk
+    uint32_t* ipx = (uint32_t*)(rec + DIST_NP_CAP);            // 4 zeros, then the inclusive prefix of item counts
+    uint32_t* stack = ipx + 4 + DIST_NP_CAP;                   // (P, idx) pairs
+    uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] keys in table | DIST_FULL_BIT [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] item cursor [12] entries of the chunk
     uint16_t* stage = (uint16_t*)(sh + 16);                    // slot indices of the selected edges of a pass
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
+    // per-wave queue of deferred inserts (bucket full / slot lost to another key): handled 64 at a time by a full
+    // wave instead of one straggler per lane and step.  Only its own wave touches it (LDS operations of one wave
+    // execute in order; volatile keeps the compiler from caching it).
+    volatile typename Tab::qitem* wq = (volatile typename Tab::qitem*)(stage + DIST_STAGE_CAP + 8) + (size_t)(t >> 6) * DIST_QCAP;
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
 #if defined(CF_DIST_STAMPS)
@@ -360,8 +402,8 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
         if (t == 0) sh[7] = 0;
         __syncthreads();
         if (one_chunk) {
-            cf_dist_setup(A, pp0, (int)(pp1 - pp0), pE0, pig, pre);
-            if (t == 0) sh[7] = pre[pp1 - pp0];
+            cf_dist_setup(A, pp0, (int)(pp1 - pp0), rec, ipx, sh);
+            if (t == 0) sh[7] = sh[12];
         } else {
             unsigned long long em = 0;
             for (int64_t p = pp0 + t; p < pp1; p += nt) {
@@ -375,7 +417,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
         __syncthreads();
         if (t == 0) {
             uint32_t P0 = 1;
-            while (P0 < 64u && (unsigned long long)sh[7] * 4ull > (unsigned long long)A.fill_limit * 5ull * P0) P0 <<= 1;
+            while (P0 < 64u && (unsigned long long)sh[7] > (unsigned long long)A.est_limit * P0) P0 <<= 1;
             for (uint32_t i = 0; i < P0; ++i) { stack[2 * i] = P0; stack[2 * i + 1] = i; }
             sh[2] = P0;
         }
@@ -387,67 +429,84 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             const uint32_t sp_now = sh[2];
             __syncthreads();  // everyone has read the stack pointer before thread 0 pops
             if (sp_now == 0) break;
-            if (t == 0) { const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[1] = 0; sh[7] = 0; sh[8] = 0; }
+            if (t == 0) { const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[7] = 0; sh[8] = 0; }
             T.clear(slots, (uint32_t)t, (uint32_t)nt);
             __syncthreads();
-            const uint32_t P = sh[3], pidx = sh[4];
+            const uint32_t P = sh[3], pidx = sh[4], pmask = P - 1u;   // P is a power of two; P == 1: every b belongs to the pass
             uint32_t my_e = 0;
             CF_STAMP(2);   // pop partition + clear table
             // ---- stream the partner clouds of every posting of a, in chunks of DIST_NP_CAP postings.
-            // The units g+min_d .. min(read end, g+max_d) of a posting are ONE contiguous range of the
-            // CSR; the ranges of all postings are concatenated into a flat index space that the waves
-            // sweep with coalesced loads (entry rank + the entry's unit index inside its read).
+            // The units g+min_d .. min(read end, g+max_d) of a posting are ONE contiguous range of the CSR, cut
+            // into items of 64 entries; the items of all postings of the chunk are numbered consecutively and
+            // waves pull DIST_UNROLL items at a time from a shared LDS cursor (dynamic balance: the cost of an
+            // entry varies).  The posting of an item is found per WAVE, not per lane: every lane keeps 4 of the
+            // 256 inclusive item prefixes in registers and 4 ballots count the prefixes <= item.
             for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
                 const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
-                if (!one_chunk) cf_dist_setup(A, c0, np, pE0, pig, pre);
-                if (t == 0) sh[11] = 0;   // shared cursor over the flat entry range of this chunk
+                if (!one_chunk) cf_dist_setup(A, c0, np, rec, ipx, sh);
+                if (t == 0) sh[11] = 0;   // shared cursor over the items of this chunk
                 __syncthreads();
-                const uint32_t total = pre[np];
-                int p_cur = 0;
-                uint32_t r_lo = 0, r_hi = pre[1];          // flat range of posting p_cur, cached in registers
-                int64_t r_e0 = pE0[0];
-                int32_t r_ig = pig[0];
-                // software pipeline: the global loads of step i+1 are issued before the LDS work of step i
-                uint32_t nb_[DIST_UNROLL], nd_[DIST_UNROLL];
-#define CF_DIST_FETCH(F0)                                                                                     \
+                const uint32_t n_items = ipx[4 + np - 1];
+                const cf_u32x4 iv = *(const cf_u32x4*)&ipx[4 + 4 * lane];
+                // software pipeline: the global loads of step i+1 are issued before the LDS work of step i; what
+                // a load returns is only touched one step later (the decode needs ig, which travels in an SGPR)
+                typename Tab::raw nx_[DIST_UNROLL];
+                uint32_t nig_[DIST_UNROLL];
+#define CF_DIST_FETCH(I0)                                                                                     \
                 _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) {                                     \
-                    const uint32_t f = (F0) + (uint32_t)u * 64u + (uint32_t)lane;                             \
-                    nb_[u] = a; nd_[u] = 0;              /* a itself is never counted: skip marker */         \
-                    if (f < total) {                                                                          \
-                        if (f >= r_hi) {                 /* monotone: f only grows */                         \
-                            while (pre[p_cur + 1] <= f) ++p_cur;                                              \
-                            r_lo = pre[p_cur]; r_hi = pre[p_cur + 1]; r_e0 = pE0[p_cur]; r_ig = pig[p_cur];   \
-                        }                                                                                     \
-                        const int64_t e = r_e0 + (int64_t)(f - r_lo);                                         \
-                        nb_[u] = (uint32_t)A.entries[e];                                                      \
-                        nd_[u] = (uint32_t)((int32_t)A.entry_i[e] - r_ig);                                    \
+                    const uint32_t item = (I0) + (uint32_t)u;                                                 \
+                    nig_[u] = 0; nx_[u] = Tab::skip(a, 0u);                                                   \
+                    if (item < n_items) {                                                                     \
+                        const uint32_t p = (uint32_t)(__popcll(__ballot(iv.x <= item)) + __popcll(__ballot(iv.y <= item))      \
+                                                    + __popcll(__ballot(iv.z <= item)) + __popcll(__ballot(iv.w <= item)));   \
+                        const cf_dist_rec r = rec[p];                                                         \
+                        const uint32_t off = ((item - ipx[3 + p]) << 6) + (uint32_t)lane;                     \
+                        const uint32_t ig = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.ig);              \
+                        nig_[u] = ig;                                                                         \
+                        if (off < r.len) nx_[u] = Tab::load(A, r.e0 + (int64_t)off);                          \
+                        else nx_[u] = Tab::skip(a, ig);                                                       \
                     }                                                                                         \
                 }
-                // waves pull 64 x DIST_UNROLL consecutive flat entries at a time from a shared cursor: the cost of
-                // an entry varies (new key, full bucket), a static split leaves waves idle at the closing barrier
-#define CF_DIST_GRAB(VAR) { uint32_t g_ = 0; if (lane == 0) g_ = atomicAdd(&sh[11], 64u * DIST_UNROLL); VAR = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_); }
-                uint32_t f0, f1;
-                CF_DIST_GRAB(f0)
-                if (f0 < total) { CF_DIST_FETCH(f0) }
-                while (f0 < total) {
-                    if (sh[1] || sh[0] > A.fill_limit) break;
-                    uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
+#define CF_DIST_GRAB(VAR) { uint32_t g_ = 0; if (lane == 0) g_ = atomicAdd(&sh[11], (uint32_t)DIST_UNROLL); VAR = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_); }
+                // pops the last N (<= 64) queued inserts, one per lane; every lane runs the general probe loop for its own
+#define CF_DIST_DRAIN(N) {                                                                                    \
+                    __builtin_amdgcn_wave_barrier();                                                          \
+                    const uint32_t n_ = (N); qtail -= n_;                                                     \
+                    uint32_t made_ = 0;                                                                       \
+                    if ((uint32_t)lane < n_) {                                                                \
+                        uint32_t xb, xd, xk;                                                                  \
+                        Tab::q_take(wq[qtail + (uint32_t)lane], n_buckets, xb, xd, xk);                       \
+                        made_ = cf_dist_insert(T, n_buckets, xk, xb, xd, sh);                                 \
+                    }                                                                                         \
+                    const uint32_t new_ = (uint32_t)__popcll(__ballot(made_ != 0u));                          \
+                    if (new_ && lane == 0) atomicAdd(&sh[0], new_);                                           \
+                    __builtin_amdgcn_wave_barrier();                                                          \
+                }
+                uint32_t qtail = 0;      // wave-uniform
+                uint32_t i0, i1;
+                CF_DIST_GRAB(i0)
+                if (i0 < n_items) { CF_DIST_FETCH(i0) }
+                while (i0 < n_items) {
+                    if (sh[0] > A.fill_limit) break;     // too full (or physically full): the pass will be split
+                    typename Tab::raw cx_[DIST_UNROLL];
+                    uint32_t cig_[DIST_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) { bb[u] = nb_[u]; dd_[u] = nd_[u]; }
-                    CF_DIST_GRAB(f1)
-                    if (f1 < total) { CF_DIST_FETCH(f1) }
-                    f0 = f1;
+                    for (int u = 0; u < DIST_UNROLL; ++u) { cx_[u] = nx_[u]; cig_[u] = nig_[u]; }
+                    CF_DIST_GRAB(i1)
+                    if (i1 < n_items) { CF_DIST_FETCH(i1) }
+                    i0 = i1;
                     // bucket reads of all unrolled emissions first (independent LDS reads in flight), then resolve
-                    uint32_t bk_[DIST_UNROLL], live = 0;
+                    uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL], bk_[DIST_UNROLL], live = 0;
                     typename Tab::bucket kb_[DIST_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
-                        const uint32_t b = bb[u];
-                        const uint32_t hb = cf_dist_hash(b);
-                        if (b != a && (P == 1 || (((hb ^ (hb >> 15)) >> 3) & (P - 1)) == pidx)) live |= 1u << u;
-                        bk_[u] = (uint32_t)(((unsigned long long)hb * (unsigned long long)n_buckets) >> 32);
+                        Tab::decode(cx_[u], cig_[u], bb[u], dd_[u]);
+                        const uint32_t hb = Tab::hash(bb[u]);
+                        live |= (uint32_t)((bb[u] != a) & ((((hb ^ (hb >> 15)) >> 3) & pmask) == pidx)) << u;
+                        bk_[u] = Tab::home(hb, n_buckets);
                         kb_[u] = T.read(bk_[u]);
                     }
+                    my_e += (uint32_t)__popcll((unsigned long long)live);
                     // (1) matches -> fire-and-forget adds, new keys -> first empty slot of the bucket already in
                     // registers; (2) all CASes of the step issued back to back; (3) leftovers (bucket full, slot
                     // lost to another key) take the general probe loop, one leftover per lane and round.
@@ -457,9 +516,8 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         cand_[u] = -1;
                         if (!((live >> u) & 1u)) continue;
-                        ++my_e;
                         const int m = Tab::match(kb_[u], bb[u], dd_[u]);
-                        if (m >= 0) { T.add(bk_[u], m); continue; }              // common case: the pair was seen before
+                        if (m >= 0) { T.add(bk_[u], m); continue; }              // the pair was seen before
                         const int e = Tab::empty(kb_[u]);
                         if (e >= 0) cand_[u] = e;
                         else { failm |= 1u << u; bk_[u] = bk_[u] + 1 == n_buckets ? 0u : bk_[u] + 1; }
@@ -477,14 +535,14 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                         if (st == 0) fresh |= 1u << u;
                         else if (st == 2) failm |= 1u << u;
                     }
-                    while (__any(failm != 0u)) {
-                        if (failm != 0u) {
-                            const int u = __ffs((int)failm) - 1;
-                            failm &= failm - 1u;
-                            uint32_t xb = bb[0], xd = dd_[0], xk = bk_[0];
+                    // (3) leftovers -> the wave's queue; a full wave of them is inserted as soon as 64 are waiting
 #pragma unroll
-                            for (int v = 1; v < DIST_UNROLL; ++v) if (u == v) { xb = bb[v]; xd = dd_[v]; xk = bk_[v]; }
-                            fresh |= cf_dist_insert(T, n_buckets, xk, xb, xd, sh) << u;
+                    for (int u = 0; u < DIST_UNROLL; ++u) {
+                        const unsigned long long fm = __ballot((failm >> u) & 1u);
+                        if (fm) {
+                            if (qtail >= 64u) { CF_DIST_DRAIN(64u) }
+                            if ((failm >> u) & 1u) wq[qtail + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = Tab::q_make(bb[u], dd_[u], bk_[u]);
+                            qtail += (uint32_t)__popcll(fm);
                         }
                     }
                     // fill level: one fire-and-forget LDS atomic per wave and step; read back at the next step
@@ -493,10 +551,11 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     for (int u = 0; u < DIST_UNROLL; ++u) wave_new += (uint32_t)__popcll(__ballot((fresh >> u) & 1u));
                     if (wave_new && lane == 0) atomicAdd(&sh[0], wave_new);
                 }
+                while (qtail > 0u && sh[0] <= A.fill_limit) { CF_DIST_DRAIN(min(qtail, 64u)) }   // (a void pass drops its queue)
                 __syncthreads();
             }
             CF_STAMP(3);   // stream + insert
-            if (sh[1] || sh[0] > A.fill_limit) {  // overflow: split this partition in two
+            if (sh[0] > A.fill_limit) {  // overflow: split this partition in two
                 if (t == 0) {
                     uint32_t sp = sh[2];
                     if (P >= (1u << 20) || sp + 2 > DIST_STACK) { atomicOr(&A.counters[4], 1ull); }
@@ -613,6 +672,8 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     int64_t* d_post_ptr = nullptr;
     int32_t *d_post = nullptr, *d_rend = nullptr, *d_rbeg = nullptr;
     uint16_t* d_entry_i = nullptr;
+    uint32_t* d_packed = nullptr;
+    bool narrow = false;
     unsigned long long* d_cnt = nullptr;
     int64_t n_post = 0;
     int rc = 0;
@@ -628,7 +689,6 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if ((rc = cf_alloc_t(ctx, &d_post_ptr, (size_t)K + 1, "posting offsets"))) break;
         if ((rc = cf_alloc_t(ctx, &d_rend, (size_t)U + 1, "unit read ends"))) break;
         if ((rc = cf_alloc_t(ctx, &d_rbeg, (size_t)U + 1, "unit read begins"))) break;
-        if ((rc = cf_alloc_t(ctx, &d_entry_i, (size_t)ctx->n_entries + 1, "entry unit indices"))) break;
         if ((rc = cf_alloc_t(ctx, &d_cnt, n_cnt, "dist counters"))) break;
         if ((rc = cf_alloc_t(ctx, &d_first, (size_t)K + 1, "first posting units"))) break;
         hipError_t e = hipMemsetAsync(d_pcnt, 0, (size_t)(K + 1) * 4, ctx->stream);
@@ -654,17 +714,6 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (R)
             hipLaunchKernelGGL(cf_unit_rend_kernel, dim3((unsigned)cf_grid_for(R, 256, max_blocks)), dim3(256), 0, ctx->stream,
                                (const int64_t*)ctx->d_unit_ptr, R, d_rend, d_rbeg);
-        if (U && ctx->n_entries)
-            hipLaunchKernelGGL(cf_entry_unit_kernel, dim3((unsigned)cf_grid_for(U * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)d_rbeg, U, d_entry_i);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
-        if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("postings: ") + hipGetErrorString(e)); break; }
-
-        cf_dist_args A;
-        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = ctx->d_cloud_ptr; A.entries = ctx->d_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.entry_i = d_entry_i;
-        A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
-        A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
         // table layout: 6-byte slots (32-bit keys, 16-bit counts) whenever ranks fit 24 bits and counts 15 bits
         uint32_t max_post = 0;
         if (K) {
@@ -672,14 +721,33 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                                (const uint32_t*)d_pcnt, K, (uint32_t*)(d_cnt + 7));
             if (hipMemcpy(&max_post, d_cnt + 7, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "max postings"); break; }
         }
-        const bool narrow = !ctx->dist_wide && K < ((int64_t)1 << 24) - 1 && max_post <= 32767u;
+        narrow = !ctx->dist_wide && K < ((int64_t)1 << 24) - 1 && max_post <= 32767u;
         if (max_post >= (1u << 23)) { rc = cf_fail(ctx, -34, "cf_dist_edges: a k-mer has more than 2^23 postings"); break; }
+        if (narrow) { if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)ctx->n_entries + 1, "packed cloud entries"))) break; }
+        else if ((rc = cf_alloc_t(ctx, &d_entry_i, (size_t)ctx->n_entries + 1, "entry unit indices"))) break;
+        if (U && ctx->n_entries)
+            hipLaunchKernelGGL(cf_entry_unit_kernel, dim3((unsigned)cf_grid_for(U * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                               (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)d_rbeg, (const int32_t*)ctx->d_entries, U, d_entry_i, d_packed);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
+        if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("postings: ") + hipGetErrorString(e)); break; }
+
+        cf_dist_args A;
+        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = ctx->d_cloud_ptr; A.entries = ctx->d_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.entry_i = d_entry_i; A.packed = d_packed;
+        A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
+        A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
         const uint32_t slot_bytes = narrow ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
-        A.slots = (int32_t)(((int64_t)ctx->dist_slots * 8 / slot_bytes) & ~7ll);   // dist_slots is the LDS budget in 8-byte slots
+        // LDS: everything but the table is fixed; dist_slots (the table budget in 8-byte units) defaults to all the rest
+        const size_t lds_fixed = sizeof(cf_dist_rec) * DIST_NP_CAP + (size_t)(4 + DIST_NP_CAP + 2 * DIST_STACK + 16) * 4 + DIST_STAGE_CAP * 2 + 16
+                               + (size_t)(ctx->dist_block / 64) * DIST_QCAP * (narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem));
+        const int64_t budget8 = ((int64_t)160 * 1024 - (int64_t)lds_fixed) / 8;
+        if (ctx->dist_slots > budget8) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_slots does not fit the 160 KiB LDS next to the work lists"); break; }
+        const int64_t slots8 = ctx->dist_slots ? ctx->dist_slots : budget8;
+        A.slots = (int32_t)((slots8 * 8 / slot_bytes) & ~7ll);
         A.fill_limit = (uint32_t)((int64_t)A.slots * ctx->dist_fill_pct / 100);   // checked once per wave step: leave slack below the physical size
+        A.est_limit = (uint32_t)((int64_t)A.fill_limit * 100 / ctx->dist_est_pct);
         A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
-        const size_t lds = (size_t)A.slots * slot_bytes + (size_t)(4 * DIST_NP_CAP + 1 + 2 * DIST_STACK + 16) * 4 + DIST_STAGE_CAP * 2 + 16;
-        if (lds > 160 * 1024) { rc = cf_fail(ctx, -22, "cf_dist_edges: LDS request exceeds 160 KiB"); break; }
+        const size_t lds = (size_t)A.slots * slot_bytes + lds_fixed;
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / ctx->dist_block));
         // locality order of the first k-mers: sort (first posting unit, a); k-mers without postings drop out
         n_a_alloc = (K > part) ? (K - part + n_parts - 1) / n_parts : 0;
@@ -736,6 +804,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     if (d_first) cf_release_t(ctx, d_first, (size_t)K + 1);
     if (d_cnt) cf_release_t(ctx, d_cnt, n_cnt);
     if (d_entry_i) cf_release_t(ctx, d_entry_i, (size_t)ctx->n_entries + 1);
+    if (d_packed) cf_release_t(ctx, d_packed, (size_t)ctx->n_entries + 1);
     if (d_rbeg) cf_release_t(ctx, d_rbeg, (size_t)U + 1);
     if (d_rend) cf_release_t(ctx, d_rend, (size_t)U + 1);
     if (d_post) cf_release_t(ctx, d_post, (size_t)n_post);
