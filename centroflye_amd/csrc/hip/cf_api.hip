@@ -259,6 +259,8 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "dist_fill_pct") {
         if (value < 10 || value > 90) return cf_fail(ctx, -22, "dist_fill_pct out of range (10 .. 90)");
         ctx->dist_fill_pct = (int)value;
+    } else if (n == "dist_sketch") {
+        ctx->dist_sketch = value != 0;
     } else if (n == "dist_est_pct") {
         if (value < 5 || value > 100) return cf_fail(ctx, -22, "dist_est_pct out of range (5 .. 100)");
         ctx->dist_est_pct = (int)value;

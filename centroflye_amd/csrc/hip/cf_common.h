@@ -99,6 +99,7 @@ struct cf_ctx {
     int dist_slots = 0;      // LDS budget of the (b,d) table in 8-byte units; 0 = all that is left next to the work lists
     int dist_wide = 0;       // 1 forces the 8-byte-slot table layout (tests)
     int dist_fill_pct = 70;  // a (b,d) table pass is split when more than this share of the slots is in use
+    int dist_sketch = 1;     // 0: every (b,d) pair goes to the exact table (no counting sketch first)
     int dist_est_pct = 80;   // expected distinct (b,d) keys per 100 pair emissions: sizes the initial number of table partitions
     int dist_stage = 2048;   // selected edges staged in LDS per table pass (0 forces the table sweep)
     int count_slots = 4096;

@@ -27,6 +27,7 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 #define DIST_STAGE_CAP 2048              /* selected slots staged per table pass (u16 slot indices) */
 #define DIST_STACK 112
 #define DIST_UNROLL 4
+#define DIST_BM_BITS 65536u              /* bitmap over hash(b): k-mers that may have a selected edge */
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
 #define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
 
@@ -120,6 +121,8 @@ struct cf_dist_args {
     int32_t slots;
     uint32_t fill_limit;
     uint32_t est_limit;            // emissions one partition is expected to hold (fill_limit / expected distinct share)
+    int32_t sketch;                // 1: count first in 8-bit counters, build the exact table only for k-mers that can pass min_cov
+    uint32_t sk_counters, sk_shift;   // counters (a power of two that fits the table's LDS) and 32 - log2 of it
     uint32_t stage_cap;            // <= DIST_STAGE_CAP
     uint32_t* edges;
     unsigned long long edge_cap;
@@ -166,6 +169,7 @@ struct cf_tab_wide {
     static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { b = r.b; dd = r.i - ig; }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return b * 0x9E3779B1u; }
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return (uint32_t)(((unsigned long long)h * (unsigned long long)n_buckets) >> 32); }
+    static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
     __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u64x2*)&tab[4 * bk], *(const cf_u64x2*)&tab[4 * bk + 2]}; }
     static __device__ __forceinline__ bool is(unsigned long long v, uint32_t b, uint32_t dd) { return (uint32_t)(v >> 32) == b && ((uint32_t)v >> 24) == dd; }
     // branch-free: one bit per slot, then find-first-set (nested ?: chains compile to a cascade of exec-mask branches)
@@ -233,6 +237,7 @@ struct cf_tab_narrow {
     static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { const uint32_t q = r.v - (ig << 24); b = q & 0xFFFFFFu; dd = q >> 24; }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }               // 24 x 24 -> low 32 bits
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return ((h >> 16) * (n_buckets & 0xFFFFu)) >> 16; }
+    static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
     __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u32x4*)&keys[8 * bk], *(const cf_u32x4*)&keys[8 * bk + 4]}; }
     static __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) { return (dd << 24) | b; }
     // branch-free: one bit per slot, then find-first-set (nested ?: chains compile to a cascade of exec-mask branches)
@@ -353,20 +358,81 @@ __device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0,
 #define CF_STAMP(i) do { } while (0)
 #endif
 
+// Sweeps the partner entries of one chunk of postings.  The units g+min_d .. min(read end, g+max_d) of a posting are
+// ONE contiguous range of the CSR, cut into items of 64 entries; the items of all postings of the chunk are numbered
+// consecutively and waves pull DIST_UNROLL items at a time from a shared LDS cursor (dynamic balance).  The posting
+// of an item is found per WAVE, not per lane: every lane keeps 4 of the 256 inclusive item prefixes in registers and
+// 4 ballots count the prefixes <= item.  Software pipeline: the global loads of step i+1 are issued before the body
+// of step i runs; what a load returns is only touched one step later (ig travels in an SGPR, validity in a bit mask).
+// body(bb, dd) gets the decoded entries of a step (bb[u] == a: nothing to count) and returns true to stop the wave.
+template <class Tab, class Body>
+__device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, uint32_t a, const cf_dist_rec* rec, const uint32_t* ipx, uint32_t* cursor, int np, Body&& body) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_items = ipx[4 + np - 1];
+    if (n_items == 0u) return;
+    const cf_u32x4 iv = *(const cf_u32x4*)&ipx[4 + 4 * lane];
+    typename Tab::raw nx_[DIST_UNROLL];
+    uint32_t nig_[DIST_UNROLL], nok = 0;
+#define CF_DIST_FETCH(I0) {                                                                                   \
+        uint32_t p_[DIST_UNROLL], st_[DIST_UNROLL];                                                           \
+        cf_dist_rec r_[DIST_UNROLL];                                                                          \
+        _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) {                                             \
+            const uint32_t item = min((I0) + (uint32_t)u, n_items - 1u);                                      \
+            p_[u] = (uint32_t)(__popcll(__ballot(iv.x <= item)) + __popcll(__ballot(iv.y <= item))            \
+                             + __popcll(__ballot(iv.z <= item)) + __popcll(__ballot(iv.w <= item)));          \
+        }                                                                                                     \
+        _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) { r_[u] = rec[p_[u]]; st_[u] = ipx[3 + p_[u]]; } \
+        nok = 0;                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) {                                             \
+            const uint32_t item = (I0) + (uint32_t)u;                                                         \
+            const uint32_t off = ((min(item, n_items - 1u) - st_[u]) << 6) + (uint32_t)lane;                  \
+            const bool ok = (item < n_items) & (off < r_[u].len);                                             \
+            nok |= (uint32_t)ok << u;                                                                         \
+            nig_[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_[u].ig);                                \
+            nx_[u] = Tab::load(A, r_[u].e0 + (int64_t)(ok ? off : 0u));   /* always inside the entry array */   \
+        }                                                                                                     \
+    }
+#define CF_DIST_GRAB(VAR) { uint32_t g_ = 0; if (lane == 0) g_ = atomicAdd(cursor, (uint32_t)DIST_UNROLL); VAR = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_); }
+    uint32_t i0, i1;
+    CF_DIST_GRAB(i0)
+    if (i0 < n_items) CF_DIST_FETCH(i0)
+    while (i0 < n_items) {
+        typename Tab::raw cx_[DIST_UNROLL];
+        uint32_t cig_[DIST_UNROLL];
+        const uint32_t cok = nok;
+#pragma unroll
+        for (int u = 0; u < DIST_UNROLL; ++u) { cx_[u] = nx_[u]; cig_[u] = nig_[u]; }
+        CF_DIST_GRAB(i1)
+        if (i1 < n_items) CF_DIST_FETCH(i1)
+        i0 = i1;
+        uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
+#pragma unroll
+        for (int u = 0; u < DIST_UNROLL; ++u) {
+            Tab::decode(cx_[u], cig_[u], bb[u], dd_[u]);
+            if (!((cok >> u) & 1u)) bb[u] = a;
+        }
+        if (body(bb, dd_)) break;
+    }
+#undef CF_DIST_FETCH
+#undef CF_DIST_GRAB
+}
+
 template <class Tab>
 __global__ void cf_dist_kernel(cf_dist_args A) {
     Tab T;
     T.init(cf_lds, (uint32_t)A.slots);
+    uint32_t* sk = (uint32_t*)cf_lds;                          // phase A: 8-bit counters over the table's LDS
     cf_dist_rec* rec = (cf_dist_rec*)(cf_lds + (size_t)A.slots * Tab::kSlotBytes);   // partner range of each posting of the chunk
     uint32_t* ipx = (uint32_t*)(rec + DIST_NP_CAP);            // 4 zeros, then the inclusive prefix of item counts
     uint32_t* stack = ipx + 4 + DIST_NP_CAP;                   // (P, idx) pairs
-    uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] keys in table | DIST_FULL_BIT [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] item cursor [12] entries of the chunk
+    uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] keys in table | DIST_FULL_BIT [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] item cursor [12] entries of the chunk [13] a counter of the sketch wrapped
     uint16_t* stage = (uint16_t*)(sh + 16);                    // slot indices of the selected edges of a pass
+    uint32_t* bm = (uint32_t*)(stage + DIST_STAGE_CAP + 8);    // DIST_BM_BITS bits: hash(b) of the k-mers b that may have a selected edge
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
-    // per-wave queue of deferred inserts (bucket full / slot lost to another key): handled 64 at a time by a full
-    // wave instead of one straggler per lane and step.  Only its own wave touches it (LDS operations of one wave
-    // execute in order; volatile keeps the compiler from caching it).
-    volatile typename Tab::qitem* wq = (volatile typename Tab::qitem*)(stage + DIST_STAGE_CAP + 8) + (size_t)(t >> 6) * DIST_QCAP;
+    // per-wave queue of pending inserts: candidates are compacted here and inserted 64 at a time by a full wave.
+    // Only its own wave touches it (LDS operations of one wave execute in order; volatile keeps the compiler from
+    // caching it).
+    volatile typename Tab::qitem* wq = (volatile typename Tab::qitem*)(bm + DIST_BM_BITS / 32) + (size_t)(t >> 6) * DIST_QCAP;
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
 #if defined(CF_DIST_STAMPS)
@@ -396,10 +462,9 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
         const uint32_t a = (uint32_t)A.order[ai];
         const int64_t pp0 = A.post_ptr[a], pp1 = A.post_ptr[a + 1];
         if (pp1 == pp0) continue;
-        // upper bound of the emissions of a -> initial number of partitions of its (b, d) table.
-        // Usual case (<= DIST_NP_CAP postings): the partner ranges are set up ONCE and reused by every pass.
+        // Usual case (<= DIST_NP_CAP postings): the partner ranges are set up ONCE and reused by every sweep.
         const bool one_chunk = (pp1 - pp0) <= DIST_NP_CAP;
-        if (t == 0) sh[7] = 0;
+        if (t == 0) { sh[7] = 0; sh[13] = 0; }
         __syncthreads();
         if (one_chunk) {
             cf_dist_setup(A, pp0, (int)(pp1 - pp0), rec, ipx, sh);
@@ -414,14 +479,65 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             for (int d = 32; d >= 1; d >>= 1) em += __shfl_down(em, (unsigned)d);
             if (lane == 0 && em) atomicAdd(&sh[7], (uint32_t)min(em, 0x3FFFFFFFull));
         }
+        CF_STAMP(1);   // prologue: posting ranges, estimate
+        // ---- phase A (min_cov >= 2): which k-mers b can have a selected edge at all?  Most (b, d) pairs of a are seen
+        // once or twice and can never reach min_cov, but an exact table would have to hold them all.  So first every
+        // pair is only COUNTED, in an array of 8-bit counters indexed by hash(b, d) that fills the table's LDS: a
+        // counter is never below the count of a pair that maps to it (collisions add), and the add whose returned
+        // value shows the counter reaching min_cov marks hash(b) in a bitmap — the last add of a pair with
+        // cnt >= min_cov always does.  Phase B then builds the exact table for the marked b only (all their d, so the
+        // totals are exact too); unmarked b have no pair with cnt >= min_cov and cannot be selected.  A counter about
+        // to wrap (255 -> 0) is seen by the add that wraps it: the first k-mer then falls back to "every b marked".
+        bool mark_all = !A.sketch;
+        if (A.sketch) {
+            const cf_u32x4 z{0u, 0u, 0u, 0u};
+            for (uint32_t s = (uint32_t)t; s < (A.sk_counters >> 4); s += (uint32_t)nt) ((cf_u32x4*)sk)[s] = z;
+            for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = z;
+            __syncthreads();
+            for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
+                const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
+                if (!one_chunk) cf_dist_setup(A, c0, np, rec, ipx, sh);
+                if (t == 0) sh[11] = 0;
+                __syncthreads();
+                cf_dist_sweep<Tab>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
+                    uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL];
+#pragma unroll
+                    for (int u = 0; u < DIST_UNROLL; ++u) {     // all counter adds of the step back to back
+                        const uint32_t idx = (Tab::hash(bb[u]) + (dd_[u] & 0xFFu) * 0x5BD1E9u) >> A.sk_shift;
+                        sft_[u] = (idx & 3u) << 3;
+                        old_[u] = 0;
+                        if (bb[u] != a) old_[u] = atomicAdd(&sk[idx >> 2], 1u << sft_[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < DIST_UNROLL; ++u) {
+                        if (bb[u] == a) continue;
+                        const uint32_t seen = (old_[u] >> sft_[u]) & 0xFFu;     // occurrences before this one
+                        if (seen + 1u >= A.min_cov) {
+                            const uint32_t hbit = Tab::bm_bit(bb[u]);
+                            if (!((bm[hbit >> 5] >> (hbit & 31u)) & 1u)) atomicOr(&bm[hbit >> 5], 1u << (hbit & 31u));
+                            if (seen == 255u) sh[13] = 1u;
+                        }
+                    }
+                    return false;
+                });
+                __syncthreads();
+            }
+            if (sh[13]) mark_all = true;
+            CF_STAMP(6);   // sketch sweep
+        }
+        if (mark_all) {
+            const cf_u32x4 ones{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = ones;
+        }
         __syncthreads();
         if (t == 0) {
+            // number of partitions of the exact (b, d) table: every pair may need a slot when all b are marked
+            // (upper bound from the emission count); with the bitmap only a fraction does — start with one
             uint32_t P0 = 1;
-            while (P0 < 64u && (unsigned long long)sh[7] > (unsigned long long)A.est_limit * P0) P0 <<= 1;
+            if (mark_all) while (P0 < 64u && (unsigned long long)sh[7] > (unsigned long long)A.est_limit * P0) P0 <<= 1;
             for (uint32_t i = 0; i < P0; ++i) { stack[2 * i] = P0; stack[2 * i + 1] = i; }
             sh[2] = P0;
         }
-        CF_STAMP(1);   // prologue: posting ranges, estimate
         bool spilled = false;
         while (true) {
             CF_STAMP(5);   // reserve + write edges of the previous pass
@@ -435,40 +551,15 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             const uint32_t P = sh[3], pidx = sh[4], pmask = P - 1u;   // P is a power of two; P == 1: every b belongs to the pass
             uint32_t my_e = 0;
             CF_STAMP(2);   // pop partition + clear table
-            // ---- stream the partner clouds of every posting of a, in chunks of DIST_NP_CAP postings.
-            // The units g+min_d .. min(read end, g+max_d) of a posting are ONE contiguous range of the CSR, cut
-            // into items of 64 entries; the items of all postings of the chunk are numbered consecutively and
-            // waves pull DIST_UNROLL items at a time from a shared LDS cursor (dynamic balance: the cost of an
-            // entry varies).  The posting of an item is found per WAVE, not per lane: every lane keeps 4 of the
-            // 256 inclusive item prefixes in registers and 4 ballots count the prefixes <= item.
+            // ---- phase B: sweep again; pairs of this partition whose b is marked go to the wave's queue and are
+            // inserted into the exact table 64 at a time by a full wave
             for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
                 const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
                 if (!one_chunk) cf_dist_setup(A, c0, np, rec, ipx, sh);
                 if (t == 0) sh[11] = 0;   // shared cursor over the items of this chunk
                 __syncthreads();
-                const uint32_t n_items = ipx[4 + np - 1];
-                const cf_u32x4 iv = *(const cf_u32x4*)&ipx[4 + 4 * lane];
-                // software pipeline: the global loads of step i+1 are issued before the LDS work of step i; what
-                // a load returns is only touched one step later (the decode needs ig, which travels in an SGPR)
-                typename Tab::raw nx_[DIST_UNROLL];
-                uint32_t nig_[DIST_UNROLL];
-#define CF_DIST_FETCH(I0)                                                                                     \
-                _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) {                                     \
-                    const uint32_t item = (I0) + (uint32_t)u;                                                 \
-                    nig_[u] = 0; nx_[u] = Tab::skip(a, 0u);                                                   \
-                    if (item < n_items) {                                                                     \
-                        const uint32_t p = (uint32_t)(__popcll(__ballot(iv.x <= item)) + __popcll(__ballot(iv.y <= item))      \
-                                                    + __popcll(__ballot(iv.z <= item)) + __popcll(__ballot(iv.w <= item)));   \
-                        const cf_dist_rec r = rec[p];                                                         \
-                        const uint32_t off = ((item - ipx[3 + p]) << 6) + (uint32_t)lane;                     \
-                        const uint32_t ig = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.ig);              \
-                        nig_[u] = ig;                                                                         \
-                        if (off < r.len) nx_[u] = Tab::load(A, r.e0 + (int64_t)off);                          \
-                        else nx_[u] = Tab::skip(a, ig);                                                       \
-                    }                                                                                         \
-                }
-#define CF_DIST_GRAB(VAR) { uint32_t g_ = 0; if (lane == 0) g_ = atomicAdd(&sh[11], (uint32_t)DIST_UNROLL); VAR = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_); }
-                // pops the last N (<= 64) queued inserts, one per lane; every lane runs the general probe loop for its own
+                uint32_t qtail = 0;      // wave-uniform
+                // pops the last N (<= 64) queued inserts, one per lane; every lane runs the probe loop for its own
 #define CF_DIST_DRAIN(N) {                                                                                    \
                     __builtin_amdgcn_wave_barrier();                                                          \
                     const uint32_t n_ = (N); qtail -= n_;                                                     \
@@ -482,76 +573,32 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     if (new_ && lane == 0) atomicAdd(&sh[0], new_);                                           \
                     __builtin_amdgcn_wave_barrier();                                                          \
                 }
-                uint32_t qtail = 0;      // wave-uniform
-                uint32_t i0, i1;
-                CF_DIST_GRAB(i0)
-                if (i0 < n_items) { CF_DIST_FETCH(i0) }
-                while (i0 < n_items) {
-                    if (sh[0] > A.fill_limit) break;     // too full (or physically full): the pass will be split
-                    typename Tab::raw cx_[DIST_UNROLL];
-                    uint32_t cig_[DIST_UNROLL];
-#pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) { cx_[u] = nx_[u]; cig_[u] = nig_[u]; }
-                    CF_DIST_GRAB(i1)
-                    if (i1 < n_items) { CF_DIST_FETCH(i1) }
-                    i0 = i1;
-                    // bucket reads of all unrolled emissions first (independent LDS reads in flight), then resolve
-                    uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL], bk_[DIST_UNROLL], live = 0;
-                    typename Tab::bucket kb_[DIST_UNROLL];
+                cf_dist_sweep<Tab>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
+                    if (sh[0] > A.fill_limit) return true;     // too full (or physically full): the pass will be split
+                    uint32_t w_[DIST_UNROLL], hbit_[DIST_UNROLL], live = 0, cand = 0;
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
-                        Tab::decode(cx_[u], cig_[u], bb[u], dd_[u]);
                         const uint32_t hb = Tab::hash(bb[u]);
                         live |= (uint32_t)((bb[u] != a) & ((((hb ^ (hb >> 15)) >> 3) & pmask) == pidx)) << u;
-                        bk_[u] = Tab::home(hb, n_buckets);
-                        kb_[u] = T.read(bk_[u]);
+                        hbit_[u] = Tab::bm_bit(bb[u]);
+                        w_[u] = bm[hbit_[u] >> 5];
                     }
                     my_e += (uint32_t)__popcll((unsigned long long)live);
-                    // (1) matches -> fire-and-forget adds, new keys -> first empty slot of the bucket already in
-                    // registers; (2) all CASes of the step issued back to back; (3) leftovers (bucket full, slot
-                    // lost to another key) take the general probe loop, one leftover per lane and round.
-                    uint32_t fresh = 0, failm = 0;   // bit u: created a new key / needs the general path
-                    int cand_[DIST_UNROLL];          // slot to claim, or -1
+#pragma unroll
+                    for (int u = 0; u < DIST_UNROLL; ++u) cand |= (((live >> u) & (w_[u] >> (hbit_[u] & 31u))) & 1u) << u;
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
-                        cand_[u] = -1;
-                        if (!((live >> u) & 1u)) continue;
-                        const int m = Tab::match(kb_[u], bb[u], dd_[u]);
-                        if (m >= 0) { T.add(bk_[u], m); continue; }              // the pair was seen before
-                        const int e = Tab::empty(kb_[u]);
-                        if (e >= 0) cand_[u] = e;
-                        else { failm |= 1u << u; bk_[u] = bk_[u] + 1 == n_buckets ? 0u : bk_[u] + 1; }
-                    }
-                    decltype(T.claim_issue(0u, 0, 0u, 0u)) old_[DIST_UNROLL];
-#pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) {
-                        old_[u] = 0;
-                        if (cand_[u] >= 0) old_[u] = T.claim_issue(bk_[u], cand_[u], bb[u], dd_[u]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) {
-                        if (cand_[u] < 0) continue;
-                        const int st = T.claim_finish(old_[u], bk_[u], cand_[u], bb[u], dd_[u]);
-                        if (st == 0) fresh |= 1u << u;
-                        else if (st == 2) failm |= 1u << u;
-                    }
-                    // (3) leftovers -> the wave's queue; a full wave of them is inserted as soon as 64 are waiting
-#pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) {
-                        const unsigned long long fm = __ballot((failm >> u) & 1u);
-                        if (fm) {
+                        const unsigned long long cm = __ballot((cand >> u) & 1u);
+                        if (cm) {
                             if (qtail >= 64u) { CF_DIST_DRAIN(64u) }
-                            if ((failm >> u) & 1u) wq[qtail + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = Tab::q_make(bb[u], dd_[u], bk_[u]);
-                            qtail += (uint32_t)__popcll(fm);
+                            if ((cand >> u) & 1u) wq[qtail + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = Tab::q_make(bb[u], dd_[u], Tab::home(Tab::hash(bb[u]), n_buckets));
+                            qtail += (uint32_t)__popcll(cm);
                         }
                     }
-                    // fill level: one fire-and-forget LDS atomic per wave and step; read back at the next step
-                    uint32_t wave_new = 0;
-#pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) wave_new += (uint32_t)__popcll(__ballot((fresh >> u) & 1u));
-                    if (wave_new && lane == 0) atomicAdd(&sh[0], wave_new);
-                }
+                    return false;
+                });
                 while (qtail > 0u && sh[0] <= A.fill_limit) { CF_DIST_DRAIN(min(qtail, 64u)) }   // (a void pass drops its queue)
+#undef CF_DIST_DRAIN
                 __syncthreads();
             }
             CF_STAMP(3);   // stream + insert
@@ -739,7 +786,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         const uint32_t slot_bytes = narrow ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
         // LDS: everything but the table is fixed; dist_slots (the table budget in 8-byte units) defaults to all the rest
         const size_t lds_fixed = sizeof(cf_dist_rec) * DIST_NP_CAP + (size_t)(4 + DIST_NP_CAP + 2 * DIST_STACK + 16) * 4 + DIST_STAGE_CAP * 2 + 16
-                               + (size_t)(ctx->dist_block / 64) * DIST_QCAP * (narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem));
+                               + DIST_BM_BITS / 8 + (size_t)(ctx->dist_block / 64) * DIST_QCAP * (narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem));
         const int64_t budget8 = ((int64_t)160 * 1024 - (int64_t)lds_fixed) / 8;
         if (ctx->dist_slots > budget8) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_slots does not fit the 160 KiB LDS next to the work lists"); break; }
         const int64_t slots8 = ctx->dist_slots ? ctx->dist_slots : budget8;
@@ -748,6 +795,10 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.est_limit = (uint32_t)((int64_t)A.fill_limit * 100 / ctx->dist_est_pct);
         A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
         const size_t lds = (size_t)A.slots * slot_bytes + lds_fixed;
+        A.sketch = (ctx->dist_sketch && min_cov >= 2 && min_cov <= 200) ? 1 : 0;
+        A.sk_shift = 32; A.sk_counters = 1;
+        while (A.sk_shift > 8 && (size_t)A.sk_counters * 2 <= (size_t)A.slots * slot_bytes) { A.sk_counters *= 2; --A.sk_shift; }
+        if (A.sk_counters < 16) A.sketch = 0;
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / ctx->dist_block));
         // locality order of the first k-mers: sort (first posting unit, a); k-mers without postings drop out
         n_a_alloc = (K > part) ? (K - part + n_parts - 1) / n_parts : 0;

@@ -48,13 +48,15 @@ def test_stage2_wide_table_layout(engine, report, oracle_stage2):
     try:
         engine.set_param("dist_slots", 1024)
         pathcheck.check_stage2(engine, report("lowcov"), tup, check_table=False)
-        engine.set_param("dist_slots", 256)   # spill path of the wide layout
+        engine.set_param("dist_slots", 256)   # spill path of the wide layout, every pair in the exact table (no sketch)
         engine.set_param("dist_stage", 2)
+        engine.set_param("dist_sketch", 0)
         pathcheck.check_stage2(engine, report("lowcov"), tup, n_parts=2, check_table=False)
         assert engine.stats()["n_spilled"] > 0
     finally:
         engine.set_param("dist_wide", 0)
         engine.set_param("dist_stage", 2048)
+        engine.set_param("dist_sketch", 1)
 
 
 def test_stage2_spill_and_partition(engine, report, oracle_stage2):
@@ -62,9 +64,13 @@ def test_stage2_spill_and_partition(engine, report, oracle_stage2):
     engine.set_param("dist_slots", 256)   # forces the (b, d) table to be split by a second hash of b
     engine.set_param("dist_block", 64)
     engine.set_param("dist_stage", 3)     # forces the marked-slot sweep instead of the staged edge list
-    pathcheck.check_stage2(engine, report("lowcov"), tup, n_parts=3, check_table=False)
-    assert engine.stats()["n_spilled"] > 0
-    engine.set_param("dist_stage", 2048)
+    engine.set_param("dist_sketch", 0)    # every (b, d) pair goes to the exact table
+    try:
+        pathcheck.check_stage2(engine, report("lowcov"), tup, n_parts=3, check_table=False)
+        assert engine.stats()["n_spilled"] > 0
+    finally:
+        engine.set_param("dist_sketch", 1)
+        engine.set_param("dist_stage", 2048)
 
 
 def test_long_posting_lists_take_the_multi_chunk_path(engine):

@@ -60,12 +60,16 @@ def test_wide_table_layout(engine, report, oracle_stage2):
     try:
         pathcheck.check_stage2(engine, report("tiny"), oracle_stage2("tiny"), check_table=False)
         engine.set_param("dist_slots", 512)
+        engine.set_param("dist_sketch", 0)      # every (b, d) pair in the exact table: forces the spill path
         pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov"), n_parts=2, check_table=False)
         assert engine.stats()["n_spilled"] > 0
+        engine.set_param("dist_sketch", 1)
+        pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov"), n_parts=2, check_table=False)
         pathcheck.check_synthetic_clouds(engine, n_reads=4, n_units=150, cloud=8, n_kmers=60)
     finally:
         engine.set_param("dist_wide", 0)
         engine.set_param("dist_slots", 0)
+        engine.set_param("dist_sketch", 1)
 
 
 def test_partitions_spill_and_slices(engine, report, oracle_stage2):
@@ -73,11 +77,17 @@ def test_partitions_spill_and_slices(engine, report, oracle_stage2):
     engine.set_param("dist_slots", 1024)
     engine.set_param("dist_stage", 5)
     try:
+        engine.set_param("dist_sketch", 0)      # every (b, d) pair in the exact table
         pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov"), n_parts=3, check_table=False)
         assert engine.stats()["n_spilled"] > 0
+        engine.set_param("dist_sketch", 1)      # counting sketch first (the default), same tiny LDS budget
+        pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov"), n_parts=3, check_table=False)
+        engine.set_param("dist_slots", 256)     # 2048 8-bit counters: they wrap -> falls back to "every b marked"
+        pathcheck.check_stage2(engine, report("hor2055"), oracle_stage2("hor2055"), check_table=False)
     finally:
         engine.set_param("dist_slots", 0)
         engine.set_param("dist_stage", 2048)
+        engine.set_param("dist_sketch", 1)
     # --min-nreads / --max-nreads slice and --min-distance 0 (kmer_clouds[:-0] is empty) and a narrow d window
     for ov in (dict(min_nreads=3, max_nreads=11), dict(min_distance=0, max_distance=4), dict(min_distance=2, max_distance=3)):
         pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov", **ov), check_table=False)
@@ -133,8 +143,9 @@ def test_full_size_properties(engine):
     inner = np.ones(ent.size, bool); inner[cp[1:-1][cp[1:-1] < ent.size]] = False
     assert np.all((np.diff(ent) > 0) | ~inner[1:])           # every cloud sorted-unique
     ref = None
-    for slots, parts in ((0, 1), (12000, 1), (8192, 2)):
+    for slots, parts, sketch in ((0, 1, 1), (12000, 1, 0), (8192, 2, 1), (2048, 1, 1)):
         engine.set_param("dist_slots", slots)
+        engine.set_param("dist_sketch", sketch)
         engine.reset_unique()
         tot_e = tot_n = 0
         chk = 0
@@ -148,6 +159,7 @@ def test_full_size_properties(engine):
             ref = got
         assert got == ref
     engine.set_param("dist_slots", 0)
+    engine.set_param("dist_sketch", 1)
     engine.reset_unique()
     ne = engine.dist_edges(0, 2 ** 62, 1, 150, 4, 0.8, 0, 1, edge_cap=1000)   # count-only beyond the cap
     assert ne == ref[0] and engine.edges(1000).shape == (1000, 4) and engine.unique_mask().tobytes() == ref[3]
