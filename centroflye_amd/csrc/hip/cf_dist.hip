@@ -211,6 +211,17 @@ struct cf_tab_wide {
         }
         return total;
     }
+    // filter side: f(slot, b, dd, cnt) for the occupied slots of bucket bk whose count is at least min_cov
+    template <class F>
+    __device__ __forceinline__ void for_counts_at_least(uint32_t bk, uint32_t min_cov, F&& f) const {
+        const bucket k = read(bk);
+        const unsigned long long v[4] = {k.lo.x, k.lo.y, k.hi.x, k.hi.y};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t cnt = (uint32_t)v[i] & 0x7FFFFFu;
+            if (v[i] != 0ull && cnt >= min_cov) f(4u * bk + (uint32_t)i, (uint32_t)(v[i] >> 32), ((uint32_t)v[i] >> 24) & 0xFFu, cnt);
+        }
+    }
     __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&tab[s], 1ull << 23); }
     __device__ __forceinline__ bool marked(uint32_t s) const { return (tab[s] >> 23) & 1ull; }
 };
@@ -284,6 +295,23 @@ struct cf_tab_narrow {
             bk = bk + 1 == n_buckets ? 0u : bk + 1;
         }
         return total;
+    }
+    template <class F>
+    __device__ __forceinline__ void for_counts_at_least(uint32_t bk, uint32_t min_cov, F&& f) const {
+        const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];
+        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+        const uint32_t need = min_cov ? min_cov - 1u : 0u;     // on the stored field (count - 1)
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) any |= ((w[j] & 0x7FFFu) >= need) | (((w[j] >> 16) & 0x7FFFu) >= need);
+        if (!any) return;
+        const bucket k = read(bk);
+        const uint32_t key[8] = {k.lo.x, k.lo.y, k.lo.z, k.lo.w, k.hi.x, k.hi.y, k.hi.z, k.hi.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t cnt = ((w[i >> 1] >> ((i & 1) * 16)) & 0x7FFFu) + 1u;
+            if (cnt >= min_cov && key[i] != kEmpty) f(8u * bk + (uint32_t)i, key[i] & 0xFFFFFFu, key[i] >> 24, cnt);
+        }
     }
     __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&cnt32[s >> 1], 0x8000u << ((s & 1u) * 16u)); }
     __device__ __forceinline__ bool marked(uint32_t s) const { return (cnt32[s >> 1] >> ((s & 1u) * 16u + 15u)) & 1u; }
@@ -616,17 +644,18 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             for (int d = 32; d >= 1; d >>= 1) my_e += __shfl_down(my_e, (unsigned)d);
             if (lane == 0 && my_e) atomicAdd(&sh[7], my_e);
             const uint32_t rounds = (slots + nt - 1) / nt;
-            for (uint32_t rd = 0; rd < rounds; ++rd) {
-                const uint32_t s = rd * nt + t;
-                uint32_t b, dd, cnt;
-                if (s < slots && T.get(s, b, dd, cnt) && cnt >= A.min_cov) {
+            // one bucket per thread and round: the counts decide first (one 16-byte read rejects 8 slots at once —
+            // the table is sparse and few pairs reach min_cov); only then keys are read and the chain of b is walked
+            for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt) {
+                T.for_counts_at_least(bk, A.min_cov, [&](uint32_t s, uint32_t b, uint32_t dd, uint32_t cnt) {
+                    (void)dd;
                     const unsigned long long total = T.total_of(b, n_buckets);
                     if (((double)cnt / (double)total) >= A.thr) {
                         T.mark(s);
                         const uint32_t pos = atomicAdd(&sh[8], 1u);
                         if (pos < A.stage_cap) stage[pos] = (uint16_t)s;
                     }
-                }
+                });
             }
             __syncthreads();
             CF_STAMP(4);   // filter
@@ -840,8 +869,8 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         {
             unsigned long long st[8];
             if (hipMemcpy(st, d_cnt + 8, 64, hipMemcpyDeviceToHost) == hipSuccess)
-                std::fprintf(stderr, "[cf_dist stamps] pop=%llu prologue=%llu clear=%llu stream=%llu filter=%llu write=%llu (shader cycles summed over %d workgroups; passes=%llu)\n",
-                             st[0], st[1], st[2], st[3], st[4], st[5], grid, h_cnt[5]);
+                std::fprintf(stderr, "[cf_dist stamps] pop=%llu prologue=%llu sketch=%llu clear=%llu stream=%llu filter=%llu write=%llu (shader cycles summed over %d workgroups; passes=%llu)\n",
+                             st[0], st[1], st[6], st[2], st[3], st[4], st[5], grid, h_cnt[5]);
         }
 #endif
         if (h_cnt[4]) { rc = cf_fail(ctx, -34, "cf_dist_edges: (b,d) table could not be partitioned far enough"); break; }
