@@ -27,6 +27,7 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 #define DIST_STAGE_CAP 2048              /* selected slots staged per table pass (u16 slot indices) */
 #define DIST_STACK 112
 #define DIST_UNROLL 4
+#define DIST_ITEM (64u * DIST_UNROLL)    /* cloud entries one wave takes per step: DIST_UNROLL consecutive ones per lane */
 #define DIST_BM_BITS 65536u              /* bitmap over hash(b): k-mers that may have a selected edge */
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
 #define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
@@ -164,8 +165,11 @@ struct cf_tab_wide {
         for (uint32_t s = t; s < (slots >> 1); s += nt) ((cf_u64x2*)tab)[s] = z;
     }
     // streaming side: one cloud entry -> (b, d)
-    static __device__ __forceinline__ raw load(const cf_dist_args& A, int64_t e) { return raw{(uint32_t)A.entries[e], (uint32_t)A.entry_i[e]}; }
-    static __device__ __forceinline__ raw skip(uint32_t a, uint32_t ig) { return raw{a, ig}; }     // decodes to b == a: never counted
+    // DIST_UNROLL consecutive entries from e on; entries whose bit in ok is clear are not touched in memory
+    static __device__ __forceinline__ void load_run(const cf_dist_args& A, int64_t e, uint32_t ok, raw (&out)[DIST_UNROLL]) {
+#pragma unroll
+        for (int u = 0; u < DIST_UNROLL; ++u) { const int64_t x = ((ok >> u) & 1u) ? e + u : 0; out[u] = raw{(uint32_t)A.entries[x], (uint32_t)A.entry_i[x]}; }
+    }
     static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { b = r.b; dd = r.i - ig; }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return b * 0x9E3779B1u; }
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return (uint32_t)(((unsigned long long)h * (unsigned long long)n_buckets) >> 32); }
@@ -242,8 +246,14 @@ struct cf_tab_narrow {
         for (uint32_t s = t; s < (slots >> 2); s += nt) ((cf_u32x4*)keys)[s] = e;
         for (uint32_t s = t; s < (slots >> 3); s += nt) ((cf_u32x4*)cnt32)[s] = z;
     }
-    static __device__ __forceinline__ raw load(const cf_dist_args& A, int64_t e) { return raw{A.packed[e]}; }
-    static __device__ __forceinline__ raw skip(uint32_t a, uint32_t ig) { return raw{(ig << 24) + a}; }   // decodes to b == a: never counted
+    // DIST_UNROLL (= 4) consecutive entries from e on with ONE 16-byte load (4-byte aligned); the packed array is
+    // padded by DIST_ITEM entries, so a run that starts inside the array may be read whole whatever ok says
+    struct __attribute__((packed, aligned(4))) run4 { uint32_t x, y, z, w; };
+    static __device__ __forceinline__ void load_run(const cf_dist_args& A, int64_t e, uint32_t ok, raw (&out)[DIST_UNROLL]) {
+        static_assert(DIST_UNROLL == 4, "one 16-byte load per lane");
+        const run4 r = *(const run4*)(A.packed + (ok ? e : 0));
+        out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
+    }
     // the unit index is kept mod 256 and 1 <= d <= max_d <= 255, so the 8-bit difference IS d; no borrow reaches b
     static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { const uint32_t q = r.v - (ig << 24); b = q & 0xFFFFFFu; dd = q >> 24; }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }               // 24 x 24 -> low 32 bits
@@ -342,7 +352,7 @@ __device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buck
 }
 
 // One posting of the first k-mer: its partner entries are ONE contiguous CSR range [e0, e0 + len); ig is the unit
-// index of the posting inside its read.  The range is swept in items of 64 entries.
+// index of the posting inside its read.  The range is swept in items of DIST_ITEM entries.
 struct alignas(16) cf_dist_rec { int64_t e0; uint32_t len; uint32_t ig; };
 
 // Partner ranges of the postings [c0, c0 + np) of one first k-mer -> LDS: rec[p], the inclusive prefix of their item
@@ -366,7 +376,7 @@ __device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0,
         uint32_t v[DIST_NP_CAP / 64], sum = 0;
         unsigned long long lens = 0;
 #pragma unroll
-        for (int i = 0; i < DIST_NP_CAP / 64; ++i) { const uint32_t len = rec[t * (DIST_NP_CAP / 64) + i].len; lens += len; sum += (len + 63u) >> 6; v[i] = sum; }
+        for (int i = 0; i < DIST_NP_CAP / 64; ++i) { const uint32_t len = rec[t * (DIST_NP_CAP / 64) + i].len; lens += len; sum += (len + DIST_ITEM - 1u) / DIST_ITEM; v[i] = sum; }
         uint32_t inc = sum;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, (unsigned)d); if (t >= d) inc += o; }
         const uint32_t base = inc - sum;
@@ -387,11 +397,12 @@ __device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0,
 #endif
 
 // Sweeps the partner entries of one chunk of postings.  The units g+min_d .. min(read end, g+max_d) of a posting are
-// ONE contiguous range of the CSR, cut into items of 64 entries; the items of all postings of the chunk are numbered
-// consecutively and waves pull DIST_UNROLL items at a time from a shared LDS cursor (dynamic balance).  The posting
-// of an item is found per WAVE, not per lane: every lane keeps 4 of the 256 inclusive item prefixes in registers and
-// 4 ballots count the prefixes <= item.  Software pipeline: the global loads of step i+1 are issued before the body
-// of step i runs; what a load returns is only touched one step later (ig travels in an SGPR, validity in a bit mask).
+// ONE contiguous range of the CSR, cut into items of DIST_ITEM = 64 x DIST_UNROLL entries; the items of all postings of
+// the chunk are numbered consecutively and waves pull one item at a time from a shared LDS cursor (dynamic balance).
+// The posting of an item is found per WAVE, not per lane: every lane keeps 4 of the 256 inclusive item prefixes in
+// registers and 4 ballots count the prefixes <= item.  A lane takes DIST_UNROLL consecutive entries of the item (one
+// 16-byte load in the narrow layout).  Software pipeline: the global load of step i+1 is issued before the body of
+// step i runs; what a load returns is only touched one step later (ig travels in an SGPR, validity in a bit mask).
 // body(bb, dd) gets the decoded entries of a step (bb[u] == a: nothing to count) and returns true to stop the wave.
 template <class Tab, class Body>
 __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, uint32_t a, const cf_dist_rec* rec, const uint32_t* ipx, uint32_t* cursor, int np, Body&& body) {
@@ -400,43 +411,34 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, uint32_t a,
     if (n_items == 0u) return;
     const cf_u32x4 iv = *(const cf_u32x4*)&ipx[4 + 4 * lane];
     typename Tab::raw nx_[DIST_UNROLL];
-    uint32_t nig_[DIST_UNROLL], nok = 0;
+    uint32_t nig = 0, nok = 0;
 #define CF_DIST_FETCH(I0) {                                                                                   \
-        uint32_t p_[DIST_UNROLL], st_[DIST_UNROLL];                                                           \
-        cf_dist_rec r_[DIST_UNROLL];                                                                          \
-        _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) {                                             \
-            const uint32_t item = min((I0) + (uint32_t)u, n_items - 1u);                                      \
-            p_[u] = (uint32_t)(__popcll(__ballot(iv.x <= item)) + __popcll(__ballot(iv.y <= item))            \
-                             + __popcll(__ballot(iv.z <= item)) + __popcll(__ballot(iv.w <= item)));          \
-        }                                                                                                     \
-        _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) { r_[u] = rec[p_[u]]; st_[u] = ipx[3 + p_[u]]; } \
+        const uint32_t item = (I0);                                                                           \
+        const uint32_t p = (uint32_t)(__popcll(__ballot(iv.x <= item)) + __popcll(__ballot(iv.y <= item))     \
+                                    + __popcll(__ballot(iv.z <= item)) + __popcll(__ballot(iv.w <= item)));   \
+        const cf_dist_rec r = rec[p];                                                                         \
+        const uint32_t off = (item - ipx[3 + p]) * DIST_ITEM + (uint32_t)lane * DIST_UNROLL;                  \
+        nig = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.ig);                                            \
         nok = 0;                                                                                              \
-        _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) {                                             \
-            const uint32_t item = (I0) + (uint32_t)u;                                                         \
-            const uint32_t off = ((min(item, n_items - 1u) - st_[u]) << 6) + (uint32_t)lane;                  \
-            const bool ok = (item < n_items) & (off < r_[u].len);                                             \
-            nok |= (uint32_t)ok << u;                                                                         \
-            nig_[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_[u].ig);                                \
-            nx_[u] = Tab::load(A, r_[u].e0 + (int64_t)(ok ? off : 0u));   /* always inside the entry array */   \
-        }                                                                                                     \
+        _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) nok |= (uint32_t)(off + (uint32_t)u < r.len) << u; \
+        Tab::load_run(A, r.e0 + (int64_t)off, nok, nx_);                                                      \
     }
-#define CF_DIST_GRAB(VAR) { uint32_t g_ = 0; if (lane == 0) g_ = atomicAdd(cursor, (uint32_t)DIST_UNROLL); VAR = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_); }
+#define CF_DIST_GRAB(VAR) { uint32_t g_ = 0; if (lane == 0) g_ = atomicAdd(cursor, 1u); VAR = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_); }
     uint32_t i0, i1;
     CF_DIST_GRAB(i0)
     if (i0 < n_items) CF_DIST_FETCH(i0)
     while (i0 < n_items) {
         typename Tab::raw cx_[DIST_UNROLL];
-        uint32_t cig_[DIST_UNROLL];
-        const uint32_t cok = nok;
+        const uint32_t cok = nok, cig = nig;
 #pragma unroll
-        for (int u = 0; u < DIST_UNROLL; ++u) { cx_[u] = nx_[u]; cig_[u] = nig_[u]; }
+        for (int u = 0; u < DIST_UNROLL; ++u) cx_[u] = nx_[u];
         CF_DIST_GRAB(i1)
         if (i1 < n_items) CF_DIST_FETCH(i1)
         i0 = i1;
         uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
 #pragma unroll
         for (int u = 0; u < DIST_UNROLL; ++u) {
-            Tab::decode(cx_[u], cig_[u], bb[u], dd_[u]);
+            Tab::decode(cx_[u], cig, bb[u], dd_[u]);
             if (!((cok >> u) & 1u)) bb[u] = a;
         }
         if (body(bb, dd_)) break;
@@ -799,7 +801,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         }
         narrow = !ctx->dist_wide && K < ((int64_t)1 << 24) - 1 && max_post <= 32767u;
         if (max_post >= (1u << 23)) { rc = cf_fail(ctx, -34, "cf_dist_edges: a k-mer has more than 2^23 postings"); break; }
-        if (narrow) { if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)ctx->n_entries + 1, "packed cloud entries"))) break; }
+        if (narrow) { if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)ctx->n_entries + DIST_ITEM, "packed cloud entries"))) break; }
         else if ((rc = cf_alloc_t(ctx, &d_entry_i, (size_t)ctx->n_entries + 1, "entry unit indices"))) break;
         if (U && ctx->n_entries)
             hipLaunchKernelGGL(cf_entry_unit_kernel, dim3((unsigned)cf_grid_for(U * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
@@ -884,7 +886,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     if (d_first) cf_release_t(ctx, d_first, (size_t)K + 1);
     if (d_cnt) cf_release_t(ctx, d_cnt, n_cnt);
     if (d_entry_i) cf_release_t(ctx, d_entry_i, (size_t)ctx->n_entries + 1);
-    if (d_packed) cf_release_t(ctx, d_packed, (size_t)ctx->n_entries + 1);
+    if (d_packed) cf_release_t(ctx, d_packed, (size_t)ctx->n_entries + DIST_ITEM);
     if (d_rbeg) cf_release_t(ctx, d_rbeg, (size_t)U + 1);
     if (d_rend) cf_release_t(ctx, d_rend, (size_t)U + 1);
     if (d_post) cf_release_t(ctx, d_post, (size_t)n_post);
