@@ -818,7 +818,8 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         // LDS: everything but the table is fixed; dist_slots (the table budget in 8-byte units) defaults to all the rest
         const size_t lds_fixed = sizeof(cf_dist_rec) * DIST_NP_CAP + (size_t)(4 + DIST_NP_CAP + 2 * DIST_STACK + 16) * 4 + DIST_STAGE_CAP * 2 + 16
                                + DIST_BM_BITS / 8 + (size_t)(ctx->dist_block / 64) * DIST_QCAP * (narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem));
-        const int64_t budget8 = ((int64_t)160 * 1024 - (int64_t)lds_fixed) / 8;
+        const int64_t budget8 = ((int64_t)160 * 1024 / ctx->dist_wgs - (int64_t)lds_fixed) / 8;
+        if (budget8 < 256) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_wgs leaves no LDS for the table"); break; }
         if (ctx->dist_slots > budget8) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_slots does not fit the 160 KiB LDS next to the work lists"); break; }
         const int64_t slots8 = ctx->dist_slots ? ctx->dist_slots : budget8;
         A.slots = (int32_t)((slots8 * 8 / slot_bytes) & ~7ll);
