@@ -143,7 +143,7 @@ def test_full_size_properties(engine):
     inner = np.ones(ent.size, bool); inner[cp[1:-1][cp[1:-1] < ent.size]] = False
     assert np.all((np.diff(ent) > 0) | ~inner[1:])           # every cloud sorted-unique
     ref = None
-    for slots, parts, sketch in ((0, 1, 1), (12000, 1, 0), (8192, 2, 1), (2048, 1, 1)):
+    for slots, parts, sketch in ((0, 1, 1), (6000, 1, 0), (4096, 2, 1), (2048, 1, 1)):
         engine.set_param("dist_slots", slots)
         engine.set_param("dist_sketch", sketch)
         engine.reset_unique()
