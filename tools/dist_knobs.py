@@ -4,11 +4,11 @@ usage: tools/dist_knobs.py <reads> "name=val,name=val" ...   (one line per setti
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from centroflye_amd import _host
+from centroflye_amd import _host, _lib
 from centroflye_amd.engine import Engine
 n = int(sys.argv[1])
 pk = _host.synth(seed=2, n_units=max(24, int(round(0.3 * n))), n_reads=n, var_len=8)
-e = Engine(0)
+e = Engine(0, _lib.load(os.path.join(ROOT, os.environ['CF_LIB']))) if os.environ.get('CF_LIB') else Engine(0)
 e.load(pk, 1); e.count_kmers(19); e.select_rare(3, 10, 32); e.build_clouds()
 for setting in sys.argv[2:]:
     kv = [x.split("=") for x in setting.split(",") if x]
