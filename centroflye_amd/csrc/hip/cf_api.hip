@@ -35,8 +35,8 @@ static void free_units(cf_ctx* c) {
     cf_release_t(c, c->d_unit_end, (size_t)c->n_units);
 }
 void cf_free_table(cf_ctx* c) {
-    if (c->d_table) { cf_release(c, c->d_table, (size_t)c->table_cap * sizeof(cf_slot)); c->d_table = nullptr; }
-    c->table_cap = 0;
+    if (c->d_table) { cf_release(c, c->d_table, (size_t)c->table_alloc * sizeof(cf_slot)); c->d_table = nullptr; }
+    c->table_cap = 0; c->table_alloc = 0;
 }
 void cf_free_kmers(cf_ctx* c) {
     cf_release_t(c, c->d_kmers, (size_t)c->n_kmers);

@@ -67,7 +67,8 @@ struct cf_ctx {
 
     // A1 table
     cf_slot* d_table = nullptr;
-    uint64_t table_cap = 0;
+    uint64_t table_cap = 0;      // slots in use (a power of two)
+    uint64_t table_alloc = 0;    // slots allocated (>= table_cap: a smaller table reuses a larger allocation)
     int k = 0;
 
     // k-mer set + lookup table

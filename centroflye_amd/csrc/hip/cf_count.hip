@@ -288,10 +288,12 @@ static int table_compact(cf_ctx* ctx, uint32_t max_nonuniq, uint32_t lo, uint32_
 }
 
 static int ensure_table(cf_ctx* ctx, uint64_t want_cap) {
-    if (ctx->d_table && ctx->table_cap == want_cap) return 0;
+    // a table no larger than the current allocation uses a prefix of it (steps of the sharded path alternate between
+    // the local count table and the merged table of owned keys: no 10-GB free + malloc per step)
+    if (ctx->d_table && want_cap <= ctx->table_alloc) { ctx->table_cap = want_cap; return 0; }
     cf_free_table(ctx);
     CF_TRY(cf_alloc(ctx, (void**)&ctx->d_table, (size_t)want_cap * sizeof(cf_slot), "k-mer table"));
-    ctx->table_cap = want_cap;
+    ctx->table_cap = want_cap; ctx->table_alloc = want_cap;
     return 0;
 }
 

@@ -31,6 +31,42 @@ def _owner(keys_i64, world):
     return ((h >> 33) & 0x7FFFFFFF) % world
 
 
+# RCCL (2.26, ROCm 7) silently drops part of a large all_to_all_single message (measured on MI355X, tools/
+# exchange_overhead.py: 480 MB arrives intact, 1.26 GB loses half its rows), so the table exchange is cut into rounds
+# of at most CHUNK_BYTES per call and rank; the all-gathers are cut the same way as a precaution.  Every rank runs the
+# same number of rounds (a MAX all-reduce of the counts).
+CHUNK_BYTES = 256 << 20
+
+
+def all_to_all_rows(payload, send_counts, recv_counts, group=None, chunk_rows=None):
+    """payload: [sum(send_counts), C] rows grouped by destination rank; returns [sum(recv_counts), C] grouped by source."""
+    W = len(send_counts)
+    dev = payload.device
+    row_bytes = payload.element_size() * (payload.shape[1] if payload.dim() > 1 else 1)
+    if chunk_rows is None:
+        chunk_rows = max(1, CHUNK_BYTES // (row_bytes * W))
+    recv = torch.empty((sum(recv_counts),) + tuple(payload.shape[1:]), dtype=payload.dtype, device=dev)
+    most = torch.tensor([max(list(send_counts) + list(recv_counts) + [0])], dtype=torch.int64, device=dev)
+    dist.all_reduce(most, op=dist.ReduceOp.MAX, group=group)
+    most = int(most.item())
+    s_off = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.int64)
+    r_off = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
+    for r0 in range(0, most, chunk_rows):
+        sc = [int(min(max(c - r0, 0), chunk_rows)) for c in send_counts]
+        rc = [int(min(max(c - r0, 0), chunk_rows)) for c in recv_counts]
+        if most <= chunk_rows:      # one round: no staging copies
+            dist.all_to_all_single(recv, payload, output_split_sizes=rc, input_split_sizes=sc, group=group)
+            break
+        sbuf = torch.cat([payload[s_off[j] + r0: s_off[j] + r0 + sc[j]] for j in range(W)]) if sum(sc) else payload[:0]
+        rbuf = torch.empty((sum(rc),) + tuple(payload.shape[1:]), dtype=payload.dtype, device=dev)
+        dist.all_to_all_single(rbuf, sbuf.contiguous(), output_split_sizes=rc, input_split_sizes=sc, group=group)
+        o = 0
+        for j in range(W):
+            recv[r_off[j] + r0: r_off[j] + r0 + rc[j]] = rbuf[o: o + rc[j]]
+            o += rc[j]
+    return recv
+
+
 class ShardedRecruiter:
     def __init__(self, device_index=0, lib=None, torch_device=None, group=None, force_exchange=False):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -52,7 +88,7 @@ class ShardedRecruiter:
         if self.dev.type == "cuda":
             torch.cuda.synchronize(self.dev)
 
-    def _all_gather_var(self, t):
+    def _all_gather_var(self, t, chunk_elems=None):
         """All-gather 1-D tensors of different lengths; returns (concatenated tensor, sizes list)."""
         if not dist.is_initialized():
             return t, [int(t.numel())]
@@ -60,12 +96,22 @@ class ShardedRecruiter:
         sizes = [torch.zeros_like(n) for _ in range(self.world)]
         dist.all_gather(sizes, n, group=self.group)
         sizes = [int(s.item()) for s in sizes]
-        m = max(max(sizes), 1)
-        pad = torch.zeros(m, dtype=t.dtype, device=self.dev)
-        pad[:t.numel()] = t
-        out = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(out, pad, group=self.group)
-        return torch.cat([o[:s] for o, s in zip(out, sizes)]), sizes
+        if chunk_elems is None:
+            chunk_elems = max(1, CHUNK_BYTES // (t.element_size() * self.world))
+        parts = [[] for _ in range(self.world)]
+        for r0 in range(0, max(max(sizes), 1), chunk_elems):      # rounds of at most CHUNK_BYTES per rank (see CHUNK_BYTES)
+            m = min(chunk_elems, max(max(sizes), 1) - r0)
+            pad = torch.zeros(m, dtype=t.dtype, device=self.dev)
+            mine = t[r0: r0 + m]
+            pad[:mine.numel()] = mine
+            out = [torch.empty_like(pad) for _ in range(self.world)]
+            dist.all_gather(out, pad, group=self.group)
+            for j in range(self.world):
+                k = min(max(sizes[j] - r0, 0), m)
+                if k:
+                    parts[j].append(out[j][:k])
+        flat = [p for ps in parts for p in ps]
+        return (torch.cat(flat) if flat else t[:0]), sizes
 
     def load(self, packed, n_motif=1):
         self.local.load(packed, n_motif)
@@ -75,9 +121,19 @@ class ShardedRecruiter:
     # ------------------------------------------------------------------ one step
     def run(self, k=19, max_nonuniq=3, lo=10, hi=32, min_d=1, max_d=150, min_cov=4, rel_threshold=0.8, edge_cap=0):
         L, G, W, dev = self.local, self.glob, self.world, self.dev
+        import time
+        sec, t_last = {}, [time.perf_counter()]
+
+        def lap(name):
+            self._sync()
+            now = time.perf_counter()
+            sec[name] = round(sec.get(name, 0.0) + now - t_last[0], 4)
+            t_last[0] = now
+        self.sections = sec
         # 1. local counts
         L.count_kmers(k)
         st_local = L.stats()
+        lap("count")
         if self.exchange:
             # 2. all-to-all of (key, pres | multi << 32) bucketed by owner
             n = L.table_size()
@@ -87,23 +143,28 @@ class ShardedRecruiter:
             self._sync()
             L.table_into(keys.data_ptr(), pres.data_ptr(), multi.data_ptr(), n)
             keys, pres, multi = keys[:n], pres[:n], multi[:n]
+            lap("x_dump")
             own = _owner(keys, W)
             order = torch.argsort(own)
             send_counts = torch.bincount(own, minlength=W).to(torch.int64)
             payload = torch.stack([keys[order], (pres[order].to(torch.int64) & 0xFFFFFFFF) | (multi[order].to(torch.int64) << 32)], dim=1).contiguous()
+            lap("x_bucket")
             recv_counts = torch.empty_like(send_counts)
             dist.all_to_all_single(recv_counts, send_counts, group=self.group)
             sc, rc = send_counts.tolist(), recv_counts.tolist()
-            recv = torch.empty((sum(rc), 2), dtype=torch.int64, device=dev)
-            dist.all_to_all_single(recv, payload, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+            recv = all_to_all_rows(payload, sc, rc, group=self.group)
+            lap("x_a2a")
             rk = recv[:, 0].contiguous()
             rp = (recv[:, 1] & 0xFFFFFFFF).to(torch.int32).contiguous()
             rm = (recv[:, 1] >> 32).to(torch.int32).contiguous()
             self._sync()
+            lap("x_split")
             L.reset_table(k, max(int(rk.numel()), 1))
+            lap("x_reset")
             if rk.numel():
                 L.merge_table_ptr(rk.data_ptr(), rp.data_ptr(), rm.data_ptr(), rk.numel())
             self.exchange_bytes = int(payload.numel() * 8)
+            lap("table_exchange")
         # 3. rare k-mers of the owned keys, gathered and sorted everywhere
         n_own = L.select_rare(max_nonuniq, lo, hi)
         st_owner = L.stats()
@@ -118,8 +179,10 @@ class ShardedRecruiter:
             n_rare = int(rare.numel())
         else:
             n_rare = n_own
+        lap("select")
         # 4. clouds of the local shard, gathered
         n_ce_local = L.build_clouds()
+        lap("clouds")
         if self.exchange:
             U = L.n_units
             cp = torch.empty(U + 1, dtype=torch.int64, device=dev)
@@ -141,12 +204,14 @@ class ShardedRecruiter:
             all_ent = all_ent.contiguous()
             G.set_clouds_ptr(cloud_ptr_g.data_ptr(), all_ent.data_ptr(), all_ent.numel())
             D = G
+            lap("cloud_gather")
         else:
             D = L
         # 5. distance + filter on this rank's first k-mers
         D.reset_unique()
         n_edges = D.dist_edges(0, 2 ** 62, min_d, max_d, min_cov, rel_threshold, self.rank, W, edge_cap)
         st_d = D.stats()
+        lap("dist")
         # 6. combine
         if self.exchange:
             mask = torch.empty(max(n_rare, 1), dtype=torch.uint8, device=dev)
@@ -166,6 +231,7 @@ class ShardedRecruiter:
                  st_owner["n_distinct"], st_owner["n_kept"], n_ce_local]
             self.unique_mask = D.unique_mask()
             self.rare = D.kmers()
+        lap("combine")
         self.local_edges = n_edges
         self.dist_engine = D
         return dict(n_edges=c[0], n_emissions=c[1], n_bases=c[2], n_windows=c[3], n_read_kmers=c[4], n_distinct=c[5],

@@ -14,6 +14,7 @@ import torch
 import torch.distributed as dist
 
 from centroflye_amd import _host, _lib
+from centroflye_amd import sharded
 from centroflye_amd.sharded import ShardedRecruiter
 from oracle import cport
 
@@ -28,6 +29,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     lib = _lib.load(os.path.join(ROOT, "tests", "emu", "libcfhip_emu.so"))
     pk = _host.synth(n_reads=READS_PER_RANK, cand_offset=rank, cand_stride=world, **SYNTH)
+    sharded.CHUNK_BYTES = 4096      # many rounds per exchange: the multi-round path of the all-to-all / all-gathers
     sr = ShardedRecruiter(0, lib=lib, torch_device="cpu")
     sr.local.set_param("dist_slots", 2048); sr.local.set_param("dist_block", 128)
     sr.glob.set_param("dist_slots", 2048); sr.glob.set_param("dist_block", 128)

@@ -217,3 +217,29 @@ dist.destroy_process_group()
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
     assert res["exchanged"] and res["n_edges"] > 1000
     assert res["counters"] and res["rare"] and res["unique"] and res["edges"], res
+
+
+def test_large_all_to_all_arrives_whole():
+    """RCCL drops part of an all_to_all_single message of more than ~1 GB; the sharded path cuts its exchanges into rounds
+    (centroflye_amd/sharded.py CHUNK_BYTES).  1.3 GB through the chunked exchange on a single-rank RCCL group."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29547"
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from centroflye_amd.sharded import all_to_all_rows
+n = 80_000_000
+g = torch.Generator(device="cuda"); g.manual_seed(3)
+payload = torch.randint(0, 2 ** 40, (n, 2), dtype=torch.int64, device="cuda", generator=g)
+recv = all_to_all_rows(payload, [n], [n])
+torch.cuda.synchronize()
+print("RESULT", bool(torch.equal(recv, payload)))
+dist.destroy_process_group()
+''' % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "RESULT True" in p.stdout, p.stdout[-2000:]
