@@ -33,13 +33,18 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 #define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
 
 __global__ void __launch_bounds__(256)
-cf_post_hist_kernel(const int32_t* __restrict__ entries, int64_t e0, int64_t e1, uint32_t* __restrict__ cnt) {
+cf_post_hist_kernel(const int32_t* __restrict__ entries, int64_t e0, int64_t e1, uint32_t part, uint32_t n_parts, uint32_t* __restrict__ cnt) {
+    // postings are only needed for the first k-mers of this partition (a % n_parts == part): at N GPUs every rank
+    // scans all clouds but keeps 1/N of the postings
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e1; i += stride) atomicAdd(&cnt[entries[i]], 1u);
+    for (int64_t i = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e1; i += stride) {
+        const uint32_t x = (uint32_t)entries[i];
+        if (n_parts == 1u || x % n_parts == part) atomicAdd(&cnt[x], 1u);
+    }
 }
 
 __global__ void __launch_bounds__(256)
-cf_post_fill_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ entries, int64_t u0, int64_t u1,
+cf_post_fill_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ entries, int64_t u0, int64_t u1, uint32_t part, uint32_t n_parts,
                     const int64_t* __restrict__ post_ptr, uint32_t* __restrict__ cursor, int32_t* __restrict__ post,
                     uint32_t* __restrict__ first_unit) {
     const int lane = threadIdx.x & 63;
@@ -49,6 +54,7 @@ cf_post_fill_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __rest
         const int64_t a = cloud_ptr[u], b = cloud_ptr[u + 1];
         for (int64_t e = a + lane; e < b; e += 64) {
             const int32_t x = entries[e];
+            if (n_parts != 1u && (uint32_t)x % n_parts != part) continue;
             post[post_ptr[x] + atomicAdd(&cursor[x], 1u)] = (int32_t)u;
             if (first_unit[x] > (uint32_t)u) atomicMin(&first_unit[x], (uint32_t)u);
         }
@@ -783,12 +789,12 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         }
         if (e1 > e0)
             hipLaunchKernelGGL(cf_post_hist_kernel, dim3((unsigned)cf_grid_for(e1 - e0, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const int32_t*)ctx->d_entries, e0, e1, d_pcnt);
+                               (const int32_t*)ctx->d_entries, e0, e1, (uint32_t)part, (uint32_t)n_parts, d_pcnt);
         if ((rc = cf_scan_exclusive_u32_to_i64(ctx, d_pcnt, d_post_ptr, K + 1, &n_post))) break;
         if ((rc = cf_alloc_t(ctx, &d_post, (size_t)n_post, "postings"))) break;
         if (u1 > u0 && n_post)
             hipLaunchKernelGGL(cf_post_fill_kernel, dim3((unsigned)cf_grid_for((u1 - u0) * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries, u0, u1, (const int64_t*)d_post_ptr, d_cursor, d_post, d_first);
+                               (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries, u0, u1, (uint32_t)part, (uint32_t)n_parts, (const int64_t*)d_post_ptr, d_cursor, d_post, d_first);
         if (R)
             hipLaunchKernelGGL(cf_unit_rend_kernel, dim3((unsigned)cf_grid_for(R, 256, max_blocks)), dim3(256), 0, ctx->stream,
                                (const int64_t*)ctx->d_unit_ptr, R, d_rend, d_rbeg);
