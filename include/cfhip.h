@@ -128,8 +128,10 @@ int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int3
 int cf_get_stats(cf_ctx* ctx, cf_stats* out);
 int cf_get_times(cf_ctx* ctx, cf_times* out);
 
-/* Tuning knobs (defaults are chosen for gfx950): name in {"dist_block", "dist_slots",
- * "count_slots", "count_tile"}. */
+/* Tuning knobs (defaults are chosen for gfx950): name in {"dist_block" (threads per workgroup), "dist_wgs"
+ * (workgroups per CU the LDS is split between), "dist_slots" (LDS budget of the (b,d) table in 8-byte units, 0 = all that
+ * is left), "dist_sketch" (0: every pair goes to the exact table), "dist_fill_pct", "dist_est_pct", "dist_stage",
+ * "dist_wide", "count_slots", "count_tile"}.  Results never depend on them (tests/test_gpu_parity.py). */
 int cf_set_param(cf_ctx* ctx, const char* name, int64_t value);
 
 /* Self-tests of the device primitives against host results (used by tests/ only). */
