@@ -70,6 +70,7 @@ def lib():
     L.cfh_write_kmers.argtypes = [C.c_char_p, C.c_void_p, i64, i32, C.c_char_p, C.c_int]
     L.cfh_write_edges.argtypes = [C.c_char_p, C.c_int, C.c_void_p, i32, C.c_void_p, i64, C.c_char_p, C.c_int]
     L.cfh_read_kmers.argtypes = [C.c_char_p, i32, C.c_void_p, i64, pi64, C.c_char_p, C.c_int]
+    L.cfh_export_read_units.argtypes = [P, C.c_void_p, C.c_void_p, i64, i64, i64, C.c_char_p, C.c_int, pi64, pi64, C.c_char_p, C.c_int]
     _lib = L
     return L
 
@@ -144,6 +145,19 @@ class PackedReads:
         out = np.zeros(self.n_reads, dtype=np.uint8)
         lib().cfh_classify(self._h, int(large_threshold), int(small_threshold), out.ctypes.data)
         return out
+
+    def export_read_units(self, rec, pos, outdir, min_pos=0, max_pos=None, n_threads=0):
+        """Per-position read-unit FASTA files (reference eltr_polisher.py:53-97).  rec / pos: record indices and
+        positions of the placed reads in read_positions.csv order; max_pos None = infinity.  Returns
+        (number of positions, number of units written)."""
+        rec = np.ascontiguousarray(rec, dtype=np.int64)
+        pos = np.ascontiguousarray(pos, dtype=np.int64)
+        err = C.create_string_buffer(512)
+        n_pos, n_units = C.c_int64(), C.c_int64()
+        _check(lib().cfh_export_read_units(self._h, rec.ctypes.data, pos.ctypes.data, rec.size, int(min_pos),
+                                           -1 if max_pos is None else int(max_pos), os.fsencode(outdir), int(n_threads),
+                                           C.byref(n_pos), C.byref(n_units), err, 512), err)
+        return n_pos.value, n_units.value
 
     def row(self, r, which):
         n = C.c_int64()

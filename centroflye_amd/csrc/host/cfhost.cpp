@@ -8,7 +8,12 @@
 //   scripts/utils/bio.py:27-29     RC
 #include "cfhost.h"
 
+#include <sys/stat.h>
+#include <sys/types.h>
+
 #include <algorithm>
+#include <cctype>
+#include <cerrno>
 #include <array>
 #include <atomic>
 #include <cmath>
@@ -22,6 +27,26 @@
 #include <vector>
 
 namespace {
+
+// os.makedirs that tolerates an existing directory (reference utils/os_utils.py:29-34)
+static int mkdir_p(const char* path) {
+    std::string cur;
+    const std::string full(path);
+    for (size_t i = 0; i <= full.size(); ++i) {
+        if (i == full.size() || full[i] == '/') {
+            if (!cur.empty() && ::mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST) return -1;
+        }
+        if (i < full.size()) cur += full[i];
+    }
+    return 0;
+}
+
+static bool write_file(const std::string& path, const std::string& data) {
+    FILE* f = std::fopen(path.c_str(), "w");
+    if (!f) return false;
+    const bool ok = std::fwrite(data.data(), 1, data.size(), f) == data.size();
+    return std::fclose(f) == 0 && ok;
+}
 
 void set_err(char* err, int errlen, const std::string& msg) {
     if (err && errlen > 0) {
@@ -816,6 +841,102 @@ int cfh_read_kmers(const char* path, int32_t k, uint64_t* out, int64_t cap, int6
     std::fclose(f);
     *n_out = cnt;
     return rc;
+}
+
+// Per-position read-unit export (reference scripts/eltr_polisher.py:53-66 ELTR_Polisher.map_pos2read and :68-97
+// export_read_units; the max_pos default of :45-51).  Placed reads come in read_positions.csv order (that is the
+// order of the reference's read_placement dict and therefore of every pos2read list and FASTA file).
+int cfh_export_read_units(cfh_pack* p, const int64_t* rec, const int64_t* pos, int64_t n_placed, int64_t min_pos,
+                          int64_t max_pos, const char* outdir, int n_threads, int64_t* n_positions,
+                          int64_t* n_units_written, char* err, int errlen) {
+    try {
+        const int64_t R = p->n_reads();
+        for (int64_t i = 0; i < n_placed; ++i)
+            if (rec[i] < 0 || rec[i] >= R || pos[i] < 0) { set_err(err, errlen, "cfh_export_read_units: bad record index or position"); return -22; }
+        auto n_units_of = [&](int64_t r) { return p->u1_ptr[(size_t)r + 1] - p->u1_ptr[(size_t)r]; };
+        if (max_pos < 0) {   // math.inf: the end of the right-most placed read (:45-51)
+            max_pos = 0;
+            for (int64_t i = 0; i < n_placed; ++i) max_pos = std::max(max_pos, pos[i] + n_units_of(rec[i]));
+        }
+        struct Item { int64_t gpos, rec, unit; };
+        std::vector<Item> items;
+        for (int64_t i = 0; i < n_placed; ++i) {
+            const int64_t n = n_units_of(rec[i]), q = pos[i];
+            if (q > max_pos) continue;
+            int64_t lo = 1, hi = n - 1;                       // inner units only (:61) ...
+            if (q == min_pos || q + n == max_pos) { lo = 0; hi = n; }   // ... unless the read touches an end (:58-59)
+            for (int64_t u = lo; u < hi; ++u)
+                if (min_pos <= q + u && q + u <= max_pos) items.push_back({q + u, rec[i], u});
+        }
+        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.gpos < b.gpos; });
+        std::vector<size_t> starts;
+        for (size_t i = 0; i < items.size(); ++i) if (i == 0 || items[i].gpos != items[i - 1].gpos) starts.push_back(i);
+        starts.push_back(items.size());
+        if (mkdir_p(outdir) != 0) { set_err(err, errlen, std::string("cannot create ") + outdir); return -2; }
+        const size_t n_pos = starts.size() - 1;
+        std::atomic<size_t> next{0};
+        std::atomic<int> failed{0};
+        auto work = [&]() {
+            std::string units, med, dir, key;
+            std::vector<std::pair<std::string, size_t>> keys;   // (header, item index)
+            for (;;) {
+                const size_t j = next.fetch_add(1);
+                if (j >= n_pos || failed.load()) break;
+                const int64_t gp = items[starts[j]].gpos;
+                dir = std::string(outdir) + "/pos_" + std::to_string(gp);
+                if (mkdir_p(dir.c_str()) != 0) { failed = 1; break; }
+                units.clear(); keys.clear();
+                std::vector<int64_t> lens;
+                for (size_t i = starts[j]; i < starts[j + 1]; ++i) {
+                    const Item& it = items[i];
+                    const int64_t u = p->u1_ptr[(size_t)it.rec] + it.unit;
+                    const int64_t b0 = p->u1_start[(size_t)u], b1 = p->u1_end[(size_t)u];
+                    key = "gen_pos=" + std::to_string(gp) + "|r_id=" +
+                          p->ids.substr((size_t)p->id_off[(size_t)it.rec], (size_t)(p->id_off[(size_t)it.rec + 1] - p->id_off[(size_t)it.rec])) +
+                          "|r_pos=" + std::to_string(it.unit);
+                    units += '>'; units += key; units += '\n';
+                    const size_t at = units.size();
+                    units.append(p->bases, (size_t)b0, (size_t)(b1 - b0));
+                    for (size_t c = at; c < units.size(); ++c) units[c] = (char)std::toupper((unsigned char)units[c]);
+                    units += '\n';
+                    lens.push_back(b1 - b0);
+                    keys.emplace_back(key, i);
+                }
+                // statistics.median_high (:82), then the first header in sorted order with that length (:84-89)
+                std::vector<int64_t> sl(lens);
+                std::sort(sl.begin(), sl.end());
+                const int64_t med_len = sl[sl.size() / 2];
+                std::sort(keys.begin(), keys.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+                med.clear();
+                for (const auto& kv : keys) {
+                    const Item& it = items[kv.second];
+                    const int64_t u = p->u1_ptr[(size_t)it.rec] + it.unit;
+                    const int64_t b0 = p->u1_start[(size_t)u], b1 = p->u1_end[(size_t)u];
+                    if (b1 - b0 != med_len) continue;
+                    med += '>'; med += kv.first; med += '\n';
+                    const size_t at = med.size();
+                    med.append(p->bases, (size_t)b0, (size_t)(b1 - b0));
+                    for (size_t c = at; c < med.size(); ++c) med[c] = (char)std::toupper((unsigned char)med[c]);
+                    med += '\n';
+                    break;
+                }
+                if (!write_file(dir + "/read_units.fasta", units) || !write_file(dir + "/median_read_unit.fasta", med)) { failed = 1; break; }
+            }
+        };
+        int nt = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+        nt = (int)std::min<size_t>((size_t)nt, std::max<size_t>(n_pos, 1));
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+        if (failed.load()) { set_err(err, errlen, std::string("cfh_export_read_units: cannot write under ") + outdir); return -5; }
+        if (n_positions) *n_positions = (int64_t)n_pos;
+        if (n_units_written) *n_units_written = (int64_t)items.size();
+        return 0;
+    } catch (const std::exception& e) {
+        set_err(err, errlen, std::string("cfh_export_read_units: ") + e.what());
+        return -12;
+    }
 }
 
 }  // extern "C"

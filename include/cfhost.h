@@ -107,6 +107,16 @@ int cfh_write_kmers(const char* path, const uint64_t* kmers, int64_t n, int32_t 
 int cfh_write_edges(const char* path, int append, const uint64_t* rare_kmers, int32_t k,
                     const uint32_t* edges /* n x 4: d,a,b,cnt */, int64_t n,
                     char* err, int errlen);
+/* Per-position read-unit export, the consumer of read_positions.csv (reference scripts/eltr_polisher.py:53-66
+ * ELTR_Polisher.map_pos2read, :68-97 export_read_units, :45-51 default max_pos).  rec[i] / pos[i]: record index and
+ * position of the i-th placed read in read_positions.csv order ("None" lines left out by the caller).  max_pos < 0
+ * means infinity (the end of the right-most placed read).  Writes outdir/pos_P/read_units.fasta (">gen_pos=P|r_id=ID|
+ * r_pos=i" + the upper-case de-gapped unit, in placement order) and outdir/pos_P/median_read_unit.fasta (the first
+ * header in sorted order whose unit has the high-median length).  SURVEY.md §8(f) rank 3. */
+int cfh_export_read_units(cfh_pack* p, const int64_t* rec, const int64_t* pos, int64_t n_placed, int64_t min_pos,
+                          int64_t max_pos, const char* outdir, int n_threads, int64_t* n_positions,
+                          int64_t* n_units_written, char* err, int errlen);
+
 /* Read a k-mer text file (one per line) into 2-bit codes; returns count via n_out, fills out
  * if non-NULL (size-query then fill). All k-mers must have length k and be ACGT. */
 int cfh_read_kmers(const char* path, int32_t k, uint64_t* out, int64_t cap, int64_t* n_out,
