@@ -27,7 +27,7 @@ class Times(C.Structure):
     """Mirror of ``cf_times``."""
     _fields_ = [(n, C.c_float) for n in (
         "load_ms", "count_ms", "select_ms", "clouds_ms", "filter_ms", "postings_ms", "dist_ms",
-        "place_ms", "dist_kernel_ms", "count_kernel_ms")]
+        "place_ms", "dist_kernel_ms", "count_kernel_ms", "rr_kernel_ms")]
 
     def as_dict(self):
         return {n: float(getattr(self, n)) for n, _ in self._fields_}
@@ -42,6 +42,7 @@ PROTOTYPES = {
     "cf_last_error": (C.c_char_p, [_P]),
     "cf_device_info": (C.c_int, [_P, C.c_char_p, C.c_int, _PI64, C.POINTER(_I32)]),
     "cf_load_reads": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
+    "cf_rr_distances": (C.c_int, [_P, _P, _I32, _P, _P, _I64, _I32, _P, _P]),
     "cf_load_units": (C.c_int, [_P, _P, _P, _P]),
     "cf_count_kmers": (C.c_int, [_P, _I32, _I64, _I64]),
     "cf_count_occurrences": (C.c_int, [_P, _I32, _I64, _I64]),

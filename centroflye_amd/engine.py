@@ -133,6 +133,19 @@ class Engine:
             self._check(self._lib.cf_top_kmers(self._ctx, int(n), _ptr(keys), _ptr(counts), C.byref(m)), "cf_top_kmers")
         return keys, counts
 
+    def rr_distances(self, unit, reads, read_off, threshold):
+        """(dist_fwd, dist_rc) int32[n_reads]: minimum edit distance between the unit / its reverse complement and a
+        substring of each read, -1 above the threshold (reference rr.cpp:73-90).  reads: uint8 bytes back to back."""
+        unit = np.frombuffer(bytes(unit), dtype=np.uint8)
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.int64)
+        n = read_off.size - 1
+        fwd = np.zeros(max(n, 0), np.int32)
+        rc = np.zeros(max(n, 0), np.int32)
+        self._check(self._lib.cf_rr_distances(self._ctx, _ptr(unit), int(unit.size), _ptr(reads) if reads.size else None, _ptr(read_off),
+                                              int(n), int(threshold), _ptr(fwd) if n else None, _ptr(rc) if n else None), "cf_rr_distances")
+        return fwd, rc
+
     def reset_table(self, k, expected_keys):
         self._check(self._lib.cf_reset_table(self._ctx, int(k), int(expected_keys)), "cf_reset_table")
         self.k = int(k)

@@ -59,6 +59,7 @@ typedef struct cf_times {
     float load_ms, count_ms, select_ms, clouds_ms, filter_ms, postings_ms, dist_ms, place_ms;
     float dist_kernel_ms;   /* the cf_dist_edges main kernel alone                          */
     float count_kernel_ms;  /* the cf_count_kmers main kernel alone                         */
+    float rr_kernel_ms;     /* the cf_rr_distances kernel alone                             */
 } cf_times;
 
 int  cf_create(int device, cf_ctx** out);
@@ -127,6 +128,14 @@ int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int3
 
 int cf_get_stats(cf_ctx* ctx, cf_stats* out);
 int cf_get_times(cf_ctx* ctx, cf_times* out);
+
+/* Read recruitment, the stage before the path (reference scripts/read_recruitment/rr.cpp:73-90:
+ * edlibAlign(unit, read) and edlibAlign(revcomp(unit), read), mode HW, k = threshold; a read is kept when either result
+ * is not -1).  Needs only a context.  unit: 1 .. 4096 upper-case ACGT; reads: any bytes back to back (matching is
+ * literal, as in edlib), read_off[n_reads + 1].  dist_fwd / dist_rc [n_reads]: minimum edit distance between the unit /
+ * its reverse complement and a substring of the read, -1 when above threshold (threshold < 0: no limit). */
+int cf_rr_distances(cf_ctx* ctx, const uint8_t* unit, int32_t unit_len, const uint8_t* reads, const int64_t* read_off,
+                    int64_t n_reads, int32_t threshold, int32_t* dist_fwd, int32_t* dist_rc);
 
 /* Tuning knobs (defaults are chosen for gfx950): name in {"dist_block" (threads per workgroup), "dist_wgs"
  * (workgroups per CU the LDS is split between), "dist_slots" (LDS budget of the (b,d) table in 8-byte units, 0 = all that

@@ -194,6 +194,12 @@ inline int __builtin_amdgcn_readfirstlane(int v) {
     return (int)(uint32_t)a[first];
 }
 
+inline int __builtin_amdgcn_readlane(int v, int lane) {
+    uint64_t mask;
+    const uint64_t* a = cfemu::wave_exchange((uint64_t)(uint32_t)v, &mask);
+    return (int)(uint32_t)a[lane & 63];
+}
+
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
