@@ -199,20 +199,26 @@ cf_place_argmax_kernel(cf_place_state S) {
     cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
     if (!S.ctl[0]) {
         const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-        const uint64_t n_words = (S.smask + 1) >> 2;   // 4 flag bytes per word
-        for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
-            uint32_t f = S.qflag[w];
-            if (!f) continue;
-            for (int j = 0; j < 4; ++j) {
-                if (!((f >> (8 * j)) & 0xFFu)) continue;
-                const uint64_t i = 4 * w + (uint64_t)j;
-                const unsigned long long k = S.skeys[i];
-                const uint32_t r = (uint32_t)((k & ~CF_OCC) >> 32), off = (uint32_t)k;
-                const uint32_t v0 = S.s0[i], v1 = S.s1[i];
-                if (!(v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters)) { ((uint8_t*)S.qflag)[i] = 0; continue; }   // stale flag
-                if (S.used[r]) continue;
-                cf_cand c; c.s0 = v0; c.s1 = v1; c.off = off; c.rank = (uint32_t)S.id_rank[r]; c.read = r; c.valid = 1;
-                if (cf_cand_better(c, mine)) mine = c;
+        const uint64_t n_quads = (S.smask + 1) >> 4;   // 16 flag bytes per 16-byte load (the map is a power of two >= 1024 slots)
+        struct alignas(16) quad { uint32_t w[4]; };
+        for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += stride) {
+            const quad fq = ((const quad*)S.qflag)[q];
+            if (!(fq.w[0] | fq.w[1] | fq.w[2] | fq.w[3])) continue;
+#pragma unroll
+            for (int wi = 0; wi < 4; ++wi) {
+                const uint32_t f = fq.w[wi];
+                if (!f) continue;
+                for (int j = 0; j < 4; ++j) {
+                    if (!((f >> (8 * j)) & 0xFFu)) continue;
+                    const uint64_t i = 16 * q + 4 * (uint64_t)wi + (uint64_t)j;
+                    const unsigned long long k = S.skeys[i];
+                    const uint32_t r = (uint32_t)((k & ~CF_OCC) >> 32), off = (uint32_t)k;
+                    const uint32_t v0 = S.s0[i], v1 = S.s1[i];
+                    if (!(v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters)) { ((uint8_t*)S.qflag)[i] = 0; continue; }   // stale flag
+                    if (S.used[r]) continue;
+                    cf_cand c; c.s0 = v0; c.s1 = v1; c.off = off; c.rank = (uint32_t)S.id_rank[r]; c.read = r; c.valid = 1;
+                    if (cf_cand_better(c, mine)) mine = c;
+                }
             }
         }
     }
