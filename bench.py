@@ -60,6 +60,36 @@ def cpu_baseline(sample_reads, seed):
                 host_cpus=os.cpu_count(), emissions_per_s=c["n_emissions"] / dt)
 
 
+def rr_leg(engine, pk, no_cpu):
+    """Read recruitment (reference scripts/read_recruitment/rr.cpp:73-90): every read against the unit and its reverse
+    complement, threshold 350; the HOR reads of the workload plus as many random bases that must NOT be recruited."""
+    unit = pk.motifs[0].encode()
+    rng = np.random.default_rng(3)
+    rand = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, pk.n_bases)]
+    flat = np.concatenate([pk.bases, rand])
+    off = np.concatenate([pk.read_off, pk.read_off[1:] + pk.n_bases])
+    for _ in range(2):
+        fwd, rc = engine.rr_distances(unit, flat, off, 350)
+    ms = engine.times()["rr_kernel_ms"]
+    kept = (fwd != -1) | (rc != -1)
+    out = {"reads": int(off.size - 1), "bases": int(flat.size), "unit_len": len(unit), "threshold": 350, "kernel_ms": ms,
+           "bases_per_s": flat.size / (ms * 1e-3), "recruited": int(kept.sum()), "recruited_hor_reads": int(kept[:pk.n_reads].sum())}
+    if not no_cpu:
+        from oracle import rr
+        sample = list(range(0, pk.n_reads, max(1, pk.n_reads // 12)))[:12] + [pk.n_reads + i for i in range(4)]
+        use_ref = rr.ref_distance(b"ACGT", b"ACGT", 1) is not None
+        dist = rr.ref_distance if use_ref else rr.distance
+        rcu = rr.revcomp(unit)
+        t0 = time.time()
+        want = [(dist(unit, flat[off[i]:off[i + 1]].tobytes(), 350), dist(rcu, flat[off[i]:off[i + 1]].tobytes(), 350)) for i in sample]
+        dt = time.time() - t0
+        sb = sum(int(off[i + 1] - off[i]) for i in sample)
+        out["cpu_baseline"] = {"value": sb / dt, "unit": "bases/s", "cores": 1, "kind": "reference" if use_ref else "port",
+                               "sample": f"{len(sample)} reads / {sb} bases; " + ("the reference's vendored edlib (oracle/_ref)" if use_ref else "oracle/c/cf_oracle_rr.c"),
+                               "equal": want == [(int(fwd[i]), int(rc[i])) for i in sample]}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +101,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--place", action="store_true", help="also run stage 3 (A4 + A8/A9 placement) once and report it (N = 1)")
+    ap.add_argument("--rr", action="store_true", help="also time read recruitment (SURVEY 8(f) rank 4) on the same reads + as many random ones (N = 1)")
     ap.add_argument("--param", action="append", default=[], help="library knob name=value (cf_set_param)")
     a = ap.parse_args()
 
@@ -184,6 +215,8 @@ def main():
                                 "classes": np.bincount(cls, minlength=3).tolist(), "clouds_filter_s": t2 - t1, "place_s": t3 - t2,
                                 "place_device_ms": e.times()["place_ms"],
                                 "end_to_end_bases_per_s": n_bases / (ms_per_step * 1e-3 + (t3 - t1))}
+        if world == 1 and a.rr:
+            res["read_recruitment"] = rr_leg(sr.local, pk, a.no_cpu_baseline)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_sample_reads, a.seed)
         else:
