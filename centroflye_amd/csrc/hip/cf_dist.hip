@@ -32,6 +32,10 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
 #define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
 
+// One posting (= one unit g holding the first k-mer): its partner entries — the clouds of the units g+min_d ..
+// min(read end, g+max_d) — are ONE contiguous CSR range [e0, e0 + len); ig is the index of g inside its read.
+struct alignas(16) cf_dist_rec { int64_t e0; uint32_t len; uint32_t ig; };
+
 __global__ void __launch_bounds__(256)
 cf_post_hist_kernel(const int32_t* __restrict__ entries, int64_t e0, int64_t e1, uint32_t part, uint32_t n_parts, uint32_t* __restrict__ cnt) {
     // postings are only needed for the first k-mers of this partition (a % n_parts == part): at N GPUs every rank
@@ -62,11 +66,19 @@ cf_post_fill_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __rest
 }
 
 __global__ void __launch_bounds__(256)
-cf_unit_rend_kernel(const int64_t* __restrict__ unit_ptr, int64_t n_reads, int32_t* __restrict__ rend, int32_t* __restrict__ rbeg) {
+cf_unit_rend_kernel(const int64_t* __restrict__ unit_ptr, const int64_t* __restrict__ cloud_ptr, int64_t n_reads, int32_t min_d, int32_t max_d,
+                    int32_t* __restrict__ rend, int32_t* __restrict__ rbeg, cf_dist_rec* __restrict__ urange) {
+    // per unit: its read's unit range and, precomputed once per launch, the partner range a posting at this unit has
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += stride) {
         const int64_t a = unit_ptr[r], b = unit_ptr[r + 1];
-        for (int64_t u = a; u < b; ++u) { rend[u] = (int32_t)b; rbeg[u] = (int32_t)a; }
+        for (int64_t u = a; u < b; ++u) {
+            rend[u] = (int32_t)b; rbeg[u] = (int32_t)a;
+            const int64_t jlo = u + min_d, jhi = min(b - 1, u + (int64_t)max_d);
+            cf_dist_rec x{0, 0u, (uint32_t)(u - a)};
+            if (jhi >= jlo) { x.e0 = cloud_ptr[jlo]; x.len = (uint32_t)(cloud_ptr[jhi + 1] - x.e0); }
+            urange[u] = x;
+        }
     }
 }
 
@@ -118,6 +130,7 @@ struct cf_dist_args {
     const int32_t* entries;
     const int32_t* unit_rend;      // one past the last unit of the unit's read
     const int32_t* unit_rbeg;      // first unit of the unit's read
+    const cf_dist_rec* urange;     // per unit: the partner range of a posting at this unit
     const uint16_t* entry_i;       // wide layout: per cloud entry the index of its unit inside its read
     const uint32_t* packed;        // narrow layout: per cloud entry [unit index inside its read mod 256 : 8 | rank : 24]
     int64_t n_kmers;
@@ -359,8 +372,6 @@ __device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buck
 
 // One posting of the first k-mer: its partner entries are ONE contiguous CSR range [e0, e0 + len); ig is the unit
 // index of the posting inside its read.  The range is swept in items of DIST_ITEM entries.
-struct alignas(16) cf_dist_rec { int64_t e0; uint32_t len; uint32_t ig; };
-
 // Partner ranges of the postings [c0, c0 + np) of one first k-mer -> LDS: rec[p], the inclusive prefix of their item
 // counts ipx[4 + p] (0xFFFFFFFF beyond np; ipx[0..3] = 0 so that ipx[3 + p] is the exclusive prefix) and the number
 // of partner entries in sh[12].  Called by all threads of the workgroup.
@@ -368,13 +379,7 @@ __device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0,
     const int t = threadIdx.x, nt = blockDim.x;
     for (int p = t; p < DIST_NP_CAP; p += nt) {
         cf_dist_rec r{0, 0u, 0u};
-        if (p < np) {
-            const int32_t g = A.post[c0 + p];
-            const int32_t jlo = g + A.min_d;
-            const int32_t jhi = min(A.unit_rend[g] - 1, g + A.max_d);
-            if (jhi >= jlo) { r.e0 = A.cloud_ptr[jlo]; r.len = (uint32_t)(A.cloud_ptr[jhi + 1] - r.e0); }
-            r.ig = (uint32_t)(g - A.unit_rbeg[g]);
-        }
+        if (p < np) r = A.urange[A.post[c0 + p]];     // two dependent loads per posting (was four, three deep)
         rec[p] = r;
     }
     __syncthreads();
@@ -508,9 +513,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
         } else {
             unsigned long long em = 0;
             for (int64_t p = pp0 + t; p < pp1; p += nt) {
-                const int32_t g = A.post[p];
-                const int32_t jlo = g + A.min_d, jhi = min(A.unit_rend[g] - 1, g + A.max_d);
-                if (jhi >= jlo) em += (unsigned long long)(A.cloud_ptr[jhi + 1] - A.cloud_ptr[jlo]);
+                em += (unsigned long long)A.urange[A.post[p]].len;
             }
             for (int d = 32; d >= 1; d >>= 1) em += __shfl_down(em, (unsigned)d);
             if (lane == 0 && em) atomicAdd(&sh[7], (uint32_t)min(em, 0x3FFFFFFFull));
@@ -757,6 +760,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     int32_t *d_post = nullptr, *d_rend = nullptr, *d_rbeg = nullptr;
     uint16_t* d_entry_i = nullptr;
     uint32_t* d_packed = nullptr;
+    cf_dist_rec* d_urange = nullptr;
     bool narrow = false;
     unsigned long long* d_cnt = nullptr;
     int64_t n_post = 0;
@@ -773,6 +777,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if ((rc = cf_alloc_t(ctx, &d_post_ptr, (size_t)K + 1, "posting offsets"))) break;
         if ((rc = cf_alloc_t(ctx, &d_rend, (size_t)U + 1, "unit read ends"))) break;
         if ((rc = cf_alloc_t(ctx, &d_rbeg, (size_t)U + 1, "unit read begins"))) break;
+        if ((rc = cf_alloc_t(ctx, &d_urange, (size_t)U + 1, "unit partner ranges"))) break;
         if ((rc = cf_alloc_t(ctx, &d_cnt, n_cnt, "dist counters"))) break;
         if ((rc = cf_alloc_t(ctx, &d_first, (size_t)K + 1, "first posting units"))) break;
         hipError_t e = hipMemsetAsync(d_pcnt, 0, (size_t)(K + 1) * 4, ctx->stream);
@@ -797,7 +802,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                                (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries, u0, u1, (uint32_t)part, (uint32_t)n_parts, (const int64_t*)d_post_ptr, d_cursor, d_post, d_first);
         if (R)
             hipLaunchKernelGGL(cf_unit_rend_kernel, dim3((unsigned)cf_grid_for(R, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const int64_t*)ctx->d_unit_ptr, R, d_rend, d_rbeg);
+                               (const int64_t*)ctx->d_unit_ptr, (const int64_t*)ctx->d_cloud_ptr, R, min_d_eff, max_d, d_rend, d_rbeg, d_urange);
         // table layout: 6-byte slots (32-bit keys, 16-bit counts) whenever ranks fit 24 bits and counts 15 bits
         uint32_t max_post = 0;
         if (K) {
@@ -817,7 +822,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("postings: ") + hipGetErrorString(e)); break; }
 
         cf_dist_args A;
-        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = ctx->d_cloud_ptr; A.entries = ctx->d_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.entry_i = d_entry_i; A.packed = d_packed;
+        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = ctx->d_cloud_ptr; A.entries = ctx->d_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.urange = d_urange; A.entry_i = d_entry_i; A.packed = d_packed;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
         A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
         const uint32_t slot_bytes = narrow ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
@@ -894,6 +899,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     if (d_cnt) cf_release_t(ctx, d_cnt, n_cnt);
     if (d_entry_i) cf_release_t(ctx, d_entry_i, (size_t)ctx->n_entries + 1);
     if (d_packed) cf_release_t(ctx, d_packed, (size_t)ctx->n_entries + DIST_ITEM);
+    if (d_urange) cf_release_t(ctx, d_urange, (size_t)U + 1);
     if (d_rbeg) cf_release_t(ctx, d_rbeg, (size_t)U + 1);
     if (d_rend) cf_release_t(ctx, d_rend, (size_t)U + 1);
     if (d_post) cf_release_t(ctx, d_post, (size_t)n_post);
