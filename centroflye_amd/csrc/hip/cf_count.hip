@@ -48,6 +48,45 @@ __device__ __forceinline__ void cf_table_add(cf_slot* __restrict__ table, uint64
     atomicOr(flags, 1u);  // table full
 }
 
+// Hash of a window for the LDS stage only (class of the k-mer from the high half, set slot from the low bits): one
+// 32-bit multiply — every window of every (read, class) item pays it, the 64-bit mixer cost 6.  The HBM table keeps
+// cf_mix64.
+__device__ __forceinline__ uint32_t cf_window_hash(unsigned long long code) {
+    uint32_t x = (uint32_t)code ^ (uint32_t)(code >> 29) ^ (uint32_t)(code >> 58);
+    x *= 0x9E3779B1u;
+    return x ^ (x >> 16);
+}
+
+// the same for CNT_FLUSH keys of one thread at once: the key loads, then the claims, then the adds are each issued back
+// to back, so a thread waits for three HBM round trips per batch instead of two or three per KEY (the flush of an
+// item's LDS set used to be the longest phase of the kernel: ~9 dependent atomic chains per thread)
+#define CNT_FLUSH 8
+__device__ __forceinline__ void cf_table_add_batch(cf_slot* __restrict__ table, uint64_t mask, const unsigned long long (&key)[CNT_FLUSH],
+                                                   const unsigned long long (&inc)[CNT_FLUSH], unsigned int live, unsigned int* __restrict__ flags) {
+    uint64_t h[CNT_FLUSH];
+    unsigned long long cur[CNT_FLUSH];
+#pragma unroll
+    for (int j = 0; j < CNT_FLUSH; ++j) { h[j] = cf_mix64(key[j]) & mask; cur[j] = ((live >> j) & 1u) ? table[h[j]].key : 1ull; }
+#pragma unroll
+    for (int j = 0; j < CNT_FLUSH; ++j) if (((live >> j) & 1u) && cur[j] == 0ull) cur[j] = atomicCAS(&table[h[j]].key, 0ull, key[j] | CF_OCC);
+#pragma unroll
+    for (int j = 0; j < CNT_FLUSH; ++j) {
+        if (!((live >> j) & 1u)) continue;
+        if (cur[j] == 0ull || cur[j] == (key[j] | CF_OCC)) { atomicAdd(&table[h[j]].val, inc[j]); continue; }
+        // home slot holds another key: the general probe loop from the next slot on
+        const unsigned long long want = key[j] | CF_OCC;
+        uint64_t g = (h[j] + 1) & mask;
+        bool done = false;
+        for (uint64_t probe = 0; probe < mask; ++probe) {
+            unsigned long long c = table[g].key;
+            if (c == 0ull) c = atomicCAS(&table[g].key, 0ull, want);
+            if (c == 0ull || c == want) { atomicAdd(&table[g].val, inc[j]); done = true; break; }
+            g = (g + 1) & mask;
+        }
+        if (!done) atomicOr(flags, 1u);  // table full
+    }
+}
+
 __global__ void __launch_bounds__(CNT_THREADS)
 cf_count_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ read_off,
                 const cf_count_item* __restrict__ items, int n_items, int k, int slots, int tile_w,
@@ -80,10 +119,10 @@ cf_count_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ r
                 for (int j = 0; j < k - 1; ++j) code = (code << 2) | cf_base2(stage[my0 + j]);
                 for (int64_t i = 0; i < my_n; ++i) {
                     code = ((code << 2) | cf_base2(stage[my0 + i + k - 1])) & kmask;
-                    const uint64_t hh = cf_mix64(code);
-                    if ((int)((hh >> 40) % (uint64_t)item.n_cls) != item.cls) continue;
+                    const uint32_t hh = cf_window_hash(code);
+                    if ((int)(((hh >> 16) * ((uint32_t)item.n_cls & 0xFFFFu)) >> 16) != item.cls) continue;   // class of the k-mer (n_cls < 65536)
                     const unsigned long long want = code | CF_OCC;
-                    uint32_t h = (uint32_t)hh & smask;
+                    uint32_t h = hh & smask;
                     bool done = false;
                     for (int probe = 0; probe < slots; ++probe) {
                         unsigned long long cur = set[h];
@@ -106,9 +145,18 @@ cf_count_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ r
         if (counters[1]) {
             if (t == 0) atomicOr(flags, 2u);
         } else {
-            for (int s = t; s < slots; s += CNT_THREADS) {
-                const unsigned long long v = set[s];
-                if (v) cf_table_add(table, tmask, v & ~(CF_OCC | CNT_DUP), 1ull + ((v & CNT_DUP) ? (1ull << 32) : 0ull), flags);
+            for (int s0 = t; s0 < slots; s0 += CNT_THREADS * CNT_FLUSH) {
+                unsigned long long key[CNT_FLUSH], inc[CNT_FLUSH];
+                unsigned int live = 0;
+#pragma unroll
+                for (int j = 0; j < CNT_FLUSH; ++j) {
+                    const int s = s0 + j * CNT_THREADS;
+                    const unsigned long long v = s < slots ? set[s] : 0ull;
+                    key[j] = v & ~(CF_OCC | CNT_DUP);
+                    inc[j] = 1ull + ((v & CNT_DUP) ? (1ull << 32) : 0ull);
+                    live |= (v != 0ull ? 1u : 0u) << j;
+                }
+                if (live) cf_table_add_batch(table, tmask, key, inc, live, flags);
             }
             if (t == 0) atomicAdd(n_rk, (unsigned long long)counters[0]);
         }
@@ -148,10 +196,10 @@ cf_occ_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ rea
                 for (int j = 0; j < k - 1; ++j) code = (code << 2) | cf_base2(stage[my0 + j]);
                 for (int64_t i = 0; i < my_n; ++i) {
                     code = ((code << 2) | cf_base2(stage[my0 + i + k - 1])) & kmask;
-                    const uint64_t hh = cf_mix64(code);
-                    if ((int)((hh >> 40) % (uint64_t)item.n_cls) != item.cls) continue;
+                    const uint32_t hh = cf_window_hash(code);
+                    if ((int)(((hh >> 16) * ((uint32_t)item.n_cls & 0xFFFFu)) >> 16) != item.cls) continue;   // class of the k-mer (n_cls < 65536)
                     const unsigned long long want = code | CF_OCC;
-                    uint32_t h = (uint32_t)hh & smask;
+                    uint32_t h = hh & smask;
                     bool done = false;
                     for (int probe = 0; probe < slots; ++probe) {
                         unsigned long long cur = set[h];
@@ -330,6 +378,7 @@ static int count_impl(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, 
             if (len < k) continue;
             const int64_t nw = len - k + 1;
             const int n_cls = (int)((nw + per_cls - 1) / per_cls);
+            if (n_cls > 65535) return cf_fail(ctx, -34, "cf_count_kmers: a read needs more than 65535 hash classes (raise count_slots)");
             for (int c = 0; c < n_cls; ++c) items.push_back({(int32_t)r, c, n_cls, 0});
         }
         CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
