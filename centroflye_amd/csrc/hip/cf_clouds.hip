@@ -20,11 +20,14 @@ void cf_free_clouds(cf_ctx* c);
 
 __global__ void __launch_bounds__(256)
 cf_lut_build_kernel(const unsigned long long* __restrict__ kmers, int64_t n, unsigned long long* __restrict__ keys,
-                    uint32_t* __restrict__ vals, uint64_t mask, unsigned int* __restrict__ flags) {
+                    uint32_t* __restrict__ vals, uint64_t mask, uint32_t* __restrict__ pre, uint64_t pre_mask, unsigned int* __restrict__ flags) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const unsigned long long want = kmers[i] | CF_OCC;
-        uint64_t h = cf_mix64(kmers[i]) & mask;
+        const uint64_t hm = cf_mix64(kmers[i]);
+        uint64_t h = hm & mask;
+        const uint64_t bit = (hm >> 24) & pre_mask;
+        atomicOr(&pre[bit >> 5], 1u << (bit & 31u));
         bool done = false;
         for (uint64_t probe = 0; probe <= mask; ++probe) {
             const unsigned long long cur = atomicCAS(&keys[h], 0ull, want);
@@ -37,10 +40,16 @@ cf_lut_build_kernel(const unsigned long long* __restrict__ kmers, int64_t n, uns
     }
 }
 
+// The set holds a small share of all k-mers (1 window in 9 of a HOR read is a rare k-mer): a hash bitmap of 8 bits per
+// lookup slot (16 MB for 7.5 M k-mers: L2 / Infinity-Cache resident, 6 % false positives) answers most windows without
+// touching the 200 MB lookup table.
 __device__ __forceinline__ uint32_t cf_lut_find(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                uint64_t mask, unsigned long long code) {
+                                                uint64_t mask, const uint32_t* __restrict__ pre, uint64_t pre_mask, unsigned long long code) {
     const unsigned long long want = code | CF_OCC;
-    uint64_t h = cf_mix64(code) & mask;
+    const uint64_t hm = cf_mix64(code);
+    const uint64_t bit = (hm >> 24) & pre_mask;
+    if (!((pre[bit >> 5] >> (bit & 31u)) & 1u)) return CL_EMPTY;
+    uint64_t h = hm & mask;
     for (uint64_t probe = 0; probe <= mask; ++probe) {
         const unsigned long long cur = keys[h];
         if (cur == want) return vals[h];
@@ -50,11 +59,12 @@ __device__ __forceinline__ uint32_t cf_lut_find(const unsigned long long* __rest
     return CL_EMPTY;
 }
 
-// mode 0: sizes[u] = |cloud(u)|; mode 1: entries[cloud_ptr[u] ...] = sorted cloud
+// mode 0: sizes[u] = |cloud(u)|; mode 1: entries[cloud_ptr[u] ...] = sorted cloud; mode 2 (one pass over the reads instead
+// of two): sizes[u] AND the sorted cloud at entries[u * row_stride ...] of a scratch buffer, compacted afterwards
 __global__ void __launch_bounds__(CL_THREADS)
 cf_cloud_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ unit_start, const int64_t* __restrict__ unit_end,
                 int64_t n_units, int k, int CL_SET /* LDS set slots, power of two */, const unsigned long long* __restrict__ lut_keys, const uint32_t* __restrict__ lut_vals,
-                uint64_t lut_mask, int mode, uint32_t* __restrict__ sizes, const int64_t* __restrict__ cloud_ptr,
+                uint64_t lut_mask, const uint32_t* __restrict__ lut_pre, uint64_t lut_pre_mask, int mode, int64_t row_stride, uint32_t* __restrict__ sizes, const int64_t* __restrict__ cloud_ptr,
                 int32_t* __restrict__ entries, unsigned int* __restrict__ flags) {
     uint32_t* set = (uint32_t*)cf_lds;                         // CL_SET
     uint32_t* list = set + CL_SET;                             // CL_SET
@@ -80,7 +90,7 @@ cf_cloud_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ u
                 for (int j = 0; j < k - 1; ++j) code = (code << 2) | cf_base2(stage[my0 + j]);
                 for (int64_t i = 0; i < my_n; ++i) {
                     code = ((code << 2) | cf_base2(stage[my0 + i + k - 1])) & kmask;
-                    const uint32_t idx = cf_lut_find(lut_keys, lut_vals, lut_mask, code);
+                    const uint32_t idx = cf_lut_find(lut_keys, lut_vals, lut_mask, lut_pre, lut_pre_mask, code);
                     if (idx == CL_EMPTY) continue;
                     uint32_t h = cf_mix32(idx) & (CL_SET - 1);
                     bool done = false;
@@ -104,6 +114,7 @@ cf_cloud_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ u
         } else if (mode == 0) {
             if (t == 0) sizes[u] = cnt;
         } else if (cnt > 0) {
+            if (mode == 2 && t == 0) sizes[u] = cnt;
             for (int s = t; s < CL_SET; s += CL_THREADS) {
                 const uint32_t v = set[s];
                 if (v != CL_EMPTY) list[atomicAdd(&counters[2], 1u)] = v;
@@ -125,7 +136,7 @@ cf_cloud_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ u
                 }
             }
             __syncthreads();
-            const int64_t o = cloud_ptr[u];
+            const int64_t o = mode == 2 ? u * row_stride : cloud_ptr[u];
             for (uint32_t s = t; s < cnt; s += CL_THREADS) entries[o + s] = (int32_t)list[s];
         }
         __syncthreads();
@@ -194,6 +205,9 @@ int cf_install_kmers(cf_ctx* ctx, int32_t k) {
     ctx->lut_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(2 * n, 1024));
     CF_TRY(cf_alloc_t(ctx, &ctx->d_lut_keys, (size_t)ctx->lut_cap, "k-mer lookup keys"));
     CF_TRY(cf_alloc_t(ctx, &ctx->d_lut_vals, (size_t)ctx->lut_cap, "k-mer lookup values"));
+    ctx->lut_pre_words = ctx->lut_cap * 8 / 32;
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_lut_pre, (size_t)ctx->lut_pre_words, "k-mer lookup prefilter"));
+    CF_HIP(hipMemsetAsync(ctx->d_lut_pre, 0, (size_t)ctx->lut_pre_words * 4, ctx->stream));
     ctx->unique_words = (n + 31) / 32 + 1;
     CF_TRY(cf_alloc_t(ctx, &ctx->d_unique_bits, (size_t)ctx->unique_words, "unique bitmap"));
     CF_HIP(hipMemsetAsync(ctx->d_lut_keys, 0, (size_t)ctx->lut_cap * 8, ctx->stream));
@@ -207,7 +221,7 @@ int cf_install_kmers(cf_ctx* ctx, int32_t k) {
     if (e == hipSuccess && n) {
         const int grid = cf_grid_for(n, 256, std::max(1, ctx->n_cu) * 8);
         hipLaunchKernelGGL(cf_lut_build_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->d_kmers,
-                           n, ctx->d_lut_keys, ctx->d_lut_vals, (uint64_t)(ctx->lut_cap - 1), d_flags);
+                           n, ctx->d_lut_keys, ctx->d_lut_vals, (uint64_t)(ctx->lut_cap - 1), ctx->d_lut_pre, (uint64_t)(ctx->lut_cap * 8 - 1), d_flags);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&flags, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -253,11 +267,28 @@ int cf_set_kmers(cf_ctx* ctx, const uint64_t* kmers, int64_t n, int32_t k) {
     return cf_install_kmers(ctx, k);
 }
 
+}  // extern "C" (reopened below)
+
+// rows of the scratch buffer (fixed stride) -> CSR (one wave per unit)
+__global__ void __launch_bounds__(256)
+cf_cloud_compact_kernel(const int32_t* __restrict__ rows, int64_t row_stride, const int64_t* __restrict__ cloud_ptr, int64_t n_units, int32_t* __restrict__ entries) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = wave; u < n_units; u += n_waves) {
+        const int64_t o = cloud_ptr[u], n = cloud_ptr[u + 1] - o;
+        for (int64_t i = lane; i < n; i += 64) entries[o + i] = rows[u * row_stride + i];
+    }
+}
+
+extern "C" {
+
 // One attempt with an LDS set of set_slots entries per unit; returns 1 when some unit's cloud did not fit.
 static int build_clouds_attempt(cf_ctx* ctx, int set_slots, int64_t* n_entries) {
     cf_free_clouds(ctx);
     const int64_t U = ctx->n_units;
     uint32_t* d_sizes = nullptr;
+    int32_t* d_rows = nullptr;
     unsigned int* d_flags = nullptr;
     CF_TRY(cf_alloc_t(ctx, &ctx->d_cloud_ptr, (size_t)U + 1, "cloud_ptr"));
     CF_TRY(cf_alloc_t(ctx, &d_sizes, (size_t)U + 1, "cloud sizes"));
@@ -272,11 +303,15 @@ static int build_clouds_attempt(cf_ctx* ctx, int set_slots, int64_t* n_entries) 
         if (e == hipSuccess) e = hipMemsetAsync(d_sizes, 0, (size_t)(U + 1) * 4, ctx->stream);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cf_cloud_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_build_clouds setup: ") + hipGetErrorString(e)); break; }
+        // one pass: every unit's sorted cloud goes to a fixed-stride row of a scratch buffer (a cloud that fits the LDS set
+        // has at most 3/4 of its slots), sizes are scanned, rows are compacted into the CSR
+        const int64_t row_stride = (int64_t)set_slots * 3 / 4;
+        if ((rc = cf_alloc_t(ctx, &d_rows, (size_t)(U * row_stride + 1), "cloud rows scratch"))) break;
         if (U) {
             hipLaunchKernelGGL(cf_cloud_kernel, dim3((unsigned)grid), dim3(CL_THREADS), lds, ctx->stream, (const uint8_t*)ctx->d_bases,
                                (const int64_t*)ctx->d_unit_start, (const int64_t*)ctx->d_unit_end, U, ctx->set_k, set_slots,
-                               (const unsigned long long*)ctx->d_lut_keys, (const uint32_t*)ctx->d_lut_vals, (uint64_t)(ctx->lut_cap - 1),
-                               0, d_sizes, (const int64_t*)nullptr, (int32_t*)nullptr, d_flags);
+                               (const unsigned long long*)ctx->d_lut_keys, (const uint32_t*)ctx->d_lut_vals, (uint64_t)(ctx->lut_cap - 1), (const uint32_t*)ctx->d_lut_pre, (uint64_t)(ctx->lut_cap * 8 - 1),
+                               2, row_stride, d_sizes, (const int64_t*)nullptr, d_rows, d_flags);
             e = hipGetLastError();
             if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_cloud_kernel: ") + hipGetErrorString(e)); break; }
         }
@@ -286,12 +321,10 @@ static int build_clouds_attempt(cf_ctx* ctx, int set_slots, int64_t* n_entries) 
         ctx->n_entries = total;
         if ((rc = cf_alloc_t(ctx, &ctx->d_entries, (size_t)total, "cloud entries"))) break;
         if (U && total) {
-            hipLaunchKernelGGL(cf_cloud_kernel, dim3((unsigned)grid), dim3(CL_THREADS), lds, ctx->stream, (const uint8_t*)ctx->d_bases,
-                               (const int64_t*)ctx->d_unit_start, (const int64_t*)ctx->d_unit_end, U, ctx->set_k, set_slots,
-                               (const unsigned long long*)ctx->d_lut_keys, (const uint32_t*)ctx->d_lut_vals, (uint64_t)(ctx->lut_cap - 1),
-                               1, d_sizes, (const int64_t*)ctx->d_cloud_ptr, ctx->d_entries, d_flags);
+            hipLaunchKernelGGL(cf_cloud_compact_kernel, dim3((unsigned)cf_grid_for(U * 64, 256, std::max(1, ctx->n_cu) * 8)), dim3(256), 0, ctx->stream,
+                               (const int32_t*)d_rows, row_stride, (const int64_t*)ctx->d_cloud_ptr, U, ctx->d_entries);
             e = hipGetLastError();
-            if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_cloud_kernel: ") + hipGetErrorString(e)); break; }
+            if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_cloud_compact_kernel: ") + hipGetErrorString(e)); break; }
         }
         e = hipEventRecord(ctx->ev1, ctx->stream);
         if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
@@ -299,6 +332,7 @@ static int build_clouds_attempt(cf_ctx* ctx, int set_slots, int64_t* n_entries) 
         (void)hipEventElapsedTime(&ctx->times.clouds_ms, ctx->ev0, ctx->ev1);
     } while (0);
     if (d_flags) cf_release_t(ctx, d_flags, 4);
+    if (d_rows) cf_release_t(ctx, d_rows, (size_t)(U * ((int64_t)set_slots * 3 / 4) + 1));
     cf_release_t(ctx, d_sizes, (size_t)U + 1);
     if (rc) { cf_free_clouds(ctx); return rc; }
     ctx->have_clouds = true;

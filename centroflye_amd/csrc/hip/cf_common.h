@@ -78,6 +78,8 @@ struct cf_ctx {
     unsigned long long* d_lut_keys = nullptr;
     uint32_t* d_lut_vals = nullptr;
     uint64_t lut_cap = 0;
+    uint32_t* d_lut_pre = nullptr;   // 8 bits per lookup slot: hash bitmap tested before the lookup table (most windows are not in the set)
+    uint64_t lut_pre_words = 0;
 
     // clouds
     int64_t* d_cloud_ptr = nullptr;  // U+1
