@@ -79,6 +79,21 @@ class ShardedRecruiter:
         self.local = Engine(device_index, lib)   # owns the read shard, the table, the local clouds
         self.glob = Engine(device_index, lib)    # owns the all-gathered clouds for the distance stage
 
+    # results of the last run(): device resident (HBM) until read, like the inputs
+    @property
+    def unique_mask(self):
+        """bool[n_rare]: rare k-mers selected by some edge (all ranks' edges when sharded)."""
+        if "mask" not in self._host:
+            self._host["mask"] = self._mask_t.cpu().numpy().astype(bool) if self._mask_t is not None else self.dist_engine.unique_mask()
+        return self._host["mask"]
+
+    @property
+    def rare(self):
+        """uint64[n_rare]: the rare k-mer set (2-bit codes, ascending)."""
+        if "rare" not in self._host:
+            self._host["rare"] = self._rare_t.cpu().numpy().astype(np.uint64) if self._rare_t is not None else self.dist_engine.kmers()
+        return self._host["rare"]
+
     def close(self):
         self.local.close()
         self.glob.close()
@@ -145,7 +160,7 @@ class ShardedRecruiter:
             keys, pres, multi = keys[:n], pres[:n], multi[:n]
             lap("x_dump")
             own = _owner(keys, W)
-            order = torch.argsort(own)
+            order = torch.sort(own.to(torch.uint8)).indices if W <= 256 else torch.argsort(own)     # one radix pass instead of eight
             send_counts = torch.bincount(own, minlength=W).to(torch.int64)
             payload = torch.stack([keys[order], (pres[order].to(torch.int64) & 0xFFFFFFFF) | (multi[order].to(torch.int64) << 32)], dim=1).contiguous()
             lap("x_bucket")
@@ -224,18 +239,18 @@ class ShardedRecruiter:
                                dtype=torch.int64, device=dev)
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.group)
             c = cnt.tolist()
-            self.unique_mask = mask.cpu().numpy().astype(bool)
-            self.rare = rare.cpu().numpy().astype(np.uint64)
+            n_unique = int(mask.sum().item())
+            self._mask_t, self._rare_t, self._host = mask, rare, {}      # results stay on the device until asked for
         else:
             c = [n_edges, st_d["n_emissions"], st_local["n_bases"], st_local["n_windows"], st_local["n_read_kmers"],
                  st_owner["n_distinct"], st_owner["n_kept"], n_ce_local]
-            self.unique_mask = D.unique_mask()
-            self.rare = D.kmers()
+            n_unique = D.stats()["n_unique"]
+            self._mask_t, self._rare_t, self._host = None, None, {}
         lap("combine")
         self.local_edges = n_edges
         self.dist_engine = D
         return dict(n_edges=c[0], n_emissions=c[1], n_bases=c[2], n_windows=c[3], n_read_kmers=c[4], n_distinct=c[5],
-                    n_kept=c[6], n_cloud_entries=c[7], n_rare=n_rare, n_unique=int(self.unique_mask.sum()),
+                    n_kept=c[6], n_cloud_entries=c[7], n_rare=n_rare, n_unique=n_unique,
                     local_emissions=st_d["n_emissions"], local_edges=n_edges, local_bases=st_local["n_bases"],
                     local_cloud_entries=n_ce_local, dist_kernel_ms=D.times()["dist_kernel_ms"],
                     n_spilled=st_d["n_spilled"], n_dist_passes=st_d["n_dist_passes"])
