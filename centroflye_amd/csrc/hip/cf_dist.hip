@@ -234,15 +234,15 @@ struct cf_tab_wide {
         }
         return total;
     }
-    // filter side: f(slot, b, dd, cnt) for the occupied slots of bucket bk whose count is at least min_cov
+    // filter side: f(slot, b, dd, cnt, sum over d of cnt(b, .)) for the occupied slots of bucket bk whose count is at least min_cov
     template <class F>
-    __device__ __forceinline__ void for_counts_at_least(uint32_t bk, uint32_t min_cov, F&& f) const {
+    __device__ __forceinline__ void for_counts_at_least(uint32_t bk, uint32_t n_buckets, uint32_t min_cov, F&& f) const {
         const bucket k = read(bk);
         const unsigned long long v[4] = {k.lo.x, k.lo.y, k.hi.x, k.hi.y};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t cnt = (uint32_t)v[i] & 0x7FFFFFu;
-            if (v[i] != 0ull && cnt >= min_cov) f(4u * bk + (uint32_t)i, (uint32_t)(v[i] >> 32), ((uint32_t)v[i] >> 24) & 0xFFu, cnt);
+            if (v[i] != 0ull && cnt >= min_cov) f(4u * bk + (uint32_t)i, (uint32_t)(v[i] >> 32), ((uint32_t)v[i] >> 24) & 0xFFu, cnt, total_of((uint32_t)(v[i] >> 32), n_buckets));
         }
     }
     __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&tab[s], 1ull << 23); }
@@ -326,7 +326,7 @@ struct cf_tab_narrow {
         return total;
     }
     template <class F>
-    __device__ __forceinline__ void for_counts_at_least(uint32_t bk, uint32_t min_cov, F&& f) const {
+    __device__ __forceinline__ void for_counts_at_least(uint32_t bk, uint32_t n_buckets, uint32_t min_cov, F&& f) const {
         const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];
         const uint32_t w[4] = {c.x, c.y, c.z, c.w};
         const uint32_t need = min_cov ? min_cov - 1u : 0u;     // on the stored field (count - 1)
@@ -336,10 +336,24 @@ struct cf_tab_narrow {
         if (!any) return;
         const bucket k = read(bk);
         const uint32_t key[8] = {k.lo.x, k.lo.y, k.lo.z, k.lo.w, k.hi.x, k.hi.y, k.hi.z, k.hi.w};
+        const bool open_bucket = key[7] == kEmpty;     // slots fill in ascending order: an empty last slot = a chain ends here
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint32_t cnt = ((w[i >> 1] >> ((i & 1) * 16)) & 0x7FFFu) + 1u;
-            if (cnt >= min_cov && key[i] != kEmpty) f(8u * bk + (uint32_t)i, key[i] & 0xFFFFFFu, key[i] >> 24, cnt);
+            if (cnt >= min_cov && key[i] != kEmpty) {
+                const uint32_t b = key[i] & 0xFFFFFFu;
+                // usual case: b lives in its home bucket and the bucket is not full, so all (b, .) keys are in the
+                // registers already — no chain walk through LDS
+                unsigned long long total = 0;
+                if (open_bucket && home(hash(b), n_buckets) == bk) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if ((key[j] & 0xFFFFFFu) == b && key[j] != kEmpty) total += ((w[j >> 1] >> ((j & 1) * 16)) & 0x7FFFu) + 1u;
+                } else {
+                    total = total_of(b, n_buckets);
+                }
+                f(8u * bk + (uint32_t)i, b, key[i] >> 24, cnt, total);
+            }
         }
     }
     __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&cnt32[s >> 1], 0x8000u << ((s & 1u) * 16u)); }
@@ -658,9 +672,8 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             // one bucket per thread and round: the counts decide first (one 16-byte read rejects 8 slots at once —
             // the table is sparse and few pairs reach min_cov); only then keys are read and the chain of b is walked
             for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt) {
-                T.for_counts_at_least(bk, A.min_cov, [&](uint32_t s, uint32_t b, uint32_t dd, uint32_t cnt) {
-                    (void)dd;
-                    const unsigned long long total = T.total_of(b, n_buckets);
+                T.for_counts_at_least(bk, n_buckets, A.min_cov, [&](uint32_t s, uint32_t b, uint32_t dd, uint32_t cnt, unsigned long long total) {
+                    (void)dd; (void)b;
                     if (((double)cnt / (double)total) >= A.thr) {
                         T.mark(s);
                         const uint32_t pos = atomicAdd(&sh[8], 1u);
