@@ -6,14 +6,38 @@ int cf_fail(cf_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
+static const size_t CF_POOL_MAX = (size_t)48 << 30;   // bytes kept for reuse per context
+
+static void cf_pool_flush(cf_ctx* ctx) {
+    for (auto& kv : ctx->pool) { ctx->block_bytes.erase(kv.second); (void)hipFree(kv.second); }
+    ctx->pool.clear();
+    ctx->pooled = 0;
+}
+
 int cf_alloc(cf_ctx* ctx, void** p, size_t bytes, const char* what) {
     *p = nullptr;
     if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(p, bytes);
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    // smallest pooled block that fits without wasting more than a quarter
+    auto it = ctx->pool.lower_bound(want);
+    if (it != ctx->pool.end() && it->first <= want + want / 4 + 4096) {
+        *p = it->second;
+        ctx->pooled -= it->first;
+        ctx->pool.erase(it);
+        ctx->live += bytes;
+        return 0;
+    }
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess || !*p) {          // give the pooled memory back and try once more
+        (void)hipGetLastError();
+        cf_pool_flush(ctx);
+        e = hipMalloc(p, want);
+    }
     if (e != hipSuccess || !*p) {
         *p = nullptr;
         return cf_fail(ctx, -12, std::string("hipMalloc of ") + std::to_string(bytes) + " bytes for " + what + ": " + hipGetErrorString(e));
     }
+    ctx->block_bytes[*p] = want;
     ctx->live += bytes;
     return 0;
 }
@@ -21,8 +45,15 @@ int cf_alloc(cf_ctx* ctx, void** p, size_t bytes, const char* what) {
 void cf_release(cf_ctx* ctx, void* p, size_t bytes) {
     if (!p) return;
     if (bytes == 0) bytes = 16;
-    (void)hipFree(p);
     ctx->live -= bytes < ctx->live ? bytes : ctx->live;
+    auto it = ctx->block_bytes.find(p);
+    if (it == ctx->block_bytes.end() || ctx->pooled + it->second > CF_POOL_MAX) {
+        if (it != ctx->block_bytes.end()) ctx->block_bytes.erase(it);
+        (void)hipFree(p);
+        return;
+    }
+    ctx->pool.emplace(it->second, p);
+    ctx->pooled += it->second;
 }
 
 static void free_reads(cf_ctx* c) {
@@ -91,6 +122,7 @@ void cf_destroy(cf_ctx* ctx) {
     cf_free_table(ctx);
     free_units(ctx);
     free_reads(ctx);
+    cf_pool_flush(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);

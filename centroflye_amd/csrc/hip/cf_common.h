@@ -6,7 +6,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "cfhip.h"
@@ -55,6 +57,11 @@ struct cf_ctx {
     int n_cu = 0;
     int64_t hbm_total = 0;
     size_t live = 0;
+    // freed device blocks are kept and reused (hipMalloc / hipFree of the per-call work buffers — hundreds of MB each —
+    // cost up to tens of ms per step and vary from box to box): size -> block, and the true size of every block handed out
+    std::multimap<size_t, void*> pool;
+    std::unordered_map<void*, size_t> block_bytes;
+    size_t pooled = 0;
 
     // reads / units
     uint8_t* d_bases = nullptr;
