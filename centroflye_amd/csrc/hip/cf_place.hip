@@ -215,7 +215,7 @@ cf_place_argmax_kernel(cf_place_state S) {
                     const uint32_t r = (uint32_t)((k & ~CF_OCC) >> 32), off = (uint32_t)k;
                     const uint32_t v0 = S.s0[i], v1 = S.s1[i];
                     if (!(v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters)) { ((uint8_t*)S.qflag)[i] = 0; continue; }   // stale flag
-                    if (S.used[r]) continue;
+                    if (S.used[r]) { ((uint8_t*)S.qflag)[i] = 0; continue; }   // a placed read is never a candidate again: drop its entry from later scans
                     cf_cand c; c.s0 = v0; c.s1 = v1; c.off = off; c.rank = (uint32_t)S.id_rank[r]; c.read = r; c.valid = 1;
                     if (cf_cand_better(c, mine)) mine = c;
                 }
