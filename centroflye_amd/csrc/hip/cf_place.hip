@@ -63,6 +63,8 @@ struct cf_place_state {
     const uint8_t* used_in; uint8_t* used;
     const int32_t* id_rank;
     cf_cand* block_best; cf_cand* best;
+    uint8_t* dirty;        // per arg-max block: an entry of its slice of the score map changed since the block's cached best was computed
+    uint32_t slice_shift;  // log2(score slots per arg-max block)
     int64_t* out_read; int64_t* out_pos; int32_t* out_s0; int32_t* out_s1;
     uint32_t thr, min_unit, min_inters, min_prop;
 };
@@ -167,7 +169,7 @@ cf_place_update_kernel(cf_place_state S) {
             // lane whose increment is the last one on the entry sees its final state, so a finally-qualifying entry is
             // always flagged; flags can be stale-true (the arg-max re-checks and clears them), never stale-false
             const uint32_t v0 = atomicAdd(&S.s0[h], 0u), v1 = atomicAdd(&S.s1[h], 0u);
-            if (v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters) ((uint8_t*)S.qflag)[h] = 1;
+            if (v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters) { ((uint8_t*)S.qflag)[h] = 1; S.dirty[h >> S.slice_shift] = 1; }
         }
     }
 }
@@ -196,12 +198,25 @@ __device__ __forceinline__ cf_cand cf_block_best(cf_cand mine) {
 
 __global__ void __launch_bounds__(PL_THREADS)
 cf_place_argmax_kernel(cf_place_state S) {
+    // Block b owns one contiguous slice of the score map and caches its best candidate in block_best[b].  The cache
+    // stays valid until an entry of the slice changes (the update kernel marks the slice dirty) or the cached read gets
+    // placed; only then is the slice scanned again — most slices are untouched by one greedy iteration.
+    if (S.ctl[0]) return;
+    uint32_t* rescan = (uint32_t*)(cf_lds + 8 * sizeof(cf_cand));
+    if (threadIdx.x == 0) {
+        const cf_cand c = S.block_best[blockIdx.x];
+        const bool r = S.dirty[blockIdx.x] || (c.valid && S.used[c.read]);
+        if (r) S.dirty[blockIdx.x] = 0;
+        *rescan = r ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!*rescan) return;
     cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
-    if (!S.ctl[0]) {
-        const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-        const uint64_t n_quads = (S.smask + 1) >> 4;   // 16 flag bytes per 16-byte load (the map is a power of two >= 1024 slots)
+    {
+        const uint64_t per = (1ull << S.slice_shift) >> 4;   // 16-byte quads (16 flag bytes) per block
+        const uint64_t q0 = (uint64_t)blockIdx.x * per;
         struct alignas(16) quad { uint32_t w[4]; };
-        for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += stride) {
+        for (uint64_t q = q0 + threadIdx.x; q < q0 + per; q += blockDim.x) {
             const quad fq = ((const quad*)S.qflag)[q];
             if (!(fq.w[0] | fq.w[1] | fq.w[2] | fq.w[3])) continue;
 #pragma unroll
@@ -320,7 +335,13 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     CF_TRY(B.get(&S.n_events, 2, "event count"));
     CF_TRY(B.get(&S.ctl, 8, "control"));
     const int n_blocks = std::max(1, ctx->n_cu) * 4;
-    CF_TRY(B.get(&S.block_best, (size_t)n_blocks, "block candidates"));
+    // arg-max blocks: a power of two, each owning a contiguous slice of at least 16 score slots
+    int n_am = 1;
+    while (2 * n_am <= n_blocks * 2 && (uint64_t)(2 * n_am) * 16 <= score_cap) n_am *= 2;
+    S.slice_shift = 0;
+    while ((score_cap >> S.slice_shift) > (uint64_t)n_am) ++S.slice_shift;
+    CF_TRY(B.get(&S.block_best, (size_t)n_am, "block candidates"));
+    CF_TRY(B.get(&S.dirty, (size_t)n_am + 16, "slice dirty flags"));
     CF_TRY(B.get(&S.best, 1, "best candidate"));
     CF_TRY(B.get(&S.out_read, (size_t)R + 1, "out_read"));
     CF_TRY(B.get(&S.out_pos, (size_t)R + 1, "out_pos"));
@@ -365,6 +386,8 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         CF_HIP(hipMemsetAsync(S.s0, 0, (size_t)score_cap * 4, st));
         CF_HIP(hipMemsetAsync(S.s1, 0, (size_t)score_cap * 4, st));
         CF_HIP(hipMemsetAsync(S.qflag, 0, (size_t)score_cap + 4, st));
+        CF_HIP(hipMemsetAsync(S.dirty, 1, (size_t)n_am, st));
+        CF_HIP(hipMemsetAsync(S.block_best, 0, (size_t)n_am * sizeof(cf_cand), st));
         CF_HIP(hipMemsetAsync(S.seen, 0, (size_t)seen_cap * 8, st));
         CF_HIP(hipMemsetAsync(S.n_events, 0, 16, st));
         CF_HIP(hipMemsetAsync(S.ctl, 0, 8, st));  // done = 0, n_out = 0 (error flags kept)
@@ -375,8 +398,8 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         const int64_t n_iter = (int64_t)stage_reads.size();
         for (int64_t it = 0; it < n_iter; ++it) {
             hipLaunchKernelGGL(cf_place_update_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
-            hipLaunchKernelGGL(cf_place_argmax_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S);
-            hipLaunchKernelGGL(cf_place_final_kernel, dim3(1), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S, n_blocks);
+            hipLaunchKernelGGL(cf_place_argmax_kernel, dim3((unsigned)n_am), dim3(PL_THREADS), 8 * sizeof(cf_cand) + 16, st, S);
+            hipLaunchKernelGGL(cf_place_final_kernel, dim3(1), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S, n_am);
             hipLaunchKernelGGL(cf_place_add_kernel, dim3(8), dim3(PL_THREADS), 0, st, S, 1, (int64_t)0);
             if ((it & 255) == 255 || it + 1 == n_iter) {
                 CF_KERNEL_CHECK("placement iteration");
