@@ -202,6 +202,7 @@ cf_place_argmax_kernel(cf_place_state S) {
     // stays valid until an entry of the slice changes (the update kernel marks the slice dirty) or the cached read gets
     // placed; only then is the slice scanned again — most slices are untouched by one greedy iteration.
     if (S.ctl[0]) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) S.n_events[0] = 0ull;   // consumed by the update kernel before this one; refilled by the next
     uint32_t* rescan = (uint32_t*)(cf_lds + 8 * sizeof(cf_cand));
     if (threadIdx.x == 0) {
         const cf_cand c = S.block_best[blockIdx.x];
@@ -241,22 +242,32 @@ cf_place_argmax_kernel(cf_place_state S) {
     if (threadIdx.x == 0) S.block_best[blockIdx.x] = b;
 }
 
-// single block: reduce the block candidates, record the placement, reset the event list
+// Every block reduces the block candidates to the same winner (a few KB, cheaper than one more kernel in the dependent
+// chain of the greedy iteration); block 0 records the placement; then all blocks lay the read onto the contig, which
+// emits the next events (the event list was reset by the arg-max kernel, after the update kernel had consumed it).
 __global__ void __launch_bounds__(PL_THREADS)
-cf_place_final_kernel(cf_place_state S, int n_blocks) {
+cf_place_pick_add_kernel(cf_place_state S, int n_cand) {
     if (S.ctl[0]) return;
     cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
-    for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) if (cf_cand_better(S.block_best[i], mine)) mine = S.block_best[i];
+    for (int i = threadIdx.x; i < n_cand; i += blockDim.x) if (cf_cand_better(S.block_best[i], mine)) mine = S.block_best[i];
     const cf_cand b = cf_block_best(mine);
-    if (threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         *S.best = b;
-        S.n_events[0] = 0ull;
         if (!b.valid) S.ctl[0] = 1;
         else {
             const unsigned int o = S.ctl[1]++;
             S.out_read[o] = (int64_t)b.read; S.out_pos[o] = (int64_t)b.off; S.out_s0[o] = (int32_t)b.s0; S.out_s1[o] = (int32_t)b.s1;
             S.used[b.read] = 1;
         }
+    }
+    if (!b.valid) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t u0 = S.unit_ptr[b.read], u1 = S.unit_ptr[b.read + 1];
+    for (int64_t u = u0 + wave; u < u1; u += n_waves) {
+        const uint32_t q = b.off + (uint32_t)(u - u0);
+        for (int64_t e = S.cloud_ptr[u] + lane; e < S.cloud_ptr[u + 1]; e += 64) cf_contig_add(S, (uint32_t)S.entries[e], q);
     }
 }
 
@@ -399,8 +410,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         for (int64_t it = 0; it < n_iter; ++it) {
             hipLaunchKernelGGL(cf_place_update_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
             hipLaunchKernelGGL(cf_place_argmax_kernel, dim3((unsigned)n_am), dim3(PL_THREADS), 8 * sizeof(cf_cand) + 16, st, S);
-            hipLaunchKernelGGL(cf_place_final_kernel, dim3(1), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S, n_am);
-            hipLaunchKernelGGL(cf_place_add_kernel, dim3(8), dim3(PL_THREADS), 0, st, S, 1, (int64_t)0);
+            hipLaunchKernelGGL(cf_place_pick_add_kernel, dim3(8), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S, n_am);
             if ((it & 255) == 255 || it + 1 == n_iter) {
                 CF_KERNEL_CHECK("placement iteration");
                 CF_HIP(hipMemcpyAsync(h_ctl, S.ctl, 16, hipMemcpyDeviceToHost, st));
