@@ -14,10 +14,10 @@
 //       if none qualifies all remaining reads of the stage are written as None.
 //
 // Device design: everything lives in HBM hash tables — contig (pos,kmer)->count, score
-// (read,offset)->(s0,s1), a seen-set of (score slot, unit) for s0.  One iteration = 4 small
-// kernels enqueued back to back with NO host round trip: apply events -> block arg-max ->
-// final arg-max (records the placement, device-side) -> add the chosen read (emits the next
-// events).  The host only polls a done flag every few hundred iterations.
+// (read,offset)->(s0,s1), a seen-set of (score slot, unit) for s0.  One iteration = 3 small
+// kernels enqueued back to back with NO host round trip: apply events -> block arg-max over
+// cached slices -> pick the winner (recorded device-side) and add the chosen read (emits the
+// next events).  The host only polls a done flag every few hundred iterations.
 #include "cf_common.h"
 
 #include <cstdlib>
