@@ -100,7 +100,6 @@ struct cf_ctx {
     uint32_t* d_unique_bits = nullptr;
     int64_t unique_words = 0;
 
-    unsigned int place_flags = 0;   // overflow flags of the last placement attempt
     cf_stats stats{};
     cf_times times{};
 
