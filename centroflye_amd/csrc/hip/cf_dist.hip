@@ -485,9 +485,10 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
     uint32_t* bm = (uint32_t*)(stage + DIST_STAGE_CAP + 8);    // DIST_BM_BITS bits: hash(b) of the k-mers b that may have a selected edge
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
     // per-wave queue of pending inserts: candidates are compacted here and inserted 64 at a time by a full wave.
-    // Only its own wave touches it (LDS operations of one wave execute in order; volatile keeps the compiler from
-    // caching it).
-    volatile typename Tab::qitem* wq = (volatile typename Tab::qitem*)(bm + DIST_BM_BITS / 32) + (size_t)(t >> 6) * DIST_QCAP;
+    // Only its own wave touches it: LDS operations of one wave execute in order, and wavefront-scope fences (no
+    // instructions) keep the compiler from moving the queue accesses across the drain; a volatile pointer would turn
+    // every push into a FLAT store followed by a full vmcnt wait (it did: 4 per step in the first version).
+    typename Tab::qitem* wq = (typename Tab::qitem*)(bm + DIST_BM_BITS / 32) + (size_t)(t >> 6) * DIST_QCAP;
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
 #if defined(CF_DIST_STAMPS)
@@ -614,6 +615,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                 uint32_t qtail = 0;      // wave-uniform
                 // pops the last N (<= 64) queued inserts, one per lane; every lane runs the probe loop for its own
 #define CF_DIST_DRAIN(N) {                                                                                    \
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                     __builtin_amdgcn_wave_barrier();                                                          \
                     const uint32_t n_ = (N); qtail -= n_;                                                     \
                     uint32_t made_ = 0;                                                                       \
@@ -625,6 +627,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     const uint32_t new_ = (uint32_t)__popcll(__ballot(made_ != 0u));                          \
                     if (new_ && lane == 0) atomicAdd(&sh[0], new_);                                           \
                     __builtin_amdgcn_wave_barrier();                                                          \
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                 }
                 cf_dist_sweep<Tab>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
                     if (sh[0] > A.fill_limit) return true;     // too full (or physically full): the pass will be split

@@ -143,6 +143,7 @@ inline unsigned long long __ballot(int pred) {
     return r;
 }
 inline int __any(int pred) { return __ballot(pred) != 0; }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)   /* lanes are fibers on one thread: program order is memory order */
 inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(1); }   // lanes of a wave run in lock step on the GPU: rendezvous here
 inline int __all(int pred) {
     uint64_t mask;
