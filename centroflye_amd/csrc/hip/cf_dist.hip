@@ -392,9 +392,8 @@ __device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buck
 __device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0, int np, cf_dist_rec* rec, uint32_t* ipx, uint32_t* sh) {
     const int t = threadIdx.x, nt = blockDim.x;
     for (int p = t; p < DIST_NP_CAP; p += nt) {
-        cf_dist_rec r{0, 0u, 0u};
-        if (p < np) r = A.urange[A.post[c0 + p]];     // two dependent loads per posting (was four, three deep)
-        rec[p] = r;
+        if (p < np) rec[p] = A.urange[A.post[c0 + p]];     // two dependent loads per posting (was four, three deep)
+        else rec[p] = cf_dist_rec{0, 0u, 0u};            // (written on both paths: a conditionally overwritten local ends up in scratch)
     }
     __syncthreads();
     if (t < 64) {   // wave 0: inclusive scan of DIST_NP_CAP (= 4 x 64) item counts, 4 per lane
