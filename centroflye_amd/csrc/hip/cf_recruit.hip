@@ -55,7 +55,8 @@ cf_rr_kernel(cf_rr_args A) {
             const int lim = (int)min((int64_t)64, n_steps - base);
             for (int s = 0; s < lim; ++s) {
                 const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)chunk, s);
-                uint32_t in = __shfl_up(pack, 1u);
+                // lane i takes what lane i - 1 produced in the previous step: a DPP wave shift (one VALU move, no LDS crossbar)
+                uint32_t in = (uint32_t)__builtin_amdgcn_update_dpp((int)pack, (int)pack, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
                 if (lane == 0) in = c0 | (1u << 8);                  // HW: the row above the unit is all zeros
                 const uint32_t code = in & 0xFFu;
                 const int hin = (int)(in >> 8) - 1;

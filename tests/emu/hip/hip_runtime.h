@@ -195,6 +195,14 @@ inline int __builtin_amdgcn_readfirstlane(int v) {
     return (int)(uint32_t)a[first];
 }
 
+// only the control used by the kernels: 0x138 = wave_shr:1 (lane i reads lane i - 1; lane 0 keeps `old`)
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
+    uint64_t mask;
+    const unsigned me = cfemu::lane_id();
+    const uint64_t* a = cfemu::wave_exchange((uint64_t)(uint32_t)src, &mask);
+    if (ctrl != 0x138) std::abort();
+    return me == 0 ? old : (int)(uint32_t)a[me - 1];
+}
 inline int __builtin_amdgcn_readlane(int v, int lane) {
     uint64_t mask;
     const uint64_t* a = cfemu::wave_exchange((uint64_t)(uint32_t)v, &mask);
