@@ -633,10 +633,16 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     uint32_t w_[DIST_UNROLL], hbit_[DIST_UNROLL], live = 0, cand = 0;
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
-                        const uint32_t hb = Tab::hash(bb[u]);
-                        live |= (uint32_t)((bb[u] != a) & ((((hb ^ (hb >> 15)) >> 3) & pmask) == pidx)) << u;
+                        live |= (uint32_t)(bb[u] != a) << u;
                         hbit_[u] = Tab::bm_bit(bb[u]);
                         w_[u] = bm[hbit_[u] >> 5];
+                    }
+                    if (pmask) {       // (wave-uniform) only a first k-mer whose table was split tests the partition of b
+#pragma unroll
+                        for (int u = 0; u < DIST_UNROLL; ++u) {
+                            const uint32_t hb = Tab::hash(bb[u]);
+                            if ((((hb ^ (hb >> 15)) >> 3) & pmask) != pidx) live &= ~(1u << u);
+                        }
                     }
                     my_e += (uint32_t)__popcll((unsigned long long)live);
 #pragma unroll
