@@ -461,9 +461,10 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, uint32_t a,
         i0 = i1;
         uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
 #pragma unroll
-        for (int u = 0; u < DIST_UNROLL; ++u) {
-            Tab::decode(cx_[u], cig, bb[u], dd_[u]);
-            if (!((cok >> u) & 1u)) bb[u] = a;
+        for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cig, bb[u], dd_[u]);
+        if (__any(cok != (1u << DIST_UNROLL) - 1u)) {      // (wave-uniform) only the last item of a posting has lanes past its end
+#pragma unroll
+            for (int u = 0; u < DIST_UNROLL; ++u) if (!((cok >> u) & 1u)) bb[u] = a;
         }
         if (body(bb, dd_)) break;
     }
