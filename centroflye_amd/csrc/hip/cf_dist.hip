@@ -441,10 +441,15 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, uint32_t a,
         const uint32_t p = (uint32_t)(__popcll(__ballot(iv.x <= item)) + __popcll(__ballot(iv.y <= item))     \
                                     + __popcll(__ballot(iv.z <= item)) + __popcll(__ballot(iv.w <= item)));   \
         const cf_dist_rec r = rec[p];                                                                         \
-        const uint32_t off = (item - ipx[3 + p]) * DIST_ITEM + (uint32_t)lane * DIST_UNROLL;                  \
+        const uint32_t base = (item - (uint32_t)__builtin_amdgcn_readfirstlane((int)ipx[3 + p])) * DIST_ITEM; \
+        const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.len);                            \
+        const uint32_t off = base + (uint32_t)lane * DIST_UNROLL;                                             \
         nig = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.ig);                                            \
-        nok = 0;                                                                                              \
-        _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) nok |= (uint32_t)(off + (uint32_t)u < r.len) << u; \
+        nok = (1u << DIST_UNROLL) - 1u;                                                                       \
+        if (base + DIST_ITEM > len) {      /* (wave-uniform) only the last item of a posting runs past its end */ \
+            nok = 0;                                                                                          \
+            _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) nok |= (uint32_t)(off + (uint32_t)u < len) << u; \
+        }                                                                                                     \
         Tab::load_run(A, r.e0 + (int64_t)off, nok, nx_);                                                      \
     }
 #define CF_DIST_GRAB(VAR) { uint32_t g_ = 0; if (lane == 0) g_ = atomicAdd(cursor, 1u); VAR = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_); }
