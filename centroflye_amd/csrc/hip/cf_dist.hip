@@ -245,8 +245,15 @@ struct cf_tab_wide {
             if (v[i] != 0ull && cnt >= min_cov) f(4u * bk + (uint32_t)i, (uint32_t)(v[i] >> 32), ((uint32_t)v[i] >> 24) & 0xFFu, cnt, total_of((uint32_t)(v[i] >> 32), n_buckets));
         }
     }
+    template <class F>
+    __device__ __forceinline__ void for_marked(uint32_t bk, F&& f) const {
+        const bucket k = read(bk);
+        const unsigned long long v[4] = {k.lo.x, k.lo.y, k.hi.x, k.hi.y};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((v[i] >> 23) & 1ull) f(4u * bk + (uint32_t)i, (uint32_t)(v[i] >> 32), ((uint32_t)v[i] >> 24) & 0xFFu, (uint32_t)v[i] & 0x7FFFFFu);
+    }
     __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&tab[s], 1ull << 23); }
-    __device__ __forceinline__ bool marked(uint32_t s) const { return (tab[s] >> 23) & 1ull; }
 };
 
 struct cf_tab_narrow {
@@ -356,8 +363,20 @@ struct cf_tab_narrow {
             }
         }
     }
+    template <class F>
+    __device__ __forceinline__ void for_marked(uint32_t bk, F&& f) const {
+        const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];
+        if (!((c.x | c.y | c.z | c.w) & 0x80008000u)) return;       // no selected slot among the 8
+        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+        const bucket k = read(bk);
+        const uint32_t key[8] = {k.lo.x, k.lo.y, k.lo.z, k.lo.w, k.hi.x, k.hi.y, k.hi.z, k.hi.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t h = w[i >> 1] >> ((i & 1) * 16);
+            if (h & 0x8000u) f(8u * bk + (uint32_t)i, key[i] & 0xFFFFFFu, key[i] >> 24, (h & 0x7FFFu) + 1u);
+        }
+    }
     __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&cnt32[s >> 1], 0x8000u << ((s & 1u) * 16u)); }
-    __device__ __forceinline__ bool marked(uint32_t s) const { return (cnt32[s >> 1] >> ((s & 1u) * 16u + 15u)) & 1u; }
 };
 
 #define DIST_QCAP 128                    /* deferred inserts per wave (pushes come in batches of <= 64, drains take 64) */
@@ -682,7 +701,6 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             // staged), reserve the edge range with ONE global atomic, then write
             for (int d = 32; d >= 1; d >>= 1) my_e += __shfl_down(my_e, (unsigned)d);
             if (lane == 0 && my_e) atomicAdd(&sh[7], my_e);
-            const uint32_t rounds = (slots + nt - 1) / nt;
             // one bucket per thread and round: the counts decide first (one 16-byte read rejects 8 slots at once —
             // the table is sparse and few pairs reach min_cov); only then keys are read and the chain of b is walked
             for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt) {
@@ -712,26 +730,19 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             __syncthreads();
             if (n_sel) {
                 const unsigned long long base = ((unsigned long long)sh[10] << 32) | sh[9];
-                const bool staged = n_sel <= A.stage_cap;   // else: sweep the table for the marked slots
-                const uint32_t n_iter = staged ? n_sel : rounds * (uint32_t)nt;
-                for (uint32_t i0 = 0; i0 < n_iter; i0 += nt) {
-                    const uint32_t i = i0 + t;
-                    uint32_t b = 0, dd = 0, cnt = 0, s = 0;
-                    bool sel = false;
-                    if (staged) { if (i < n_sel) { s = stage[i]; sel = T.get(s, b, dd, cnt); } }
-                    else if (i < slots) { s = i; sel = T.marked(s) && T.get(s, b, dd, cnt); }
-                    unsigned long long o = base + i;
-                    if (!staged) {   // order of the sweep: wave-aggregated cursor
-                        const unsigned long long m = __ballot(sel);
-                        uint32_t off = 0;
-                        if (m) { const int leader = __ffsll((long long)m) - 1; if (lane == leader) off = atomicAdd(&sh[8], (uint32_t)__popcll(m)); off = __shfl(off, leader); }
-                        o = base + off + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                auto emit = [&](unsigned long long o, uint32_t b, uint32_t dd, uint32_t cnt) {
+                    if (o < A.edge_cap) { uint32_t* E = A.edges + 4 * o; E[0] = dd; E[1] = a; E[2] = b; E[3] = cnt; }
+                    const uint32_t bit = 1u << (b & 31);
+                    if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
+                };
+                if (n_sel <= A.stage_cap) {           // the staged slot list
+                    for (uint32_t i = (uint32_t)t; i < n_sel; i += (uint32_t)nt) {
+                        uint32_t b, dd, cnt;
+                        if (T.get(stage[i], b, dd, cnt)) emit(base + i, b, dd, cnt);
                     }
-                    if (sel) {
-                        if (o < A.edge_cap) { uint32_t* E = A.edges + 4 * o; E[0] = dd; E[1] = a; E[2] = b; E[3] = cnt; }
-                        const uint32_t bit = 1u << (b & 31);
-                        if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
-                    }
+                } else {                               // more selected edges than the stage holds: sweep the marked slots, a bucket per thread
+                    for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt)
+                        T.for_marked(bk, [&](uint32_t, uint32_t b, uint32_t dd, uint32_t cnt) { emit(base + atomicAdd(&sh[8], 1u), b, dd, cnt); });
                 }
             }
         }
