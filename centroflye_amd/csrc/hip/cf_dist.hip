@@ -504,7 +504,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
     cf_dist_rec* rec = (cf_dist_rec*)(cf_lds + (size_t)A.slots * Tab::kSlotBytes);   // partner range of each posting of the chunk
     uint32_t* ipx = (uint32_t*)(rec + DIST_NP_CAP);            // 4 zeros, then the inclusive prefix of item counts
     uint32_t* stack = ipx + 4 + DIST_NP_CAP;                   // (P, idx) pairs
-    uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] keys in table | DIST_FULL_BIT [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] item cursor [12] entries of the chunk [13] a counter of the sketch wrapped
+    uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] keys in table | DIST_FULL_BIT [1] first k-mer [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] item cursor [12] entries of the chunk [13] a counter of the sketch wrapped [14,15] its first posting
     uint16_t* stage = (uint16_t*)(sh + 16);                    // slot indices of the selected edges of a pass
     uint32_t* bm = (uint32_t*)(stage + DIST_STAGE_CAP + 8);    // DIST_BM_BITS bits: hash(b) of the k-mers b that may have a selected edge
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
@@ -519,29 +519,48 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_amdgcn_s_memtime();
 #endif
 
+    // 8 ticket queues over 8 contiguous ranges of the locality-sorted first k-mers: workgroups with equal blockIdx % 8
+    // (observed to share an XCD, i.e. an L2) drain one range; idle ones steal
+    auto pop = [&]() -> long long {
+        long long idx = -1;
+        const int64_t per = (A.n_order + 7) / 8;
+        for (int s8 = 0; s8 < 8 && idx < 0; ++s8) {
+            const int x = (int)((blockIdx.x + s8) & 7);
+            const int64_t lo = x * per, hi = min((int64_t)(x + 1) * per, A.n_order);
+            if (lo >= hi) continue;
+            const unsigned long long q = atomicAdd(&A.counters[16 + 16 * x], 1ull);
+            if (lo + (int64_t)q < hi) idx = lo + (int64_t)q;
+        }
+        return idx;
+    };
+    // Thread 0 fetches the NEXT first k-mer (ticket -> order[] -> post_ptr[]: three dependent HBM round trips) while the
+    // workgroup works on the current one; the values wait in its registers until the loop comes around.
+    long long nx_idx = -1;
+    uint32_t nx_a = 0;
+    int64_t nx_pp0 = 0, nx_pp1 = 0;
+    if (t == 0) {
+        nx_idx = pop();
+        if (nx_idx >= 0) { nx_a = (uint32_t)A.order[nx_idx]; nx_pp0 = A.post_ptr[nx_a]; nx_pp1 = A.post_ptr[nx_a + 1]; }
+    }
+
     while (true) {
         __syncthreads();
         if (t == 0) {
-            // 8 ticket queues over 8 contiguous ranges of the locality-sorted first k-mers: workgroups with
-            // equal blockIdx % 8 (observed to share an XCD, i.e. an L2) drain one range; idle ones steal
-            long long idx = -1;
-            const int64_t per = (A.n_order + 7) / 8;
-            for (int s8 = 0; s8 < 8 && idx < 0; ++s8) {
-                const int x = (int)((blockIdx.x + s8) & 7);
-                const int64_t lo = x * per, hi = min((int64_t)(x + 1) * per, A.n_order);
-                if (lo >= hi) continue;
-                const unsigned long long q = atomicAdd(&A.counters[16 + 16 * x], 1ull);
-                if (lo + (int64_t)q < hi) idx = lo + (int64_t)q;
-            }
-            sh[5] = (uint32_t)(unsigned long long)idx; sh[6] = (uint32_t)((unsigned long long)idx >> 32);
+            sh[5] = (uint32_t)(unsigned long long)nx_idx; sh[6] = (uint32_t)((unsigned long long)nx_idx >> 32);
+            sh[1] = nx_a; sh[14] = (uint32_t)(unsigned long long)nx_pp0; sh[15] = (uint32_t)((unsigned long long)nx_pp0 >> 32);
+            sh[12] = (uint32_t)(nx_pp1 - nx_pp0);
         }
         __syncthreads();
         const int64_t ai = (int64_t)(((unsigned long long)sh[6] << 32) | sh[5]);
         if (ai < 0) break;
+        const uint32_t a = sh[1];
+        const int64_t pp0 = (int64_t)(((unsigned long long)sh[15] << 32) | sh[14]), pp1 = pp0 + (int64_t)sh[12];
+        if (t == 0) nx_idx = pop();                                  // next: the ticket (used after phase A)
         CF_STAMP(0);   // queue pop
-        const uint32_t a = (uint32_t)A.order[ai];
-        const int64_t pp0 = A.post_ptr[a], pp1 = A.post_ptr[a + 1];
-        if (pp1 == pp0) continue;
+        if (pp1 == pp0) {                                            // (order[] holds only k-mers with postings)
+            if (t == 0 && nx_idx >= 0) { nx_a = (uint32_t)A.order[nx_idx]; nx_pp0 = A.post_ptr[nx_a]; nx_pp1 = A.post_ptr[nx_a + 1]; }
+            continue;
+        }
         // Usual case (<= DIST_NP_CAP postings): the partner ranges are set up ONCE and reused by every sweep.
         const bool one_chunk = (pp1 - pp0) <= DIST_NP_CAP;
         if (t == 0) { sh[7] = 0; sh[13] = 0; }
@@ -603,6 +622,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             if (sh[13]) mark_all = true;
             CF_STAMP(6);   // sketch sweep
         }
+        if (t == 0 && nx_idx >= 0) nx_a = (uint32_t)A.order[nx_idx];      // next: its rank (used before phase B)
         if (mark_all) {
             const cf_u32x4 ones{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = ones;
@@ -616,6 +636,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             for (uint32_t i = 0; i < P0; ++i) { stack[2 * i] = P0; stack[2 * i + 1] = i; }
             sh[2] = P0;
         }
+        if (t == 0 && nx_idx >= 0) { nx_pp0 = A.post_ptr[nx_a]; nx_pp1 = A.post_ptr[nx_a + 1]; }   // next: its posting range (used at the loop top)
         bool spilled = false;
         while (true) {
             CF_STAMP(5);   // reserve + write edges of the previous pass
