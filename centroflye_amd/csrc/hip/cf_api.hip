@@ -282,10 +282,10 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return -22;
     const std::string n(name);
     if (n == "dist_block") {
-        if (value < 64 || value > 1024 || value % 64) return cf_fail(ctx, -22, "dist_block must be a multiple of 64 in [64, 1024]");
+        if (value != 0 && (value < 64 || value > 1024 || value % 64)) return cf_fail(ctx, -22, "dist_block must be 0 (auto) or a multiple of 64 in [64, 1024]");
         ctx->dist_block = (int)value;
     } else if (n == "dist_wgs") {
-        if (value < 1 || value > 8) return cf_fail(ctx, -22, "dist_wgs out of range (1 .. 8)");
+        if (value < 0 || value > 8) return cf_fail(ctx, -22, "dist_wgs out of range (0 = auto, 1 .. 8)");
         ctx->dist_wgs = (int)value;
     } else if (n == "dist_slots") {
         if (value != 0 && (value < 256 || value > 19200)) return cf_fail(ctx, -22, "dist_slots out of range (0 = auto, 256 .. 19200: table + work lists must fit the 160 KiB LDS)");

@@ -104,8 +104,8 @@ struct cf_ctx {
     cf_times times{};
 
     // knobs
-    int dist_block = 512;
-    int dist_wgs = 2;        // workgroups per CU the LDS is split between (they overlap each other's latency-bound phases)
+    int dist_block = 0;      // threads per workgroup; 0 = chosen with dist_wgs
+    int dist_wgs = 0;        // workgroups per CU the LDS is split between; 0 = 2 x 512 threads or 1 x 1024, by the pair emissions per first k-mer
     int dist_slots = 0;      // LDS budget of the (b,d) table in 8-byte units; 0 = all that is left next to the work lists
     int dist_wide = 0;       // 1 forces the 8-byte-slot table layout (tests)
     int dist_fill_pct = 70;  // a (b,d) table pass is split when more than this share of the slots is in use

@@ -779,6 +779,16 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
     }
 }
 
+// sum over all postings of their partner-range length = the number of pair emissions of the launch (before a != b)
+__global__ void __launch_bounds__(256)
+cf_sum_partner_kernel(const int32_t* __restrict__ post, int64_t n_post, const cf_dist_rec* __restrict__ urange, unsigned long long* __restrict__ out) {
+    unsigned long long s = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_post; i += stride) s += urange[post[i]].len;
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, (unsigned)d);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
 __global__ void __launch_bounds__(256)
 cf_max_u32_kernel(const uint32_t* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
     uint32_t m = 0;
@@ -885,10 +895,25 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
         A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
         const uint32_t slot_bytes = narrow ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
+        // launch shape: two 512-thread workgroups per CU (80 KiB of LDS each) overlap each other's latency-bound phases
+        // and win when a first k-mer has few pair emissions; with many (long reads, high coverage) the halved table and
+        // sketch cost more than the overlap gains, and one 1024-thread workgroup with the whole LDS wins (measured:
+        // 20 k emissions per first k-mer: 480 vs 716 ms; 53 k: 437 vs 274 ms; 160 k: 2097 vs 739 ms)
+        unsigned long long h_partner = 0;
+        if (n_post && (ctx->dist_wgs == 0 || ctx->dist_block == 0)) {
+            hipLaunchKernelGGL(cf_sum_partner_kernel, dim3((unsigned)cf_grid_for(n_post, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                               (const int32_t*)d_post, n_post, (const cf_dist_rec*)d_urange, d_cnt + 3);
+            if (hipMemcpy(&h_partner, d_cnt + 3, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "partner sum"); break; }
+            if (hipMemsetAsync(d_cnt + 3, 0, 8, ctx->stream) != hipSuccess) { rc = cf_fail(ctx, -5, "partner sum reset"); break; }
+        }
+        const double per_first = (double)h_partner / (double)std::max<int64_t>(1, (K - part + n_parts - 1) / n_parts);
+        int wgs = ctx->dist_wgs, block = ctx->dist_block;
+        if (wgs == 0) wgs = (block > 512 || per_first > 32768.0) ? 1 : 2;
+        if (block == 0) block = wgs == 1 ? 1024 : 512;
         // LDS: everything but the table is fixed; dist_slots (the table budget in 8-byte units) defaults to all the rest
         const size_t lds_fixed = sizeof(cf_dist_rec) * DIST_NP_CAP + (size_t)(4 + DIST_NP_CAP + 2 * DIST_STACK + 16) * 4 + DIST_STAGE_CAP * 2 + 16
-                               + DIST_BM_BITS / 8 + (size_t)(ctx->dist_block / 64) * DIST_QCAP * (narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem));
-        const int64_t budget8 = ((int64_t)160 * 1024 / ctx->dist_wgs - (int64_t)lds_fixed) / 8;
+                               + DIST_BM_BITS / 8 + (size_t)(block / 64) * DIST_QCAP * (narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem));
+        const int64_t budget8 = ((int64_t)160 * 1024 / wgs - (int64_t)lds_fixed) / 8;
         if (budget8 < 256) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_wgs leaves no LDS for the table"); break; }
         if (ctx->dist_slots > budget8) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_slots does not fit the 160 KiB LDS next to the work lists"); break; }
         const int64_t slots8 = ctx->dist_slots ? ctx->dist_slots : budget8;
@@ -901,7 +926,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.sk_shift = 32; A.sk_counters = 1;
         while (A.sk_shift > 8 && (size_t)A.sk_counters * 2 <= (size_t)A.slots * slot_bytes) { A.sk_counters *= 2; --A.sk_shift; }
         if (A.sk_counters < 16) A.sketch = 0;
-        const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / ctx->dist_block));
+        const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / block));
         // locality order of the first k-mers: sort (first posting unit, a); k-mers without postings drop out
         n_a_alloc = (K > part) ? (K - part + n_parts - 1) / n_parts : 0;
         if ((rc = cf_alloc_t(ctx, &d_okeys, (size_t)n_a_alloc, "order keys"))) break;
@@ -928,8 +953,8 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                    : hipFuncSetAttribute((const void*)cf_dist_kernel<cf_tab_wide>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("dist LDS attribute: ") + hipGetErrorString(e)); break; }
         if (n_a > 0 && max_d >= min_d_eff && n_post > 0) {
-            if (narrow) hipLaunchKernelGGL((cf_dist_kernel<cf_tab_narrow>), dim3((unsigned)grid), dim3((unsigned)ctx->dist_block), lds, ctx->stream, A);
-            else hipLaunchKernelGGL((cf_dist_kernel<cf_tab_wide>), dim3((unsigned)grid), dim3((unsigned)ctx->dist_block), lds, ctx->stream, A);
+            if (narrow) hipLaunchKernelGGL((cf_dist_kernel<cf_tab_narrow>), dim3((unsigned)grid), dim3((unsigned)block), lds, ctx->stream, A);
+            else hipLaunchKernelGGL((cf_dist_kernel<cf_tab_wide>), dim3((unsigned)grid), dim3((unsigned)block), lds, ctx->stream, A);
             e = hipGetLastError();
             if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_dist_kernel: ") + hipGetErrorString(e)); break; }
         }

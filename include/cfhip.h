@@ -137,8 +137,8 @@ int cf_get_times(cf_ctx* ctx, cf_times* out);
 int cf_rr_distances(cf_ctx* ctx, const uint8_t* unit, int32_t unit_len, const uint8_t* reads, const int64_t* read_off,
                     int64_t n_reads, int32_t threshold, int32_t* dist_fwd, int32_t* dist_rc);
 
-/* Tuning knobs (defaults are chosen for gfx950): name in {"dist_block" (threads per workgroup), "dist_wgs"
- * (workgroups per CU the LDS is split between), "dist_slots" (LDS budget of the (b,d) table in 8-byte units, 0 = all that
+/* Tuning knobs (defaults are chosen for gfx950): name in {"dist_block" (threads per workgroup, 0 = auto), "dist_wgs"
+ * (workgroups per CU the LDS is split between, 0 = auto: by the pair emissions per first k-mer), "dist_slots" (LDS budget of the (b,d) table in 8-byte units, 0 = all that
  * is left), "dist_sketch" (0: every pair goes to the exact table), "dist_fill_pct", "dist_est_pct", "dist_stage",
  * "dist_wide", "count_slots", "count_tile"}.  Results never depend on them (tests/test_gpu_parity.py). */
 int cf_set_param(cf_ctx* ctx, const char* name, int64_t value);

@@ -160,14 +160,15 @@ def test_full_size_properties(engine):
         assert got == ref
     engine.set_param("dist_slots", 0)
     engine.set_param("dist_sketch", 1)
-    # launch shape: one 1024-thread workgroup per CU with the whole LDS instead of two 512-thread ones
-    engine.set_param("dist_block", 1024); engine.set_param("dist_wgs", 1)
+    # launch shape (chosen by the library from the pair emissions per first k-mer): both shapes forced
     try:
-        engine.reset_unique()
-        ne = engine.dist_edges(0, 2 ** 62, 1, 150, 4, 0.8, 0, 1, edge_cap=60_000_000)
-        assert (ne, engine.stats()["n_emissions"], cport.edge_checksum(engine.edges(ne)), engine.unique_mask().tobytes()) == ref
+        for block, wgs in ((1024, 1), (512, 2)):
+            engine.set_param("dist_block", block); engine.set_param("dist_wgs", wgs)
+            engine.reset_unique()
+            ne = engine.dist_edges(0, 2 ** 62, 1, 150, 4, 0.8, 0, 1, edge_cap=60_000_000)
+            assert (ne, engine.stats()["n_emissions"], cport.edge_checksum(engine.edges(ne)), engine.unique_mask().tobytes()) == ref
     finally:
-        engine.set_param("dist_block", 512); engine.set_param("dist_wgs", 2)
+        engine.set_param("dist_block", 0); engine.set_param("dist_wgs", 0)
     engine.reset_unique()
     ne = engine.dist_edges(0, 2 ** 62, 1, 150, 4, 0.8, 0, 1, edge_cap=1000)   # count-only beyond the cap
     assert ne == ref[0] and engine.edges(1000).shape == (1000, 4) and engine.unique_mask().tobytes() == ref[3]
