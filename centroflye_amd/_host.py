@@ -70,10 +70,6 @@ def lib():
     L.cfh_write_kmers.argtypes = [C.c_char_p, C.c_void_p, i64, i32, C.c_char_p, C.c_int]
     L.cfh_write_edges.argtypes = [C.c_char_p, C.c_int, C.c_void_p, i32, C.c_void_p, i64, C.c_char_p, C.c_int]
     L.cfh_read_kmers.argtypes = [C.c_char_p, i32, C.c_void_p, i64, pi64, C.c_char_p, C.c_int]
-    L.cfh_seq_open.argtypes = [C.c_char_p, C.POINTER(P), C.c_char_p, C.c_int]
-    L.cfh_seq_next.argtypes = [P, i64, pi64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
-    L.cfh_seq_close.argtypes = [P]
-    L.cfh_seq_close.restype = None
     L.cfh_export_read_units.argtypes = [P, C.c_void_p, C.c_void_p, i64, i64, i64, C.c_char_p, C.c_int, pi64, pi64, C.c_char_p, C.c_int]
     _lib = L
     return L
@@ -199,30 +195,6 @@ def synth(report_path=None, pack=True, keep_rows=False, **kw):
     _check(L.cfh_synth(C.byref(sp), os.fsencode(report_path) if report_path else None,
                        int(keep_rows), C.byref(h) if pack else None, err, 512), err)
     return PackedReads(h) if pack else None
-
-
-def read_seq_batches(path, max_bases=1 << 30):
-    """Batches (names list[bytes], bases uint8[...], read_off int64[n + 1]) of a FASTA / FASTQ file, plain or gzip, read
-    by the compiled reader (kseq record rules, reference rr.cpp:67-73).  Arrays are copies."""
-    L = lib()
-    err = C.create_string_buffer(512)
-    h = C.c_void_p()
-    _check(L.cfh_seq_open(os.fsencode(path), C.byref(h), err, 512), err)
-    try:
-        while True:
-            n = C.c_int64()
-            p = [C.c_void_p() for _ in range(4)]
-            _check(L.cfh_seq_next(h, int(max_bases), C.byref(n), C.byref(p[0]), C.byref(p[1]), C.byref(p[2]), C.byref(p[3]), err, 512), err)
-            if n.value == 0:
-                return
-            name_off = _view(p[1].value, n.value + 1, np.int64).copy()
-            read_off = _view(p[3].value, n.value + 1, np.int64).copy()
-            raw = _view(p[0].value, int(name_off[-1]), np.uint8).tobytes() if name_off[-1] else b""
-            names = [raw[name_off[i]:name_off[i + 1]] for i in range(n.value)]
-            bases = _view(p[2].value, int(read_off[-1]), np.uint8).copy() if read_off[-1] else np.zeros(0, np.uint8)
-            yield names, bases, read_off
-    finally:
-        L.cfh_seq_close(h)
 
 
 def write_kmers(path, kmers, k):

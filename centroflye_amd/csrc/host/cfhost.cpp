@@ -9,7 +9,6 @@
 #include "cfhost.h"
 
 #include <sys/stat.h>
-#include <zlib.h>
 #include <sys/types.h>
 
 #include <algorithm>
@@ -936,100 +935,6 @@ int cfh_export_read_units(cfh_pack* p, const int64_t* rec, const int64_t* pos, i
         return 0;
     } catch (const std::exception& e) {
         set_err(err, errlen, std::string("cfh_export_read_units: ") + e.what());
-        return -12;
-    }
-}
-
-// FASTA / FASTQ reader, plain or gzip (zlib reads both), for the read-recruitment CLI (reference
-// scripts/read_recruitment/rr.cpp:67-73 reads its input with kseq; same record rules: name = header up to the first
-// white space, sequence lines joined until a line starting with '>', '@' or '+', after '+' as many quality characters as
-// the sequence has bases are skipped).  Records come in batches of about max_bases bases, packed back to back.
-struct cfh_seq_reader {
-    gzFile f = nullptr;
-    std::vector<char> buf;
-    size_t pos = 0, end = 0;
-    bool eof = false;
-    std::string pending;            // a header line already read (starts the next record)
-    bool have_pending = false;
-    // current batch
-    std::string names, bases;
-    std::vector<int64_t> name_off, read_off;
-
-    bool getline(std::string& line) {       // without the trailing newline / carriage return
-        line.clear();
-        for (;;) {
-            if (pos == end) {
-                if (eof) return !line.empty();
-                const int n = gzread(f, buf.data(), (unsigned)buf.size());
-                if (n <= 0) { eof = true; if (line.empty()) return false; break; }
-                pos = 0; end = (size_t)n;
-            }
-            const char* b = buf.data() + pos;
-            const char* nl = (const char*)std::memchr(b, '\n', end - pos);
-            if (nl) { line.append(b, (size_t)(nl - b)); pos += (size_t)(nl - b) + 1; break; }
-            line.append(b, end - pos); pos = end;
-        }
-        while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
-        return true;
-    }
-};
-
-int cfh_seq_open(const char* path, cfh_seq_reader** out, char* err, int errlen) {
-    auto* r = new cfh_seq_reader();
-    r->f = gzopen(path, "rb");
-    if (!r->f) { delete r; set_err(err, errlen, std::string("cannot open ") + path); return -2; }
-    gzbuffer(r->f, 1 << 20);
-    r->buf.resize(1 << 20);
-    *out = r;
-    return 0;
-}
-
-void cfh_seq_close(cfh_seq_reader* r) {
-    if (!r) return;
-    if (r->f) gzclose(r->f);
-    delete r;
-}
-
-// Next batch: *n = 0 at the end of the file.  Pointers are borrowed until the next call.
-int cfh_seq_next(cfh_seq_reader* r, int64_t max_bases, int64_t* n, const char** names, const int64_t** name_off,
-                 const uint8_t** bases, const int64_t** read_off, char* err, int errlen) {
-    try {
-        r->names.clear(); r->bases.clear(); r->name_off.assign(1, 0); r->read_off.assign(1, 0);
-        std::string line;
-        while ((int64_t)r->bases.size() < max_bases || r->read_off.size() == 1) {
-            // find the header of the next record
-            if (!r->have_pending) {
-                bool found = false;
-                while (r->getline(line)) if (!line.empty() && (line[0] == '>' || line[0] == '@')) { found = true; break; }
-                if (!found) break;
-                r->pending = line;
-            }
-            r->have_pending = false;
-            size_t e = 1;
-            while (e < r->pending.size() && !std::isspace((unsigned char)r->pending[e])) ++e;
-            r->names.append(r->pending, 1, e - 1);
-            r->name_off.push_back((int64_t)r->names.size());
-            const size_t seq0 = r->bases.size();
-            bool plus = false;
-            while (r->getline(line)) {
-                if (line.empty()) continue;
-                if (line[0] == '>' || line[0] == '@') { r->pending = line; r->have_pending = true; break; }
-                if (line[0] == '+') { plus = true; break; }
-                r->bases += line;
-            }
-            if (plus) {                       // FASTQ: skip the qualities, then look for the next header
-                size_t got = 0;
-                const size_t need = r->bases.size() - seq0;
-                while (r->getline(line)) { got += line.size(); if (got >= need) break; }
-            }
-            r->read_off.push_back((int64_t)r->bases.size());
-        }
-        *n = (int64_t)r->read_off.size() - 1;
-        *names = r->names.data(); *name_off = r->name_off.data();
-        *bases = (const uint8_t*)r->bases.data(); *read_off = r->read_off.data();
-        return 0;
-    } catch (const std::exception& e) {
-        set_err(err, errlen, std::string("cfh_seq_next: ") + e.what());
         return -12;
     }
 }

@@ -7,9 +7,8 @@ complement, the unit being allowed to sit anywhere inside the read (edlib mode H
     rr.py unit.fasta reads.fasta[.gz] output.fasta edit_distance_threshold
 
 and the same output (``>name`` + sequence on one line, input order, rr.cpp:83-87).  The distances are computed on the
-GPU (``cf_rr_distances``, one wavefront per read and strand); the FASTA / FASTQ input (plain or gzip; kseq record rules:
-name = header up to the first white space, multi-line sequences joined, qualities ignored) is read by the compiled host
-library (``cfh_seq_next``); ``iter_seqs`` below is the same reader in plain Python.
+GPU (``cf_rr_distances``, one wavefront per read and strand); reading the FASTA / FASTQ input (kseq semantics: name =
+header up to the first white space, multi-line sequences joined, qualities ignored) stays on the host.
 One deliberate difference: rr.cpp builds the reverse complement into a buffer without a terminating NUL and reverses it
 with strlen (rr.cpp:56-62, undefined behaviour that happens to work when the byte after the buffer is zero); here the
 reverse complement is simply correct.
@@ -66,22 +65,36 @@ def iter_seqs(path):
 
 
 def recruit(unit, reads_path, output_path, threshold, engine=None):
-    """Writes the recruited reads; returns (reads seen, reads recruited).  The input is read in batches of about
-    BATCH_BASES bases by the compiled reader (``libcfhost.so``), distances come from the GPU."""
-    from . import _host
+    """Writes the recruited reads; returns (reads seen, reads recruited)."""
     from .engine import Engine
     own = engine is None
     engine = engine or Engine(0)
     n_seen = n_kept = 0
     try:
         with open(output_path, "wb") as out:
-            for names, flat, off in _host.read_seq_batches(reads_path, BATCH_BASES):
+            batch, size = [], 0
+
+            def flush():
+                nonlocal n_kept, batch, size
+                if not batch:
+                    return
+                off = np.zeros(len(batch) + 1, np.int64)
+                np.cumsum([len(s) for _, s in batch], out=off[1:])
+                flat = np.frombuffer(b"".join(s for _, s in batch), dtype=np.uint8)
                 fwd, rc = engine.rr_distances(unit, flat, off, threshold)
-                keep = np.flatnonzero((fwd != -1) | (rc != -1))      # rr.cpp:84
-                for i in keep:
-                    out.write(b">" + names[i] + b"\n" + flat[off[i]:off[i + 1]].tobytes() + b"\n")
-                n_seen += len(names)
-                n_kept += int(keep.size)
+                for (name, seq), a, b in zip(batch, fwd, rc):
+                    if a != -1 or b != -1:      # rr.cpp:84
+                        out.write(b">" + name + b"\n" + seq + b"\n")
+                        n_kept += 1
+                batch, size = [], 0
+
+            for name, seq in iter_seqs(reads_path):
+                batch.append((name, seq))
+                size += len(seq)
+                n_seen += 1
+                if size >= BATCH_BASES:
+                    flush()
+            flush()
     finally:
         if own:
             engine.close()

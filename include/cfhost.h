@@ -117,16 +117,6 @@ int cfh_export_read_units(cfh_pack* p, const int64_t* rec, const int64_t* pos, i
                           int64_t max_pos, const char* outdir, int n_threads, int64_t* n_positions,
                           int64_t* n_units_written, char* err, int errlen);
 
-/* FASTA / FASTQ reader, plain or gzip, for the read-recruitment CLI (reference scripts/read_recruitment/rr.cpp:67-73 reads
- * with kseq: name = header up to the first white space, sequence lines joined until a line starting with '>', '@' or '+',
- * qualities skipped).  cfh_seq_next returns batches of about max_bases bases packed back to back (names concatenated with
- * offsets, bases with read offsets); *n = 0 at the end; pointers are borrowed until the next call. */
-typedef struct cfh_seq_reader cfh_seq_reader;
-int  cfh_seq_open(const char* path, cfh_seq_reader** out, char* err, int errlen);
-int  cfh_seq_next(cfh_seq_reader* r, int64_t max_bases, int64_t* n, const char** names, const int64_t** name_off,
-                  const uint8_t** bases, const int64_t** read_off, char* err, int errlen);
-void cfh_seq_close(cfh_seq_reader* r);
-
 /* Read a k-mer text file (one per line) into 2-bit codes; returns count via n_out, fills out
  * if non-NULL (size-query then fill). All k-mers must have length k and be ACGT. */
 int cfh_read_kmers(const char* path, int32_t k, uint64_t* out, int64_t cap, int64_t* n_out,

@@ -91,25 +91,6 @@ def test_fasta_fastq_reader_follows_kseq(tmp_path):
     with gzip.open(fq, "wb") as f:
         f.write(b"@q1 c\nACGT\nTT\n+\n@@II\n>I\n@q2\nAA\n+q2\n>>\n")
     assert list(R.iter_seqs(fq)) == [(b"q1", b"ACGTTT"), (b"q2", b"AA")]
-    # the compiled reader (libcfhost.so) follows the same rules, in one batch and in batches of one record
-    from centroflye_amd import _host
-    for path in (fa, fq):
-        want = list(R.iter_seqs(path))
-        for max_bases in (1 << 30, 1):
-            got = []
-            for names, flat, off in _host.read_seq_batches(path, max_bases):
-                got += [(nm, flat[off[i]:off[i + 1]].tobytes()) for i, nm in enumerate(names)]
-            assert got == want
-    big = os.path.join(str(tmp_path), "big.fa.gz")
-    rng = random.Random(3)
-    recs = [(b"r%d" % i, bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 5000)))) for i in range(300)]
-    with gzip.open(big, "wb") as f:
-        for nm, sq in recs:
-            f.write(b">" + nm + b" extra\n" + b"\n".join(sq[j:j + 70] for j in range(0, len(sq), 70)) + b"\n")
-    got = []
-    for names, flat, off in _host.read_seq_batches(big, 100000):
-        got += [(nm, flat[off[i]:off[i + 1]].tobytes()) for i, nm in enumerate(names)]
-    assert got == recs == list(R.iter_seqs(big))
 
 
 @pytest.mark.gpu
