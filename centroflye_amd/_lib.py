@@ -66,6 +66,14 @@ PROTOTYPES = {
     "cf_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "cf_get_times": (C.c_int, [_P, C.POINTER(Times)]),
     "cf_set_param": (C.c_int, [_P, C.c_char_p, _I64]),
+    "cf_comm_init": (C.c_int, [_P, _I32, _I32, C.c_char_p]),
+    "cf_comm_free": (C.c_int, [_P]),
+    "cf_comm_info": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32)]),
+    "cf_comm_allreduce_i64": (C.c_int, [_P, _P, _I64, _I32]),
+    "cf_exchange_table": (C.c_int, [_P, _PI64]),
+    "cf_allgather_kmers": (C.c_int, [_P, _PI64]),
+    "cf_allgather_clouds": (C.c_int, [_P, _PI64]),
+    "cf_allreduce_unique": (C.c_int, [_P, _PI64]),
     "cf_selftest_sort": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "cf_selftest_scan": (C.c_int, [_P, _P, _I64, _P]),
 }

@@ -77,7 +77,9 @@ void cf_free_kmers(cf_ctx* c) {
     cf_release_t(c, c->d_unique_bits, (size_t)c->unique_words);
     c->n_kmers = 0; c->lut_cap = 0; c->lut_pre_words = 0; c->unique_words = 0;
 }
+void cf_free_gview(cf_ctx* c);   // cf_exchange.hip
 void cf_free_clouds(cf_ctx* c) {
+    cf_free_gview(c);           // the all-gathered view is derived from the local clouds
     cf_release_t(c, c->d_cloud_ptr, (size_t)c->n_units + 1);
     cf_release_t(c, c->d_entries, (size_t)c->n_entries);
     c->n_entries = 0; c->have_clouds = false;
@@ -116,6 +118,7 @@ int cf_create(int device, cf_ctx** out) {
 void cf_destroy(cf_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)cf_comm_free(ctx);
     cf_free_edges(ctx);
     cf_free_clouds(ctx);
     cf_free_kmers(ctx);

@@ -13,6 +13,7 @@
 
 void cf_free_kmers(cf_ctx* c);
 void cf_free_clouds(cf_ctx* c);
+void cf_free_gview(cf_ctx* c);
 
 #define CL_THREADS 256
 #define CL_TILE_W 8
@@ -401,6 +402,7 @@ int cf_filter_clouds(cf_ctx* ctx, uint32_t min_mult, uint32_t max_mult, int64_t*
         if (d_new_ptr) cf_release_t(ctx, d_new_ptr, (size_t)U + 1);
         return rc;
     }
+    cf_free_gview(ctx);
     cf_release_t(ctx, ctx->d_cloud_ptr, (size_t)U + 1);
     cf_release_t(ctx, ctx->d_entries, (size_t)N);
     ctx->d_cloud_ptr = d_new_ptr;

@@ -94,6 +94,17 @@ struct cf_ctx {
     int64_t n_entries = 0;
     bool have_clouds = false;
 
+    // multi-GPU (cf_exchange.hip): the transport, and the all-gathered clouds of every rank's reads — what the distance
+    // stage works on when present (units in rank-major order; reads and bases stay those of the local shard)
+    struct cf_comm* comm = nullptr;
+    bool have_gview = false;
+    int64_t g_reads = 0, g_units = 0, g_entries = 0;
+    int64_t* g_unit_ptr = nullptr;    // g_reads + 1
+    int64_t* g_cloud_ptr = nullptr;   // g_units + 1
+    int32_t* g_entries_d = nullptr;   // g_entries
+    std::vector<int64_t> g_h_unit_ptr;
+    int64_t exchange_bytes = 0;       // bytes this rank sent in the last cf_exchange_table
+
     // edges / unique bitmap
     uint32_t* d_edges = nullptr;  // n x 4
     int64_t edge_cap = 0, n_edges_stored = 0;
@@ -159,6 +170,8 @@ static inline int cf_grid_for(int64_t items, int per_block, int max_blocks) {
     if (b > max_blocks) b = max_blocks;
     return (int)b;
 }
+
+extern "C" int cf_comm_free(cf_ctx* ctx);   // cf_exchange.hip
 
 // primitives (cf_prims.hip)
 int cf_scan_exclusive_i64(cf_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_t n, int64_t* total);

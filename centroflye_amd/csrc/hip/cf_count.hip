@@ -335,7 +335,7 @@ static int table_compact(cf_ctx* ctx, uint32_t max_nonuniq, uint32_t lo, uint32_
     return rc;
 }
 
-static int ensure_table(cf_ctx* ctx, uint64_t want_cap) {
+int cf_table_ensure(cf_ctx* ctx, uint64_t want_cap) {
     // a table no larger than the current allocation uses a prefix of it (steps of the sharded path alternate between
     // the local count table and the merged table of owned keys: no 10-GB free + malloc per step)
     if (ctx->d_table && want_cap <= ctx->table_alloc) { ctx->table_cap = want_cap; return 0; }
@@ -369,7 +369,7 @@ static int count_impl(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, 
     const int slots = ctx->count_slots;
     int shrink = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {
-        CF_TRY(ensure_table(ctx, cap));
+        CF_TRY(cf_table_ensure(ctx, cap));
         // items: each read is split into n_cls hash classes so that a class fits the LDS set
         const int64_t per_cls = std::max<int64_t>(32, ((int64_t)slots * 3 / 8) >> shrink);
         std::vector<cf_count_item> items;
@@ -516,7 +516,7 @@ int cf_reset_table(cf_ctx* ctx, int32_t k, int64_t expected_keys) {
     if (k < 1 || k > 31) return cf_fail(ctx, -22, "k must be in [1, 31]");
     CF_HIP(hipSetDevice(ctx->device));
     const uint64_t cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(2 * expected_keys, 1024));
-    CF_TRY(ensure_table(ctx, cap));
+    CF_TRY(cf_table_ensure(ctx, cap));
     CF_HIP(hipMemsetAsync(ctx->d_table, 0, (size_t)cap * sizeof(cf_slot), ctx->stream));
     CF_HIP(hipStreamSynchronize(ctx->stream));
     ctx->k = k;

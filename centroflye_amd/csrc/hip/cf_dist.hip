@@ -803,22 +803,29 @@ extern "C" {
 int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int32_t max_d, uint32_t min_cov,
                   double rel_threshold, int32_t part, int32_t n_parts, int64_t edge_cap, int64_t* n_edges) {
     if (!ctx) return -22;
-    if (!ctx->have_clouds) return cf_fail(ctx, -22, "cf_dist_edges: no clouds built");
+    if (!ctx->have_clouds && !ctx->have_gview) return cf_fail(ctx, -22, "cf_dist_edges: no clouds built");
+    // the clouds the stage works on: the all-gathered ones of every rank (multi-GPU) or the local ones
+    const bool gv = ctx->have_gview;
+    const int64_t* v_unit_ptr = gv ? ctx->g_unit_ptr : ctx->d_unit_ptr;
+    const int64_t* v_cloud_ptr = gv ? ctx->g_cloud_ptr : ctx->d_cloud_ptr;
+    const int32_t* v_entries = gv ? ctx->g_entries_d : ctx->d_entries;
+    const std::vector<int64_t>& v_h_unit_ptr = gv ? ctx->g_h_unit_ptr : ctx->h_unit_ptr;
+    const int64_t v_n_entries = gv ? ctx->g_entries : ctx->n_entries;
     if (n_parts < 1 || part < 0 || part >= n_parts) return cf_fail(ctx, -22, "cf_dist_edges: bad partition");
     if (max_d > 255) return cf_fail(ctx, -22, "cf_dist_edges: max_d > 255 does not fit the 8-bit distance field");
     if (edge_cap < 0) edge_cap = 0;
-    for (int64_t r = 0; r < ctx->n_reads; ++r)
-        if (ctx->h_unit_ptr[(size_t)r + 1] - ctx->h_unit_ptr[(size_t)r] > 65535)
+    const int64_t R = gv ? ctx->g_reads : ctx->n_reads, U = gv ? ctx->g_units : ctx->n_units, K = ctx->n_kmers;
+    for (int64_t r = 0; r < R; ++r)
+        if (v_h_unit_ptr[(size_t)r + 1] - v_h_unit_ptr[(size_t)r] > 65535)
             return cf_fail(ctx, -22, "cf_dist_edges: a read has more than 65535 units (16-bit unit index per cloud entry)");
     CF_HIP(hipSetDevice(ctx->device));
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    const int64_t R = ctx->n_reads, U = ctx->n_units, K = ctx->n_kmers;
     // Python slice semantics of itertools.islice(items, min_n, max_n) for non-negative bounds
     if (min_n < 0) min_n = 0;
     if (max_n > R) max_n = R;
     if (max_n < min_n) max_n = min_n;
     if (min_n > R) min_n = R;
-    const int64_t u0 = ctx->h_unit_ptr[(size_t)min_n], u1 = ctx->h_unit_ptr[(size_t)max_n];
+    const int64_t u0 = v_h_unit_ptr[(size_t)min_n], u1 = v_h_unit_ptr[(size_t)max_n];
     const int32_t min_d_eff = min_d < 1 ? 1 : min_d;  // kmer_clouds[:-0] is empty: d = 0 emits nothing
 
     uint32_t *d_pcnt = nullptr, *d_cursor = nullptr, *d_first = nullptr;
@@ -857,21 +864,21 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         int64_t e0 = 0, e1 = 0;
         {
             int64_t tmp[2] = {0, 0};
-            if (hipMemcpy(&tmp[0], ctx->d_cloud_ptr + u0, 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                hipMemcpy(&tmp[1], ctx->d_cloud_ptr + u1, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "cloud_ptr read"); break; }
+            if (hipMemcpy(&tmp[0], v_cloud_ptr + u0, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(&tmp[1], v_cloud_ptr + u1, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "cloud_ptr read"); break; }
             e0 = tmp[0]; e1 = tmp[1];
         }
         if (e1 > e0)
             hipLaunchKernelGGL(cf_post_hist_kernel, dim3((unsigned)cf_grid_for(e1 - e0, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const int32_t*)ctx->d_entries, e0, e1, (uint32_t)part, (uint32_t)n_parts, d_pcnt);
+                               v_entries, e0, e1, (uint32_t)part, (uint32_t)n_parts, d_pcnt);
         if ((rc = cf_scan_exclusive_u32_to_i64(ctx, d_pcnt, d_post_ptr, K + 1, &n_post))) break;
         if ((rc = cf_alloc_t(ctx, &d_post, (size_t)n_post, "postings"))) break;
         if (u1 > u0 && n_post)
             hipLaunchKernelGGL(cf_post_fill_kernel, dim3((unsigned)cf_grid_for((u1 - u0) * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries, u0, u1, (uint32_t)part, (uint32_t)n_parts, (const int64_t*)d_post_ptr, d_cursor, d_post, d_first);
+                               v_cloud_ptr, v_entries, u0, u1, (uint32_t)part, (uint32_t)n_parts, (const int64_t*)d_post_ptr, d_cursor, d_post, d_first);
         if (R)
             hipLaunchKernelGGL(cf_unit_rend_kernel, dim3((unsigned)cf_grid_for(R, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const int64_t*)ctx->d_unit_ptr, (const int64_t*)ctx->d_cloud_ptr, R, min_d_eff, max_d, d_rend, d_rbeg, d_urange);
+                               v_unit_ptr, v_cloud_ptr, R, min_d_eff, max_d, d_rend, d_rbeg, d_urange);
         // table layout: 6-byte slots (32-bit keys, 16-bit counts) whenever ranks fit 24 bits and counts 15 bits
         uint32_t max_post = 0;
         if (K) {
@@ -881,17 +888,17 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         }
         narrow = !ctx->dist_wide && K < ((int64_t)1 << 24) - 1 && max_post <= 32767u;
         if (max_post >= (1u << 23)) { rc = cf_fail(ctx, -34, "cf_dist_edges: a k-mer has more than 2^23 postings"); break; }
-        if (narrow) { if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)ctx->n_entries + DIST_ITEM, "packed cloud entries"))) break; }
-        else if ((rc = cf_alloc_t(ctx, &d_entry_i, (size_t)ctx->n_entries + 1, "entry unit indices"))) break;
-        if (U && ctx->n_entries)
+        if (narrow) { if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)v_n_entries + DIST_ITEM, "packed cloud entries"))) break; }
+        else if ((rc = cf_alloc_t(ctx, &d_entry_i, (size_t)v_n_entries + 1, "entry unit indices"))) break;
+        if (U && v_n_entries)
             hipLaunchKernelGGL(cf_entry_unit_kernel, dim3((unsigned)cf_grid_for(U * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)d_rbeg, (const int32_t*)ctx->d_entries, U, d_entry_i, d_packed);
+                               v_cloud_ptr, (const int32_t*)d_rbeg, v_entries, U, d_entry_i, d_packed);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("postings: ") + hipGetErrorString(e)); break; }
 
         cf_dist_args A;
-        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = ctx->d_cloud_ptr; A.entries = ctx->d_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.urange = d_urange; A.entry_i = d_entry_i; A.packed = d_packed;
+        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = v_cloud_ptr; A.entries = v_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.urange = d_urange; A.entry_i = d_entry_i; A.packed = d_packed;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
         A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
         const uint32_t slot_bytes = narrow ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
@@ -981,8 +988,8 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     if (d_okeys) cf_release_t(ctx, d_okeys, (size_t)n_a_alloc);
     if (d_first) cf_release_t(ctx, d_first, (size_t)K + 1);
     if (d_cnt) cf_release_t(ctx, d_cnt, n_cnt);
-    if (d_entry_i) cf_release_t(ctx, d_entry_i, (size_t)ctx->n_entries + 1);
-    if (d_packed) cf_release_t(ctx, d_packed, (size_t)ctx->n_entries + DIST_ITEM);
+    if (d_entry_i) cf_release_t(ctx, d_entry_i, (size_t)v_n_entries + 1);
+    if (d_packed) cf_release_t(ctx, d_packed, (size_t)v_n_entries + DIST_ITEM);
     if (d_urange) cf_release_t(ctx, d_urange, (size_t)U + 1);
     if (d_rbeg) cf_release_t(ctx, d_rbeg, (size_t)U + 1);
     if (d_rend) cf_release_t(ctx, d_rend, (size_t)U + 1);

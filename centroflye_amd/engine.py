@@ -262,6 +262,43 @@ class Engine:
     def reset_unique(self):
         self._check(self._lib.cf_reset_unique(self._ctx), "cf_reset_unique")
 
+    # ------------------------------------------------------------------ multi-GPU
+    def comm_init(self, rank, world, rendezvous=None):
+        self._check(self._lib.cf_comm_init(self._ctx, int(rank), int(world), (rendezvous or "").encode()), "cf_comm_init")
+
+    def comm_free(self):
+        self._check(self._lib.cf_comm_free(self._ctx), "cf_comm_free")
+
+    def comm_info(self):
+        r, w = C.c_int32(), C.c_int32()
+        self._check(self._lib.cf_comm_info(self._ctx, C.byref(r), C.byref(w)), "cf_comm_info")
+        return r.value, w.value
+
+    def allreduce(self, values, op="sum"):
+        v = np.ascontiguousarray(values, np.int64).copy()
+        self._check(self._lib.cf_comm_allreduce_i64(self._ctx, _ptr(v), v.size, 1 if op == "max" else 0), "cf_comm_allreduce_i64")
+        return v
+
+    def exchange_table(self):
+        n = C.c_int64()
+        self._check(self._lib.cf_exchange_table(self._ctx, C.byref(n)), "cf_exchange_table")
+        return n.value
+
+    def allgather_kmers(self):
+        n = C.c_int64()
+        self._check(self._lib.cf_allgather_kmers(self._ctx, C.byref(n)), "cf_allgather_kmers")
+        return n.value
+
+    def allgather_clouds(self):
+        n = C.c_int64()
+        self._check(self._lib.cf_allgather_clouds(self._ctx, C.byref(n)), "cf_allgather_clouds")
+        return n.value
+
+    def allreduce_unique(self):
+        n = C.c_int64()
+        self._check(self._lib.cf_allreduce_unique(self._ctx, C.byref(n)), "cf_allreduce_unique")
+        return n.value
+
     # ------------------------------------------------------------------ A8 + A9
     def place_reads(self, classes, id_rank, min_cloud_kmer_freq=2, min_unit=2, min_inters=10, min_prop=3):
         """Returns (read, pos, s0, s1) arrays in the order the reference writes read_positions.csv;

@@ -137,6 +137,30 @@ int cf_get_times(cf_ctx* ctx, cf_times* out);
 int cf_rr_distances(cf_ctx* ctx, const uint8_t* unit, int32_t unit_len, const uint8_t* reads, const int64_t* read_off,
                     int64_t n_reads, int32_t threshold, int32_t* dist_fwd, int32_t* dist_rc);
 
+/* Multi-GPU (new design — the reference has no distributed code, scripts/ is single-process): one
+ * process per GPU, reads sharded across ranks, RCCL over xGMI inside the library on the context's stream.
+ *   cf_comm_init         joins the communicator: rank 0 publishes the RCCL unique id at `rendezvous` (a path all ranks
+ *                        share), the others read it.  world = 1 is allowed (every collective degenerates).
+ *   cf_exchange_table    after cf_count_kmers on the local shard: (key, pres, multi) records are bucketed by
+ *                        owner = hash(key) % world on the device and exchanged with one all-to-all (ncclSend/ncclRecv
+ *                        pairs in rounds of <= 256 MB); the table then holds the exact global counts of the OWNED keys
+ *                        (what distance_based_kmer_recruitment.py:39-63 computes over all reads), so cf_select_rare
+ *                        selects the owned rare k-mers.  bytes_sent: bytes this rank sent to its peers.
+ *   cf_allgather_kmers   all-gather of the owned rare lists; every rank installs the sorted union (= :66-82's set).
+ *   cf_allgather_clouds  after cf_build_clouds on the local shard: all-gather of every rank's per-unit clouds
+ *                        (read_kmer_cloud.py:34-40 over all reads, units in rank order); cf_dist_edges then works on
+ *                        them, each rank on the first k-mers a % n_parts == part, with no reduction.
+ *   cf_allreduce_unique  OR of the selected-k-mer masks of all ranks (filter_dist_tuples' set, :145-148).
+ *   cf_comm_allreduce_i64  host values summed (op 0) or maximised (op 1) over ranks: counters, timing, barrier. */
+int cf_comm_init(cf_ctx* ctx, int32_t rank, int32_t world, const char* rendezvous);
+int cf_comm_free(cf_ctx* ctx);
+int cf_comm_info(cf_ctx* ctx, int32_t* rank, int32_t* world);
+int cf_comm_allreduce_i64(cf_ctx* ctx, int64_t* vals, int64_t n, int32_t op);
+int cf_exchange_table(cf_ctx* ctx, int64_t* bytes_sent);
+int cf_allgather_kmers(cf_ctx* ctx, int64_t* n_out);
+int cf_allgather_clouds(cf_ctx* ctx, int64_t* n_entries);
+int cf_allreduce_unique(cf_ctx* ctx, int64_t* n_unique);
+
 /* Tuning knobs (defaults are chosen for gfx950): name in {"dist_block" (threads per workgroup, 0 = auto), "dist_wgs"
  * (workgroups per CU the LDS is split between, 0 = auto: by the pair emissions per first k-mer), "dist_slots" (LDS budget of the (b,d) table in 8-byte units, 0 = all that
  * is left), "dist_sketch" (0: every pair goes to the exact table), "dist_fill_pct", "dist_est_pct", "dist_stage",

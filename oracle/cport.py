@@ -1,4 +1,5 @@
-"""ctypes wrapper of oracle/c/cf_oracle.c (plain-C stage 2).  TEST INFRASTRUCTURE ONLY."""
+"""ctypes wrapper of oracle/c (plain-C stage 2: cf_oracle.c single thread, cf_oracle_mt.c OpenMP; plain-C placement:
+cf_oracle_place.c).  TEST INFRASTRUCTURE ONLY."""
 import ctypes as C
 import os
 import subprocess
@@ -23,8 +24,8 @@ _lib = None
 
 
 def build():
-    src = os.path.join(_DIR, "cf_oracle.c")
-    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_DIR, f) for f in os.listdir(_DIR) if f.endswith(".c")]
+    if not os.path.exists(_SO) or any(os.path.exists(s_) and os.path.getmtime(_SO) < os.path.getmtime(s_) for s_ in srcs):
         subprocess.check_call(["make", "-s", "-C", _DIR])
     return _SO
 
@@ -37,6 +38,10 @@ def lib():
         L.cfo_stage2.argtypes = [P, P, C.c_int64, P, P, P, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64,
                                  C.c_int, C.c_int, C.c_uint32, C.c_double, C.POINTER(Result), P, C.c_int64, P, P, C.c_int64,
                                  P, C.c_int64, P]
+        L.cfo_stage2_mt.argtypes = L.cfo_stage2.argtypes + [C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        L.cfo_place_reads.argtypes = [C.c_int64, C.c_int64, P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P]
+        L.cfo_table_mix.restype = C.c_uint64
+        L.cfo_table_mix.argtypes = [C.c_uint64] * 3
         for f in ("cfo_edge_mix", "cfo_cloud_mix", "cfo_key_mix"):
             getattr(L, f).restype = C.c_uint64
         L.cfo_edge_mix.argtypes = [C.c_uint64] * 4
@@ -74,9 +79,39 @@ def cloud_checksum(cloud_ptr, entries):
         return int(_mix64(_mix64(units + np.uint64(0x51ED)) ^ np.asarray(entries).astype(np.uint64)).sum(dtype=np.uint64))
 
 
+def table_checksum(keys, pres, multi):
+    """Order-independent checksum of a (key, pres, multi) table — same mix as cf_oracle_mt.c (cfo_table_mix)."""
+    with np.errstate(over="ignore"):
+        h = _mix64(_mix64(_mix64(np.asarray(keys, np.uint64) + np.uint64(0x7AB1E)) ^ np.asarray(pres).astype(np.uint64))
+                   ^ (np.asarray(multi).astype(np.uint64) << np.uint64(1)))
+        return int(h.sum(dtype=np.uint64))
+
+
+def place_reads(classes, id_rank, unit_ptr, cloud_ptr, entries, n_kmers, min_cloud_kmer_freq=2, min_unit=2, min_inters=10, min_prop=3):
+    """Plain-C greedy placement (cf_oracle_place.c); returns (read, pos, s0, s1) like Engine.place_reads."""
+    classes = np.ascontiguousarray(classes, np.uint8)
+    id_rank = np.ascontiguousarray(id_rank, np.int32)
+    unit_ptr = np.ascontiguousarray(unit_ptr, np.int64)
+    cloud_ptr = np.ascontiguousarray(cloud_ptr, np.int64)
+    entries = np.ascontiguousarray(entries, np.int32)
+    R = classes.size
+    rd, pos = np.zeros(R, np.int64), np.zeros(R, np.int64)
+    s0, s1 = np.zeros(R, np.int32), np.zeros(R, np.int32)
+    rc = lib().cfo_place_reads(R, int(n_kmers), classes.ctypes.data, id_rank.ctypes.data, unit_ptr.ctypes.data, cloud_ptr.ctypes.data,
+                               entries.ctypes.data, min_cloud_kmer_freq, min_unit, min_inters, min_prop,
+                               rd.ctypes.data, pos.ctypes.data, s0.ctypes.data, s1.ctypes.data)
+    if rc:
+        raise RuntimeError(f"cfo_place_reads failed ({rc})")
+    return rd, pos, s0, s1
+
+
 def stage2(bases, read_off, unit_ptr, unit_start, unit_end, k=19, max_nonuniq=3, lo=10, hi=32, min_n=0, max_n=2 ** 62,
-           min_d=1, max_d=150, min_cov=4, rel_threshold=0.8, want_arrays=False, edges_cap=0):
-    """Run the plain-C stage 2.  Returns (counters dict, arrays dict or None)."""
+           min_d=1, max_d=150, min_cov=4, rel_threshold=0.8, want_arrays=False, edges_cap=0, threads=None, stop_after=0):
+    """Run the plain-C stage 2.  Returns (counters dict, arrays dict or None).  threads=None: cf_oracle.c (single thread);
+    threads=N (0 = all cores): cf_oracle_mt.c (OpenMP; adds "table_checksum"; stop_after=1 ends after A2, 2 after A3)."""
+    if threads is not None:
+        return _stage2_mt(bases, read_off, unit_ptr, unit_start, unit_end, k, max_nonuniq, lo, hi, min_n, max_n, min_d, max_d,
+                          min_cov, rel_threshold, want_arrays, threads, stop_after)
     bases = np.ascontiguousarray(bases, np.uint8)
     read_off = np.ascontiguousarray(read_off, np.int64)
     unit_ptr = np.ascontiguousarray(unit_ptr, np.int64)
@@ -106,3 +141,35 @@ def stage2(bases, read_off, unit_ptr, unit_start, unit_end, k=19, max_nonuniq=3,
     if rc:
         raise RuntimeError(f"cfo_stage2 failed ({rc})")
     return res.as_dict(), arrays
+
+
+def _stage2_mt(bases, read_off, unit_ptr, unit_start, unit_end, k, max_nonuniq, lo, hi, min_n, max_n, min_d, max_d, min_cov,
+               rel_threshold, want_arrays, threads, stop_after):
+    bases = np.ascontiguousarray(bases, np.uint8)
+    read_off = np.ascontiguousarray(read_off, np.int64)
+    unit_ptr = np.ascontiguousarray(unit_ptr, np.int64)
+    unit_start = np.ascontiguousarray(unit_start, np.int64)
+    unit_end = np.ascontiguousarray(unit_end, np.int64)
+    R = read_off.size - 1
+    res, tchk = Result(), C.c_uint64()
+    args = [bases.ctypes.data, read_off.ctypes.data, R, unit_ptr.ctypes.data, unit_start.ctypes.data, unit_end.ctypes.data,
+            k, max_nonuniq, lo, hi, min_n, min(max_n, 2 ** 62), min_d, max_d, min_cov, rel_threshold, C.byref(res)]
+    tail = [int(threads), int(stop_after), C.byref(tchk)]
+    arrays = None
+    rc = lib().cfo_stage2_mt(*args, None, 0, None, None, 0, None, 0, None, *tail)
+    if rc == 0 and want_arrays:
+        rare = np.zeros(res.n_rare, np.uint64)
+        cptr = np.zeros(res.n_units + 1, np.int64)
+        ent = np.zeros(res.n_cloud_entries, np.int32)
+        ne = res.n_edges
+        edges = np.zeros((ne, 4), np.uint32)
+        uniq = np.zeros(res.n_rare, np.uint8)
+        rc = lib().cfo_stage2_mt(*args, rare.ctypes.data, rare.size, cptr.ctypes.data if stop_after != 1 else None,
+                                 ent.ctypes.data if stop_after != 1 else None, ent.size,
+                                 edges.ctypes.data if stop_after == 0 else None, ne, uniq.ctypes.data if stop_after == 0 else None, *tail)
+        arrays = dict(rare=rare, cloud_ptr=cptr, entries=ent, edges=edges, unique=uniq.astype(bool))
+    if rc:
+        raise RuntimeError(f"cfo_stage2_mt failed ({rc})")
+    out = res.as_dict()
+    out["table_checksum"] = int(tchk.value)
+    return out, arrays

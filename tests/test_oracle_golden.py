@@ -123,6 +123,55 @@ def test_c_oracle_equals_numpy_oracle(name, report, oracle_stage2):
 
 
 @pytest.mark.parametrize("name", NAMES)
+def test_openmp_c_oracle_equals_single_thread_c_oracle(name, report):
+    """cf_oracle_mt.c (the checker of the full-size GPU tests and the all-core CPU baseline) == cf_oracle.c, which is
+    pinned to the numpy oracle and through it to the reference goldens; also the table checksum against numpy."""
+    from centroflye_amd import _host
+    p2 = fixtures.stage2_params(name)
+    lo, hi = recruit.rare_bounds(p2["bottom"], p2["top"], p2["coverage"], p2["kmer_survival_rate"])
+    pk = _host.parse_report(report(name))
+    up, us, ue, _ = pk.units(1)
+    args = (pk.bases, pk.read_off, up, us, ue, p2["k"], p2["max_nonuniq"], lo, hi, 0, 2 ** 62, p2["min_distance"], min(p2["max_distance"], 6), p2["min_coverage"], 0.8)
+    c1, a1 = cport.stage2(*args, want_arrays=True)
+    for threads in (3, 0):
+        c2, a2 = cport.stage2(*args, want_arrays=True, threads=threads)
+        assert {k: v for k, v in c2.items() if k != "table_checksum"} == c1
+        assert np.array_equal(a1["rare"], a2["rare"]) and np.array_equal(a1["cloud_ptr"], a2["cloud_ptr"]) and np.array_equal(a1["entries"], a2["entries"])
+        srt = lambda e: e[np.lexsort((e[:, 2], e[:, 1], e[:, 0]))]
+        assert np.array_equal(srt(a1["edges"]), srt(a2["edges"])) and np.array_equal(a1["unique"], a2["unique"])
+    # the table checksum against an independent numpy count of (k-mer, pres, multi) over all reads
+    per = [np.unique(recruit.encode_windows(pk.bases[pk.read_off[r]:pk.read_off[r + 1]].tobytes(), p2["k"]), return_counts=True) for r in range(pk.n_reads)]
+    allk = np.concatenate([u for u, _ in per]); allm = np.concatenate([c > 1 for _, c in per])
+    o = np.argsort(allk, kind="stable")
+    keys, start, pres = np.unique(allk[o], return_index=True, return_counts=True)
+    multi = np.add.reduceat(allm[o].astype(np.int64), start)
+    assert c2["table_checksum"] == cport.table_checksum(keys, pres, multi)
+    c3, _ = cport.stage2(*args, threads=2, stop_after=1)
+    assert (c3["n_rare"], c3["rare_checksum"], c3["n_distinct"], c3["n_kept"], c3["table_checksum"]) == (c1["n_rare"], c1["rare_checksum"], c1["n_distinct"], c1["n_kept"], c2["table_checksum"])
+    assert c3["n_cloud_entries"] == 0 and c3["n_emissions"] == 0
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_c_placer_equals_python_placer(name, report, golden):
+    """cf_oracle_place.c (the checker of the GPU placement test at thousands of reads) writes the lines oracle/placer.py
+    writes, which are the reference's own read_positions.csv (test_G3_G6_stage3)."""
+    g = golden(name)
+    p3 = g["stage3"]
+    records, alns, lens = ncrf.parse_report(report(name))
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.unique_kmers.txt")) as f:
+        gk = np.array(sorted(recruit.encode_kmer(x.strip()) for x in f if x.strip()), dtype=np.uint64)
+    r3 = placer.stage3(records, alns, lens, gk, n_motif=p3["n_motif"], k_cloud=p3["k_cloud"],
+                       min_cloud_kmer_freq=p3["min_cloud_kmer_freq"], min_kmer_mult=p3["min_kmer_mult"],
+                       min_unit=p3["min_unit"], min_inters=p3["min_inters"], prefix_threshold=p3["prefix_threshold"])
+    ids = list(records)
+    rank = np.argsort(np.argsort(np.array(ids, dtype=object), kind="stable"), kind="stable").astype(np.int32)
+    rd, pos, s0, s1 = cport.place_reads(r3["classes"], rank, r3["unit_ptr"], r3["f_cloud_ptr"], r3["f_entries"], gk.size,
+                                        p3["min_cloud_kmer_freq"], p3["min_unit"], p3["min_inters"], 3)
+    from conftest import lines_from_placement
+    assert lines_from_placement(ids, rd.tolist(), pos.tolist(), s0.tolist(), s1.tolist()) == r3["lines"]
+
+
+@pytest.mark.parametrize("name", NAMES)
 def test_unit_kmer_oracle_against_reference_golden(name, report):
     """§8(f) rank 2: occurrence counts and top-n (k = 30 and 19) of oracle/unit_kmers.py vs the reference."""
     import json

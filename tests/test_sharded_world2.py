@@ -1,0 +1,36 @@
+"""The N > 1 path (reads sharded, device-side owner bucketing, all-to-all count merge, all-gathers, first-k-mer
+partition, mask all-reduce) on world_size 2: two processes running the host-emulated kernels, exchanging through the
+emulator's file transport behind the C entry points of include/cfhip.h (cf_comm_init, cf_exchange_table,
+cf_allgather_kmers, cf_allgather_clouds, cf_allreduce_unique); compared with the C oracle run on the union of the shards."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_equals_single_process_oracle(emu_lib, tmp_path, world):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    rdv = tmp_path / "rdv"
+    rdv.mkdir()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"), str(r), str(world), str(rdv)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=900))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-3000:] + se[-3000:]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("SHARDED_RESULT ")]
+    assert line, outs[0][0][-2000:]
+    res = json.loads(line[0].split(" ", 1)[1])
+    assert res["world"] == world and res["n_rare"] > 100 and res["n_edges"] > 100 and res["exchange_bytes"] > 0
+    assert res["rare"] and res["unique"] and res["counters"] and res["edge_checksum"] and res["steps_identical"], res
