@@ -5,59 +5,81 @@
 
 A "step" is one full pass of the hot path over the synthetic read set, with the packed reads
 already resident in HBM: A1 presence table -> A2 rare window + sort -> A3 unit clouds ->
-postings -> A5+A6 distance histogram + edge filter.  Workload at N = 1:
-BASELINE.json configs[1]/[2] — 50 000 synthetic DXZ1-HOR reads (~1 Gb), k = 19, coverage 32;
-for N > 1 every rank holds 50 000 reads of an N-times longer array (weak scaling), counts are
-merged with an all-to-all over RCCL, rare lists and clouds are all-gathered, and the distance
-stage is partitioned by first k-mer (centroflye_amd/sharded.py).
+postings -> A5+A6 distance histogram + edge filter, every selected edge stored.
+Workload at N = 1: BASELINE.json configs[1]/[2] — 50 000 synthetic DXZ1-HOR reads (~1 Gb),
+k = 19, coverage 32; for N > 1 every rank holds 50 000 reads of an N-times longer array (weak
+scaling): counts are merged with an all-to-all over RCCL, rare lists and clouds are all-gathered,
+the distance stage is partitioned by first k-mer (centroflye_amd/sharded.py; all of it inside
+libcfhip.so — this process never imports torch).
 
-Rank 0 prints ONE JSON line (contract in the task brief) with two extra objects:
-  roofline      the dominant kernel (cf_dist_kernel): algorithmic bytes per launch
-                (4 B per pair emission + 4 B per cloud entry + 16 B per stored edge) over its mean
-                launch duration, measured with HIP events on the library's own stream
-  cpu_baseline  oracle/c (plain-C port of the reference's stage 2) timed on this host on a
-                bounded sample of the same workload
+N > 1: either launched once per rank by `python -m torch.distributed.run` (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_PORT read from the environment; the RCCL unique id travels through a file named after
+the launcher's pid), or started plainly as `python bench.py --gpus N`, in which case this process
+— which never touches a GPU — starts the N ranks as child processes itself.
+
+Rank 0 prints ONE JSON line (contract in the task brief) with these extra objects:
+  roofline              the dominant kernel (cf_dist_kernel): algorithmic bytes per launch (4 B per pair
+                        emission + 4 B per cloud entry + 16 B per stored edge) over its mean launch
+                        duration, measured with HIP events on the library's own stream; plus
+                        whole_step_frac = SURVEY §8(d)'s B_alg of the whole step / ms_per_step / 8 TB/s
+  value_incl_transfers  the same step with the H2D of the packed reads and the D2H of the rare set,
+                        the unique mask and stored edges inside the timed region
+  cpu_baseline          oracle/c (plain-C port of the reference's stage 2) timed on this host on
+                        bounded samples of the same workload: one thread, and all cores (OpenMP)
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
-
-import torch  # before libcfhip: both must share one HIP runtime
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-from centroflye_amd import _host  # noqa: E402
-from centroflye_amd.sharded import ShardedRecruiter  # noqa: E402
-
 K = 19
 COVERAGE = 32
+VAR_LEN = 8
 PARAMS = dict(k=K, max_nonuniq=3, lo=10, hi=32, min_d=1, max_d=150, min_cov=4, rel_threshold=0.8)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
 
 def synth_kwargs(total_reads, seed):
     # M copies of the 2055-bp unit so that aligned bases / (M * 2055) ~= 32 (reads average ~19.5 kb aligned)
-    return dict(seed=seed, n_units=max(24, int(round(0.3 * total_reads))), var_len=8)
+    return dict(seed=seed, n_units=max(24, int(round(0.3 * total_reads))), var_len=VAR_LEN)
 
 
-def cpu_baseline(sample_reads, seed):
+def cpu_leg(sample_reads, seed, threads):
+    from centroflye_amd import _host
     from oracle import cport
     pk = _host.synth(n_reads=sample_reads, **synth_kwargs(sample_reads, seed))
     up, us, ue, _ = pk.units(1)
     t0 = time.time()
     c, _ = cport.stage2(pk.bases, pk.read_off, up, us, ue, K, PARAMS["max_nonuniq"], PARAMS["lo"], PARAMS["hi"], 0, 2 ** 62,
-                        PARAMS["min_d"], PARAMS["max_d"], PARAMS["min_cov"], PARAMS["rel_threshold"])
+                        PARAMS["min_d"], PARAMS["max_d"], PARAMS["min_cov"], PARAMS["rel_threshold"], threads=threads)
     dt = time.time() - t0
-    return dict(value=pk.n_bases / dt, unit="bases/s", cores=1, kind="port",
-                sample=f"{pk.n_reads} reads / {pk.n_bases} bases of the same generator at coverage {COVERAGE} "
-                       f"({c['n_emissions']} pair emissions, {dt:.1f} s, oracle/c/cf_oracle.c single thread)",
-                host_cpus=os.cpu_count(), emissions_per_s=c["n_emissions"] / dt)
+    cores = 1 if threads is None else (os.cpu_count() if threads == 0 else threads)
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0))) if threads == 0 else cores
+    except AttributeError:
+        pass
+    return dict(value=pk.n_bases / dt, unit="bases/s", cores=cores, kind="port",
+                sample=f"{pk.n_reads} reads / {pk.n_bases} bases of the same generator (var_len {VAR_LEN}) at coverage {COVERAGE} "
+                       f"({c['n_emissions']} pair emissions, {dt:.1f} s, "
+                       + ("oracle/c/cf_oracle.c single thread)" if threads is None else f"oracle/c/cf_oracle_mt.c OpenMP, {cores} threads)"),
+                emissions_per_s=c["n_emissions"] / dt)
+
+
+def cpu_baseline(a):
+    one = cpu_leg(a.cpu_sample_reads, a.seed, None)
+    allc = cpu_leg(a.cpu_sample_reads_all, a.seed, 0)
+    out = dict(allc)                 # the headline leg: every core of the host
+    out["host_cpus"] = os.cpu_count()
+    out["legs"] = [one, allc]
+    return out
 
 
 def rr_leg(engine, pk, no_cpu):
@@ -90,91 +112,136 @@ def rr_leg(engine, pk, no_cpu):
     return out
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=50000, help="reads per GPU")
     ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--edge-cap", type=int, default=1 << 26, help="edges stored per GPU (all are counted)")
-    ap.add_argument("--cpu-sample-reads", type=int, default=150)
+    ap.add_argument("--edge-cap", type=int, default=-1, help="edges stored per GPU (all are counted); -1 = every selected edge")
+    ap.add_argument("--cpu-sample-reads", type=int, default=150, help="reads of the single-thread CPU leg")
+    ap.add_argument("--cpu-sample-reads-all", type=int, default=1200, help="reads of the all-core CPU leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--transfer-steps", type=int, default=1, help="extra steps timed with H2D / D2H inside (0 = skip)")
+    ap.add_argument("--d2h-edge-bytes", type=int, default=4 << 30, help="stored edges copied back in the transfer-inclusive steps, in bytes")
     ap.add_argument("--place", action="store_true", help="also run stage 3 (A4 + A8/A9 placement) once and report it (N = 1)")
     ap.add_argument("--rr", action="store_true", help="also time read recruitment (SURVEY 8(f) rank 4) on the same reads + as many random ones (N = 1)")
     ap.add_argument("--param", action="append", default=[], help="library knob name=value (cf_set_param)")
-    a = ap.parse_args()
+    ap.add_argument("--lib", default=None, help="test hook: another build of libcfhip (the CPU suite passes the host-emulated one to check this harness)")
+    return ap.parse_args()
 
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as children (this process never initialises HIP)."""
+    idf = os.path.join(tempfile.gettempdir(), f"cfcomm_{os.getuid()}_{os.getpid()}_{int(time.time() * 1e3)}.id")
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), CF_COMM_ID_FILE=idf)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    if os.path.isdir(idf):          # (the emulator's file transport of --lib uses a directory)
+        import shutil
+        shutil.rmtree(idf, ignore_errors=True)
+    elif os.path.exists(idf):
+        os.remove(idf)
+    sys.exit(rc)
+
+
+def main():
+    a = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 or world > 1:
-        if world != a.gpus:
-            raise SystemExit(f"--gpus {a.gpus} needs WORLD_SIZE={a.gpus} (launch with torch.distributed.run)")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+    if a.gpus > 1 and world == 1:
+        launch_ranks(a)
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    from centroflye_amd import _host
+    from centroflye_amd.sharded import ShardedRecruiter, default_rendezvous
 
     total_reads = a.reads * world
     t0 = time.time()
     pk = _host.synth(n_reads=a.reads, cand_offset=rank, cand_stride=world, **synth_kwargs(total_reads, a.seed))
     t_synth = time.time() - t0
-    sr = ShardedRecruiter(local_rank)
+    lib = None
+    if a.lib:
+        from centroflye_amd import _lib
+        lib = _lib.load(a.lib)
+    sr = ShardedRecruiter(local_rank if not a.lib else 0, lib=lib, rank=rank, world=world)
+    E = sr.engine
     for p in a.param:
         name, val = p.split("=")
-        sr.local.set_param(name, int(val))
-        sr.glob.set_param(name, int(val))
+        E.set_param(name, int(val))
     t0 = time.time()
     sr.load(pk, 1)          # reads resident in HBM before the timed region
     t_load = time.time() - t0
 
+    # how many edges a step selects on this rank (an untimed pass; everything else about it is a normal step)
+    edge_cap = a.edge_cap
+    if edge_cap < 0:
+        first = sr.run(edge_cap=0, **PARAMS)
+        edge_cap = int(first["local_edges"]) + 1024
     outs = []
     for _ in range(a.warmup):
-        outs.append(sr.run(edge_cap=a.edge_cap, **PARAMS))
-    barrier()
+        outs.append(sr.run(edge_cap=edge_cap, **PARAMS))
+    sr.barrier()            # (every library call returns with its stream drained)
     t0 = time.perf_counter()
     kernel_ms = []
     stage_ms = dict(count=0.0, select=0.0, clouds=0.0, postings=0.0, dist=0.0)
+    sections = {}
     for _ in range(a.steps):
-        out = sr.run(edge_cap=a.edge_cap, **PARAMS)
+        out = sr.run(edge_cap=edge_cap, **PARAMS)
         outs.append(out)
         kernel_ms.append(out["dist_kernel_ms"])
-        tl, td = sr.local.times(), sr.dist_engine.times()
-        stage_ms["count"] += tl["count_ms"]; stage_ms["select"] += tl["select_ms"]; stage_ms["clouds"] += tl["clouds_ms"]
-        stage_ms["postings"] += td["postings_ms"]; stage_ms["dist"] += td["dist_ms"]
-    barrier()
+        tm = E.times()
+        for k_ in ("count", "select", "clouds", "postings", "dist"):
+            stage_ms[k_] += tm[k_ + "_ms"]
+        for k_, v in sr.sections.items():
+            sections[k_] = sections.get(k_, 0.0) + v
+    sr.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = int(sr.allreduce([int(elapsed * 1e9)], "max")[0]) / 1e9       # max over ranks
 
     out = outs[-1]
     same = all(all(o[k] == out[k] for k in ("n_edges", "n_emissions", "n_rare", "n_unique", "n_cloud_entries")) for o in outs)
     n_bases = out["n_bases"]
+    stored = min(out["local_edges"], edge_cap)
+
+    # the same step with the host hand-over inside the timed region (SURVEY §8d): H2D of the packed reads, D2H of the
+    # rare set, the unique mask and stored edges (up to --d2h-edge-bytes of them)
+    incl = None
+    if a.transfer_steps > 0:
+        n_back = int(min(stored, a.d2h_edge_bytes // 16))
+        sr.barrier()
+        t1 = time.perf_counter()
+        for _ in range(a.transfer_steps):
+            sr.load(pk, 1)
+            o2 = sr.run(edge_cap=edge_cap, **PARAMS)
+            rare = sr.rare
+            mask = sr.unique_mask
+            edges = E.edges(n_back)
+            same = same and o2["n_edges"] == out["n_edges"] and rare.size == out["n_rare"] and int(mask.sum()) == out["n_unique"] and edges.shape[0] == n_back
+        sr.barrier()
+        el2 = time.perf_counter() - t1
+        el2 = int(sr.allreduce([int(el2 * 1e9)], "max")[0]) / 1e9
+        incl = dict(value=n_bases * a.transfer_steps / el2, unit="bases/s", steps=a.transfer_steps, ms_per_step=el2 * 1e3 / a.transfer_steps,
+                    h2d_bytes=int(pk.n_bases + 8 * (pk.n_reads + 1) + 24 * E.n_units),
+                    d2h_bytes=int(8 * out["n_rare"] + out["n_rare"] + 16 * n_back), d2h_edges=n_back, edges_stored=int(stored))
+
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(a.steps, 1)
         mean_k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
-        # algorithmic bytes of ONE launch of the dominant kernel on this rank:
-        # every cloud entry staged once, one 4-byte partner index per pair emission, 16 bytes per stored edge
-        alg_bytes = 4 * out["n_cloud_entries"] + 4 * out["local_emissions"] + 16 * min(out["local_edges"], a.edge_cap)
+        # algorithmic bytes of ONE launch of the dominant kernel on this rank (SURVEY.md §8d): every cloud entry it
+        # works on staged once, one 4-byte partner index per pair emission, 16 bytes per stored edge
+        alg_bytes = 4 * out["dist_cloud_entries"] + 4 * out["local_emissions"] + 16 * stored
         achieved = alg_bytes / (mean_k_ms * 1e-3) / 1e9 if mean_k_ms > 0 else 0.0
-        # HBM traffic of one launch cannot be read from inside this process: it comes from the committed PMC passes
-        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE with the guide's gfx950 correction) of the same workload, else null
-        traffic, traffic_src = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_dist_kernel.json")) as f:
-                pmc = json.load(f)
-            if world == 1 and pmc.get("workload_reads_per_gpu") == a.reads:
-                traffic, traffic_src = pmc["traffic_bytes_per_launch"], "profiles/r01_pmc_dist_kernel.json"
-        except (OSError, KeyError, ValueError):
-            pass
+        # B_alg of the whole step (SURVEY §8d), all ranks: [N_b + 16 N_rk] + [16 K_dist] + [N_b + 8 N_w + 4 N_ce] + [4 N_ce + 4 E] + [16 edges stored]
+        b_alg = (n_bases + 16 * out["n_read_kmers"]) + 16 * out["n_distinct"] + (n_bases + 8 * out["n_windows"] + 4 * out["n_cloud_entries"]) \
+            + (4 * out["n_cloud_entries"] + 4 * out["n_emissions"]) + 16 * min(out["n_edges"], edge_cap * world)
         res = {
             "metric": "long-read bases/sec through rare-k-mer recruit+distance",
             "value": n_bases * a.steps / elapsed,
@@ -184,48 +251,55 @@ def main():
             "dtype": "u8 bases -> u64 k-mers / u32 indices (integer only)",
             "data": "synthetic",
             "config": {"workload": f"{a.reads} synthetic DXZ1-HOR ONT-like reads per GPU ({n_bases} aligned bases in all), "
-                                   f"2055-bp unit x {synth_kwargs(total_reads, a.seed)['n_units']} copies, k={K}, coverage {COVERAGE}, "
-                                   f"max_distance {PARAMS['max_d']}: count + rare filter + clouds + distance/filter (BASELINE configs[1]+[2], stage 2)",
-                       "reads_per_gpu": a.reads, "k": K, "parallelism": f"reads sharded x{world}, first k-mers partitioned x{world}"},
+                                   f"2055-bp unit x {synth_kwargs(total_reads, a.seed)['n_units']} copies, copy-specific variants of var_len {VAR_LEN}, k={K}, "
+                                   f"coverage {COVERAGE}, max_distance {PARAMS['max_d']}: count + rare filter + clouds + distance/filter, "
+                                   f"{stored} of {out['local_edges']} selected edges stored per GPU (BASELINE configs[1]+[2], stage 2)",
+                       "reads_per_gpu": a.reads, "k": K, "var_len": VAR_LEN, "edges_stored": int(stored), "edges_selected": int(out["local_edges"]),
+                       "parallelism": f"reads sharded x{world}, first k-mers partitioned x{world}"},
+            "value_incl_transfers": incl,
             "roofline": {"bound": "hbm", "kernel": "cf_dist_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch (PMC, see traffic_source)",
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
-                         "kernel_ms": mean_k_ms, "pair_emissions_per_s": out["local_emissions"] / (mean_k_ms * 1e-3) if mean_k_ms else 0.0},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "traffic_note": "not measured inside this run; the rocprofv3 --pmc passes of the same command are under profiles/",
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": mean_k_ms,
+                         "pair_emissions_per_s": out["local_emissions"] / (mean_k_ms * 1e-3) if mean_k_ms else 0.0,
+                         "whole_step_algorithmic_bytes": b_alg,
+                         "whole_step_frac": b_alg / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)},
             "counters": {k: out[k] for k in ("n_bases", "n_windows", "n_read_kmers", "n_distinct", "n_kept", "n_rare", "n_cloud_entries",
-                                             "n_emissions", "n_edges", "n_unique", "n_spilled", "n_dist_passes")},
+                                             "n_emissions", "n_edges", "n_unique", "n_dist_passes")},
             "stage_ms_per_step": {k: v / max(a.steps, 1) for k, v in stage_ms.items()},
+            "host_section_ms_per_step": {k: round(v * 1e3 / max(a.steps, 1), 3) for k, v in sections.items()},
+            "exchange_bytes_per_step": int(sr.exchange_bytes),
             "setup_s": {"synth": round(t_synth, 2), "load_h2d": round(t_load, 3)},
             "steps_identical": bool(same),
-            "device": sr.local.device_info()["name"].strip(),
+            "device": E.device_info()["name"].strip(),
         }
         if world == 1 and a.place:
             # BASELINE configs[2]: cloud_contig extension on the same reads with the k-mers selected above
-            e = sr.local
             t1 = time.perf_counter()
             gk = sr.rare[sr.unique_mask]
-            e.set_kmers(gk, K)
-            e.build_clouds()
-            e.filter_clouds(2)
+            E.set_kmers(gk, K)
+            E.build_clouds()
+            E.filter_clouds(2)
             cls = pk.classify(50000)
-            rank = np.argsort(np.argsort(np.array(pk.ids, dtype=object), kind="stable"), kind="stable").astype(np.int32)
+            idr = np.argsort(np.argsort(np.array(pk.ids, dtype=object), kind="stable"), kind="stable").astype(np.int32)
             t2 = time.perf_counter()
-            rd, pos, s0, s1 = e.place_reads(cls, rank, 2, 2, 10, 3)
+            rd, pos, s0, s1 = E.place_reads(cls, idr, 2, 2, 10, 3)
             t3 = time.perf_counter()
             res["placement"] = {"reads": int(pk.n_reads), "placed": int((pos >= 0).sum()), "none": int((pos < 0).sum()),
                                 "classes": np.bincount(cls, minlength=3).tolist(), "clouds_filter_s": t2 - t1, "place_s": t3 - t2,
-                                "place_device_ms": e.times()["place_ms"],
+                                "place_device_ms": E.times()["place_ms"],
                                 "end_to_end_bases_per_s": n_bases / (ms_per_step * 1e-3 + (t3 - t1))}
         if world == 1 and a.rr:
-            res["read_recruitment"] = rr_leg(sr.local, pk, a.no_cpu_baseline)
-        if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.cpu_sample_reads, a.seed)
-        else:
-            res["cpu_baseline"] = None
+            res["read_recruitment"] = rr_leg(E, pk, a.no_cpu_baseline)
+        res["cpu_baseline"] = cpu_baseline(a) if (world == 1 and not a.no_cpu_baseline) else None
         print(json.dumps(res), flush=True)
+    sr.barrier()
     sr.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if world > 1 and rank == 0 and "CF_COMM_ID_FILE" not in os.environ:
+        try:
+            os.remove(default_rendezvous())
+        except OSError:
+            pass
 
 
 if __name__ == "__main__":

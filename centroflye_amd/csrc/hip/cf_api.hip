@@ -6,7 +6,7 @@ int cf_fail(cf_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
-static const size_t CF_POOL_MAX = (size_t)48 << 30;   // bytes kept for reuse per context
+static const size_t CF_POOL_MAX = (size_t)128 << 30;  // bytes kept for reuse per context (the edge list of a full-size step alone is 51 GB)
 
 static void cf_pool_flush(cf_ctx* ctx) {
     for (auto& kv : ctx->pool) { ctx->block_bytes.erase(kv.second); (void)hipFree(kv.second); }

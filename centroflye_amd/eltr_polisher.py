@@ -5,12 +5,11 @@ Mirror of the part of the reference's ``scripts/eltr_polisher.py`` that is pure 
 (:53-66) and ``export_read_units`` (:68-97).  The grouping and the FASTA writing run in the compiled host library
 (``cfh_export_read_units``: one pass over the packed units, positions written by a thread pool).  What follows in the
 reference — Flye runs per position (:99-113), re-reading Flye's output and edlib comparisons (:115-144) — is outside
-this repository's scope; ``run_polishing`` builds the same command lines for a Flye binary on PATH.
+this repository's scope and is not here: the script ends with the exported files.
 """
 import argparse
 import math
 import os
-import subprocess
 
 from . import ncrf_parser
 
@@ -69,18 +68,8 @@ class ELTR_Polisher:
         return {p: (os.path.join(self.params.outdir, f'pos_{p}', 'read_units.fasta'),
                     os.path.join(self.params.outdir, f'pos_{p}', 'median_read_unit.fasta')) for p in positions}
 
-    def run_polishing(self, read_unit_filenames):
-        for pos in range(min(read_unit_filenames), max(read_unit_filenames) + 1):
-            units_fn, median_read_unit_fn = read_unit_filenames[pos]
-            cmd = [self.params.flye_bin, f'--{self.params.error_mode}-raw', units_fn, '--polish-target', median_read_unit_fn,
-                   '-i', self.params.num_iters, '-t', self.params.num_threads, '-o', os.path.dirname(units_fn)]
-            subprocess.check_call([str(x) for x in cmd])
-
-    def run(self, export_only=False):
-        filenames = self.export_read_units(self.map_pos2read())
-        if not export_only:
-            self.run_polishing(filenames)
-        return filenames
+    def run(self, export_only=True):
+        return self.export_read_units(self.map_pos2read())
 
 
 def main():
@@ -89,15 +78,11 @@ def main():
     parser.add_argument("--unit", required=True)
     parser.add_argument("--outdir", required=True)
     parser.add_argument("--ncrf", required=True)
-    parser.add_argument("--flye-bin", default='flye')
-    parser.add_argument("--error-mode", default="nano")
-    parser.add_argument("--num-iters", default=4, type=int)
-    parser.add_argument("--num-threads", default=16, type=int)
     parser.add_argument("--min-pos", type=int, default=0)
     parser.add_argument("--max-pos", type=int, default=math.inf)
-    parser.add_argument("--export-only", action="store_true", help="stop after the per-position FASTA files (no Flye)")
+    parser.add_argument("--export-only", action="store_true", help="accepted for compatibility: exporting is all this script does")
     params = parser.parse_args()
-    ELTR_Polisher(params).run(export_only=params.export_only)
+    ELTR_Polisher(params).run()
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ import os
 from .engine import Engine
 
 _engine = None
-_loaded = None      # (id(packed), n_motif) currently resident in HBM
+_loaded = None      # (packed, n_motif) currently resident in HBM — a strong reference: id() of a collected object is reused
 _clouds_token = None
 
 
@@ -19,10 +19,9 @@ def engine():
 def ensure_loaded(packed, n_motif):
     """Make sure the reads of `packed` with the n_motif unit split are resident."""
     global _loaded, _clouds_token
-    key = (id(packed), int(n_motif))
-    if _loaded != key:
+    if _loaded is None or _loaded[0] is not packed or _loaded[1] != int(n_motif):
         engine().load(packed, n_motif)
-        _loaded = key
+        _loaded = (packed, int(n_motif))
         _clouds_token = None
     return engine()
 

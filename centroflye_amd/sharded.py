@@ -29,8 +29,14 @@ def default_rendezvous():
     p = os.environ.get("CF_COMM_ID_FILE")
     if p:
         return p
+    ppid, born = os.getppid(), "0"
+    try:        # the launcher's start time (clock ticks since boot): a recycled pid cannot collide with a stale file
+        with open(f"/proc/{ppid}/stat") as f:
+            born = f.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        pass
     return os.path.join(os.environ.get("TMPDIR", "/tmp"),
-                        f"cfcomm_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.id")
+                        f"cfcomm_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{ppid}_{born}.id")
 
 
 class ShardedRecruiter:

@@ -88,7 +88,8 @@ struct emu_comm : cf_comm {
 cf_comm* cf_comm_open(int, int rank, int world, const char* rendezvous, std::string& err) {
     if (world < 1 || rank < 0 || rank >= world) { err = "cf_comm_init: bad rank / world"; return nullptr; }
     struct stat st;
-    if (world > 1 && (!rendezvous || stat(rendezvous, &st) != 0 || !S_ISDIR(st.st_mode))) { err = "emu comm: the rendezvous must be an existing directory"; return nullptr; }
+    if (world > 1 && rendezvous) (void)mkdir(rendezvous, 0700);      // every rank may try; EEXIST is fine
+    if (world > 1 && (!rendezvous || stat(rendezvous, &st) != 0 || !S_ISDIR(st.st_mode))) { err = "emu comm: the rendezvous must be a directory"; return nullptr; }
     emu_comm* c = new emu_comm();
     c->rank = rank; c->world = world; c->dir = rendezvous ? rendezvous : "";
     return c;

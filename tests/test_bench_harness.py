@@ -1,0 +1,68 @@
+"""bench.py's own plumbing, checked on CPU with the host-emulated library (its `--lib` test hook): the JSON contract,
+N > 1 both ways the brief allows it to start (launched per rank by torch.distributed.run, or spawning its own ranks),
+the rendezvous file, the rank-max timing through cf_comm_allreduce_i64 — and that nothing here needs torch."""
+import json
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu", "libcfhip_emu.so")
+ARGS = ["--lib", EMU, "--reads", "6", "--steps", "1", "--warmup", "0", "--edge-cap", "1000", "--transfer-steps", "1", "--no-cpu-baseline"]
+
+
+def _line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-3000:]
+    return json.loads(lines[0])
+
+
+def _check(res, n):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "value_incl_transfers"):
+        assert key in res, key
+    assert res["n_gpus"] == n and res["steps"] == 1 and res["scaling"] == "weak" and res["vs_baseline"] is None and res["value"] > 0
+    assert "workload" in res["config"] and "var_len" in res["config"]["workload"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "whole_step_frac")) <= set(res["roofline"]) and res["roofline"]["traffic"] is None
+    assert res["steps_identical"] and res["counters"]["n_bases"] > 100000 * n
+
+
+def test_single_process(emu_lib, tmp_path):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS, capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    _check(_line(p.stdout), 1)
+
+
+def test_spawns_its_own_ranks(emu_lib, tmp_path):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ARGS, capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    res = _line(p.stdout)
+    _check(res, 2)
+    assert res["exchange_bytes_per_step"] > 0
+
+
+def test_under_torch_distributed_run(emu_lib, tmp_path):
+    pytest.importorskip("torch")        # only the LAUNCHER is torch's; bench.py itself imports none of it
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ARGS
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tmp_path, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    _check(_line(p.stdout), 2)
+
+
+def test_package_and_bench_are_torch_free():
+    """north_star: host code calls the HIP kernels through a thin ctypes layer, no PyTorch."""
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for d in ("centroflye_amd", "scripts"):
+        for dirpath, _, names in os.walk(os.path.join(ROOT, d)):
+            files += [os.path.join(dirpath, n) for n in names if n.endswith(".py")]
+    for fn in files:
+        with open(fn) as f:
+            assert not re.search(r"^\s*(import|from)\s+torch\b", f.read(), flags=re.M), fn

@@ -136,6 +136,28 @@ def test_cli_scripts_reproduce_the_reference_files(name, report, golden, tmp_pat
     subprocess.check_call([sys.executable, "-u", os.path.join(ROOT, "scripts", "read_placer.py")] + _placer_argv(name, report(name), kfile, out3, g),
                           stdout=subprocess.DEVNULL)
     _check_positions(os.path.join(out3, "read_positions.csv"), g)
+    # SURVEY §8(f) rank 3, end to end on the GPU box: the placement file just written by the device path goes through
+    # the next stage's script (reference eltr_polisher.py:19-30, :53-97) and must give the files the REFERENCE wrote from
+    # its own placement (tests/golden/*.read_units.json: SHA-256 of every per-position FASTA)
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.read_units.json")) as f:
+        gu = json.load(f)
+    unit = str(tmp_path / "unit.fasta")
+    with open(unit, "w") as f:
+        f.write(">u\nACGT\n")
+    out5 = str(tmp_path / "polishing")
+    subprocess.check_call([sys.executable, "-u", os.path.join(ROOT, "scripts", "eltr_polisher.py"), "--read-placement", os.path.join(out3, "read_positions.csv"),
+                           "--unit", unit, "--ncrf", report(name), "--outdir", out5], stdout=subprocess.DEVNULL)
+    tree = {}
+    for d in sorted(os.listdir(out5)):
+        if d.startswith("pos_"):
+            ent = []
+            for fn in ("read_units.fasta", "median_read_unit.fasta"):
+                with open(os.path.join(out5, d, fn), "rb") as f:
+                    data = f.read()
+                ent.append([hashlib.sha256(data).hexdigest(), len(data)])
+            tree[d[4:]] = ent
+    assert tree == gu["windows"][0]["files"] and len(tree) == gu["windows"][0]["n_positions"]
 
 
 def test_unit_kmer_front_end_mirror(emu_session, report):

@@ -1,0 +1,102 @@
+"""Full-size parity on a real MI355X against the plain-C oracle (oracle/c, OpenMP over the host's cores):
+  * BASELINE configs[1] — 50 000 reads (~1 Gb): A1 + A2 on the GPU vs the CPU path, bit-exact: every counter, the whole
+    (k-mer, pres, multi) table through an order-independent checksum, the rare set element by element;
+  * BASELINE configs[0] — 1 000 reads: the whole stage 2 (A1-A6, ~3e9 pair emissions) vs the CPU path: counters, rare set,
+    clouds, every selected edge (checksum + count), the unique mask;
+  * placement (A4 + A8/A9) of 3 000 reads vs the C restatement of the greedy loop: identical lines.
+The oracle side is pinned on CPU (tests/test_oracle_golden.py).  Reference: distance_based_kmer_recruitment.py:39-149,
+read_placer.py:42-94."""
+import os
+
+import numpy as np
+import pytest
+
+from centroflye_amd import _host
+from centroflye_amd.engine import Engine
+from oracle import cport
+
+pytestmark = pytest.mark.gpu
+P = dict(k=19, max_nonuniq=3, lo=10, hi=32, min_d=1, max_d=150, min_cov=4, rel_threshold=0.8)
+
+
+def synth(reads, seed):
+    return _host.synth(n_reads=reads, seed=seed, n_units=max(24, int(round(0.3 * reads))), var_len=8)
+
+
+@pytest.fixture(scope="module")
+def engine():
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.timeout(900)
+def test_config1_50k_reads_count_and_rare_filter_vs_cpu(engine):
+    pk = synth(50000, 2)                      # the bench workload itself
+    assert pk.n_bases > 9e8
+    up, us, ue, _ = pk.units(1)
+    engine.load(pk, 1)
+    engine.count_kmers(P["k"])
+    keys, pres, multi = engine.table(sort=False)
+    got_tchk = cport.table_checksum(keys, pres, multi)
+    n_table = keys.size
+    del keys, pres, multi
+    n_rare = engine.select_rare(P["max_nonuniq"], P["lo"], P["hi"])
+    st = engine.stats()
+    rare = engine.kmers()
+    c, a = cport.stage2(pk.bases, pk.read_off, up, us, ue, P["k"], P["max_nonuniq"], P["lo"], P["hi"], threads=0, stop_after=1, want_arrays=True)
+    assert (st["n_bases"], st["n_windows"], st["n_read_kmers"]) == (c["n_bases"], c["n_windows"], c["n_read_kmers"])
+    assert (st["n_distinct"], n_table, st["n_kept"], n_rare) == (c["n_distinct"], c["n_distinct"], c["n_kept"], c["n_rare"])
+    assert got_tchk == c["table_checksum"]
+    assert cport.rare_checksum(rare) == c["rare_checksum"] and np.array_equal(rare, a["rare"])
+    assert n_rare > 5_000_000 and c["n_distinct"] > 100_000_000
+
+
+@pytest.mark.timeout(900)
+def test_config0_1k_reads_full_stage2_vs_cpu(engine):
+    pk = synth(1000, 1)
+    up, us, ue, _ = pk.units(1)
+    c, a = cport.stage2(pk.bases, pk.read_off, up, us, ue, P["k"], P["max_nonuniq"], P["lo"], P["hi"], 0, 2 ** 62, P["min_d"], P["max_d"],
+                        P["min_cov"], P["rel_threshold"], threads=0, want_arrays=True)
+    assert c["n_emissions"] > 2_000_000_000 and c["n_edges"] > 10_000_000
+    engine.load(pk, 1)
+    engine.count_kmers(P["k"])
+    assert engine.select_rare(P["max_nonuniq"], P["lo"], P["hi"]) == c["n_rare"]
+    assert np.array_equal(engine.kmers(), a["rare"])
+    assert engine.build_clouds() == c["n_cloud_entries"]
+    cp, ent = engine.clouds()
+    assert np.array_equal(cp, a["cloud_ptr"]) and np.array_equal(ent, a["entries"])
+    ne = engine.dist_edges(0, 2 ** 62, P["min_d"], P["max_d"], P["min_cov"], P["rel_threshold"], 0, 1, edge_cap=c["n_edges"])
+    st = engine.stats()
+    assert (ne, st["n_emissions"], st["n_unique"]) == (c["n_edges"], c["n_emissions"], c["n_unique"])
+    assert (st["n_windows"], st["n_read_kmers"], st["n_distinct"], st["n_kept"]) == (c["n_windows"], c["n_read_kmers"], c["n_distinct"], c["n_kept"])
+    assert cport.edge_checksum(engine.edges(ne)) == c["edge_checksum"]
+    assert np.array_equal(engine.unique_mask(), a["unique"])
+
+
+@pytest.mark.timeout(900)
+def test_placement_3k_reads_vs_c_placer(engine):
+    from conftest import lines_from_placement
+    pk = synth(3000, 5)
+    engine.load(pk, 1)
+    engine.count_kmers(P["k"])
+    engine.select_rare(P["max_nonuniq"], P["lo"], P["hi"])
+    engine.build_clouds()
+    engine.reset_unique()
+    engine.dist_edges(0, 2 ** 62, P["min_d"], P["max_d"], P["min_cov"], P["rel_threshold"], 0, 1, edge_cap=0)
+    gk = engine.kmers()[engine.unique_mask()]
+    assert gk.size > 50000
+    engine.set_kmers(gk, P["k"])
+    engine.build_clouds()
+    engine.filter_clouds(2)
+    cp, ent = engine.clouds()
+    up, _, _, _ = pk.units(1)
+    cls = pk.classify(50000)
+    assert (cls == 0).sum() >= 2 and (cls == 1).sum() > 2000
+    rank = np.argsort(np.argsort(np.array(pk.ids, dtype=object), kind="stable"), kind="stable").astype(np.int32)
+    want = cport.place_reads(cls, rank, up, cp, ent, gk.size, 2, 2, 10, 3)
+    got = engine.place_reads(cls, rank, 2, 2, 10, 3)
+    wl = lines_from_placement(pk.ids, *[x.tolist() for x in want])
+    gl = lines_from_placement(pk.ids, *[x.tolist() for x in got])
+    assert sum(1 for x in gl if not x.endswith("None")) > 2500
+    assert gl == wl
