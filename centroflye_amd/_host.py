@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libcfhost.so")
+_LIB_PATH = os.environ.get("CF_HOST_LIB") or os.path.join(_HERE, "libcfhost.so")     # CF_HOST_LIB: the sanitizer build (tests)
 
 
 class SynthParams(C.Structure):

@@ -261,8 +261,9 @@ int cf_set_clouds(cf_ctx* ctx, const int64_t* cloud_ptr, const int32_t* entries,
 
 int cf_get_edges(cf_ctx* ctx, uint32_t* out, int64_t cap) {
     if (!ctx) return -22;
-    if (cap < ctx->n_edges_stored) return cf_fail(ctx, -22, "cf_get_edges: buffer too small");
-    if (ctx->n_edges_stored) CF_HIP(hipMemcpy(out, ctx->d_edges, (size_t)ctx->n_edges_stored * 16, hipMemcpyDefault));
+    const int64_t n = std::min(cap, ctx->n_edges_stored);      // the first min(cap, stored) edges
+    if (n < 0 || (n && !out)) return cf_fail(ctx, -22, "cf_get_edges: bad buffer");
+    if (n) CF_HIP(hipMemcpy(out, ctx->d_edges, (size_t)n * 16, hipMemcpyDefault));
     return 0;
 }
 

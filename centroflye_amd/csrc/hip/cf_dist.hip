@@ -447,7 +447,22 @@ __device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0,
 // 16-byte load in the narrow layout).  Software pipeline: the global load of step i+1 is issued before the body of
 // step i runs; what a load returns is only touched one step later (ig travels in an SGPR, validity in a bit mask).
 // body(bb, dd) gets the decoded entries of a step (bb[u] == a: nothing to count) and returns true to stop the wave.
-template <class Tab, class Body>
+// Item hand-out of the two sweeps: 0 = dealt round robin to the waves (default), 1 = pulled from a shared LDS cursor
+// (round 1).  Measured at 50 000 reads (profiles/r02_dist_ab.log): cursor in both sweeps 480.8 ms, round robin in the sketch
+// sweep only 472.2, in the table sweep only 476.9, in both 465.5.  Other round-2 experiments on this kernel that LOST and
+// are not in the source (same log): byte counters on hash(b) alone with fire-and-forget ds_add and a counter bitmap made
+// by a pass over the counters (sketch sweep 186 -> 127 G cycles, but the pass costs 69 and the table sweep grows: 504 ms);
+// the next first k-mer's partner ranges fetched during filter/write, edge data and unique words read before the edge
+// range is reserved (465.8 / 469.6 ms: those latencies already hide behind the CU's second workgroup; anything that adds
+// live registers spills — the kernel sits at 125 of the 128 VGPRs that four waves per SIMD allow, and 16 more bytes of
+// LDS take the table below the 64 KiB its 65 536 sketch counters need).
+#ifndef CF_DIST_DYN_A
+#define CF_DIST_DYN_A 0
+#endif
+#ifndef CF_DIST_DYN_B
+#define CF_DIST_DYN_B 0
+#endif
+template <class Tab, bool Dyn, class Body>
 __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, uint32_t a, const cf_dist_rec* rec, const uint32_t* ipx, uint32_t* cursor, int np, Body&& body) {
     const int lane = threadIdx.x & 63;
     const uint32_t n_items = ipx[4 + np - 1];
@@ -471,7 +486,8 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, uint32_t a,
         }                                                                                                     \
         Tab::load_run(A, r.e0 + (int64_t)off, nok, nx_);                                                      \
     }
-#define CF_DIST_GRAB(VAR) { uint32_t g_ = 0; if (lane == 0) g_ = atomicAdd(cursor, 1u); VAR = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_); }
+#define CF_DIST_GRAB(VAR) { if (Dyn) { uint32_t g_ = 0; if (lane == 0) g_ = atomicAdd(cursor, 1u); VAR = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_); } else { VAR = nxt_static; nxt_static += (uint32_t)(blockDim.x >> 6); } }
+    uint32_t nxt_static = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t i0, i1;
     CF_DIST_GRAB(i0)
     if (i0 < n_items) CF_DIST_FETCH(i0)
@@ -596,7 +612,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                 if (!one_chunk) cf_dist_setup(A, c0, np, rec, ipx, sh);
                 if (t == 0) sh[11] = 0;
                 __syncthreads();
-                cf_dist_sweep<Tab>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
+                cf_dist_sweep<Tab, CF_DIST_DYN_A != 0>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
                     uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {     // all counter adds of the step back to back
@@ -674,7 +690,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     __builtin_amdgcn_wave_barrier();                                                          \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                 }
-                cf_dist_sweep<Tab>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
+                cf_dist_sweep<Tab, CF_DIST_DYN_B != 0>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
                     if (sh[0] > A.fill_limit) return true;     // too full (or physically full): the pass will be split
                     uint32_t w_[DIST_UNROLL], hbit_[DIST_UNROLL], live = 0, cand = 0;
 #pragma unroll

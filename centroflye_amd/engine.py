@@ -245,6 +245,7 @@ class Engine:
         return n.value
 
     def edges(self, n):
+        """The first n stored edges as (n, 4) uint32 rows (d, a, b, cnt)."""
         out = np.zeros((n, 4), np.uint32)
         self._check(self._lib.cf_get_edges(self._ctx, _ptr(out), n), "cf_get_edges")
         return out

@@ -114,7 +114,7 @@ int cf_set_clouds(cf_ctx* ctx, const int64_t* cloud_ptr, const int32_t* entries,
 int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int32_t max_d,
                   uint32_t min_cov, double rel_threshold, int32_t part, int32_t n_parts,
                   int64_t edge_cap, int64_t* n_edges);
-int cf_get_edges(cf_ctx* ctx, uint32_t* out /* n x 4: d, a, b, cnt */, int64_t cap);
+int cf_get_edges(cf_ctx* ctx, uint32_t* out /* n x 4: d, a, b, cnt */, int64_t cap);   /* the first min(cap, stored) edges */
 int cf_get_unique_mask(cf_ctx* ctx, uint8_t* mask /* n_kmers bytes of 0/1 */);
 int cf_or_unique_mask(cf_ctx* ctx, const uint8_t* mask);
 int cf_reset_unique(cf_ctx* ctx);
