@@ -67,7 +67,7 @@ static void free_units(cf_ctx* c) {
 }
 void cf_free_table(cf_ctx* c) {
     if (c->d_table) { cf_release(c, c->d_table, (size_t)c->table_alloc * sizeof(cf_slot)); c->d_table = nullptr; }
-    c->table_cap = 0; c->table_alloc = 0;
+    c->table_cap = 0; c->table_alloc = 0; c->table_dense = false;
 }
 void cf_free_kmers(cf_ctx* c) {
     cf_release_t(c, c->d_kmers, (size_t)c->n_kmers);
@@ -307,6 +307,11 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "dist_stage") {
         if (value < 0 || value > 2048) return cf_fail(ctx, -22, "dist_stage out of range (0 .. 2048)");
         ctx->dist_stage = (int)value;
+    } else if (n == "count_mode") {
+        ctx->count_mode = value != 0;
+    } else if (n == "count_bits") {
+        if (value < 0 || value > 27) return cf_fail(ctx, -22, "count_bits out of range (0 = auto, 1 .. 27)");
+        ctx->count_bits = (int)value;
     } else if (n == "count_slots") {
         if (value < 256 || (value & (value - 1)) || value * 8 > 128 * 1024) return cf_fail(ctx, -22, "count_slots must be a power of two in [256, 16384]");
         ctx->count_slots = (int)value;

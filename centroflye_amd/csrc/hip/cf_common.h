@@ -76,6 +76,7 @@ struct cf_ctx {
     cf_slot* d_table = nullptr;
     uint64_t table_cap = 0;      // slots in use (a power of two)
     uint64_t table_alloc = 0;    // slots allocated (>= table_cap: a smaller table reuses a larger allocation)
+    bool table_dense = false;    // the table is a dense array of table_cap occupied slots (cf_count2.hip): scan it, do not probe it
     int k = 0;
 
     // k-mer set + lookup table
@@ -123,6 +124,8 @@ struct cf_ctx {
     int dist_sketch = 1;     // 0: every (b,d) pair goes to the exact table (no counting sketch first)
     int dist_est_pct = 80;   // expected distinct (b,d) keys per 100 pair emissions: sizes the initial number of table partitions
     int dist_stage = 2048;   // selected edges staged in LDS per table pass (0 forces the table sweep)
+    int count_mode = 1;          // 1: sort and reduce (cf_count2.hip) when it applies; 0: the atomic table of round 1 (cf_count.hip)
+    int count_bits = 0;          // bucket bits of the sort-and-reduce path; 0 = from the number of windows (tests force small / large values)
     int count_slots = 4096;
     int count_tile = 16;
 };

@@ -335,7 +335,10 @@ static int table_compact(cf_ctx* ctx, uint32_t max_nonuniq, uint32_t lo, uint32_
     return rc;
 }
 
+int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, int64_t n_w);   // cf_count2.hip
+
 int cf_table_ensure(cf_ctx* ctx, uint64_t want_cap) {
+    ctx->table_dense = false;
     // a table no larger than the current allocation uses a prefix of it (steps of the sharded path alternate between
     // the local count table and the merged table of owned keys: no 10-GB free + malloc per step)
     if (ctx->d_table && want_cap <= ctx->table_alloc) { ctx->table_cap = want_cap; return 0; }
@@ -366,6 +369,10 @@ static int count_impl(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, 
     if (2 * k < 62 && cap > (2ull << (2 * k))) cap = cf_pow2_ceil(2ull << (2 * k));
     ctx->k = k;
     ctx->stats.n_windows = n_w;
+    if (mode == 0 && ctx->count_mode) {      // A1 by sort and reduce; 1 = does not apply here (long k, too many reads, a crowded bucket)
+        const int rc2 = cf_count_sorted(ctx, k, read_lo, read_hi, n_w);
+        if (rc2 <= 0) return rc2;
+    }
     const int slots = ctx->count_slots;
     int shrink = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {
@@ -556,6 +563,7 @@ int cf_get_table(cf_ctx* ctx, uint64_t* keys, uint32_t* pres, uint32_t* multi, i
 int cf_merge_table(cf_ctx* ctx, const uint64_t* keys, const uint32_t* pres, const uint32_t* multi, int64_t n) {
     if (!ctx) return -22;
     if (!ctx->d_table) return cf_fail(ctx, -22, "cf_merge_table: no table (call cf_count_kmers first)");
+    if (ctx->table_dense) return cf_fail(ctx, -22, "cf_merge_table: the table of cf_count_kmers is a dense array (call cf_reset_table first)");
     if (n <= 0) return 0;
     CF_HIP(hipSetDevice(ctx->device));
     unsigned long long* d_keys = nullptr; uint32_t *d_pres = nullptr, *d_multi = nullptr; unsigned int* d_flags = nullptr;

@@ -1,0 +1,649 @@
+// cf_count2.hip — A1 without a single global atomic per k-mer: sort and reduce.
+//
+// Reference: scripts/distance_based_kmer_recruitment.py:39-63 (closed form: pres[x] = #reads containing x,
+// multi[x] = #reads where x occurs >= 2x; see cf_count.hip).
+//
+// Round 1 built the presence table with one 64-bit CAS + one 64-bit add per distinct (read, k-mer) into a 16 GiB open
+// addressed table: 8e8 x 2 device-scope atomics on random lines run at ~2e10 per second whatever their locality
+// (DESIGN §3.1), i.e. 80 ms per Gbase at 2 % of the HBM roofline.  Here nothing is updated in place:
+//   1. every window becomes ONE 8-byte record [k-mer : 2k | read : RB]                       (no per-read work yet)
+//   2. the records are partitioned by a hash of the k-mer with stable LSD radix passes (<= 9 bits each; the first pass
+//      makes its records straight from the bases), so all records of a k-mer end up in one bucket, in read order
+//   3. one streaming pass reduces every bucket in LDS: a tile of records goes through a (k-mer, read) set, which tells
+//      first and repeated occurrences inside the tile; a per-bucket table keyed by k-mer carries pres, multi and the last
+//      read seen (records of one k-mer arrive in read order), so a read that spans tiles is not counted twice
+//   4. the result is a DENSE array of table slots {key | OCC, pres | multi << 32}: every consumer that scans the table
+//      (A2 select, cf_get_table, the multi-GPU bucketing) reads it like a table without holes.
+// All traffic is streamed: N_b x 2 + 8 N_w x 5 + 16 K_dist bytes (~45 GB per Gbase).  Needs 2k + bits(reads) <= 64 and
+// reads < 2^27; otherwise (and for the occurrence counts of cf_count_occurrences) the table path of cf_count.hip runs.
+#include "cf_common.h"
+
+void cf_free_table(cf_ctx* c);
+
+#define C2_THREADS 256
+#define C2_ITEMS 16                         /* windows (pass 1) / records (later passes) per thread and tile */
+#define C2_TILE (C2_THREADS * C2_ITEMS)
+#define C2_MAXBITS 9                        /* radix bits per pass */
+#define C2_RTHREADS 512                     /* threads of a reduce workgroup */
+#define C2_RTILE 2048                       /* records per reduce tile */
+#define C2_SET 4096                         /* (k-mer, read) set slots: twice the tile */
+#define C2_TAB 2048                         /* k-mers per bucket table */
+#define C2_DUP (1ull << 63)
+
+struct cf_c2_tile { int32_t read; int32_t chunk; };      // pass-1 tile: windows [chunk * C2_TILE, ...) of a read
+
+// Hashes of this file: ONE 32-bit multiply each (a 64-bit mixer is two 64 x 64 multiplies = eight quarter-rate 32-bit
+// ones, and the reduce evaluates three hashes per record).  A k-mer is folded to 32 bits first; the bucket takes the top
+// `bits` (<= 27) bits of the product, the two LDS tables use other multipliers.
+__device__ __forceinline__ uint32_t cf_c2_fold(unsigned long long x) { const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32); return lo ^ (hi * 0x85EBCA6Bu) ^ (hi >> 7); }
+__device__ __forceinline__ uint32_t cf_c2_bucket(unsigned long long kmer, int bits) { uint32_t h = cf_c2_fold(kmer); h ^= h >> 15; h *= 0x9E3779B1u; h ^= h >> 13; h *= 0xC2B2AE35u; return h >> (32 - bits); }
+__device__ __forceinline__ uint32_t cf_c2_hash_set(unsigned long long rec) { uint32_t h = cf_c2_fold(rec); h ^= h >> 16; h *= 0x7FEB352Du; return h ^ (h >> 15); }
+__device__ __forceinline__ uint32_t cf_c2_hash_tab(unsigned long long kmer) { uint32_t h = cf_c2_fold(kmer); h ^= h >> 14; h *= 0x846CA68Bu; return h ^ (h >> 16); }
+
+// ---- stable ranking of one round (one record per thread) by digit, as in cf_radix_scatter (cf_prims.hip)
+struct cf_c2_rank { uint32_t rank, count; };
+template <int NB>
+__device__ __forceinline__ cf_c2_rank cf_c2_wave_rank(uint32_t digit, bool valid, int lane) {
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int bit = (digit >> b) & 1;
+        const unsigned long long m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return cf_c2_rank{(uint32_t)__popcll(peers & ((1ull << lane) - 1ull)), (uint32_t)__popcll(peers)};
+}
+
+// windows of a pass-1 tile -> records, 16 consecutive windows per thread (rolled); calls f(j, record, valid) for j < 16
+template <class F>
+__device__ __forceinline__ void cf_c2_tile_records(const uint8_t* __restrict__ bases, const int64_t* __restrict__ read_off, cf_c2_tile tl, int k, int rb,
+                                                   uint8_t* stage, F&& f) {
+    const int t = threadIdx.x;
+    const int64_t r0 = read_off[tl.read], r1 = read_off[tl.read + 1];
+    const int64_t n_win = r1 - r0 - k + 1, w0 = (int64_t)tl.chunk * C2_TILE;
+    const int64_t nb = min((int64_t)C2_TILE + k - 1, r1 - r0 - w0);
+    for (int64_t i = t; i < nb; i += C2_THREADS) stage[i] = bases[r0 + w0 + i];
+    __syncthreads();
+    const unsigned long long kmask = (1ull << (2 * k)) - 1ull;
+    const int64_t my0 = (int64_t)t * C2_ITEMS;
+    const int64_t my_n = min((int64_t)C2_ITEMS, n_win - w0 - my0);
+    // the thread's 16 + k - 1 <= 46 bases: three 16-byte LDS reads (lane stride 16 bytes: conflict free; byte reads at that
+    // stride are 8-way bank conflicts), 2-bit codes packed into 92 bits (first base highest), a window = a 128-bit shift
+    struct alignas(16) q4 { uint32_t x, y, z, w; };
+    const q4 qa = *(const q4*)(stage + my0), qb = *(const q4*)(stage + my0 + 16), qc = *(const q4*)(stage + my0 + 32);
+    const uint32_t w32[12] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w};
+    unsigned long long hi = 0, lo = 0;      // codes of bases 0 .. 13 in hi (28 bits), 14 .. 45 in lo (64 bits)
+#pragma unroll
+    for (int i = 0; i < 46; ++i) {
+        const unsigned long long c = cf_base2((w32[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+        if (i < 14) hi |= c << (2 * (13 - i)); else lo |= c << (2 * (45 - i));
+    }
+#pragma unroll
+    for (int j = 0; j < C2_ITEMS; ++j) {
+        const bool valid = j < my_n;
+        const int s2 = 2 * (46 - j - k);                 // bits to drop behind the window [j, j + k): 0 .. 90
+        unsigned long long code = s2 >= 64 ? hi >> (s2 - 64) : (s2 ? (lo >> s2) | (hi << (64 - s2)) : lo);
+        code &= kmask;
+        f(j, (code << rb) | (unsigned long long)(uint32_t)tl.read, valid);
+    }
+}
+
+// pass 1, histogram: digit counts of every tile -> hist[digit * n_tiles + tile]
+__global__ void __launch_bounds__(C2_THREADS)
+cf_c2_hist1_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ read_off, const cf_c2_tile* __restrict__ tiles, int n_tiles,
+                   int k, int rb, int bits, int shift, int nb, uint32_t* __restrict__ hist) {
+    uint32_t* h = (uint32_t*)cf_lds;                          // 1 << nb counters
+    uint8_t* stage = cf_lds + ((((size_t)4 << nb) + 15) & ~(size_t)15);
+    const uint32_t mask = (1u << nb) - 1u;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        for (int d = threadIdx.x; d < (1 << nb); d += C2_THREADS) h[d] = 0;
+        __syncthreads();
+        cf_c2_tile_records(bases, read_off, tiles[tile], k, rb, stage, [&](int, unsigned long long rec, bool valid) {
+            if (valid) atomicAdd(&h[(cf_c2_bucket(rec >> rb, bits) >> shift) & mask], 1u);
+        });
+        __syncthreads();
+        for (int d = threadIdx.x; d < (1 << nb); d += C2_THREADS) hist[(int64_t)d * n_tiles + tile] = h[d];
+        __syncthreads();
+    }
+}
+
+// Stable scatter of one tile.  The tile's order is wave-major: wave w holds the records [w * 64 * C2_ITEMS, ...) of the
+// tile, C2_ITEMS rounds of 64.  A wave ranks its own records by itself — per round a ballot match per digit bit, across
+// rounds a running count per digit in the wave's private LDS row — so the workgroup meets only twice per tile: to turn
+// the rows into exclusive offsets across waves, and before the rows are reused.
+//   rank_[j]  rank of the thread's j-th record among the records of its wave with the same digit (filled by cf_c2_rank_round)
+template <int NB>
+__device__ __forceinline__ uint32_t cf_c2_rank_round(uint32_t digit, bool valid, uint32_t* wrow) {     // wrow: this wave's 1 << NB counters
+    const int lane = threadIdx.x & 63;
+    const cf_c2_rank rk = cf_c2_wave_rank<NB>(digit, valid, lane);
+    uint32_t before = 0;
+    if (valid) before = wrow[digit];                       // records of earlier rounds (only this wave writes the row; LDS ops of a wave are in order)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rk.rank == 0) wrow[digit] = before + rk.count;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return before + rk.rank;
+}
+// after all rounds: wcount rows -> exclusive prefix over the waves (in place), dstart[d] = first position of digit d in
+// the tile sorted by digit (exclusive scan of the tile's digit counts; 1 << NB <= 2 * C2_THREADS)
+template <int NB>
+__device__ __forceinline__ void cf_c2_tile_bases(uint32_t* dstart, uint32_t* wcount, uint32_t* scan_tmp) {
+    __syncthreads();
+    const int t = threadIdx.x;
+    uint32_t tot[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int d = 2 * t + h;
+        if (d < (1 << NB)) {
+            uint32_t s = 0;
+            for (int w = 0; w < C2_THREADS / 64; ++w) { const uint32_t c = wcount[w * (1 << NB) + d]; wcount[w * (1 << NB) + d] = s; s += c; }
+            tot[h] = s;
+        }
+    }
+    // exclusive scan of tot over the threads (2 digits each)
+    const int lane = t & 63, wave = t >> 6;
+    uint32_t inc = tot[0] + tot[1];
+    const uint32_t mine = inc;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
+    if (lane == 63) scan_tmp[wave] = inc;
+    __syncthreads();
+    uint32_t off = inc - mine;
+    for (int w = 0; w < wave; ++w) off += scan_tmp[w];
+    if (2 * t < (1 << NB)) dstart[2 * t] = off;
+    if (2 * t + 1 < (1 << NB)) dstart[2 * t + 1] = off + tot[0];
+    __syncthreads();
+}
+// records staged in digit order -> global: consecutive threads write consecutive addresses inside a digit's run
+template <int NB>
+__device__ __forceinline__ void cf_c2_copy_out(const unsigned long long* stage_recs, uint32_t n_tile, const uint32_t* dstart, const int64_t* gbase,
+                                               int rb, int bits, int shift, unsigned long long* __restrict__ out) {
+    const uint32_t mask = (1u << NB) - 1u;
+    for (uint32_t i = threadIdx.x; i < n_tile; i += C2_THREADS) {
+        const unsigned long long rec = stage_recs[i];
+        const uint32_t d = (cf_c2_bucket(rec >> rb, bits) >> shift) & mask;
+        out[gbase[d] + (int64_t)(i - dstart[d])] = rec;
+    }
+}
+
+// pass 1, scatter: offs = exclusive scan of hist
+// LDS of a scatter workgroup: gbase int64[D] | wcount u32[waves][D] | dstart u32[D] | scan_tmp u32[8] | staged records u64[C2_TILE] | (pass 1) bases
+template <int NB>
+__global__ void __launch_bounds__(C2_THREADS)
+cf_c2_scatter1_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ read_off, const cf_c2_tile* __restrict__ tiles, int n_tiles,
+                      int k, int rb, int bits, int shift, const int64_t* __restrict__ offs, unsigned long long* __restrict__ out) {
+    constexpr int D = 1 << NB;
+    int64_t* gbase = (int64_t*)cf_lds;
+    uint32_t* wcount = (uint32_t*)(gbase + D);
+    uint32_t* dstart = wcount + (C2_THREADS / 64) * D;
+    uint32_t* scan_tmp = dstart + D;
+    unsigned long long* srec = (unsigned long long*)(((uintptr_t)(scan_tmp + 8) + 15) & ~(uintptr_t)15);
+    uint8_t* stage = (uint8_t*)(srec + C2_TILE);
+    const uint32_t mask = D - 1u;
+    const int wave = threadIdx.x >> 6;
+    for (int d = threadIdx.x; d < (C2_THREADS / 64) * D; d += C2_THREADS) wcount[d] = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        for (int d = threadIdx.x; d < D; d += C2_THREADS) gbase[d] = offs[(int64_t)d * n_tiles + tile];
+        unsigned long long rec_[C2_ITEMS];
+        uint32_t rank_[C2_ITEMS];
+        uint32_t ok = 0;
+        // (the windows of a tile belong to ONE read: their order inside the tile is free; thread t takes 16 consecutive ones)
+        cf_c2_tile_records(bases, read_off, tiles[tile], k, rb, stage, [&](int j, unsigned long long rec, bool valid) {
+            rec_[j] = rec; ok |= (uint32_t)valid << j;
+            rank_[j] = cf_c2_rank_round<NB>((cf_c2_bucket(rec >> rb, bits) >> shift) & mask, valid, wcount + wave * D);
+        });
+        cf_c2_tile_bases<NB>(dstart, wcount, scan_tmp);
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < C2_ITEMS; ++j)
+            if ((ok >> j) & 1u) { const uint32_t d = (cf_c2_bucket(rec_[j] >> rb, bits) >> shift) & mask; srec[dstart[d] + wcount[wave * D + d] + rank_[j]] = rec_[j]; ++mine; }
+        // records of the tile: its windows (the last tile of a read is short)
+        const int64_t n_win = read_off[tiles[tile].read + 1] - read_off[tiles[tile].read] - k + 1;
+        const uint32_t n_tile = (uint32_t)min((int64_t)C2_TILE, n_win - (int64_t)tiles[tile].chunk * C2_TILE);
+        (void)mine;
+        __syncthreads();
+        cf_c2_copy_out<NB>(srec, n_tile, dstart, gbase, rb, bits, shift, out);
+        __syncthreads();
+        for (int d = threadIdx.x; d < (C2_THREADS / 64) * D; d += C2_THREADS) wcount[d] = 0;
+    }
+}
+
+// later passes: records -> records
+__global__ void __launch_bounds__(C2_THREADS)
+cf_c2_hist_kernel(const unsigned long long* __restrict__ in, int64_t n, int n_tiles, int rb, int bits, int shift, int nb, uint32_t* __restrict__ hist) {
+    uint32_t* h = (uint32_t*)cf_lds;
+    const uint32_t mask = (1u << nb) - 1u;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        for (int d = threadIdx.x; d < (1 << nb); d += C2_THREADS) h[d] = 0;
+        __syncthreads();
+        const int64_t base = (int64_t)tile * C2_TILE;
+#pragma unroll
+        for (int j = 0; j < C2_ITEMS; ++j) {
+            const int64_t i = base + (int64_t)j * C2_THREADS + threadIdx.x;
+            if (i < n) atomicAdd(&h[(cf_c2_bucket(in[i] >> rb, bits) >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < (1 << nb); d += C2_THREADS) hist[(int64_t)d * n_tiles + tile] = h[d];
+        __syncthreads();
+    }
+}
+
+template <int NB>
+__global__ void __launch_bounds__(C2_THREADS)
+cf_c2_scatter_kernel(const unsigned long long* __restrict__ in, int64_t n, int n_tiles, int rb, int bits, int shift, const int64_t* __restrict__ offs,
+                     unsigned long long* __restrict__ out) {
+    constexpr int D = 1 << NB;
+    int64_t* gbase = (int64_t*)cf_lds;
+    uint32_t* wcount = (uint32_t*)(gbase + D);
+    uint32_t* dstart = wcount + (C2_THREADS / 64) * D;
+    uint32_t* scan_tmp = dstart + D;
+    unsigned long long* srec = (unsigned long long*)(((uintptr_t)(scan_tmp + 8) + 15) & ~(uintptr_t)15);
+    const uint32_t mask = D - 1u;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int d = threadIdx.x; d < (C2_THREADS / 64) * D; d += C2_THREADS) wcount[d] = 0;
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        for (int d = threadIdx.x; d < D; d += C2_THREADS) gbase[d] = offs[(int64_t)d * n_tiles + tile];
+        // wave w takes the records [w * 64 * C2_ITEMS, ...) of the tile in rounds of 64: array order = (wave, round, lane)
+        const int64_t base = (int64_t)tile * C2_TILE + (int64_t)wave * 64 * C2_ITEMS + lane;
+        unsigned long long rec_[C2_ITEMS];
+        uint32_t rank_[C2_ITEMS];
+#pragma unroll
+        for (int j = 0; j < C2_ITEMS; ++j) { const int64_t i = base + (int64_t)j * 64; rec_[j] = i < n ? in[i] : 0ull; }
+#pragma unroll
+        for (int j = 0; j < C2_ITEMS; ++j)
+            rank_[j] = cf_c2_rank_round<NB>((cf_c2_bucket(rec_[j] >> rb, bits) >> shift) & mask, base + (int64_t)j * 64 < n, wcount + wave * D);
+        cf_c2_tile_bases<NB>(dstart, wcount, scan_tmp);
+#pragma unroll
+        for (int j = 0; j < C2_ITEMS; ++j)
+            if (base + (int64_t)j * 64 < n) { const uint32_t d = (cf_c2_bucket(rec_[j] >> rb, bits) >> shift) & mask; srec[dstart[d] + wcount[wave * D + d] + rank_[j]] = rec_[j]; }
+        const uint32_t n_tile = (uint32_t)min((int64_t)C2_TILE, n - (int64_t)tile * C2_TILE);
+        __syncthreads();
+        cf_c2_copy_out<NB>(srec, n_tile, dstart, gbase, rb, bits, shift, out);
+        __syncthreads();
+        for (int d = threadIdx.x; d < (C2_THREADS / 64) * D; d += C2_THREADS) wcount[d] = 0;
+    }
+}
+
+// ---- the reduce.  Records are sorted by bucket; inside a bucket they are in emission order, so the records of one
+// k-mer come in read order.  Every workgroup takes a contiguous range of buckets, finds its first record by binary
+// search and streams on from there.
+// counters: [0] slots reserved (chunks) [1] sum of pres (= N_rk) [2] flags (1: a bucket holds more k-mers than the LDS
+// table) [3] k-mers written
+// first record of every chunk of `per` buckets (binary search on the bucket-sorted records; one thread per chunk)
+__global__ void __launch_bounds__(256)
+cf_c2_chunk_starts_kernel(const unsigned long long* __restrict__ recs, int64_t n, int rb, int bits, int64_t per, int64_t n_chunks, int64_t* __restrict__ starts) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_chunks) return;
+    const int64_t b0 = c * per;
+    int64_t lo = 0, hi = n;
+    if (c == n_chunks) lo = n;
+    while (lo < hi) { const int64_t m = (lo + hi) >> 1; if ((int64_t)cf_c2_bucket(recs[m] >> rb, bits) < b0) lo = m + 1; else hi = m; }
+    starts[c] = lo;
+}
+
+// Buckets are handed out in chunks of `per` through a ticket (counters[4]): a bucket of a repeat's consensus k-mer has 40 x the
+// records of an average one, and with a fixed range per workgroup the unlucky ones took three times the mean.
+#if defined(CF_C2_STAMPS)
+#define C2_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_t; st_t = now_; } } while (0)
+#else
+#define C2_STAMP(i) do { } while (0)
+#endif
+// The dense table is written in chunks a workgroup reserves with one global atomic each (one reservation per bucket
+// cost a round trip of ~2 us per ~4000 records); the part of a chunk it does not fill is zeroed: empty slots, which every
+// consumer of the table skips.
+__global__ void __launch_bounds__(C2_RTHREADS)
+cf_c2_reduce_kernel(const unsigned long long* __restrict__ recs, int64_t n, int rb, int bits, cf_slot* __restrict__ out, unsigned long long out_cap,
+                    unsigned long long chunk, int64_t per, int64_t n_chunks, const int64_t* __restrict__ starts, unsigned long long* __restrict__ counters) {
+    unsigned long long* set = (unsigned long long*)cf_lds;                     // C2_SET x [DUP | k-mer | read]
+    unsigned long long* tkey = set + C2_SET;                                    // C2_TAB x (k-mer + 1); 0 = empty
+    uint32_t* tpres = (uint32_t*)(tkey + C2_TAB);
+    uint32_t* tmulti = tpres + C2_TAB;
+    uint32_t* tlast = tmulti + C2_TAB;                                          // (read + 1) << 1 | "that read already counted in multi"
+    unsigned long long* sh64 = (unsigned long long*)(tlast + C2_TAB);           // [0] current position [1] next free slot of the chunk [2] end of the chunk
+    uint32_t* sh = (uint32_t*)(sh64 + 3);                                       // [0] records of the tile in the bucket [1] k-mers in the table [2] sum of pres
+    const int t = threadIdx.x, lane = t & 63;
+    const unsigned long long read_mask = (1ull << rb) - 1ull;
+    const int64_t n_buckets = (int64_t)1 << bits;
+    if (t == 0) { sh64[1] = 0; sh64[2] = 0; }
+    for (int s = t; s < C2_SET; s += C2_RTHREADS) set[s] = 0ull;
+    unsigned long long n_dist = 0;      // thread 0: k-mers written by this workgroup
+    unsigned long long psum_all = 0;    // sum of pres of the k-mers this thread flushed
+#if defined(CF_C2_STAMPS)
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+#endif
+    while (true) {
+    __syncthreads();
+    if (t == 0) sh64[0] = atomicAdd(&counters[4], 1ull);
+    __syncthreads();
+    const int64_t ck = (int64_t)sh64[0];
+    C2_STAMP(0);   // ticket
+    if (ck >= n_chunks) break;
+    const int64_t b0 = ck * per, b1 = min(n_buckets, b0 + per);
+    int64_t pos = starts[ck];
+    // ld[] holds the records [ld_pos, ld_pos + C2_RTILE): the loads of the NEXT tile are issued as soon as this tile knows
+    // where it ends (right behind its first barrier) and land while its table phase and the bucket's flush run
+    unsigned long long ld[C2_RTILE / C2_RTHREADS];
+    int64_t ld_pos = -1;
+    for (int64_t b = b0; b < b1; ++b) {
+        for (int s = t; s < C2_TAB; s += C2_RTHREADS) { tkey[s] = 0ull; tpres[s] = 0; tmulti[s] = 0; tlast[s] = 0; }
+        if (t == 0) { sh[1] = 0; sh[2] = 0; }
+        __syncthreads();
+        C2_STAMP(1);   // table clear
+        bool more = true;
+        while (more) {
+            // ---- a tile: the next C2_RTILE records, as far as they belong to bucket b (a prefix: the array is sorted by bucket)
+            if (t == 0) sh[0] = 0;
+            __syncthreads();
+            unsigned long long rec[C2_RTILE / C2_RTHREADS];
+            uint32_t own = 0;                 // bit j: this thread created the set slot of its j-th record
+            uint32_t slot[C2_RTILE / C2_RTHREADS];
+            uint32_t mine = 0;
+            if (ld_pos != pos) {
+#pragma unroll
+                for (int j = 0; j < C2_RTILE / C2_RTHREADS; ++j) {      // all loads of the tile in flight before the first is used
+                    const int64_t i = pos + (int64_t)j * C2_RTHREADS + t;
+                    ld[j] = i < n ? recs[i] : ~0ull;
+                }
+                ld_pos = pos;
+            }
+            // (k-mer, read) set: the first record of a pair creates the slot, later ones flag it.  The thread's records probe in
+            // lockstep — every round issues the LDS reads of all unfinished ones, then their CAS — so the dependent LDS round
+            // trips of the probe chains overlap instead of adding up (a wave runs as long as its slowest lane's chain)
+            constexpr int RJ = C2_RTILE / C2_RTHREADS;
+            uint32_t hh[RJ];
+            uint32_t act = 0;
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) {
+                const int64_t i = pos + (int64_t)j * C2_RTHREADS + t;
+                rec[j] = 0ull; slot[j] = 0; hh[j] = 0;
+                if (i < n && (int64_t)cf_c2_bucket(ld[j] >> rb, bits) == b) { rec[j] = ld[j]; ++mine; act |= 1u << j; hh[j] = cf_c2_hash_set(ld[j]) & (C2_SET - 1); }
+            }
+            while (__any(act != 0u)) {
+                unsigned long long cur[RJ];
+#pragma unroll
+                for (int j = 0; j < RJ; ++j) cur[j] = ((act >> j) & 1u) ? set[hh[j]] : 1ull;
+#pragma unroll
+                for (int j = 0; j < RJ; ++j)          // + 1: record 0 (k-mer AAA.., read 0) is not "empty"; bit 63 stays free (2k + rb <= 62)
+                    if (((act >> j) & 1u) && cur[j] == 0ull) cur[j] = atomicCAS(&set[hh[j]], 0ull, rec[j] + 1ull);     // 0: created; else who was faster
+#pragma unroll
+                for (int j = 0; j < RJ; ++j) {
+                    if (!((act >> j) & 1u)) continue;
+                    if (cur[j] == 0ull) { own |= 1u << j; slot[j] = hh[j]; act &= ~(1u << j); }
+                    else if ((cur[j] & ~C2_DUP) == rec[j] + 1ull) { if (!(cur[j] & C2_DUP)) atomicOr(&set[hh[j]], C2_DUP); act &= ~(1u << j); }
+                    else hh[j] = (hh[j] + 1) & (C2_SET - 1);
+                }
+            }
+            for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, (unsigned)d);
+            if (lane == 0 && mine) atomicAdd(&sh[0], mine);
+            C2_STAMP(2);   // loads + set phase (thread 0's own)
+            __syncthreads();
+            C2_STAMP(3);   // wait for the others
+            const uint32_t got = sh[0];
+            if (got) {          // the next tile (of this bucket or of the next one) starts at pos + got: fetch it now
+#pragma unroll
+                for (int j = 0; j < C2_RTILE / C2_RTHREADS; ++j) {
+                    const int64_t i = pos + (int64_t)got + (int64_t)j * C2_RTHREADS + t;
+                    ld[j] = i < n ? recs[i] : ~0ull;
+                }
+                ld_pos = pos + (int64_t)got;
+            }
+            // ---- the distinct (k-mer, read) pairs of the tile, by their creators: table entry, old "last read", increments
+            uint32_t ent[RJ], packed[RJ], th[RJ];
+            uint32_t tact = own, made = 0;
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) { ent[j] = 0; packed[j] = 0; th[j] = cf_c2_hash_tab(rec[j] >> rb) & (C2_TAB - 1); }
+            for (int probe = 0; probe < C2_TAB && __any(tact != 0u); ++probe) {      // the k-mer's table entry, probe chains in lockstep as above
+                unsigned long long cur[RJ];
+#pragma unroll
+                for (int j = 0; j < RJ; ++j) cur[j] = ((tact >> j) & 1u) ? tkey[th[j]] : 1ull;
+#pragma unroll
+                for (int j = 0; j < RJ; ++j)
+                    if (((tact >> j) & 1u) && cur[j] == 0ull) { cur[j] = atomicCAS(&tkey[th[j]], 0ull, (rec[j] >> rb) + 1ull); if (cur[j] == 0ull) { ++made; cur[j] = (rec[j] >> rb) + 1ull; } }
+#pragma unroll
+                for (int j = 0; j < RJ; ++j) {
+                    if (!((tact >> j) & 1u)) continue;
+                    if (cur[j] == (rec[j] >> rb) + 1ull) { ent[j] = th[j] + 1u; tact &= ~(1u << j); }
+                    else th[j] = (th[j] + 1) & (C2_TAB - 1);
+                }
+            }
+            if (tact) atomicOr(&counters[2], 1ull);       // the bucket holds more k-mers than the table: the caller falls back
+            for (int d = 32; d >= 1; d >>= 1) made += __shfl_down(made, (unsigned)d);
+            if (lane == 0 && made) atomicAdd(&sh[1], made);
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) {
+                if (!ent[j]) continue;
+                const uint32_t h = ent[j] - 1u;
+                const bool dup = (set[slot[j]] & C2_DUP) != 0ull;
+                const uint32_t rd1 = (uint32_t)(rec[j] & read_mask) + 1u;
+                const uint32_t last = tlast[h];                 // written only behind the next barrier
+                if ((last >> 1) == rd1) {                       // the read continues from an earlier tile: already in pres
+                    if (!(last & 1u)) atomicAdd(&tmulti[h], 1u);    // ... and now it has its second occurrence
+                    packed[j] = (rd1 << 1) | 1u;
+                } else {
+                    atomicAdd(&tpres[h], 1u);
+                    if (dup) atomicAdd(&tmulti[h], 1u);
+                    packed[j] = (rd1 << 1) | (dup ? 1u : 0u);
+                }
+            }
+            C2_STAMP(4);   // table phase
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < C2_RTILE / C2_RTHREADS; ++j) {
+                if (ent[j]) atomicMax(&tlast[ent[j] - 1u], packed[j]);
+                if ((own >> j) & 1u) set[slot[j]] = 0ull;       // leave the set empty for the next tile
+            }
+            pos += got;
+            more = got == C2_RTILE && pos < n;                  // a full tile: the bucket may go on
+            __syncthreads();
+            C2_STAMP(5);   // last-read update, set clean-up
+        }
+        // ---- bucket done: its k-mers go to the table, into the workgroup's current chunk or a fresh one
+        const uint32_t n_k = sh[1];
+        const unsigned long long c_free = sh64[1], c_end = sh64[2];
+        __syncthreads();            // everyone has the count and the chunk before thread 0 changes them
+        const bool fresh = n_k > c_end - c_free;
+        if (fresh) for (unsigned long long o = c_free + t; o < c_end; o += C2_RTHREADS) if (o < out_cap) { cf_slot z; z.key = 0ull; z.val = 0ull; out[o] = z; }
+        if (t == 0) {
+            unsigned long long at = c_free;
+            if (fresh) { at = atomicAdd(&counters[0], chunk); sh64[2] = at + chunk; }
+            sh64[1] = at + n_k;
+            sh64[0] = at;            // (the position word is free during the flush: base of this bucket)
+            sh[1] = 0;
+            n_dist += n_k;
+        }
+        __syncthreads();
+        if (n_k) {
+            const unsigned long long base = sh64[0];
+            uint32_t psum = 0;
+            for (int s0 = 0; s0 < C2_TAB; s0 += C2_RTHREADS) {
+                const int s = s0 + t;
+                const bool occ = tkey[s] != 0ull;
+                const unsigned long long m = __ballot(occ);
+                uint32_t off = 0;
+                if (m) {
+                    const int leader = __ffsll((long long)m) - 1;
+                    if (lane == leader) off = atomicAdd(&sh[1], (uint32_t)__popcll(m));
+                    off = (uint32_t)__shfl((int)off, leader);
+                }
+                if (occ) {
+                    const unsigned long long o = base + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    psum += tpres[s];
+                    if (o < out_cap) { cf_slot sl; sl.key = (tkey[s] - 1ull) | CF_OCC; sl.val = (unsigned long long)tpres[s] | ((unsigned long long)tmulti[s] << 32); out[o] = sl; }
+                }
+            }
+            psum_all += psum;       // (one global atomic per wave at the END: 2 million adds to one word take 11 ns each, in a row)
+        }
+        __syncthreads();
+        C2_STAMP(6);   // flush
+    }
+    }
+    for (unsigned long long o = sh64[1] + t; o < sh64[2]; o += C2_RTHREADS) if (o < out_cap) { cf_slot z; z.key = 0ull; z.val = 0ull; out[o] = z; }
+    if (t == 0 && n_dist) atomicAdd(&counters[3], n_dist);
+    for (int d = 32; d >= 1; d >>= 1) psum_all += __shfl_down(psum_all, (unsigned)d);
+    if (lane == 0 && psum_all) atomicAdd(&counters[1], psum_all);
+#if defined(CF_C2_STAMPS)
+    if (t == 0) for (int i = 0; i < 8; ++i) atomicAdd(&counters[8 + i], st_acc[i]);
+#endif
+}
+
+namespace {
+struct Bufs2 {
+    cf_ctx* ctx;
+    std::vector<std::pair<void*, size_t>> v;
+    explicit Bufs2(cf_ctx* c) : ctx(c) {}
+    ~Bufs2() { for (auto it = v.rbegin(); it != v.rend(); ++it) cf_release(ctx, it->first, it->second); }
+    template <class T> int get(T** p, size_t n, const char* what) {
+        int rc = cf_alloc_t(ctx, p, n, what);
+        if (rc == 0) v.emplace_back((void*)*p, n * sizeof(T));
+        return rc;
+    }
+    void keep(void* p) { for (auto& e : v) if (e.first == p) e.first = nullptr; }
+};
+
+template <class K>
+int launch_nb(int nb, K&& k) {      // radix bits of a pass -> template instance
+    switch (nb) {
+        case 1: k(std::integral_constant<int, 1>()); break; case 2: k(std::integral_constant<int, 2>()); break;
+        case 3: k(std::integral_constant<int, 3>()); break; case 4: k(std::integral_constant<int, 4>()); break;
+        case 5: k(std::integral_constant<int, 5>()); break; case 6: k(std::integral_constant<int, 6>()); break;
+        case 7: k(std::integral_constant<int, 7>()); break; case 8: k(std::integral_constant<int, 8>()); break;
+        case 9: k(std::integral_constant<int, 9>()); break; default: return -22;
+    }
+    return 0;
+}
+}  // namespace
+
+// Returns 0 on success, 1 when the sort-and-reduce path does not apply (caller falls back to the table path), < 0 on error.
+int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, int64_t n_w) {
+    const int64_t R = ctx->n_reads;
+    int rb = 1;
+    while (((int64_t)1 << rb) < std::max<int64_t>(R, 2)) ++rb;
+    if (2 * k + rb > 62 || rb > 26) return 1;
+    // tiles of pass 1
+    std::vector<cf_c2_tile> tiles;
+    for (int64_t r = read_lo; r < read_hi; ++r) {
+        const int64_t len = ctx->h_read_off[(size_t)r + 1] - ctx->h_read_off[(size_t)r];
+        if (len < k) continue;
+        const int64_t nw = len - k + 1;
+        for (int64_t c = 0; c * C2_TILE < nw; ++c) tiles.push_back(cf_c2_tile{(int32_t)r, (int32_t)c});
+    }
+    if (tiles.size() >= (size_t)1 << 31) return 1;
+    const int n_tiles1 = (int)tiles.size();
+    // buckets: ~2000 records each, so that a bucket's k-mers fit the LDS table with room to spare — but not at the price
+    // of one more pass over all records when up to 5000 per bucket do without it
+    int bits = 1, bits_min = 1;
+    while (bits < 27 && (n_w >> bits) > 2000) ++bits;
+    while (bits_min < 27 && (n_w >> bits_min) > 5000) ++bits_min;
+    const int passes_min = (bits_min + C2_MAXBITS - 1) / C2_MAXBITS;
+    if ((bits + C2_MAXBITS - 1) / C2_MAXBITS > passes_min) bits = passes_min * C2_MAXBITS;
+    if (ctx->count_bits) bits = ctx->count_bits;
+    const int n_pass = (bits + C2_MAXBITS - 1) / C2_MAXBITS;
+    CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    cf_free_table(ctx);
+    Bufs2 tmp(ctx);
+    unsigned long long *d_a = nullptr, *d_b = nullptr;
+    cf_c2_tile* d_tiles = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    CF_TRY(tmp.get(&d_a, (size_t)std::max<int64_t>(n_w, 2), "count records"));
+    CF_TRY(tmp.get(&d_b, (size_t)std::max<int64_t>(n_w, 2), "count records (pong)"));
+    CF_TRY(tmp.get(&d_tiles, tiles.size() + 1, "count tiles"));
+    CF_TRY(tmp.get(&d_cnt, 16, "count counters"));
+    if (n_tiles1) CF_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(cf_c2_tile), hipMemcpyHostToDevice, ctx->stream));
+    CF_HIP(hipMemsetAsync(d_cnt, 0, 64, ctx->stream));
+    const int max_grid = std::max(1, ctx->n_cu) * 8;
+    unsigned long long *src = nullptr, *dst = d_a;
+    (void)hipEventRecord(ctx->ev2, ctx->stream);
+    for (int p = 0; p < n_pass && n_w > 0; ++p) {
+        // LSD: low digit first; stable passes leave the array sorted by the whole bucket number
+        const int shift = p * C2_MAXBITS, nb = std::min(C2_MAXBITS, bits - shift);
+        const int n_tiles = p == 0 ? n_tiles1 : (int)((n_w + C2_TILE - 1) / C2_TILE);
+        const int64_t nh = (int64_t)n_tiles << nb;
+        uint32_t* d_hist = nullptr;
+        int64_t* d_offs = nullptr;
+        Bufs2 pass(ctx);
+        CF_TRY(pass.get(&d_hist, (size_t)nh + 1, "count histogram"));
+        CF_TRY(pass.get(&d_offs, (size_t)nh + 1, "count offsets"));
+        const int grid = std::min(n_tiles, max_grid);
+        const size_t lds_h = ((((size_t)4 << nb) + 15) & ~(size_t)15) + (p == 0 ? C2_TILE + 64 : 0);
+        const size_t lds_s = ((size_t)8 << nb) + (size_t)(C2_THREADS / 64 + 1) * ((size_t)4 << nb) + 32 + 16 + (size_t)C2_TILE * 8 + (p == 0 ? C2_TILE + 64 : 0);
+        if (p == 0)
+            hipLaunchKernelGGL(cf_c2_hist1_kernel, dim3((unsigned)grid), dim3(C2_THREADS), lds_h, ctx->stream, (const uint8_t*)ctx->d_bases,
+                               (const int64_t*)ctx->d_read_off, (const cf_c2_tile*)d_tiles, n_tiles, (int)k, rb, bits, shift, nb, d_hist);
+        else
+            hipLaunchKernelGGL(cf_c2_hist_kernel, dim3((unsigned)grid), dim3(C2_THREADS), lds_h, ctx->stream, (const unsigned long long*)src, n_w, n_tiles, rb, bits,
+                               shift, nb, d_hist);
+        CF_KERNEL_CHECK("cf_c2_hist");
+        CF_TRY(cf_scan_exclusive_u32_to_i64(ctx, d_hist, d_offs, nh, nullptr));
+        const int rc = launch_nb(nb, [&](auto NB) {
+            if (p == 0)
+                hipLaunchKernelGGL((cf_c2_scatter1_kernel<decltype(NB)::value>), dim3((unsigned)grid), dim3(C2_THREADS), lds_s, ctx->stream, (const uint8_t*)ctx->d_bases,
+                                   (const int64_t*)ctx->d_read_off, (const cf_c2_tile*)d_tiles, n_tiles, (int)k, rb, bits, shift, (const int64_t*)d_offs, dst);
+            else
+                hipLaunchKernelGGL((cf_c2_scatter_kernel<decltype(NB)::value>), dim3((unsigned)grid), dim3(C2_THREADS), lds_s, ctx->stream, (const unsigned long long*)src,
+                                   n_w, n_tiles, rb, bits, shift, (const int64_t*)d_offs, dst);
+        });
+        if (rc) return cf_fail(ctx, rc, "cf_count_kmers: bad radix width");
+        CF_KERNEL_CHECK("cf_c2_scatter");
+        CF_HIP(hipStreamSynchronize(ctx->stream));
+        src = dst;
+        dst = (src == d_a) ? d_b : d_a;
+    }
+    // reduce into the free buffer (2 records = 1 slot); when more k-mers turn up than fit, an exact-size table is taken
+    unsigned long long h_cnt[4] = {0, 0, 0, 0};
+    cf_slot* d_out = (cf_slot*)dst;
+    unsigned long long out_cap = (unsigned long long)std::max<int64_t>(n_w, 2) / 2;
+    size_t out_bytes = (size_t)std::max<int64_t>(n_w, 2) * 8;
+    const size_t lds_r = (size_t)C2_SET * 8 + (size_t)C2_TAB * (8 + 4 + 4 + 4) + 24 + 16;
+    cf_slot* d_exact = nullptr;
+    const int64_t n_buckets = (int64_t)1 << bits;
+    const int64_t per = std::max<int64_t>(1, n_buckets / ((int64_t)std::max(1, ctx->n_cu) * 64));     // ~16 k chunks
+    const int64_t n_chunks = (n_buckets + per - 1) / per;
+    int64_t* d_starts = nullptr;
+    CF_TRY(tmp.get(&d_starts, (size_t)n_chunks + 2, "count chunk starts"));
+    if (n_w > 0) {
+        hipLaunchKernelGGL(cf_c2_chunk_starts_kernel, dim3((unsigned)((n_chunks + 256) / 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)src, n_w, rb, bits,
+                           per, n_chunks, d_starts);
+        CF_KERNEL_CHECK("cf_c2_chunk_starts_kernel");
+    }
+    for (int attempt = 0; attempt < 2 && n_w > 0; ++attempt) {
+        CF_HIP(hipMemsetAsync(d_cnt, 0, 128, ctx->stream));
+        const int grid = (int)std::min<int64_t>(n_chunks, (int64_t)std::max(1, ctx->n_cu) * 2);
+        const unsigned long long chunk = (unsigned long long)std::min<int64_t>(32768, std::max<int64_t>(C2_TAB, n_w / grid / 4));
+        hipLaunchKernelGGL(cf_c2_reduce_kernel, dim3((unsigned)grid), dim3(C2_RTHREADS), lds_r, ctx->stream, (const unsigned long long*)src, n_w, rb, bits, d_out,
+                           out_cap, chunk, per, n_chunks, (const int64_t*)d_starts, d_cnt);
+        CF_KERNEL_CHECK("cf_c2_reduce_kernel");
+        CF_HIP(hipMemcpy(h_cnt, d_cnt, 32, hipMemcpyDeviceToHost));
+#if defined(CF_C2_STAMPS)
+        { unsigned long long st[8]; if (hipMemcpy(st, d_cnt + 8, 64, hipMemcpyDeviceToHost) == hipSuccess)
+            std::fprintf(stderr, "[cf_c2 stamps] ticket=%llu clear=%llu set=%llu wait=%llu table=%llu last=%llu flush=%llu (shader cycles over %d workgroups)\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], grid); }
+#endif
+        if (h_cnt[2] & 1ull) { if (d_exact) cf_release(ctx, d_exact, out_bytes); return 1; }     // a bucket with too many k-mers for the LDS table: table path
+        if (h_cnt[0] <= out_cap) break;
+        if (attempt == 1) { if (d_exact) cf_release(ctx, d_exact, out_bytes); return cf_fail(ctx, -5, "cf_count_kmers: reduce output overflow"); }
+        // (chunks are handed out dynamically: the next run may leave other holes) what was written + two chunks per workgroup
+        out_cap = h_cnt[3] + 2ull * chunk * (unsigned long long)grid; out_bytes = (size_t)out_cap * sizeof(cf_slot);
+        CF_TRY(cf_alloc(ctx, (void**)&d_exact, out_bytes, "k-mer table (dense)"));
+        d_out = d_exact;
+    }
+    (void)hipEventRecord(ctx->ev3, ctx->stream);
+    // hand the dense table to the context
+    if (n_w > 0) {
+        if (!d_exact) tmp.keep(dst);
+        ctx->d_table = d_out;
+        ctx->table_alloc = out_bytes / sizeof(cf_slot);
+    } else {
+        CF_TRY(cf_alloc(ctx, (void**)&ctx->d_table, 16 * sizeof(cf_slot), "k-mer table (dense)"));
+        ctx->table_alloc = 16;
+    }
+    ctx->table_cap = h_cnt[0];
+    ctx->table_dense = true;
+    ctx->k = k;
+    ctx->stats.n_windows = n_w;
+    ctx->stats.n_read_kmers = (int64_t)h_cnt[1];
+    CF_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    CF_HIP(hipEventSynchronize(ctx->ev1));
+    (void)hipEventElapsedTime(&ctx->times.count_ms, ctx->ev0, ctx->ev1);
+    (void)hipEventElapsedTime(&ctx->times.count_kernel_ms, ctx->ev2, ctx->ev3);
+    return 0;
+}

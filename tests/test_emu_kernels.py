@@ -134,3 +134,46 @@ def test_degenerate_inputs(engine):
     assert engine.build_clouds() == 2                              # unit 0 (20 bases) has 2 windows; units 1, 2 are shorter than k
     cp, ent = engine.clouds()
     assert cp.tolist() == [0, 2, 2, 2]
+
+
+def _presence_oracle(seqs, k):
+    per = [np.unique(recruit.encode_windows(s, k), return_counts=True) for s in seqs]
+    allk = np.concatenate([u for u, _ in per]); allm = np.concatenate([c > 1 for _, c in per])
+    o = np.argsort(allk, kind="stable")
+    keys, start, pres = np.unique(allk[o], return_index=True, return_counts=True)
+    return keys, pres.astype(np.uint32), np.add.reduceat(allm[o].astype(np.int64), start).astype(np.uint32), int(sum(u.size for u, _ in per))
+
+
+@pytest.mark.parametrize("bits,mode", [(1, 1), (4, 1), (11, 1), (0, 1), (0, 0)])
+def test_count_sort_and_reduce_buckets_spanning_tiles(engine, bits, mode):
+    """A1 by sort and reduce (cf_count2.hip): heavy k-mers (a short period repeated hundreds of times in every read, so
+    one k-mer's records fill many reduce tiles and a read's records straddle tile borders), reads that share a k-mer
+    once, twice or not at all, one bucket pass (bits 1, 4) and two (bits 11); against a numpy count — and the atomic
+    table of round 1 (mode 0) against the same."""
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    period = alpha[rng.integers(0, 4, 41)].tobytes()
+    seqs = []
+    for r in range(14):
+        body = period * int(rng.integers(150, 400))
+        noise = alpha[rng.integers(0, 4, int(rng.integers(200, 3000)))].tobytes()
+        seqs.append(noise[: len(noise) // 2] + body + noise[len(noise) // 2:] + (period * 2 if r % 3 == 0 else b""))
+    seqs.append(b"ACGTACGTAC")                                   # shorter than k: no window
+    seqs.append(alpha[rng.integers(0, 4, 5000)].tobytes())      # shares nothing
+    bases = np.frombuffer(b"".join(seqs), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])])
+    engine.load_arrays(bases, off, np.zeros(len(seqs) + 1, np.int64), [], [])
+    engine.set_param("count_mode", mode); engine.set_param("count_bits", bits)
+    try:
+        engine.count_kmers(19)
+        keys, pres, multi = engine.table()
+        wk, wp, wm, n_rk = _presence_oracle(seqs, 19)
+        assert np.array_equal(keys, wk) and np.array_equal(pres, wp) and np.array_equal(multi, wm)
+        st = engine.stats()
+        assert st["n_read_kmers"] == n_rk and st["n_windows"] == sum(max(0, len(s) - 18) for s in seqs)
+        n = engine.select_rare(3, 2, 14)
+        sel = (wm <= 3) & (wp >= 2) & (wp <= 14)
+        assert n == int(sel.sum()) and np.array_equal(engine.kmers(), wk[sel])
+        assert engine.stats()["n_distinct"] == wk.size and engine.stats()["n_kept"] == int((wm <= 3).sum())
+    finally:
+        engine.set_param("count_mode", 1); engine.set_param("count_bits", 0)
