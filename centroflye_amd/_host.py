@@ -53,6 +53,7 @@ def lib():
         getattr(L, name).restype = i64
     L.cfh_non_acgt.argtypes = [P]
     L.cfh_non_acgt.restype = i32
+    L.cfh_exotic_summary.argtypes = [P, i32, i32, C.c_uint32, C.c_uint32, i64, i64, pi64]
     for name in ("cfh_bases", "cfh_read_off", "cfh_ids", "cfh_id_off", "cfh_meta"):
         getattr(L, name).argtypes = [P]
         getattr(L, name).restype = C.c_void_p
@@ -145,6 +146,19 @@ class PackedReads:
         out = np.zeros(self.n_reads, dtype=np.uint8)
         lib().cfh_classify(self._h, int(large_threshold), int(small_threshold), out.ctypes.data)
         return out
+
+    def exotic_summary(self, k, max_nonuniq, lo, hi, read_lo=0, read_hi=None):
+        """The k-mer windows that hold a symbol other than upper-case A, C, G, T, counted as the reference counts every
+        window (scripts/distance_based_kmer_recruitment.py:39-63, strings of the raw row): dict with n_distinct, n_read_kmers,
+        n_kept (multi <= max_nonuniq), n_rare (in the rare window) and n_blocking (rare AND free of lower-case letters:
+        only those could match a window of an upper-cased unit, read_kmer_cloud.py:25, and reach the outputs).  The device
+        path skips these windows; with n_blocking == 0 its outputs equal the reference's."""
+        out = (C.c_int64 * 5)()
+        rc = lib().cfh_exotic_summary(self._h, int(k), int(max_nonuniq), int(lo), int(min(hi, 2 ** 32 - 1)), int(read_lo),
+                                      int(self.n_reads if read_hi is None else read_hi), out)
+        if rc:
+            raise HostError(f"cfh_exotic_summary failed ({rc})")
+        return dict(n_distinct=out[0], n_read_kmers=out[1], n_kept=out[2], n_rare=out[3], n_blocking=out[4])
 
     def export_read_units(self, rec, pos, outdir, min_pos=0, max_pos=None, n_threads=0):
         """Per-position read-unit FASTA files (reference eltr_polisher.py:53-97).  rec / pos: record indices and

@@ -185,14 +185,18 @@ int cf_load_reads(cf_ctx* ctx, const uint8_t* bases, const int64_t* read_off, in
     for (int64_t r = 0; r < n_reads; ++r)
         if (read_off[r + 1] < read_off[r]) return cf_fail(ctx, -22, "read_off must be non-decreasing");
     const int64_t nb = read_off[n_reads];
-    // alphabet check on the host (never silently 2-bit-encode other symbols)
+    if (nb > 0 && !bases) return cf_fail(ctx, -22, "cf_load_reads: null bases");
+    // alphabet (never silently 2-bit-encode other symbols): windows that hold anything but
+    // upper-case A, C, G, T are skipped by cf_count_kmers (they have no code; the reference counts them as strings of their
+    // own — the host keeps that side: cfh_exotic_summary), and cf_build_clouds upper-cases a, c, g, t as the reference does
+    bool exotic = false;
     {
         unsigned char bad = 0;
         for (int64_t i = 0; i < nb; ++i) {
             const unsigned char c = bases[i];
             bad |= (unsigned char)!(c == 'A' || c == 'C' || c == 'G' || c == 'T');
         }
-        if (bad) return cf_fail(ctx, -22, "read bases outside upper-case ACGT: the device path refuses them (no silent 2-bit encoding)");
+        exotic = bad != 0;
     }
     CF_HIP(hipSetDevice(ctx->device));
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
@@ -203,6 +207,7 @@ int cf_load_reads(cf_ctx* ctx, const uint8_t* bases, const int64_t* read_off, in
     free_reads(ctx);
     ctx->n_reads = n_reads;
     ctx->n_bases = nb;
+    ctx->has_exotic = exotic;
     ctx->h_read_off.assign(read_off, read_off + n_reads + 1);
     CF_TRY(cf_alloc_t(ctx, &ctx->d_bases, (size_t)nb + 64, "bases"));
     CF_TRY(cf_alloc_t(ctx, &ctx->d_read_off, (size_t)n_reads + 1, "read_off"));

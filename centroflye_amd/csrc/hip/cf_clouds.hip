@@ -87,10 +87,16 @@ cf_cloud_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ u
             const int64_t my0 = (int64_t)t * CL_TILE_W;
             const int64_t my_n = min((int64_t)CL_TILE_W, n_win - w0 - my0);
             if (my_n > 0) {
+                // the unit's row is upper-cased first (reference read_kmer_cloud.py:25): the code ignores the case, and a window
+                // holding anything but A, C, G, T (either case) can match no k-mer of the 2-bit set: skipped
                 unsigned long long code = 0;
-                for (int j = 0; j < k - 1; ++j) code = (code << 2) | cf_base2(stage[my0 + j]);
+                int run = 0;                 // valid bases in a row, ending at the current one
+                for (int j = 0; j < k - 1; ++j) { const uint32_t c = stage[my0 + j]; code = (code << 2) | cf_base2(c); run = cf_is_acgt_nocase(c) ? run + 1 : 0; }
                 for (int64_t i = 0; i < my_n; ++i) {
-                    code = ((code << 2) | cf_base2(stage[my0 + i + k - 1])) & kmask;
+                    const uint32_t c = stage[my0 + i + k - 1];
+                    code = ((code << 2) | cf_base2(c)) & kmask;
+                    run = cf_is_acgt_nocase(c) ? run + 1 : 0;
+                    if (run < k) continue;
                     const uint32_t idx = cf_lut_find(lut_keys, lut_vals, lut_mask, lut_pre, lut_pre_mask, code);
                     if (idx == CL_EMPTY) continue;
                     uint32_t h = cf_mix32(idx) & (CL_SET - 1);

@@ -31,8 +31,12 @@ __device__ __forceinline__ uint32_t cf_mix32(uint32_t x) {
     x ^= x >> 16;
     return x;
 }
-// ASCII base -> 2-bit code with A<C<G<T (A 0x41, C 0x43, G 0x47, T 0x54)
+// ASCII base -> 2-bit code with A<C<G<T (A 0x41, C 0x43, G 0x47, T 0x54); bit 5 (the case) plays no part
 __device__ __forceinline__ uint32_t cf_base2(uint32_t c) { return ((c >> 1) ^ (c >> 2)) & 3u; }
+// upper-case A, C, G or T?  (x = c - 'A': bits 0, 2, 6, 19 of the mask)  A window holding anything else has no 2-bit code:
+// the device paths skip it (what the reference does with such windows: centroflye_amd/_host.py exotic_summary)
+__device__ __forceinline__ bool cf_is_acgt(uint32_t c) { const uint32_t x = c - 0x41u; return x < 20u && ((0x80045u >> x) & 1u); }
+__device__ __forceinline__ bool cf_is_acgt_nocase(uint32_t c) { return cf_is_acgt(c & 0xDFu); }
 
 // bit 63 marks an occupied slot in every k-mer keyed table (k <= 31 -> key < 2^62)
 #define CF_OCC (1ull << 63)
@@ -71,6 +75,7 @@ struct cf_ctx {
     int64_t* d_unit_end = nullptr;
     std::vector<int64_t> h_read_off, h_unit_ptr;
     int64_t n_reads = 0, n_bases = 0, n_units = 0;
+    bool has_exotic = false;     // some base is not upper-case A, C, G, T
 
     // A1 table
     cf_slot* d_table = nullptr;

@@ -373,6 +373,9 @@ static int count_impl(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, 
         const int rc2 = cf_count_sorted(ctx, k, read_lo, read_hi, n_w);
         if (rc2 <= 0) return rc2;
     }
+    if (ctx->has_exotic)
+        return cf_fail(ctx, -22, mode == 1 ? "cf_count_occurrences: reads with symbols other than upper-case A, C, G, T are not supported"
+                                           : "cf_count_kmers: reads with symbols other than upper-case A, C, G, T need the sort-and-reduce path (2k + bits(reads) <= 62, count_mode 1)");
     const int slots = ctx->count_slots;
     int shrink = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {

@@ -73,14 +73,18 @@ __device__ __forceinline__ void cf_c2_tile_records(const uint8_t* __restrict__ b
     const q4 qa = *(const q4*)(stage + my0), qb = *(const q4*)(stage + my0 + 16), qc = *(const q4*)(stage + my0 + 32);
     const uint32_t w32[12] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w};
     unsigned long long hi = 0, lo = 0;      // codes of bases 0 .. 13 in hi (28 bits), 14 .. 45 in lo (64 bits)
+    unsigned long long bad = 0;             // bit i: base i is not upper-case A, C, G, T (A1 does not upper-case: reference :47-53)
 #pragma unroll
     for (int i = 0; i < 46; ++i) {
-        const unsigned long long c = cf_base2((w32[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+        const uint32_t ch = (w32[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+        const unsigned long long c = cf_base2(ch);
         if (i < 14) hi |= c << (2 * (13 - i)); else lo |= c << (2 * (45 - i));
+        bad |= (unsigned long long)!cf_is_acgt(ch) << i;
     }
+    const unsigned long long wmask = (1ull << k) - 1ull;
 #pragma unroll
     for (int j = 0; j < C2_ITEMS; ++j) {
-        const bool valid = j < my_n;
+        const bool valid = j < my_n && ((bad >> j) & wmask) == 0ull;      // a window with another symbol has no code: counted on the host side
         const int s2 = 2 * (46 - j - k);                 // bits to drop behind the window [j, j + k): 0 .. 90
         unsigned long long code = s2 >= 64 ? hi >> (s2 - 64) : (s2 ? (lo >> s2) | (hi << (64 - s2)) : lo);
         code &= kmask;
@@ -152,6 +156,7 @@ __device__ __forceinline__ void cf_c2_tile_bases(uint32_t* dstart, uint32_t* wco
     for (int w = 0; w < wave; ++w) off += scan_tmp[w];
     if (2 * t < (1 << NB)) dstart[2 * t] = off;
     if (2 * t + 1 < (1 << NB)) dstart[2 * t + 1] = off + tot[0];
+    if (t == C2_THREADS - 1) scan_tmp[7] = off + mine;          // records of the tile
     __syncthreads();
 }
 // records staged in digit order -> global: consecutive threads write consecutive addresses inside a digit's run
@@ -197,9 +202,7 @@ cf_c2_scatter1_kernel(const uint8_t* __restrict__ bases, const int64_t* __restri
 #pragma unroll
         for (int j = 0; j < C2_ITEMS; ++j)
             if ((ok >> j) & 1u) { const uint32_t d = (cf_c2_bucket(rec_[j] >> rb, bits) >> shift) & mask; srec[dstart[d] + wcount[wave * D + d] + rank_[j]] = rec_[j]; ++mine; }
-        // records of the tile: its windows (the last tile of a read is short)
-        const int64_t n_win = read_off[tiles[tile].read + 1] - read_off[tiles[tile].read] - k + 1;
-        const uint32_t n_tile = (uint32_t)min((int64_t)C2_TILE, n_win - (int64_t)tiles[tile].chunk * C2_TILE);
+        const uint32_t n_tile = scan_tmp[7];      // records of the tile: its windows of plain A, C, G, T
         (void)mine;
         __syncthreads();
         cf_c2_copy_out<NB>(srec, n_tile, dstart, gbase, rb, bits, shift, out);
@@ -553,11 +556,12 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
     CF_HIP(hipMemsetAsync(d_cnt, 0, 64, ctx->stream));
     const int max_grid = std::max(1, ctx->n_cu) * 8;
     unsigned long long *src = nullptr, *dst = d_a;
+    int64_t n_rec = n_w;
     (void)hipEventRecord(ctx->ev2, ctx->stream);
     for (int p = 0; p < n_pass && n_w > 0; ++p) {
         // LSD: low digit first; stable passes leave the array sorted by the whole bucket number
         const int shift = p * C2_MAXBITS, nb = std::min(C2_MAXBITS, bits - shift);
-        const int n_tiles = p == 0 ? n_tiles1 : (int)((n_w + C2_TILE - 1) / C2_TILE);
+        const int n_tiles = p == 0 ? n_tiles1 : (int)std::max<int64_t>(1, (n_rec + C2_TILE - 1) / C2_TILE);
         const int64_t nh = (int64_t)n_tiles << nb;
         uint32_t* d_hist = nullptr;
         int64_t* d_offs = nullptr;
@@ -571,17 +575,19 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
             hipLaunchKernelGGL(cf_c2_hist1_kernel, dim3((unsigned)grid), dim3(C2_THREADS), lds_h, ctx->stream, (const uint8_t*)ctx->d_bases,
                                (const int64_t*)ctx->d_read_off, (const cf_c2_tile*)d_tiles, n_tiles, (int)k, rb, bits, shift, nb, d_hist);
         else
-            hipLaunchKernelGGL(cf_c2_hist_kernel, dim3((unsigned)grid), dim3(C2_THREADS), lds_h, ctx->stream, (const unsigned long long*)src, n_w, n_tiles, rb, bits,
+            hipLaunchKernelGGL(cf_c2_hist_kernel, dim3((unsigned)grid), dim3(C2_THREADS), lds_h, ctx->stream, (const unsigned long long*)src, n_rec, n_tiles, rb, bits,
                                shift, nb, d_hist);
         CF_KERNEL_CHECK("cf_c2_hist");
-        CF_TRY(cf_scan_exclusive_u32_to_i64(ctx, d_hist, d_offs, nh, nullptr));
+        int64_t n_made = 0;
+        CF_TRY(cf_scan_exclusive_u32_to_i64(ctx, d_hist, d_offs, nh, &n_made));
+        if (p == 0) n_rec = n_made;         // windows holding other symbols than A, C, G, T make no record
         const int rc = launch_nb(nb, [&](auto NB) {
             if (p == 0)
                 hipLaunchKernelGGL((cf_c2_scatter1_kernel<decltype(NB)::value>), dim3((unsigned)grid), dim3(C2_THREADS), lds_s, ctx->stream, (const uint8_t*)ctx->d_bases,
                                    (const int64_t*)ctx->d_read_off, (const cf_c2_tile*)d_tiles, n_tiles, (int)k, rb, bits, shift, (const int64_t*)d_offs, dst);
             else
                 hipLaunchKernelGGL((cf_c2_scatter_kernel<decltype(NB)::value>), dim3((unsigned)grid), dim3(C2_THREADS), lds_s, ctx->stream, (const unsigned long long*)src,
-                                   n_w, n_tiles, rb, bits, shift, (const int64_t*)d_offs, dst);
+                                   n_rec, n_tiles, rb, bits, shift, (const int64_t*)d_offs, dst);
         });
         if (rc) return cf_fail(ctx, rc, "cf_count_kmers: bad radix width");
         CF_KERNEL_CHECK("cf_c2_scatter");
@@ -602,7 +608,7 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
     int64_t* d_starts = nullptr;
     CF_TRY(tmp.get(&d_starts, (size_t)n_chunks + 2, "count chunk starts"));
     if (n_w > 0) {
-        hipLaunchKernelGGL(cf_c2_chunk_starts_kernel, dim3((unsigned)((n_chunks + 256) / 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)src, n_w, rb, bits,
+        hipLaunchKernelGGL(cf_c2_chunk_starts_kernel, dim3((unsigned)((n_chunks + 256) / 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)src, n_rec, rb, bits,
                            per, n_chunks, d_starts);
         CF_KERNEL_CHECK("cf_c2_chunk_starts_kernel");
     }
@@ -610,7 +616,7 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
         CF_HIP(hipMemsetAsync(d_cnt, 0, 128, ctx->stream));
         const int grid = (int)std::min<int64_t>(n_chunks, (int64_t)std::max(1, ctx->n_cu) * 2);
         const unsigned long long chunk = (unsigned long long)std::min<int64_t>(32768, std::max<int64_t>(C2_TAB, n_w / grid / 4));
-        hipLaunchKernelGGL(cf_c2_reduce_kernel, dim3((unsigned)grid), dim3(C2_RTHREADS), lds_r, ctx->stream, (const unsigned long long*)src, n_w, rb, bits, d_out,
+        hipLaunchKernelGGL(cf_c2_reduce_kernel, dim3((unsigned)grid), dim3(C2_RTHREADS), lds_r, ctx->stream, (const unsigned long long*)src, n_rec, rb, bits, d_out,
                            out_cap, chunk, per, n_chunks, (const int64_t*)d_starts, d_cnt);
         CF_KERNEL_CHECK("cf_c2_reduce_kernel");
         CF_HIP(hipMemcpy(h_cnt, d_cnt, 32, hipMemcpyDeviceToHost));

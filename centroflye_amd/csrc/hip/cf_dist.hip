@@ -159,7 +159,7 @@ struct cf_dist_args {
 // when it was inserted; slots of a bucket fill in ascending order and never empty, so every (b, .) key sits
 // between home(b) and the first bucket that still has an empty slot, and a key is never inserted twice.
 // Two layouts with one interface:
-//   cf_tab_wide    4 slots of 64 bits  [b:32 | d:8 | sel:1 | cnt:23]            any k-mer set size
+//   cf_tab_wide    4 slots of 64 bits  [b:32 | d:8 | sel:1 | cnt:23]            any k-mer set size (cf_tab_wide16: [b:32 | d:16 | sel:1 | cnt:15] for max_d > 255)
 //   cf_tab_narrow  8 keys of 32 bits   [d:8 | b:24] + 8 x 16-bit [sel:1 | cnt-1:15]  (6 bytes per slot: a third
 //                  more slots in the same LDS, half as many full buckets, 32-bit compares) when the set has
 //                  < 2^24 - 1 k-mers and no k-mer has more than 32767 postings.  A claimed slot counts 1 with
@@ -170,13 +170,16 @@ struct cf_dist_args {
 struct alignas(16) cf_u64x2 { unsigned long long x, y; };
 struct alignas(16) cf_u32x4 { uint32_t x, y, z, w; };
 
-struct cf_tab_wide {
+// DB = bits of the distance field: 8 (count 23 bits) for max_d <= 255, 16 (count 15 bits) beyond
+template <int DB>
+struct cf_tab_wide_t {
+    static constexpr uint32_t kCntBits = 31 - DB, kCntMask = (1u << kCntBits) - 1u, kDMask = (1u << DB) - 1u, kDShift = 32 - DB;
     static constexpr uint32_t kSlotBytes = 8, kPerBucket = 4;
     struct bucket { cf_u64x2 lo, hi; };
     struct raw { uint32_t b, i; };
     typedef unsigned long long qitem;   // deferred insert: [b:32 | d:8 | bucket to look at next:24]
-    static __device__ __forceinline__ qitem q_make(uint32_t b, uint32_t dd, uint32_t bk) { return ((unsigned long long)b << 32) | ((unsigned long long)dd << 24) | bk; }
-    static __device__ __forceinline__ void q_take(qitem q, uint32_t n_buckets, uint32_t& b, uint32_t& dd, uint32_t& bk) { b = (uint32_t)(q >> 32); dd = ((uint32_t)q >> 24) & 0xFFu; bk = (uint32_t)q & 0xFFFFFFu; }
+    static __device__ __forceinline__ qitem q_make(uint32_t b, uint32_t dd, uint32_t bk) { return ((unsigned long long)b << 32) | ((unsigned long long)dd << kDShift) | bk; }
+    static __device__ __forceinline__ void q_take(qitem q, uint32_t n_buckets, uint32_t& b, uint32_t& dd, uint32_t& bk) { b = (uint32_t)(q >> 32); dd = ((uint32_t)q >> kDShift) & kDMask; bk = (uint32_t)q & ((1u << kDShift) - 1u); }
     unsigned long long* tab;
     __device__ __forceinline__ void init(unsigned char* lds, uint32_t) { tab = (unsigned long long*)lds; }
     __device__ __forceinline__ void clear(uint32_t slots, uint32_t t, uint32_t nt) const {
@@ -189,12 +192,12 @@ struct cf_tab_wide {
 #pragma unroll
         for (int u = 0; u < DIST_UNROLL; ++u) { const int64_t x = ((ok >> u) & 1u) ? e + u : 0; out[u] = raw{(uint32_t)A.entries[x], (uint32_t)A.entry_i[x]}; }
     }
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { b = r.b; dd = r.i - ig; }
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { b = r.b; dd = (r.i - ig) & 0xFFFFu; }   // unit indices are kept mod 65536 and d <= max_d < 65536: the 16-bit difference IS d
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return b * 0x9E3779B1u; }
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return (uint32_t)(((unsigned long long)h * (unsigned long long)n_buckets) >> 32); }
     static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
     __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u64x2*)&tab[4 * bk], *(const cf_u64x2*)&tab[4 * bk + 2]}; }
-    static __device__ __forceinline__ bool is(unsigned long long v, uint32_t b, uint32_t dd) { return (uint32_t)(v >> 32) == b && ((uint32_t)v >> 24) == dd; }
+    static __device__ __forceinline__ bool is(unsigned long long v, uint32_t b, uint32_t dd) { return (uint32_t)(v >> 32) == b && ((uint32_t)v >> kDShift) == dd; }
     // branch-free: one bit per slot, then find-first-set (nested ?: chains compile to a cascade of exec-mask branches)
     static __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) {   // dd >= 1: an empty slot never matches
         const uint32_t m = (uint32_t)is(k.lo.x, b, dd) | ((uint32_t)is(k.lo.y, b, dd) << 1) | ((uint32_t)is(k.hi.x, b, dd) << 2) | ((uint32_t)is(k.hi.y, b, dd) << 3);
@@ -207,7 +210,7 @@ struct cf_tab_wide {
     __device__ __forceinline__ void add(uint32_t bk, int i) const { atomicAdd(&tab[4 * bk + i], 1ull); }
     // claim slot i of bucket bk for (b, dd): 0 = claimed (count 1), 1 = the same key got there first (counted), 2 = another key
     __device__ __forceinline__ unsigned long long claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const {
-        return atomicCAS(&tab[4 * bk + i], 0ull, ((unsigned long long)b << 32) | ((unsigned long long)dd << 24) | 1ull);
+        return atomicCAS(&tab[4 * bk + i], 0ull, ((unsigned long long)b << 32) | ((unsigned long long)dd << kDShift) | 1ull);
     }
     __device__ __forceinline__ int claim_finish(unsigned long long old, uint32_t bk, int i, uint32_t b, uint32_t dd) const {
         if (old == 0ull) return 0;
@@ -217,7 +220,7 @@ struct cf_tab_wide {
     // filter side: slot s -> (b, dd, cnt) or false when empty
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
         const unsigned long long v = tab[s];
-        b = (uint32_t)(v >> 32); dd = ((uint32_t)v >> 24) & 0xFFu; cnt = (uint32_t)v & 0x7FFFFFu;
+        b = (uint32_t)(v >> 32); dd = ((uint32_t)v >> kDShift) & kDMask; cnt = (uint32_t)v & kCntMask;
         return v != 0ull;
     }
     __device__ __forceinline__ unsigned long long total_of(uint32_t b, uint32_t n_buckets) const {
@@ -225,10 +228,10 @@ struct cf_tab_wide {
         uint32_t bk = home(hash(b), n_buckets);
         for (uint32_t probe = 0; probe < n_buckets; ++probe) {
             const bucket k = read(bk);
-            if ((uint32_t)(k.lo.x >> 32) == b && k.lo.x) total += k.lo.x & 0x7FFFFFull;
-            if ((uint32_t)(k.lo.y >> 32) == b && k.lo.y) total += k.lo.y & 0x7FFFFFull;
-            if ((uint32_t)(k.hi.x >> 32) == b && k.hi.x) total += k.hi.x & 0x7FFFFFull;
-            if ((uint32_t)(k.hi.y >> 32) == b && k.hi.y) total += k.hi.y & 0x7FFFFFull;
+            if ((uint32_t)(k.lo.x >> 32) == b && k.lo.x) total += k.lo.x & (unsigned long long)kCntMask;
+            if ((uint32_t)(k.lo.y >> 32) == b && k.lo.y) total += k.lo.y & (unsigned long long)kCntMask;
+            if ((uint32_t)(k.hi.x >> 32) == b && k.hi.x) total += k.hi.x & (unsigned long long)kCntMask;
+            if ((uint32_t)(k.hi.y >> 32) == b && k.hi.y) total += k.hi.y & (unsigned long long)kCntMask;
             if (empty(k) >= 0) break;
             bk = bk + 1 == n_buckets ? 0u : bk + 1;
         }
@@ -241,8 +244,8 @@ struct cf_tab_wide {
         const unsigned long long v[4] = {k.lo.x, k.lo.y, k.hi.x, k.hi.y};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t cnt = (uint32_t)v[i] & 0x7FFFFFu;
-            if (v[i] != 0ull && cnt >= min_cov) f(4u * bk + (uint32_t)i, (uint32_t)(v[i] >> 32), ((uint32_t)v[i] >> 24) & 0xFFu, cnt, total_of((uint32_t)(v[i] >> 32), n_buckets));
+            const uint32_t cnt = (uint32_t)v[i] & kCntMask;
+            if (v[i] != 0ull && cnt >= min_cov) f(4u * bk + (uint32_t)i, (uint32_t)(v[i] >> 32), ((uint32_t)v[i] >> kDShift) & kDMask, cnt, total_of((uint32_t)(v[i] >> 32), n_buckets));
         }
     }
     template <class F>
@@ -251,10 +254,12 @@ struct cf_tab_wide {
         const unsigned long long v[4] = {k.lo.x, k.lo.y, k.hi.x, k.hi.y};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if ((v[i] >> 23) & 1ull) f(4u * bk + (uint32_t)i, (uint32_t)(v[i] >> 32), ((uint32_t)v[i] >> 24) & 0xFFu, (uint32_t)v[i] & 0x7FFFFFu);
+            if ((v[i] >> kCntBits) & 1ull) f(4u * bk + (uint32_t)i, (uint32_t)(v[i] >> 32), ((uint32_t)v[i] >> kDShift) & kDMask, (uint32_t)v[i] & kCntMask);
     }
-    __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&tab[s], 1ull << 23); }
+    __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&tab[s], 1ull << kCntBits); }
 };
+typedef cf_tab_wide_t<8> cf_tab_wide;
+typedef cf_tab_wide_t<16> cf_tab_wide16;
 
 struct cf_tab_narrow {
     static constexpr uint32_t kSlotBytes = 6, kPerBucket = 8;
@@ -616,7 +621,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {     // all counter adds of the step back to back
-                        const uint32_t idx = (Tab::hash(bb[u]) + (dd_[u] & 0xFFu) * 0x5BD1E9u) >> A.sk_shift;
+                        const uint32_t idx = (Tab::hash(bb[u]) + dd_[u] * 0x5BD1E9u) >> A.sk_shift;
                         sft_[u] = (idx & 3u) << 3;
                         old_[u] = 0;
                         if (bb[u] != a) old_[u] = atomicAdd(&sk[idx >> 2], 1u << sft_[u]);
@@ -828,12 +833,10 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     const std::vector<int64_t>& v_h_unit_ptr = gv ? ctx->g_h_unit_ptr : ctx->h_unit_ptr;
     const int64_t v_n_entries = gv ? ctx->g_entries : ctx->n_entries;
     if (n_parts < 1 || part < 0 || part >= n_parts) return cf_fail(ctx, -22, "cf_dist_edges: bad partition");
-    if (max_d > 255) return cf_fail(ctx, -22, "cf_dist_edges: max_d > 255 does not fit the 8-bit distance field");
+    if (max_d > 65535) return cf_fail(ctx, -22, "cf_dist_edges: max_d > 65535 does not fit the 16-bit distance field");
     if (edge_cap < 0) edge_cap = 0;
     const int64_t R = gv ? ctx->g_reads : ctx->n_reads, U = gv ? ctx->g_units : ctx->n_units, K = ctx->n_kmers;
-    for (int64_t r = 0; r < R; ++r)
-        if (v_h_unit_ptr[(size_t)r + 1] - v_h_unit_ptr[(size_t)r] > 65535)
-            return cf_fail(ctx, -22, "cf_dist_edges: a read has more than 65535 units (16-bit unit index per cloud entry)");
+    // (no limit on the units of a read: unit indices travel mod 256 / mod 65536 and a difference <= max_d is exact)
     CF_HIP(hipSetDevice(ctx->device));
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     // Python slice semantics of itertools.islice(items, min_n, max_n) for non-negative bounds
@@ -853,7 +856,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     uint16_t* d_entry_i = nullptr;
     uint32_t* d_packed = nullptr;
     cf_dist_rec* d_urange = nullptr;
-    bool narrow = false;
+    bool narrow = false, wide16 = false;
     unsigned long long* d_cnt = nullptr;
     int64_t n_post = 0;
     int rc = 0;
@@ -902,8 +905,9 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                                (const uint32_t*)d_pcnt, K, (uint32_t*)(d_cnt + 7));
             if (hipMemcpy(&max_post, d_cnt + 7, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "max postings"); break; }
         }
-        narrow = !ctx->dist_wide && K < ((int64_t)1 << 24) - 1 && max_post <= 32767u;
-        if (max_post >= (1u << 23)) { rc = cf_fail(ctx, -34, "cf_dist_edges: a k-mer has more than 2^23 postings"); break; }
+        wide16 = max_d > 255;          // 16-bit distance field: [b:32 | d:16 | sel:1 | cnt:15]
+        narrow = !wide16 && !ctx->dist_wide && K < ((int64_t)1 << 24) - 1 && max_post <= 32767u;
+        if (max_post >= (1u << 23) || (wide16 && max_post > 32767u)) { rc = cf_fail(ctx, -34, wide16 ? "cf_dist_edges: max_d > 255 with a k-mer of more than 32767 postings" : "cf_dist_edges: a k-mer has more than 2^23 postings"); break; }
         if (narrow) { if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)v_n_entries + DIST_ITEM, "packed cloud entries"))) break; }
         else if ((rc = cf_alloc_t(ctx, &d_entry_i, (size_t)v_n_entries + 1, "entry unit indices"))) break;
         if (U && v_n_entries)
@@ -973,10 +977,12 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("order: ") + hipGetErrorString(e)); break; }
         e = narrow ? hipFuncSetAttribute((const void*)cf_dist_kernel<cf_tab_narrow>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                   : wide16 ? hipFuncSetAttribute((const void*)cf_dist_kernel<cf_tab_wide16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                    : hipFuncSetAttribute((const void*)cf_dist_kernel<cf_tab_wide>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("dist LDS attribute: ") + hipGetErrorString(e)); break; }
         if (n_a > 0 && max_d >= min_d_eff && n_post > 0) {
             if (narrow) hipLaunchKernelGGL((cf_dist_kernel<cf_tab_narrow>), dim3((unsigned)grid), dim3((unsigned)block), lds, ctx->stream, A);
+            else if (wide16) hipLaunchKernelGGL((cf_dist_kernel<cf_tab_wide16>), dim3((unsigned)grid), dim3((unsigned)block), lds, ctx->stream, A);
             else hipLaunchKernelGGL((cf_dist_kernel<cf_tab_wide>), dim3((unsigned)grid), dim3((unsigned)block), lds, ctx->stream, A);
             e = hipGetLastError();
             if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_dist_kernel: ") + hipGetErrorString(e)); break; }

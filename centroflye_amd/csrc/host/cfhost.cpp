@@ -687,6 +687,51 @@ int64_t cfh_n_reads(const cfh_pack* p) { return p->n_reads(); }
 int64_t cfh_n_bases(const cfh_pack* p) { return (int64_t)p->bases.size(); }
 int64_t cfh_n_seen(const cfh_pack* p) { return (int64_t)p->seen.size(); }
 int32_t cfh_non_acgt(const cfh_pack* p) { return p->non_acgt ? 1 : 0; }
+
+// The windows the device path skips (reference scripts/distance_based_kmer_recruitment.py:39-63 counts EVERY window of the raw,
+// not upper-cased row as a string): those holding a symbol other than upper-case A, C, G, T.  They are rare (N calls,
+// soft-masked stretches), so a dictionary keyed by the window's text is enough.
+int cfh_exotic_summary(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, int64_t read_lo, int64_t read_hi, int64_t out[5]) {
+    if (!p || !out || k < 1) return -22;
+    const int64_t R = (int64_t)p->read_off.size() - 1;
+    if (read_lo < 0) read_lo = 0;
+    if (read_hi > R) read_hi = R;
+    std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> all;      // k-mer -> (reads holding it, reads holding it twice)
+    int64_t n_pairs = 0, n_windows = 0;
+    std::unordered_map<std::string, uint32_t> mine;
+    for (int64_t r = read_lo; r < read_hi; ++r) {
+        const int64_t b0 = p->read_off[(size_t)r], len = p->read_off[(size_t)r + 1] - b0;
+        if (len < k) continue;
+        mine.clear();
+        int64_t next_w = 0;                  // windows below this start were taken already
+        for (int64_t i = 0; i < len; ++i) {
+            const char c = p->bases[(size_t)(b0 + i)];
+            if (c == 'A' || c == 'C' || c == 'G' || c == 'T') continue;
+            const int64_t w_lo = std::max<int64_t>(next_w, i - k + 1), w_hi = std::min<int64_t>(i, len - k);
+            for (int64_t w = w_lo; w <= w_hi; ++w) { ++mine[p->bases.substr((size_t)(b0 + w), (size_t)k)]; ++n_windows; }
+            if (w_hi + 1 > next_w) next_w = w_hi + 1;
+        }
+        for (const auto& kv : mine) {
+            auto& e = all[kv.first];
+            ++e.first;
+            if (kv.second > 1) ++e.second;
+            ++n_pairs;
+        }
+    }
+    int64_t n_kept = 0, n_rare = 0, n_block = 0;
+    for (const auto& kv : all) {
+        if (max_nonuniq < 0 || kv.second.second > (uint32_t)max_nonuniq) continue;
+        ++n_kept;
+        if (kv.second.first < lo || kv.second.first > hi) continue;
+        ++n_rare;
+        bool lower = false;
+        for (char c : kv.first) lower |= (c >= 'a' && c <= 'z');
+        if (!lower) ++n_block;               // equals its own upper-case form: could match a window of an upper-cased unit (read_kmer_cloud.py:25)
+    }
+    out[0] = (int64_t)all.size(); out[1] = n_pairs; out[2] = n_kept; out[3] = n_rare; out[4] = n_block;
+    (void)n_windows;
+    return 0;
+}
 const uint8_t* cfh_bases(const cfh_pack* p) { return (const uint8_t*)p->bases.data(); }
 const int64_t* cfh_read_off(const cfh_pack* p) { return p->read_off.data(); }
 const char* cfh_ids(const cfh_pack* p) { return p->ids.data(); }

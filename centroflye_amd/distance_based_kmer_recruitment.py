@@ -74,10 +74,27 @@ def get_kmer_freqs_from_ncrf_report(reads_ncrf_report, k, verbose, max_nonuniq):
     return km.KmerFreqs(keys[keep], pres[keep], k)
 
 
+def check_exotic_windows(packed, k, max_nonuniq, lo, hi, verbose=False):
+    """Reads with symbols other than upper-case A, C, G, T (N calls, soft-masked stretches): the reference counts the
+    windows that hold one as k-mers of their own (reference :47-53, no upper-casing there) — the device path skips them.
+    That changes an output only if such a k-mer is rare AND can match a window of an upper-cased unit
+    (read_kmer_cloud.py:25), i.e. holds no lower-case letter; then the input is refused rather than answered differently."""
+    if not packed.non_acgt:
+        return None
+    ex = packed.exotic_summary(k, max_nonuniq, lo, hi)
+    if verbose:
+        print(f"# k-mers with symbols other than ACGT: {ex['n_distinct']} (rare: {ex['n_rare']})")
+    if ex["n_blocking"]:
+        raise ValueError(f"{ex['n_blocking']} rare k-mer(s) hold a symbol other than A, C, G, T and no lower-case letter (e.g. N): "
+                         "the device path has no code for them; mask or drop those reads")
+    return ex
+
+
 def get_rare_kmers(reads_ncrf_report, k, bottom, top, coverage, kmer_survival_rate, max_nonuniq, verbose):
     e = session.ensure_loaded(reads_ncrf_report.packed, 1)
     e.count_kmers(k)
     lo, hi = rare_window(bottom, top, coverage, kmer_survival_rate)
+    check_exotic_windows(reads_ncrf_report.packed, k, max_nonuniq, lo, hi, verbose)
     e.select_rare(max_nonuniq, lo, hi)
     rare = km.KmerSet(e.kmers(), k)
     if verbose:

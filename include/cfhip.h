@@ -67,8 +67,11 @@ void cf_destroy(cf_ctx* ctx);
 const char* cf_last_error(const cf_ctx* ctx);
 int  cf_device_info(cf_ctx* ctx, char* name, int name_len, int64_t* hbm_bytes, int32_t* n_cu);
 
-/* Reads: ASCII bases (upper-case ACGT only, else -EINVAL), read_off[R+1]; units: unit_ptr[R+1]
- * indexes global units, unit_start/unit_end are absolute offsets into bases. */
+/* Reads: ASCII bases, read_off[R+1]; units: unit_ptr[R+1] indexes global units, unit_start/unit_end are absolute
+ * offsets into bases.  Symbols other than upper-case A, C, G, T are allowed: cf_count_kmers skips the windows that hold
+ * one (the reference counts those as k-mers of their own, distance_based_kmer_recruitment.py:47-53 — the host side-path
+ * cfh_exotic_summary of cfhost.h keeps that count and tells whether any of them could matter downstream), and
+ * cf_build_clouds upper-cases a, c, g, t first, as read_kmer_cloud.py:25 does. */
 int cf_load_reads(cf_ctx* ctx, const uint8_t* bases, const int64_t* read_off, int64_t n_reads,
                   const int64_t* unit_ptr, const int64_t* unit_start, const int64_t* unit_end);
 /* Replace the unit table only (n_motif change). */

@@ -70,6 +70,13 @@ int64_t cfh_n_reads(const cfh_pack* p);      /* kept records, in first-insertion
 int64_t cfh_n_bases(const cfh_pack* p);      /* N_b = sum of de-gapped aligned lengths */
 int64_t cfh_n_seen(const cfh_pack* p);       /* distinct read ids seen (kept + discarded) */
 int32_t cfh_non_acgt(const cfh_pack* p);     /* 1 if any kept base is outside {A,C,G,T} */
+/* The k-mer windows of reads [read_lo, read_hi) that hold a symbol other than upper-case A, C, G, T — the ones the device
+ * path has no 2-bit code for and skips — counted as the reference counts every window (as strings of the raw row,
+ * scripts/distance_based_kmer_recruitment.py:39-63): out[0] distinct such k-mers, out[1] sum over reads of distinct ones,
+ * out[2] of them with multi <= max_nonuniq, out[3] of those with lo <= pres <= hi (they are "rare" k-mers of the
+ * reference), out[4] of those holding no lower-case letter: only these could match a window of an upper-cased unit
+ * (read_kmer_cloud.py:25) and reach the outputs; the others cannot.  The caller refuses the input when out[4] > 0. */
+int cfh_exotic_summary(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, int64_t read_lo, int64_t read_hi, int64_t out[5]);
 
 /* Flat arrays. */
 const uint8_t* cfh_bases(const cfh_pack* p);     /* ASCII, de-gapped oriented r_al, length N_b */

@@ -35,6 +35,48 @@ FIXTURES = {
     ),
 }
 
+# Fixtures outside the generic parity lists (their own tests): reads with symbols the 2-bit code does not have.
+# "exotic": soft-masked (lower-case) stretches and N calls written into the alignment rows of the report after it was
+# generated; max_distance 2 so that the host-emulated kernels can run the whole CLI against the reference's files.
+EXTRA_FIXTURES = {
+    "exotic": dict(
+        synth=dict(seed=19, unit_len=200, monomer_len=50, n_units=60, flank=60000, n_reads=30,
+                   mean_len=6500, sigma=0.2, min_len=6000, max_len=7000, unit_div=0.03,
+                   n_prefix=3, n_suffix=3, prefix_threshold=50000, p_split=0.15),
+        mutate=dict(seed=5, n_lower=18, lower_len=60, n_N=12),
+        stage2=dict(k=19, coverage=14, min_coverage=3, max_distance=2),
+        stage3=dict(prefix_threshold=50000),
+    ),
+}
+
+
+def _spec(name):
+    return FIXTURES[name] if name in FIXTURES else EXTRA_FIXTURES[name]
+
+
+def mutate_report(path, seed, n_lower, lower_len, n_N):
+    """Lower-case n_lower stretches of lower_len aligned bases and turn n_N bases into N, in the read rows of the report."""
+    import random
+    rng = random.Random(seed)
+    with open(path) as f:
+        lines = f.read().split("\n")
+    recs = [i for i, ln in enumerate(lines) if ln and not ln.startswith("#")][::2]
+    for what in ["lower"] * n_lower + ["N"] * n_N:
+        i = rng.choice(recs)
+        head = lines[i].split(None, 4)
+        row = list(lines[i].split(None, 4)[4])
+        c = rng.randrange(len(row))
+        todo = lower_len if what == "lower" else 1
+        while todo and c < len(row):
+            if row[c] != "-":
+                row[c] = row[c].lower() if what == "lower" else "N"
+                todo -= 1
+            c += 1
+        lines[i] = " ".join(head[:4]) + " " + "".join(row)
+    with open(path, "w") as f:
+        f.write("\n".join(lines))
+
+
 STAGE2_DEFAULTS = dict(k=19, min_coverage=4, min_nreads=0, max_nreads=2 ** 63 - 1, min_distance=1,
                        max_distance=150, bottom=0.9, top=3.0, kmer_survival_rate=0.34, max_nonuniq=3)
 STAGE3_DEFAULTS = dict(n_motif=1, k_cloud=19, min_cloud_kmer_freq=2, min_kmer_mult=2, min_unit=2,
@@ -43,24 +85,27 @@ STAGE3_DEFAULTS = dict(n_motif=1, k_cloud=19, min_cloud_kmer_freq=2, min_kmer_mu
 
 def stage2_params(name):
     p = dict(STAGE2_DEFAULTS)
-    p.update(FIXTURES[name]["stage2"])
+    p.update(_spec(name)["stage2"])
     return p
 
 
 def stage3_params(name):
     p = dict(STAGE3_DEFAULTS)
-    p.update(FIXTURES[name]["stage3"])
+    p.update(_spec(name)["stage3"])
     return p
 
 
 def make_report(name, outdir):
     """Write the fixture's NCRF report into outdir; returns its path."""
     from centroflye_amd import _host
-    tag = hashlib.sha1(repr(sorted(FIXTURES[name]["synth"].items())).encode()).hexdigest()[:10]
+    spec = _spec(name)
+    tag = hashlib.sha1(repr(sorted(spec["synth"].items()) + sorted(spec.get("mutate", {}).items())).encode()).hexdigest()[:10]
     path = os.path.join(outdir, f"{name}_{tag}.ncrf")
     if not os.path.exists(path):
         tmp = path + f".tmp{os.getpid()}"
-        _host.synth(report_path=tmp, pack=False, **FIXTURES[name]["synth"])
+        _host.synth(report_path=tmp, pack=False, **spec["synth"])
+        if "mutate" in spec:
+            mutate_report(tmp, **spec["mutate"])
         os.replace(tmp, path)
     return path
 

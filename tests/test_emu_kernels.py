@@ -80,6 +80,18 @@ def test_long_posting_lists_take_the_multi_chunk_path(engine):
     pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=40, max_d=7, min_d=3, seed=5)
 
 
+def test_max_distance_beyond_255_takes_the_16_bit_distance_layout(engine):
+    """--max-distance > 255 (the reference has no limit): [b:32 | d:16 | sel:1 | cnt:15] slots; one read of 330 units, so
+    distances up to 320 occur and unit indices pass 255."""
+    engine.set_param("dist_slots", 4096)
+    engine.set_param("dist_block", 128)
+    try:
+        pathcheck.check_synthetic_clouds(engine, n_reads=1, n_units=330, cloud=3, n_kmers=25, max_d=320, seed=3)
+    finally:
+        engine.set_param("dist_slots", 0)
+        engine.set_param("dist_block", 0)
+
+
 def test_stage3_against_reference_golden(engine, report, golden):
     from centroflye_amd import _host
     from oracle import ncrf

@@ -1,0 +1,143 @@
+"""Reads with symbols the 2-bit k-mer code does not have — soft-masked (lower-case) stretches and N calls — through the
+drop-in CLIs, against files the REFERENCE wrote from the same report (tests/golden/exotic.json, captured by
+make_golden.py under two hash seeds).  Reference semantics: A1 counts the windows of the RAW row
+(distance_based_kmer_recruitment.py:47-53), so a window holding such a symbol is a k-mer of its own; A3 upper-cases the row
+first (read_kmer_cloud.py:25).  Here the device skips those windows in A1 (the host side-path cfh_exotic_summary counts them
+and proves they cannot reach an output), upper-cases in A3, and the files come out identical."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import canon
+import fixtures
+from centroflye_amd import _host, distance_based_kmer_recruitment as dbkr, read_placer, session
+from centroflye_amd.engine import Engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def g():
+    with open(os.path.join(ROOT, "tests", "golden", "exotic.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def exotic_report(fx_dir, g):
+    path = fixtures.make_report("exotic", fx_dir)
+    assert fixtures.sha256_file(path) == g["report_sha256"]
+    return path
+
+
+def _argv2(report, outdir, p2):
+    return ["--ncrf", report, "--coverage", str(p2["coverage"]), "--min-coverage", str(p2["min_coverage"]), "--outdir", outdir,
+            "-k", str(p2["k"]), "--max-distance", str(p2["max_distance"]), "--min-distance", str(p2["min_distance"])]
+
+
+def _argv3(report, kfile, outdir, p3):
+    return ["--ncrf", report, "--genomic-kmers", kfile, "--outdir", outdir, "--n-motif", str(p3["n_motif"]),
+            "--min-cloud-kmer-freq", str(p3["min_cloud_kmer_freq"]), "--min-kmer-mult", str(p3["min_kmer_mult"]),
+            "--min-unit", str(p3["min_unit"]), "--min-inters", str(p3["min_inters"]), "--prefix-threshold", str(p3["prefix_threshold"])]
+
+
+def _check_files(out2, out3, g):
+    p2 = g["stage2"]
+    with open(os.path.join(out2, f"unique_kmers_min_edge_cov_{p2['min_coverage']}.txt"), "rb") as f:
+        assert hashlib.sha256(f.read()).hexdigest() == g["unique_kmers"]["sha256"]
+    with open(os.path.join(out2, f"unique_edges_min_edge_cov_{p2['min_coverage']}.txt")) as f:
+        elines = f.read().splitlines()
+    assert len(elines) == g["edges"]["n"] and canon.edge_lines_digest(elines) == g["edges"]["digest"]
+    with open(os.path.join(out3, "read_positions.csv")) as f:
+        lines = f.read().splitlines()
+    assert [ln for ln in lines if not ln.endswith(" None")] == g["read_positions"]["placed"]
+    assert sorted(ln for ln in lines if ln.endswith(" None")) == g["read_positions"]["none"]
+
+
+def test_the_report_really_holds_such_symbols_and_the_side_path_counts_them(exotic_report, g):
+    pk = _host.parse_report(exotic_report)
+    assert pk.non_acgt
+    raw = pk.bases.tobytes()
+    assert raw.count(b"N") >= 5 and sum(raw.count(c) for c in (b"a", b"c", b"g", b"t")) >= 500
+    p2 = g["stage2"]
+    lo, hi = dbkr.rare_window(p2["bottom"], p2["top"], p2["coverage"], p2["kmer_survival_rate"])
+    ex = pk.exotic_summary(p2["k"], p2["max_nonuniq"], lo, hi)
+    # an independent count of the same windows
+    seen = {}
+    for r in range(pk.n_reads):
+        s = raw[pk.read_off[r]:pk.read_off[r + 1]]
+        mine = {}
+        for w in range(len(s) - p2["k"] + 1):
+            x = s[w:w + p2["k"]]
+            if x.strip(b"ACGT"):
+                mine[x] = mine.get(x, 0) + 1
+        for x, c in mine.items():
+            a = seen.setdefault(x, [0, 0]); a[0] += 1; a[1] += c > 1
+    assert ex["n_distinct"] == len(seen) > 100 and ex["n_read_kmers"] == sum(v[0] for v in seen.values())
+    assert ex["n_kept"] == sum(v[1] <= p2["max_nonuniq"] for v in seen.values())
+    assert ex["n_rare"] == sum(v[1] <= p2["max_nonuniq"] and lo <= v[0] <= hi for v in seen.values())
+    assert ex["n_blocking"] == 0
+
+
+def test_presence_and_rare_counts_add_up_to_the_reference(emu_lib, exotic_report, g):
+    """reference's dict of kept k-mers (G1) = kept 2-bit k-mers of the device + kept k-mers of the host side-path; its rare
+    set (G2) likewise."""
+    pk = _host.parse_report(exotic_report)
+    p2 = g["stage2"]
+    lo, hi = dbkr.rare_window(p2["bottom"], p2["top"], p2["coverage"], p2["kmer_survival_rate"])
+    ex = pk.exotic_summary(p2["k"], p2["max_nonuniq"], lo, hi)
+    with Engine(0, emu_lib) as e:
+        e.load(pk, 1)
+        e.count_kmers(p2["k"])
+        n_rare = e.select_rare(p2["max_nonuniq"], lo, hi)
+        st = e.stats()
+    assert st["n_kept"] + ex["n_kept"] == g["presence"]["n"]
+    assert n_rare + ex["n_rare"] == g["rare"]["n"]
+
+
+def test_blocking_rare_kmer_is_refused_not_answered_differently(tmp_path):
+    """A k-mer with an N that IS rare (the same N-holding window in many reads) could match a window of an upper-cased
+    unit: the drop-in refuses the input."""
+    unit = "ACGTTGCAAGGCTTAACCGGATCGATTACAGGCATCGGAT"
+    lines = []
+    for r in range(12):
+        row = unit * 200
+        row = row[:333] + "N" + row[334:]
+        lines += [f"read{r} {len(row) + 50} {len(row)}bp 10-{10 + len(row)} {row}", f"{unit}+ {len(row)}bp score=9 {row}"]
+    path = tmp_path / "n.ncrf"
+    path.write_text("\n".join(lines) + "\n")
+    pk = _host.parse_report(str(path))
+    ex = pk.exotic_summary(19, 3, 10, 32)
+    assert ex["n_blocking"] > 0
+    with pytest.raises(ValueError, match="symbol other than"):
+        dbkr.check_exotic_windows(pk, 19, 3, 10, 32)
+
+
+def test_cli_files_equal_the_reference_on_emulated_kernels(emu_lib, exotic_report, g, tmp_path):
+    session.reset()
+    session._engine = Engine(0, emu_lib)
+    session._engine.set_param("dist_slots", 2048)
+    session._engine.set_param("dist_block", 128)
+    try:
+        out2, out3 = str(tmp_path / "s2"), str(tmp_path / "s3")
+        dbkr.main(_argv2(exotic_report, out2, g["stage2"]))
+        kfile = os.path.join(out2, f"unique_kmers_min_edge_cov_{g['stage2']['min_coverage']}.txt")
+        read_placer.main(_argv3(exotic_report, kfile, out3, g["stage3"]))
+        _check_files(out2, out3, g)
+    finally:
+        session.reset()
+
+
+@pytest.mark.gpu
+def test_cli_files_equal_the_reference_on_the_gpu(exotic_report, g, tmp_path):
+    out2, out3 = str(tmp_path / "s2"), str(tmp_path / "s3")
+    subprocess.check_call([sys.executable, "-u", os.path.join(ROOT, "scripts", "distance_based_kmer_recruitment.py")] + _argv2(exotic_report, out2, g["stage2"]),
+                          stdout=subprocess.DEVNULL)
+    kfile = os.path.join(out2, f"unique_kmers_min_edge_cov_{g['stage2']['min_coverage']}.txt")
+    subprocess.check_call([sys.executable, "-u", os.path.join(ROOT, "scripts", "read_placer.py")] + _argv3(exotic_report, kfile, out3, g["stage3"]),
+                          stdout=subprocess.DEVNULL)
+    _check_files(out2, out3, g)

@@ -106,6 +106,14 @@ def test_long_posting_lists_take_the_multi_chunk_path(engine):
     pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=40, max_d=7, min_d=3, seed=5)
 
 
+def test_max_distance_beyond_255_and_reads_of_many_units(engine):
+    """Limits the reference does not have: --max-distance > 255 takes the 16-bit distance layout
+    ([b:32 | d:16 | sel:1 | cnt:15]); unit indices travel mod 256 / mod 65536, so a read may have any number of units
+    (here 70 000 units in one read, narrow layout, and 700 units with max_d 600, 16-bit layout)."""
+    pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=700, cloud=4, n_kmers=40, max_d=600, seed=3)
+    pathcheck.check_synthetic_clouds(engine, n_reads=1, n_units=70000, cloud=3, n_kmers=2000, max_d=3, seed=4)
+
+
 def test_against_c_oracle_on_bench_like_sample(engine):
     """Same generator and parameters as the benchmark workload, at a size the C oracle finishes in
     ~20 s: every counter and the order-independent checksums of rare set, clouds and edges."""
@@ -189,7 +197,7 @@ def test_errors_and_degenerate_inputs(engine):
     assert np.array_equal(keys, codes) and (pres == 1).all() and np.array_equal(multi, (cnt > 1).astype(np.uint32))
     assert engine.select_rare(0, 1, 1) == int((cnt == 1).sum())
     with pytest.raises(DeviceError, match="max_d"):
-        engine.select_rare(3, 1, 1); engine.build_clouds(); engine.dist_edges(0, 10, 1, 300, 1, 0.8)
+        engine.select_rare(3, 1, 1); engine.build_clouds(); engine.dist_edges(0, 10, 1, 70000, 1, 0.8)
 
 
 def test_exchange_path_on_one_rank_rccl():
