@@ -50,9 +50,10 @@ struct cf_place_state {
     unsigned long long* ckeys; uint32_t* ccnt; uint64_t cmask;
     uint8_t* freq_flag;
     // postings of the stage
-    const int64_t* post_ptr; const int32_t* post;
-    // score map: key (read<<32|off)|OCC, s0, s1
-    unsigned long long* skeys; uint32_t* s0; uint32_t* s1; uint64_t smask;
+    const int64_t* post_ptr; const unsigned long long* post_ri;   // posting = read << 32 | unit index inside the read
+    // score map: key (read<<32|off)|OCC, value s0 << 32 | s1 in ONE word: the lane whose add is the last one on an entry gets
+    // the entry's final state back from that add
+    unsigned long long* skeys; unsigned long long* s01; uint64_t smask;
     uint32_t* qflag;   // one byte per score slot (4 per word): some view of the entry qualified; the arg-max scans these bytes only
     // seen set of (score slot << 32 | unit index)
     unsigned long long* seen; uint64_t seen_mask;
@@ -121,6 +122,43 @@ cf_place_seed_kernel(cf_place_state S) {
     }
 }
 
+// one hit: k-mer frequent at contig position q, posting (read r, unit i) -> scores[r][q - i][i] += 1 (reference cloud_contig.py:90-94)
+__device__ __forceinline__ void cf_score_hit(const cf_place_state& S, uint32_t r, uint32_t i, uint32_t q) {
+    if (q < i) return;
+    const uint32_t off = q - i;
+    const unsigned long long want = (((unsigned long long)r << 32) | off) | CF_OCC;
+    uint64_t h = cf_mix64(want) & S.smask;
+    bool ok = false;
+    for (uint64_t probe = 0; probe <= S.smask && probe < 4096; ++probe) {   // a long probe = table too full: grow and restart
+        unsigned long long cur = S.skeys[h];
+        if (cur == 0ull) {
+            cur = atomicCAS(&S.skeys[h], 0ull, want);
+            if (cur == 0ull && atomicAdd(&S.ctl[4], 1u) > (unsigned int)(S.smask >> 1)) atomicOr(&S.ctl[2], 2u);   // load > 0.5
+        }
+        if (cur == 0ull || cur == want) { ok = true; break; }
+        h = (h + 1) & S.smask;
+    }
+    if (!ok) { atomicOr(&S.ctl[2], 2u); return; }
+    // first hit of unit i at this (read, offset)?
+    const unsigned long long sk = ((((unsigned long long)h) << 24) ^ ((unsigned long long)i)) | CF_OCC;  // slot < 2^38, i < 2^24
+    uint64_t hs = cf_mix64(sk) & S.seen_mask;
+    bool fresh = false, placed = false;
+    for (uint64_t probe = 0; probe <= S.seen_mask && probe < 4096; ++probe) {
+        unsigned long long cur = S.seen[hs];
+        if (cur == 0ull) { cur = atomicCAS(&S.seen[hs], 0ull, sk); if (cur == 0ull) { fresh = true; placed = true; break; } }
+        if (cur == sk) { placed = true; break; }
+        hs = (hs + 1) & S.seen_mask;
+    }
+    if (!placed) atomicOr(&S.ctl[2], 4u);
+    // s1 += 1, s0 += fresh in one add; what comes back plus the increment is the entry as this lane left it: the lane whose
+    // add is the last one on the entry sees its final state, so a finally-qualifying entry is always flagged; flags can be
+    // stale-true (the arg-max re-checks and clears them), never stale-false
+    const unsigned long long inc = 1ull | ((unsigned long long)(fresh ? 1u : 0u) << 32);
+    const unsigned long long v = atomicAdd(&S.s01[h], inc) + inc;
+    const uint32_t v0 = (uint32_t)(v >> 32), v1 = (uint32_t)v;
+    if (v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters) { ((uint8_t*)S.qflag)[h] = 1; S.dirty[h >> S.slice_shift] = 1; }
+}
+
 // apply the pending events to the scores: one wave per event, lanes over the k-mer's postings
 __global__ void __launch_bounds__(PL_THREADS)
 cf_place_update_kernel(cf_place_state S) {
@@ -134,42 +172,8 @@ cf_place_update_kernel(cf_place_state S) {
         const uint32_t x = (uint32_t)(E >> 32), q = (uint32_t)E;
         const int64_t p0 = S.post_ptr[x], p1 = S.post_ptr[x + 1];
         for (int64_t pp = p0 + lane; pp < p1; pp += 64) {
-            const int32_t g = S.post[pp];
-            const uint32_t r = (uint32_t)S.unit2read[g];
-            const uint32_t i = (uint32_t)(g - S.unit_ptr[r]);
-            if (q < i) continue;
-            const uint32_t off = q - i;
-            const unsigned long long want = (((unsigned long long)r << 32) | off) | CF_OCC;
-            uint64_t h = cf_mix64(want) & S.smask;
-            bool ok = false;
-            for (uint64_t probe = 0; probe <= S.smask && probe < 4096; ++probe) {   // a long probe = table too full: grow and restart
-                unsigned long long cur = S.skeys[h];
-                if (cur == 0ull) {
-                    cur = atomicCAS(&S.skeys[h], 0ull, want);
-                    if (cur == 0ull && atomicAdd(&S.ctl[4], 1u) > (unsigned int)(S.smask >> 1)) atomicOr(&S.ctl[2], 2u);   // load > 0.5
-                }
-                if (cur == 0ull || cur == want) { ok = true; break; }
-                h = (h + 1) & S.smask;
-            }
-            if (!ok) { atomicOr(&S.ctl[2], 2u); continue; }
-            atomicAdd(&S.s1[h], 1u);
-            // first hit of unit i at this (read, offset)?
-            const unsigned long long sk = ((((unsigned long long)h) << 24) ^ ((unsigned long long)i)) | CF_OCC;  // slot < 2^38, i < 2^24
-            uint64_t hs = cf_mix64(sk) & S.seen_mask;
-            bool fresh = false, placed = false;
-            for (uint64_t probe = 0; probe <= S.seen_mask && probe < 4096; ++probe) {
-                unsigned long long cur = S.seen[hs];
-                if (cur == 0ull) { cur = atomicCAS(&S.seen[hs], 0ull, sk); if (cur == 0ull) { fresh = true; placed = true; break; } }
-                if (cur == sk) { placed = true; break; }
-                hs = (hs + 1) & S.seen_mask;
-            }
-            if (!placed) atomicOr(&S.ctl[2], 4u);
-            if (fresh) atomicAdd(&S.s0[h], 1u);
-            // flag the slot when the entry qualifies in this lane's view, read back at L2 AFTER its own increments: the
-            // lane whose increment is the last one on the entry sees its final state, so a finally-qualifying entry is
-            // always flagged; flags can be stale-true (the arg-max re-checks and clears them), never stale-false
-            const uint32_t v0 = atomicAdd(&S.s0[h], 0u), v1 = atomicAdd(&S.s1[h], 0u);
-            if (v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters) { ((uint8_t*)S.qflag)[h] = 1; S.dirty[h >> S.slice_shift] = 1; }
+            const unsigned long long ri = S.post_ri[pp];
+            cf_score_hit(S, (uint32_t)(ri >> 32), (uint32_t)ri, q);
         }
     }
 }
@@ -229,7 +233,8 @@ cf_place_argmax_kernel(cf_place_state S) {
                     const uint64_t i = 16 * q + 4 * (uint64_t)wi + (uint64_t)j;
                     const unsigned long long k = S.skeys[i];
                     const uint32_t r = (uint32_t)((k & ~CF_OCC) >> 32), off = (uint32_t)k;
-                    const uint32_t v0 = S.s0[i], v1 = S.s1[i];
+                    const unsigned long long v01 = S.s01[i];
+                    const uint32_t v0 = (uint32_t)(v01 >> 32), v1 = (uint32_t)v01;
                     if (!(v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters)) { ((uint8_t*)S.qflag)[i] = 0; continue; }   // stale flag
                     if (S.used[r]) { ((uint8_t*)S.qflag)[i] = 0; continue; }   // a placed read is never a candidate again: drop its entry from later scans
                     cf_cand c; c.s0 = v0; c.s1 = v1; c.off = off; c.rank = (uint32_t)S.id_rank[r]; c.read = r; c.valid = 1;
@@ -271,6 +276,13 @@ cf_place_pick_add_kernel(cf_place_state S, int n_cand) {
     }
 }
 
+
+// (Round 2 tried the greedy loop of a stage as ONE persistent launch — flag scan per workgroup, grid barrier, pick + add +
+// score updates by the waves that raise the events, grid barrier: 58 us per placed read against 32 us for the three
+// kernels below at 50 000 reads (two agent-scope barriers under load cost more than three dependent launches whose
+// grids fit their work), and entries updated by other XCDs' atomics were read stale through this XCD's L2 by the plain
+// loads of the scan.  Removed; the kernel boundary is the cheapest correct grid-wide barrier this loop has.)
+
 __global__ void __launch_bounds__(256)
 cf_unit2read_kernel(const int64_t* __restrict__ unit_ptr, int64_t n_reads, int32_t* __restrict__ u2r) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -282,16 +294,18 @@ cf_unit2read_kernel(const int64_t* __restrict__ unit_ptr, int64_t n_reads, int32
 __global__ void __launch_bounds__(256)
 cf_place_post_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ entries, const int32_t* __restrict__ u2r,
                      const uint8_t* __restrict__ cls, int want_cls, int64_t n_units, int mode, uint32_t* __restrict__ cnt,
-                     const int64_t* __restrict__ post_ptr, int32_t* __restrict__ post) {
+                     const int64_t* __restrict__ post_ptr, unsigned long long* __restrict__ post, const int64_t* __restrict__ unit_ptr) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t u = wave; u < n_units; u += n_waves) {
-        if (cls[u2r[u]] != want_cls) continue;
+        const int32_t r = u2r[u];
+        if (cls[r] != want_cls) continue;
+        const unsigned long long ri = mode == 0 ? 0ull : (((unsigned long long)(uint32_t)r << 32) | (unsigned long long)(uint32_t)(u - unit_ptr[r]));
         for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) {
             const int32_t x = entries[e];
             if (mode == 0) atomicAdd(&cnt[x], 1u);
-            else post[post_ptr[x] + atomicAdd(&cnt[x], 1u)] = (int32_t)u;
+            else post[post_ptr[x] + atomicAdd(&cnt[x], 1u)] = ri;
         }
     }
 }
@@ -322,7 +336,8 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     S.unit_ptr = ctx->d_unit_ptr; S.cloud_ptr = ctx->d_cloud_ptr; S.entries = ctx->d_entries;
     S.thr = (uint32_t)std::max(1, min_freq); S.min_unit = (uint32_t)std::max(0, min_unit);
     S.min_inters = (uint32_t)std::max(0, min_inters); S.min_prop = (uint32_t)std::max(0, min_prop);
-    int32_t *d_u2r = nullptr, *d_post = nullptr, *d_rank = nullptr;
+    int32_t *d_u2r = nullptr, *d_rank = nullptr;
+    unsigned long long* d_post = nullptr;
     uint8_t *d_cls = nullptr, *d_used = nullptr;
     uint32_t* d_pcnt = nullptr;
     int64_t* d_post_ptr = nullptr;
@@ -338,8 +353,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     CF_TRY(B.get(&d_post_ptr, (size_t)K + 1, "stage posting offsets"));
     CF_TRY(B.get(&d_post, (size_t)N + 1, "stage postings"));
     CF_TRY(B.get(&S.skeys, (size_t)score_cap, "score keys"));
-    CF_TRY(B.get(&S.s0, (size_t)score_cap, "score s0"));
-    CF_TRY(B.get(&S.s1, (size_t)score_cap, "score s1"));
+    CF_TRY(B.get(&S.s01, (size_t)score_cap, "score s0 | s1"));
     CF_TRY(B.get(&S.qflag, (size_t)score_cap / 4 + 1, "score flags"));
     CF_TRY(B.get(&S.seen, (size_t)seen_cap, "seen set"));
     CF_TRY(B.get(&S.events, (size_t)N + 1, "events"));
@@ -359,7 +373,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     CF_TRY(B.get(&S.out_s0, (size_t)R + 1, "out_s0"));
     CF_TRY(B.get(&S.out_s1, (size_t)R + 1, "out_s1"));
     S.unit2read = d_u2r; S.cmask = ccap - 1; S.smask = score_cap - 1; S.seen_mask = seen_cap - 1;
-    S.used = d_used; S.id_rank = d_rank; S.post_ptr = d_post_ptr; S.post = d_post;
+    S.used = d_used; S.id_rank = d_rank; S.post_ptr = d_post_ptr; S.post_ri = d_post;
     hipStream_t st = ctx->stream;
     CF_HIP(hipMemcpyAsync(d_cls, cls, (size_t)R, hipMemcpyHostToDevice, st));
     CF_HIP(hipMemcpyAsync(d_rank, id_rank, (size_t)R * 4, hipMemcpyHostToDevice, st));
@@ -386,16 +400,15 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         // postings of the stage
         CF_HIP(hipMemsetAsync(d_pcnt, 0, (size_t)(K + 1) * 4, st));
         hipLaunchKernelGGL(cf_place_post_kernel, dim3((unsigned)g_units), dim3(256), 0, st, (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries,
-                           (const int32_t*)d_u2r, (const uint8_t*)d_cls, stage_cls, U, 0, d_pcnt, (const int64_t*)nullptr, (int32_t*)nullptr);
+                           (const int32_t*)d_u2r, (const uint8_t*)d_cls, stage_cls, U, 0, d_pcnt, (const int64_t*)nullptr, (unsigned long long*)nullptr, (const int64_t*)ctx->d_unit_ptr);
         int64_t n_post = 0;
         CF_TRY(cf_scan_exclusive_u32_to_i64(ctx, d_pcnt, d_post_ptr, K + 1, &n_post));
         CF_HIP(hipMemsetAsync(d_pcnt, 0, (size_t)(K + 1) * 4, st));
         hipLaunchKernelGGL(cf_place_post_kernel, dim3((unsigned)g_units), dim3(256), 0, st, (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries,
-                           (const int32_t*)d_u2r, (const uint8_t*)d_cls, stage_cls, U, 1, d_pcnt, (const int64_t*)d_post_ptr, d_post);
+                           (const int32_t*)d_u2r, (const uint8_t*)d_cls, stage_cls, U, 1, d_pcnt, (const int64_t*)d_post_ptr, d_post, (const int64_t*)ctx->d_unit_ptr);
         // fresh scores, seed events
         CF_HIP(hipMemsetAsync(S.skeys, 0, (size_t)score_cap * 8, st));
-        CF_HIP(hipMemsetAsync(S.s0, 0, (size_t)score_cap * 4, st));
-        CF_HIP(hipMemsetAsync(S.s1, 0, (size_t)score_cap * 4, st));
+        CF_HIP(hipMemsetAsync(S.s01, 0, (size_t)score_cap * 8, st));
         CF_HIP(hipMemsetAsync(S.qflag, 0, (size_t)score_cap + 4, st));
         CF_HIP(hipMemsetAsync(S.dirty, 1, (size_t)n_am, st));
         CF_HIP(hipMemsetAsync(S.block_best, 0, (size_t)n_am * sizeof(cf_cand), st));

@@ -217,6 +217,7 @@ inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 inline void __builtin_amdgcn_s_sleep(int) {}
 
+
 // atomics (single OS thread: plain RMW)
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = (T)(o + v); return o; }
 template <class T> inline T atomicSub(T* p, T v) { T o = *p; *p = (T)(o - v); return o; }

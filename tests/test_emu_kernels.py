@@ -113,9 +113,14 @@ def test_unit_kmer_occurrences_and_top_n(engine, report):
 
 
 def test_errors(engine):
-    bases = np.frombuffer(b"ACGTNACGT", np.uint8)
-    with pytest.raises(DeviceError, match="ACGT"):
-        engine.load_arrays(bases, [0, 9], [0, 1], [0], [9])
+    # symbols other than upper-case ACGT are accepted (their windows have no 2-bit code and are skipped; see
+    # tests/test_exotic_symbols.py) — except by the occurrence counts
+    engine.load_arrays(np.frombuffer(b"ACGTNACGTACGTACGTACGTACGTACGTAC", np.uint8), [0, 31], [0, 1], [0], [31])
+    engine.count_kmers(4)
+    keys, pres, multi = engine.table()
+    assert recruit.decode_kmer(keys[0], 4) == "ACGT" and len(keys) == 4 and not any("N" in recruit.decode_kmer(x, 4) for x in keys)
+    with pytest.raises(DeviceError, match="symbols"):
+        engine.count_occurrences(4)
     engine.load_arrays(np.frombuffer(b"ACGTACGTAC", np.uint8), [0, 10], [0, 1], [0], [10])
     with pytest.raises(DeviceError):
         engine.count_kmers(32)

@@ -183,8 +183,11 @@ def test_full_size_properties(engine):
 
 
 def test_errors_and_degenerate_inputs(engine):
-    with pytest.raises(DeviceError, match="ACGT"):
-        engine.load_arrays(np.frombuffer(b"ACGTNACGT", np.uint8), [0, 9], [0, 1], [0], [9])
+    engine.load_arrays(np.frombuffer(b"ACGTNACGTACGTACGTACGTACGTACGTAC", np.uint8), [0, 31], [0, 1], [0], [31])   # N: its windows are skipped
+    engine.count_kmers(4)
+    assert engine.table()[0].size == 4
+    with pytest.raises(DeviceError, match="symbols"):
+        engine.count_occurrences(4)
     engine.load_arrays(np.zeros(0, np.uint8), [0], [0], [], [])
     engine.count_kmers(19)
     assert engine.select_rare(3, 1, 10) == 0 and engine.build_clouds() == 0
