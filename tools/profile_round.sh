@@ -1,16 +1,19 @@
 #!/usr/bin/env bash
-# Runs ON THE GPU BOX (through gpurun): kernel-trace stats of the default bench, then PMC passes of one
-# cf_dist_kernel launch (one rocprofv3 run per counter group, never combined with tracing domains).
+# Runs ON THE GPU BOX (through gpurun): kernel-trace stats of the default bench, the plain bench line, then PMC passes of
+# ONE step (one rocprofv3 run per counter group, never combined with tracing domains: --kernel-trace only).
 # Results land under gpurun_out/prof_<tag>/ ; tools/pmc_summary.py turns them into profiles/<tag>_*.
 # usage: bash tools/profile_round.sh <tag>
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o bench -- python3 bench.py --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
 python3 bench.py > "$out/bench_line.json" 2> "$out/bench.err"
-pmc() { name=$1; shift; rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d "$out/pmc_$name" -o "$name" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> "$out/pmc_$name.err"; }
+python3 bench.py --no-cpu-baseline --place --rr > "$out/bench_line_place_rr.json" 2> "$out/bench_place_rr.err"
+# one step, one launch of every kernel of the path (edge cap as in round 1 so that the dist kernel's counters compare)
+ONE="bench.py --steps 1 --warmup 0 --no-cpu-baseline --transfer-steps 0 --edge-cap 67108864"
+pmc() { name=$1; shift; rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d "$out/pmc_$name" -o "$name" -- python3 $ONE > /dev/null 2> "$out/pmc_$name.err"; }
 pmc A SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
 pmc B SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU TCC_HIT TCC_MISS
 pmc C FETCH_SIZE
