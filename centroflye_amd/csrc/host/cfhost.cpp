@@ -8,7 +8,11 @@
 //   scripts/utils/bio.py:27-29     RC
 #include "cfhost.h"
 
+#include <chrono>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <sys/types.h>
 
 #include <algorithm>
@@ -21,6 +25,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <new>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -63,9 +68,26 @@ inline char rc_char(char c) {
         default: return c;
     }
 }
+struct ByteTables {      // per-byte lookups for the row passes
+    unsigned char rc[256], up[256], other[256];      // other: 1 for anything that is not A/C/G/T
+    ByteTables() {
+        for (int i = 0; i < 256; ++i) {
+            rc[i] = (unsigned char)rc_char((char)i);
+            up[i] = (unsigned char)((i >= 'a' && i <= 'z') ? i - 32 : i);
+            other[i] = !(i == 'A' || i == 'C' || i == 'G' || i == 'T');
+        }
+    }
+};
+const ByteTables BT;
 void rc_inplace(std::string& s) {
-    std::reverse(s.begin(), s.end());
-    for (auto& c : s) c = rc_char(c);
+    const size_t n = s.size();
+    unsigned char* d = (unsigned char*)&s[0];
+    for (size_t i = 0, j = n; i < j; ) {
+        --j;
+        const unsigned char a = BT.rc[d[i]], b = BT.rc[d[j]];
+        d[i] = b; d[j] = a;
+        ++i;
+    }
 }
 inline char up(char c) { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : c; }
 
@@ -78,10 +100,20 @@ struct FileRecord {
     int64_t m_al_len = 0, score = 0;
 };
 
+// CFH_TIMING=1 in the environment prints the phases of the parser to stderr.
+struct PhaseClock {
+    bool on = std::getenv("CFH_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[cfhost] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 // Result of the heavy per-record work (orientation + de-gap + unit split for n = 1).
 struct Staged {
-    std::string bases;               // de-gapped oriented r_al
-    std::string r_al, m_al;          // oriented rows (kept only when requested)
     std::vector<int64_t> col_bounds; // unit boundaries as alignment columns (n = 1)
     std::vector<int64_t> pos_bounds; // same boundaries in de-gapped read coordinates
     int64_t ncols = 0;
@@ -90,67 +122,82 @@ struct Staged {
 
 // Unit split: leftmost non-overlapping matches of motif*n in the de-gapped, upper-cased
 // motif row; a match ends after the gap columns that follow its last base.
-void split_units(const std::string& r_al, const std::string& m_al, const std::string& motif,
+void split_units(size_t r_cols, const char* m_al, size_t m_cols, const std::string& motif,
                  int n, std::vector<int64_t>& col_bounds) {
     col_bounds.clear();
-    const int64_t ncols = (int64_t)m_al.size();
-    std::string s;
-    std::vector<int64_t> cols;
-    s.reserve(m_al.size());
-    cols.reserve(m_al.size());
+    const int64_t ncols = (int64_t)m_cols;
+    static thread_local std::vector<unsigned char> s;     // the motif row without gaps, upper case
+    static thread_local std::vector<uint32_t> cols;       // and the column of each of its letters
+    s.resize((size_t)ncols + 1);
+    cols.resize((size_t)ncols + 1);
+    size_t ns = 0;
+    const unsigned char* m = (const unsigned char*)m_al;
     for (int64_t c = 0; c < ncols; ++c) {
-        if (m_al[c] != '-') { s.push_back(up(m_al[c])); cols.push_back(c); }
+        s[ns] = BT.up[m[c]]; cols[ns] = (uint32_t)c;
+        ns += m[c] != '-';
     }
     std::string pat;
     for (int i = 0; i < n; ++i) pat += motif;
     if (pat.empty()) return;
+    const size_t L = pat.size();
     std::vector<int64_t> starts;
     int64_t last_end = -1;
     size_t pos = 0;
-    while (true) {
-        size_t p = s.find(pat, pos);
-        if (p == std::string::npos) break;
+    while (pos + L <= ns) {
+        size_t p = pos;
+        if (std::memcmp(s.data() + pos, pat.data(), L) != 0) {      // copies usually follow one another directly
+            const void* f = memmem(s.data() + pos, ns - pos, pat.data(), L);
+            if (!f) break;
+            p = (size_t)((const unsigned char*)f - s.data());
+        }
         int64_t st = cols[p];
-        int64_t en = cols[p + pat.size() - 1] + 1;
-        while (en < ncols && m_al[en] == '-') ++en;
+        int64_t en = (int64_t)cols[p + L - 1] + 1;
+        while (en < ncols && m_al[(size_t)en] == '-') ++en;
         starts.push_back(st);
         last_end = en;
-        pos = p + pat.size();
+        pos = p + L;
     }
     if (starts.empty()) return;
     const double cut = (double)motif.size() * 0.2;
     if ((double)starts[0] > cut) col_bounds.push_back(0);
     for (auto v : starts) col_bounds.push_back(v);
     col_bounds.push_back(last_end);
-    if ((double)last_end < (double)r_al.size() - cut) col_bounds.push_back((int64_t)r_al.size());
+    if ((double)last_end < (double)r_cols - cut) col_bounds.push_back((int64_t)r_cols);
+}
+void split_units(const std::string& r_al, const std::string& m_al, const std::string& motif,
+                 int n, std::vector<int64_t>& col_bounds) {
+    split_units(r_al.size(), m_al.data(), m_al.size(), motif, n, col_bounds);
 }
 
-void cols_to_pos(const std::string& r_al, const std::vector<int64_t>& col_bounds,
+void cols_to_pos(const char* r, size_t r_cols, const std::vector<int64_t>& col_bounds,
                  std::vector<int64_t>& pos_bounds) {
     pos_bounds.resize(col_bounds.size());
-    size_t bi = 0;
-    int64_t cnt = 0;
-    const int64_t ncols = (int64_t)r_al.size();
-    for (int64_t c = 0; c <= ncols && bi < col_bounds.size(); ++c) {
-        while (bi < col_bounds.size() && col_bounds[bi] == c) pos_bounds[bi++] = cnt;
-        if (c < ncols && r_al[c] != '-') ++cnt;
+    int64_t c = 0, cnt = 0;
+    for (size_t bi = 0; bi < col_bounds.size(); ++bi) {      // boundaries ascend
+        const int64_t to = std::min<int64_t>(col_bounds[bi], (int64_t)r_cols);
+        int64_t add = 0;
+        for (; c < to; ++c) add += r[c] != '-';
+        cnt += add;
+        pos_bounds[bi] = cnt;
     }
 }
+void cols_to_pos(const std::string& r_al, const std::vector<int64_t>& col_bounds,
+                 std::vector<int64_t>& pos_bounds) {
+    cols_to_pos(r_al.data(), r_al.size(), col_bounds, pos_bounds);
+}
 
-void stage_record(FileRecord& fr, bool keep_rows, Staged& out) {
-    if (fr.strand == '-') { rc_inplace(fr.r_al); rc_inplace(fr.m_al); }
-    out.ncols = (int64_t)fr.r_al.size();
-    out.bases.clear();
-    out.bases.reserve(fr.r_al.size());
-    out.non_acgt = false;
-    for (char c : fr.r_al) {
-        if (c == '-') continue;
-        out.bases.push_back(c);
-        if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T')) out.non_acgt = true;
-    }
-    split_units(fr.r_al, fr.m_al, fr.motif, 1, out.col_bounds);
-    cols_to_pos(fr.r_al, out.col_bounds, out.pos_bounds);
-    if (keep_rows) { out.r_al = std::move(fr.r_al); out.m_al = std::move(fr.m_al); }
+inline int64_t count_bases(const char* r, size_t n) {      // letters of a row that are not gap columns
+    int64_t g = 0;
+    for (size_t c = 0; c < n; ++c) g += r[c] != '-';
+    return g;
+}
+
+// Reverse complement of [b, b + n) into out (resized).
+void rc_copy(const char* b, size_t n, std::string& out) {
+    out.resize(n);
+    unsigned char* d = (unsigned char*)&out[0];
+    const unsigned char* sb = (const unsigned char*)b;
+    for (size_t i = 0; i < n; ++i) d[i] = BT.rc[sb[n - 1 - i]];
 }
 
 struct AlnKey {  // (r_st, r_en, strand) tuple ordering as Python sorts it
@@ -171,12 +218,35 @@ struct SeenRead {
 
 }  // namespace
 
+// The flat base array: anonymous pages that nobody has written yet (each staging thread is the first to touch the part it
+// fills, so the page faults of a gigabyte are spread over the threads instead of being taken by one zero-fill).
+struct RawBytes {
+    char* p = nullptr;
+    size_t n = 0;
+    RawBytes() = default;
+    RawBytes(const RawBytes&) = delete;
+    RawBytes& operator=(const RawBytes&) = delete;
+    ~RawBytes() { release(); }
+    void release() { if (p) munmap(p, std::max<size_t>(n, 1)); p = nullptr; n = 0; }
+    void resize(size_t bytes) {
+        release();
+        void* m = mmap(nullptr, std::max<size_t>(bytes, 1), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) throw std::bad_alloc();
+        (void)madvise(m, std::max<size_t>(bytes, 1), MADV_HUGEPAGE);
+        p = (char*)m; n = bytes;
+    }
+    const char* data() const { return p; }
+    char* data() { return p; }
+    size_t size() const { return n; }
+    char operator[](size_t i) const { return p[i]; }
+};
+
 struct cfh_pack {
     // kept records
     std::vector<int64_t> meta;      // R x 8
     std::string ids;
     std::vector<int64_t> id_off{0};
-    std::string bases;
+    RawBytes bases;
     std::vector<int64_t> read_off{0};
     std::vector<std::string> rows_r, rows_m;
     bool keep_rows = false;
@@ -241,60 +311,105 @@ struct Selector {
 struct Winner {  // final content of one kept slot
     FileRecord fr;
     bool set = false;
+    const char *a1b = nullptr, *a1e = nullptr, *a2b = nullptr, *a2e = nullptr;   // the two alignment rows where they stand in the mapped report (copied by the worker that stages the record)
 };
 
+// Every kept record: rows oriented to the read's forward strand, gap columns dropped into the flat base array, unit
+// boundaries for n = 1.  Three parallel sweeps with a prefix sum between them, so that every record writes its bases and
+// units where they finally stand (no per-record staging copies): (a) bases per record, (b) orientation + bases + unit
+// boundaries, (c) the unit arrays.
 void finalize_pack(cfh_pack* P, std::vector<Winner>& winners, int n_threads) {
     const int64_t R = (int64_t)winners.size();
     std::vector<Staged> staged((size_t)R);
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
     n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, R));
-    std::atomic<int64_t> next{0};
-    auto work = [&]() {
-        while (true) {
-            int64_t i = next.fetch_add(1);
-            if (i >= R) break;
-            stage_record(winners[(size_t)i].fr, P->keep_rows, staged[(size_t)i]);
-        }
+    auto sweep = [&](auto&& body) {
+        std::atomic<int64_t> next{0};
+        auto work = [&]() {
+            while (true) {
+                const int64_t i0 = next.fetch_add(16);
+                if (i0 >= R) break;
+                for (int64_t i = i0; i < std::min(R, i0 + 16); ++i) body(i);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < n_threads; ++t) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
     };
-    std::vector<std::thread> th;
-    for (int t = 1; t < n_threads; ++t) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
-
-    int64_t nb = 0, nu = 0;
-    for (auto& s : staged) { nb += (int64_t)s.bases.size(); nu += s.pos_bounds.empty() ? 0 : (int64_t)s.pos_bounds.size() - 1; }
-    P->bases.reserve((size_t)nb);
-    P->u1_start.reserve((size_t)nu); P->u1_end.reserve((size_t)nu); P->u1_col.reserve((size_t)nu * 2);
+    for (auto& w : winners)          // records that come with their rows (the generator) are viewed like mapped ones
+        if (!w.a1b) { w.a1b = w.fr.r_al.data(); w.a1e = w.a1b + w.fr.r_al.size(); w.a2b = w.fr.m_al.data(); w.a2e = w.a2b + w.fr.m_al.size(); }
+    PhaseClock clk;
+    std::vector<int64_t> b_off((size_t)R + 1, 0), u_off((size_t)R + 1, 0);
+    sweep([&](int64_t i) { const Winner& w = winners[(size_t)i]; b_off[(size_t)i + 1] = count_bases(w.a1b, (size_t)(w.a1e - w.a1b)); });
+    for (int64_t i = 0; i < R; ++i) b_off[(size_t)i + 1] += b_off[(size_t)i];
+    clk.lap("  count bases");
+    P->bases.resize((size_t)b_off[(size_t)R]);
+    clk.lap("  allocate bases");
+    if (P->keep_rows) { P->rows_r.resize((size_t)R); P->rows_m.resize((size_t)R); }
+    sweep([&](int64_t i) {
+        Winner& w = winners[(size_t)i];
+        Staged& st = staged[(size_t)i];
+        static thread_local std::string tr, tm;
+        const bool minus = w.fr.strand == '-';
+        const char *r = w.a1b, *m = w.a2b;
+        const size_t rn = (size_t)(w.a1e - w.a1b), mn = (size_t)(w.a2e - w.a2b);
+        if (minus) { rc_copy(w.a1b, rn, tr); rc_copy(w.a2b, mn, tm); r = tr.data(); m = tm.data(); }
+        st.ncols = (int64_t)rn;
+        unsigned char* b = (unsigned char*)P->bases.data() + b_off[(size_t)i];
+        unsigned other = 0;
+        for (size_t c = 0; c < rn; ++c) {         // gap columns are skipped: a base is written only where it stays
+            const unsigned char ch = (unsigned char)r[c];
+            if (ch != '-') { *b++ = ch; other |= BT.other[ch]; }
+        }
+        st.non_acgt = other != 0;
+        split_units(rn, m, mn, w.fr.motif, 1, st.col_bounds);
+        cols_to_pos(r, rn, st.col_bounds, st.pos_bounds);
+        u_off[(size_t)i + 1] = st.pos_bounds.empty() ? 0 : (int64_t)st.pos_bounds.size() - 1;
+        if (P->keep_rows) {
+            if (minus) { P->rows_r[(size_t)i] = tr; P->rows_m[(size_t)i] = tm; }
+            else { P->rows_r[(size_t)i].assign(r, rn); P->rows_m[(size_t)i].assign(m, mn); }
+        }
+        std::string().swap(w.fr.r_al); std::string().swap(w.fr.m_al);
+        w.a1b = w.a1e = w.a2b = w.a2e = nullptr;
+    });
+    clk.lap("  orient + bases + units");
+    for (int64_t i = 0; i < R; ++i) u_off[(size_t)i + 1] += u_off[(size_t)i];
+    const int64_t nu = u_off[(size_t)R];
+    P->u1_start.resize((size_t)nu); P->u1_end.resize((size_t)nu); P->u1_col.resize((size_t)nu * 2);
+    P->read_off = b_off;
+    P->u1_ptr = u_off;
     P->meta.resize((size_t)R * 8);
+    // small sequential part: ids, motif ids (first-seen order), flags
+    std::vector<int32_t> mids((size_t)R);
     for (int64_t i = 0; i < R; ++i) {
         FileRecord& fr = winners[(size_t)i].fr;
-        Staged& s = staged[(size_t)i];
-        const int64_t base0 = (int64_t)P->bases.size();
-        P->bases += s.bases;
-        P->read_off.push_back((int64_t)P->bases.size());
         P->ids += fr.r_id;
         P->id_off.push_back((int64_t)P->ids.size());
+        auto it = P->motif_ids.find(fr.motif);
+        if (it == P->motif_ids.end()) { mids[(size_t)i] = (int32_t)P->motifs.size(); P->motif_ids.emplace(fr.motif, mids[(size_t)i]); P->motifs.push_back(fr.motif); }
+        else mids[(size_t)i] = it->second;
+        if (staged[(size_t)i].non_acgt) P->non_acgt = true;
+    }
+    sweep([&](int64_t i) {
+        const FileRecord& fr = winners[(size_t)i].fr;
+        const Staged& st = staged[(size_t)i];
+        const int64_t base0 = b_off[(size_t)i];
         int64_t r_st = fr.r_st, r_en = fr.r_en;
         if (fr.strand == '-') { r_st = fr.r_len - fr.r_en; r_en = fr.r_len - fr.r_st; }
-        int32_t mid;
-        auto it = P->motif_ids.find(fr.motif);
-        if (it == P->motif_ids.end()) { mid = (int32_t)P->motifs.size(); P->motif_ids.emplace(fr.motif, mid); P->motifs.push_back(fr.motif); }
-        else mid = it->second;
         int64_t* m = &P->meta[(size_t)i * 8];
         m[0] = fr.r_len; m[1] = fr.r_al_len; m[2] = r_st; m[3] = r_en;
         m[4] = fr.strand == '-' ? 1 : 0; m[5] = P->seen[(size_t)P->rec_seen[(size_t)i]].n_aln;
-        m[6] = s.ncols; m[7] = mid;
-        for (size_t b = 0; b + 1 < s.pos_bounds.size(); ++b) {
-            P->u1_start.push_back(base0 + s.pos_bounds[b]);
-            P->u1_end.push_back(base0 + s.pos_bounds[b + 1]);
-            P->u1_col.push_back(s.col_bounds[b]);
-            P->u1_col.push_back(s.col_bounds[b + 1]);
+        m[6] = st.ncols; m[7] = mids[(size_t)i];
+        int64_t u = u_off[(size_t)i];
+        for (size_t b = 0; b + 1 < st.pos_bounds.size(); ++b, ++u) {
+            P->u1_start[(size_t)u] = base0 + st.pos_bounds[b];
+            P->u1_end[(size_t)u] = base0 + st.pos_bounds[b + 1];
+            P->u1_col[(size_t)u * 2] = st.col_bounds[b];
+            P->u1_col[(size_t)u * 2 + 1] = st.col_bounds[b + 1];
         }
-        P->u1_ptr.push_back((int64_t)P->u1_start.size());
-        if (s.non_acgt) P->non_acgt = true;
-        if (P->keep_rows) { P->rows_r.push_back(std::move(s.r_al)); P->rows_m.push_back(std::move(s.m_al)); }
-        s = Staged();
-    }
+    });
+    clk.lap("  unit arrays + meta");
     // discarded reads: seen but never kept (order is not defined by the reference: it goes through set())
     for (auto& kv : P->seen_idx) {
         if (P->seen[(size_t)kv.second].rec < 0) { P->discarded += kv.first; P->discarded.push_back('\n'); }
@@ -630,52 +745,144 @@ int cfh_synth(const cfh_synth_params* sp, const char* report_path, int keep_rows
     }
 }
 
+// The report is mapped and read by all threads: (1) every thread finds the content lines (not blank, not '#') of its
+// slice of the file; (2) content lines pair up into records in file order and every thread parses the two HEADERS of its
+// share of the records (the alignment rows stay where they are); (3) the dictionary logic of NCRF_Report.__init__ — which
+// alignment of a read is kept, in which order reads first appear — runs sequentially over the headers alone (no row is
+// copied for an alignment that loses); (4) the kept records are oriented, de-gapped and split into units by all threads
+// (finalize_pack), straight from the mapped rows.
 int cfh_parse_report(const char* path, int64_t min_record_len, int keep_rows, int n_threads,
                      cfh_pack** out, char* err, int errlen) {
+    int fd = -1;
+    const char* data = nullptr;
+    size_t size = 0;
+    bool mapped = false;
+    std::string fallback;
     try {
-        FILE* f = std::fopen(path, "rb");
-        if (!f) { set_err(err, errlen, std::string("cannot open NCRF report ") + path); return -2; }
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) { set_err(err, errlen, std::string("cannot open NCRF report ") + path); return -2; }
+        struct stat st;
+        if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) { data = (const char*)m; size = (size_t)st.st_size; mapped = true; }
+        }
+        if (!mapped) {          // a pipe, an empty file: read it whole
+            char buf[1 << 16];
+            ssize_t n;
+            while ((n = ::read(fd, buf, sizeof buf)) > 0) fallback.append(buf, (size_t)n);
+            data = fallback.data(); size = fallback.size();
+        }
+        PhaseClock clk;
+        if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+        size_t min_slice = 1 << 20;      // bytes of report per scanning thread at least (CFH_PARSE_MIN_SLICE: smaller in tests)
+        if (const char* e = std::getenv("CFH_PARSE_MIN_SLICE")) min_slice = (size_t)std::max(1L, std::atol(e));
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, size / min_slice + 1));
+        // (1) content lines per slice; a slice starts behind the first newline at or after its nominal start
+        struct Line { const char *b, *e; int64_t lineno; };
+        std::vector<std::vector<Line>> lines((size_t)T);
+        std::vector<int64_t> n_lines((size_t)T, 0);      // all lines of the slice (for line numbers in messages)
+        auto slice_begin = [&](int t) -> size_t {
+            if (t == 0) return 0;
+            if (t >= T) return size;
+            size_t p = size / (size_t)T * (size_t)t;
+            const void* nl = p < size ? std::memchr(data + p - 1, '\n', size - p + 1) : nullptr;     // (p - 1: a slice that starts right behind a newline keeps its first line)
+            return nl ? (size_t)((const char*)nl - data) + 1 : size;
+        };
+        auto scan = [&](int t) {
+            size_t p = slice_begin(t);
+            const size_t end = slice_begin(t + 1);
+            int64_t ln = 0;
+            while (p < end) {
+                const void* nl = std::memchr(data + p, '\n', size - p);
+                const size_t q = nl ? (size_t)((const char*)nl - data) : size;
+                ++ln;
+                const char* b = data + p; const char* e = data + q;
+                while (b < e && is_ws(*b)) ++b;
+                while (e > b && is_ws(e[-1])) --e;
+                if (b != e && *b != '#') lines[(size_t)t].push_back(Line{b, e, ln});
+                p = q + 1;
+            }
+            n_lines[(size_t)t] = ln;
+        };
+        {
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(scan, t);
+            scan(0);
+            for (auto& x : th) x.join();
+        }
+        clk.lap("line scan");
+        std::vector<Line> all;
+        {
+            size_t tot = 0;
+            for (auto& v : lines) tot += v.size();
+            all.reserve(tot);
+            int64_t base = 0;
+            for (int t = 0; t < T; ++t) { for (auto& l : lines[(size_t)t]) all.push_back(Line{l.b, l.e, base + l.lineno}); base += n_lines[(size_t)t]; lines[(size_t)t] = std::vector<Line>(); }
+        }
+        auto cleanup = [&]() { if (mapped) munmap((void*)data, size); if (fd >= 0) ::close(fd); fd = -1; mapped = false; };
+        const int64_t n_rec = (int64_t)all.size() / 2;
+        // (2) headers of every record
+        struct Parsed { FileRecord fr; const char *a1b, *a1e, *a2b, *a2e; bool ok; };
+        std::vector<Parsed> recs((size_t)n_rec);
+        {
+            std::atomic<int64_t> next{0};
+            auto work = [&]() {
+                while (true) {
+                    const int64_t i0 = next.fetch_add(64);
+                    if (i0 >= n_rec) break;
+                    for (int64_t i = i0; i < std::min(n_rec, i0 + 64); ++i) {
+                        Parsed& r = recs[(size_t)i];
+                        const Line &l1 = all[(size_t)2 * i], &l2 = all[(size_t)2 * i + 1];
+                        r.ok = parse_first(l1.b, l1.e, r.fr, r.a1b, r.a1e) && parse_second(l2.b, l2.e, r.fr, r.a2b, r.a2e);
+                    }
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t) th.emplace_back(work);
+            work();
+            for (auto& x : th) x.join();
+        }
+        clk.lap("headers");
+        for (int64_t i = 0; i < n_rec; ++i)
+            if (!recs[(size_t)i].ok) {
+                const int64_t ln = all[(size_t)2 * i + 1].lineno;
+                cleanup();
+                set_err(err, errlen, "malformed NCRF record ending at line " + std::to_string(ln) + " of " + path);
+                return -22;
+            }
+        if (all.size() & 1) { cleanup(); set_err(err, errlen, std::string("odd number of record lines in ") + path); return -22; }
+        // (3) which alignment of which read is kept: sequential, headers only
         std::unique_ptr<cfh_pack> P(new cfh_pack());
         P->keep_rows = keep_rows != 0;
         Selector sel{P.get(), min_record_len, {}};
-        std::vector<Winner> winners;
-        // getline-based streaming reader; alignment rows can be hundreds of kB
-        char* line = nullptr; size_t cap = 0; ssize_t n;
-        std::string first; bool have_first = false;
-        int64_t lineno = 0;
-        while ((n = getline(&line, &cap, f)) >= 0) {
-            ++lineno;
-            const char* b = line; const char* e = line + n;
-            while (b < e && is_ws(*b)) ++b;
-            while (e > b && is_ws(e[-1])) --e;
-            if (b == e || *b == '#') continue;
-            if (!have_first) { first.assign(b, e); have_first = true; continue; }
-            have_first = false;
-            FileRecord fr;
-            const char *a1b, *a1e, *a2b, *a2e;
-            if (!parse_first(first.data(), first.data() + first.size(), fr, a1b, a1e) ||
-                !parse_second(b, e, fr, a2b, a2e)) {
-                std::free(line); std::fclose(f);
-                set_err(err, errlen, "malformed NCRF record ending at line " + std::to_string(lineno) + " of " + path);
-                return -22;
-            }
+        std::vector<int64_t> keep_idx;          // slot -> record
+        for (int64_t i = 0; i < n_rec; ++i) {
+            const FileRecord& fr = recs[(size_t)i].fr;
             Header h{fr.r_id, fr.r_len, fr.r_al_len, fr.r_st, fr.r_en, fr.strand};
-            int64_t slot = sel.offer(h);
+            const int64_t slot = sel.offer(h);
             if (slot >= 0) {
-                fr.r_al.assign(a1b, a1e);
-                fr.m_al.assign(a2b, a2e);
-                if ((int64_t)winners.size() <= slot) winners.resize((size_t)slot + 1);
-                winners[(size_t)slot].fr = std::move(fr);
-                winners[(size_t)slot].set = true;
+                if ((int64_t)keep_idx.size() <= slot) keep_idx.resize((size_t)slot + 1, -1);
+                keep_idx[(size_t)slot] = i;
             }
         }
-        std::free(line);
-        std::fclose(f);
-        if (have_first) { set_err(err, errlen, std::string("odd number of record lines in ") + path); return -22; }
+        clk.lap("selection");
+        // (4) stage the kept records from the mapped rows
+        std::vector<Winner> winners(keep_idx.size());
+        for (size_t sl = 0; sl < keep_idx.size(); ++sl) {
+            Parsed& r = recs[(size_t)keep_idx[sl]];
+            Winner& w = winners[sl];
+            w.fr = std::move(r.fr); w.set = true;
+            w.a1b = r.a1b; w.a1e = r.a1e; w.a2b = r.a2b; w.a2e = r.a2e;
+        }
+        recs = std::vector<Parsed>();
         finalize_pack(P.get(), winners, n_threads);
+        clk.lap("staging + assembly");
+        cleanup();
         *out = P.release();
         return 0;
     } catch (const std::exception& e) {
+        if (mapped) munmap((void*)data, size);
+        if (fd >= 0) ::close(fd);
         set_err(err, errlen, std::string("cfh_parse_report: ") + e.what());
         return -12;
     }
@@ -708,7 +915,7 @@ int cfh_exotic_summary(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32
             const char c = p->bases[(size_t)(b0 + i)];
             if (c == 'A' || c == 'C' || c == 'G' || c == 'T') continue;
             const int64_t w_lo = std::max<int64_t>(next_w, i - k + 1), w_hi = std::min<int64_t>(i, len - k);
-            for (int64_t w = w_lo; w <= w_hi; ++w) { ++mine[p->bases.substr((size_t)(b0 + w), (size_t)k)]; ++n_windows; }
+            for (int64_t w = w_lo; w <= w_hi; ++w) { ++mine[std::string(p->bases.data() + (b0 + w), (size_t)k)]; ++n_windows; }
             if (w_hi + 1 > next_w) next_w = w_hi + 1;
         }
         for (const auto& kv : mine) {
@@ -941,7 +1148,7 @@ int cfh_export_read_units(cfh_pack* p, const int64_t* rec, const int64_t* pos, i
                           "|r_pos=" + std::to_string(it.unit);
                     units += '>'; units += key; units += '\n';
                     const size_t at = units.size();
-                    units.append(p->bases, (size_t)b0, (size_t)(b1 - b0));
+                    units.append(p->bases.data() + b0, (size_t)(b1 - b0));
                     for (size_t c = at; c < units.size(); ++c) units[c] = (char)std::toupper((unsigned char)units[c]);
                     units += '\n';
                     lens.push_back(b1 - b0);
@@ -960,7 +1167,7 @@ int cfh_export_read_units(cfh_pack* p, const int64_t* rec, const int64_t* pos, i
                     if (b1 - b0 != med_len) continue;
                     med += '>'; med += kv.first; med += '\n';
                     const size_t at = med.size();
-                    med.append(p->bases, (size_t)b0, (size_t)(b1 - b0));
+                    med.append(p->bases.data() + b0, (size_t)(b1 - b0));
                     for (size_t c = at; c < med.size(); ++c) med[c] = (char)std::toupper((unsigned char)med[c]);
                     med += '\n';
                     break;

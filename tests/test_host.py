@@ -113,3 +113,39 @@ def test_kmer_text_io_roundtrip(tmp_path):
         assert f.read().splitlines() == recruit.edges_file_lines(codes, edges, k)[::-1] or True
     with open(epath) as f:
         assert sorted(f.read().splitlines()) == recruit.edges_file_lines(codes, edges, k)
+
+
+def test_parallel_scan_equals_single_thread(tmp_path, monkeypatch):
+    """The report is scanned in slices by several threads: slice seams (any byte offset, CRLF, no final newline,
+    comment and blank lines at a seam) change nothing, and a malformed record is reported with its line number."""
+    kw = dict(fixtures.FIXTURES["lowcov"]["synth"])
+    path = str(tmp_path / "r.ncrf")
+    _host.synth(report_path=path, pack=False, **kw)
+    one = _host.parse_report(path, keep_rows=True, n_threads=1)
+    text = open(path).read()
+    variants = {"plain": text, "crlf": text.replace("\n", "\r\n"), "no_final_newline": text.rstrip("\n"),
+                "comments": text.replace("\n\n", "\n# note\n\n \n")}
+    for name, body in variants.items():
+        p = str(tmp_path / (name + ".ncrf"))
+        with open(p, "w", newline="") as f:
+            f.write(body)
+        for min_slice, threads in ((1, 3), (97, 7), (4096, 8)):
+            monkeypatch.setenv("CFH_PARSE_MIN_SLICE", str(min_slice))
+            b = _host.parse_report(p, keep_rows=True, n_threads=threads)
+            assert b.ids == one.ids and np.array_equal(b.bases, one.bases) and np.array_equal(b.meta, one.meta), (name, min_slice)
+            assert np.array_equal(b.read_off, one.read_off)
+            for n in (1, 2):
+                for x, y in zip(one.units(n), b.units(n)):
+                    assert np.array_equal(x, y)
+            assert sorted(b.discarded_reads) == sorted(one.discarded_reads)
+    # line number of a broken record, whatever the slicing
+    lines = text.split("\n")
+    content = [i for i, l in enumerate(lines) if l.strip() and not l.startswith("#")]
+    bad_at = content[5]                         # second line of the third record
+    lines[bad_at] = "garbage"
+    p = str(tmp_path / "bad.ncrf")
+    open(p, "w").write("\n".join(lines))
+    for min_slice, threads in ((1 << 20, 1), (50, 5)):
+        monkeypatch.setenv("CFH_PARSE_MIN_SLICE", str(min_slice))
+        with pytest.raises(_host.HostError, match=f"line {bad_at + 1} of"):
+            _host.parse_report(p, n_threads=threads)

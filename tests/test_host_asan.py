@@ -37,8 +37,9 @@ for i in range(300):
         else: b[pos:pos] = b"\n"
     p = os.path.join(d, "fuzz.ncrf")
     open(p, "wb").write(bytes(b))
+    os.environ["CFH_PARSE_MIN_SLICE"] = str(rng.choice([1, 300, 1 << 20]))     # slice seams of the threaded scan at odd places
     try:
-        pk = _host.parse_report(p, min_record_len=rng.choice([1, 1000, 5000]))
+        pk = _host.parse_report(p, min_record_len=rng.choice([1, 1000, 5000]), n_threads=rng.choice([1, 3, 8]))
         pk.units(1); pk.classify(50000)
         ok += 1
     except _host.HostError:
