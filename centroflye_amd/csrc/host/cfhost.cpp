@@ -665,6 +665,69 @@ void write_record(FILE* f, const FileRecord& fr) {
 }  // namespace
 
 // ================================================================== C ABI
+static void decode_kmer(uint64_t code, int k, char* out) {
+    for (int i = k - 1; i >= 0; --i) { out[i] = "ACGT"[code & 3]; code >>= 2; }
+}
+
+// Text files written in record order by many threads: the records [0, n) are cut into tasks, workers render tasks into
+// the buffers of a ring and the calling thread writes the buffers to the file in task order (rendering 150 GB of edge
+// lines — BASELINE configs[1] — is the work; the file system takes whole buffers).
+template <class Render>      // render(lo, hi, std::vector<char>& out) appends the text of records [lo, hi)
+static int write_ordered(int fd, int64_t n, int64_t per_task, Render&& render) {
+    const int64_t n_tasks = (n + per_task - 1) / per_task;
+    auto put = [&](const std::vector<char>& buf) -> bool {
+        size_t off = 0;
+        while (off < buf.size()) {
+            const ssize_t w = ::write(fd, buf.data() + off, buf.size() - off);
+            if (w < 0) { if (errno == EINTR) continue; return false; }
+            off += (size_t)w;
+        }
+        return true;
+    };
+    if (n_tasks <= 1) {
+        std::vector<char> buf;
+        if (n > 0) render((int64_t)0, n, buf);
+        return put(buf) ? 0 : -5;
+    }
+    const int nt = (int)std::min<int64_t>(std::min<int64_t>(n_tasks, 32), std::max(1u, std::thread::hardware_concurrency()));
+    const int64_t S = std::min<int64_t>(n_tasks, 2 * (int64_t)nt);
+    struct Slot { std::vector<char> buf; std::atomic<int64_t> turn{0}, full{0}; };     // turn: the task that may render into the slot; full: task + 1 once rendered
+    std::vector<Slot> ring((size_t)S);
+    for (int64_t i = 0; i < S; ++i) ring[(size_t)i].turn = i;
+    std::atomic<int64_t> next{0};
+    std::atomic<bool> stop{false};
+    auto work = [&]() {
+        while (!stop.load(std::memory_order_relaxed)) {
+            const int64_t t = next.fetch_add(1);
+            if (t >= n_tasks) break;
+            Slot& sl = ring[(size_t)(t % S)];
+            while (sl.turn.load(std::memory_order_acquire) != t) { if (stop.load(std::memory_order_relaxed)) return; std::this_thread::yield(); }
+            sl.buf.clear();
+            render(t * per_task, std::min(n, (t + 1) * per_task), sl.buf);
+            sl.full.store(t + 1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 0; i < nt; ++i) th.emplace_back(work);
+    int rc = 0;
+    for (int64_t t = 0; t < n_tasks; ++t) {
+        Slot& sl = ring[(size_t)(t % S)];
+        while (sl.full.load(std::memory_order_acquire) != t + 1) std::this_thread::yield();
+        if (!put(sl.buf)) { rc = -5; stop = true; break; }
+        sl.turn.store(t + S, std::memory_order_release);
+    }
+    for (auto& x : th) x.join();
+    return rc;
+}
+
+static inline char* put_u32(char* p, uint32_t v) {      // decimal, no padding
+    char tmp[10];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10u); v /= 10u; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
 extern "C" {
 
 void cfh_synth_defaults(cfh_synth_params* p) {
@@ -1019,48 +1082,41 @@ const char* cfh_row(const cfh_pack* p, int64_t r, int32_t which, int64_t* len) {
     return s.data();
 }
 
-static void decode_kmer(uint64_t code, int k, char* out) {
-    for (int i = k - 1; i >= 0; --i) { out[i] = "ACGT"[code & 3]; code >>= 2; }
-}
 
 int cfh_write_kmers(const char* path, const uint64_t* kmers, int64_t n, int32_t k, char* err, int errlen) {
     if (k < 1 || k > 32) { set_err(err, errlen, "cfh_write_kmers: k out of range"); return -22; }
-    FILE* f = std::fopen(path, "w");
-    if (!f) { set_err(err, errlen, std::string("cannot open ") + path); return -2; }
-    std::vector<char> buf;
-    buf.reserve(1 << 20);
-    char tmp[40];
-    for (int64_t i = 0; i < n; ++i) {
-        decode_kmer(kmers[i], k, tmp);
-        tmp[k] = '\n';
-        buf.insert(buf.end(), tmp, tmp + k + 1);
-        if (buf.size() > (1u << 20) - 64) { std::fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
-    }
-    std::fwrite(buf.data(), 1, buf.size(), f);
-    if (std::fclose(f) != 0) { set_err(err, errlen, std::string("write failed: ") + path); return -5; }
-    return 0;
+    const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) { set_err(err, errlen, std::string("cannot open ") + path); return -2; }
+    int rc = write_ordered(fd, n, (int64_t)1 << 17, [&](int64_t lo, int64_t hi, std::vector<char>& out) {
+        out.resize((size_t)(hi - lo) * (size_t)(k + 1));
+        char* p = out.data();
+        for (int64_t i = lo; i < hi; ++i) { decode_kmer(kmers[i], k, p); p[k] = '\n'; p += k + 1; }
+    });
+    if (::close(fd) != 0 && rc == 0) rc = -5;
+    if (rc) set_err(err, errlen, std::string("write failed: ") + path);
+    return rc;
 }
 
 int cfh_write_edges(const char* path, int append, const uint64_t* rare, int32_t k,
                     const uint32_t* edges, int64_t n, char* err, int errlen) {
     if (k < 1 || k > 32) { set_err(err, errlen, "cfh_write_edges: k out of range"); return -22; }
-    FILE* f = std::fopen(path, append ? "a" : "w");
-    if (!f) { set_err(err, errlen, std::string("cannot open ") + path); return -2; }
-    std::vector<char> buf;
-    buf.reserve(1 << 20);
-    char tmp[128];
-    for (int64_t i = 0; i < n; ++i) {
-        const uint32_t* e = edges + 4 * i;
-        int len = std::snprintf(tmp, sizeof tmp, "%u ", e[0]);
-        decode_kmer(rare[e[1]], k, tmp + len); len += k; tmp[len++] = ' ';
-        decode_kmer(rare[e[2]], k, tmp + len); len += k;
-        len += std::snprintf(tmp + len, sizeof tmp - (size_t)len, " %u\n", e[3]);
-        buf.insert(buf.end(), tmp, tmp + len);
-        if (buf.size() > (1u << 20) - 256) { std::fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
-    }
-    std::fwrite(buf.data(), 1, buf.size(), f);
-    if (std::fclose(f) != 0) { set_err(err, errlen, std::string("write failed: ") + path); return -5; }
-    return 0;
+    const int fd = ::open(path, O_WRONLY | O_CREAT | (append ? O_APPEND : O_TRUNC), 0666);
+    if (fd < 0) { set_err(err, errlen, std::string("cannot open ") + path); return -2; }
+    int rc = write_ordered(fd, n, (int64_t)1 << 16, [&](int64_t lo, int64_t hi, std::vector<char>& out) {
+        out.resize((size_t)(hi - lo) * (size_t)(2 * k + 24));      // "d a b cnt\n": two k-mers, two numbers of <= 10 digits, 4 separators
+        char* p = out.data();
+        for (int64_t i = lo; i < hi; ++i) {
+            const uint32_t* e = edges + 4 * i;
+            p = put_u32(p, e[0]); *p++ = ' ';
+            decode_kmer(rare[e[1]], k, p); p += k; *p++ = ' ';
+            decode_kmer(rare[e[2]], k, p); p += k; *p++ = ' ';
+            p = put_u32(p, e[3]); *p++ = '\n';
+        }
+        out.resize((size_t)(p - out.data()));
+    });
+    if (::close(fd) != 0 && rc == 0) rc = -5;
+    if (rc) set_err(err, errlen, std::string("write failed: ") + path);
+    return rc;
 }
 
 int cfh_read_kmers(const char* path, int32_t k, uint64_t* out, int64_t cap, int64_t* n_out,

@@ -209,6 +209,12 @@ inline int __builtin_amdgcn_readlane(int v, int lane) {
     return (int)(uint32_t)a[lane & 63];
 }
 
+// v_bfe_u32: offset and width are taken from the low 5 bits of their operands
+inline unsigned __builtin_amdgcn_ubfe(unsigned v, unsigned offset, unsigned width) {
+    offset &= 31u; width &= 31u;
+    return width == 0 ? 0u : (v >> offset) & ((1u << width) - 1u);
+}
+
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(int v) { return __builtin_ffs(v); }

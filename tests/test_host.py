@@ -149,3 +149,31 @@ def test_parallel_scan_equals_single_thread(tmp_path, monkeypatch):
         monkeypatch.setenv("CFH_PARSE_MIN_SLICE", str(min_slice))
         with pytest.raises(_host.HostError, match=f"line {bad_at + 1} of"):
             _host.parse_report(p, n_threads=threads)
+
+
+def test_text_writers_keep_record_order_across_tasks(tmp_path):
+    """unique_edges / unique_kmers files are rendered by a thread pool in tasks of 2^16 / 2^17 records and written in
+    task order: the bytes equal a plain sequential rendering, also when appending."""
+    rng = np.random.default_rng(5)
+    k = 19
+    rare = np.unique(rng.integers(0, 4 ** k, 50000, dtype=np.uint64))
+    n = 300001
+    edges = np.stack([rng.integers(1, 151, n), rng.integers(0, rare.size, n), rng.integers(0, rare.size, n),
+                      rng.integers(4, 3000000000, n)], axis=1).astype(np.uint32)
+
+    def word(c):
+        return "".join("ACGT"[(int(c) >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+    words = [word(c) for c in rare]
+    want = "".join(f"{d} {words[a]} {words[b]} {c}\n" for d, a, b, c in edges.tolist())
+    p = str(tmp_path / "e.txt")
+    _host.write_edges(p, rare, k, edges[:200000])
+    _host.write_edges(p, rare, k, edges[200000:], append=True)
+    assert open(p).read() == want
+    kk = rng.integers(0, 4 ** k, 400003, dtype=np.uint64)
+    p = str(tmp_path / "k.txt")
+    _host.write_kmers(p, kk, k)
+    got = open(p).read().split("\n")
+    assert got[-1] == "" and len(got) == kk.size + 1
+    assert got[0] == word(kk[0]) and got[131072] == word(kk[131072]) and got[-2] == word(kk[-1])
+    assert np.array_equal(_host.read_kmers(p, k), kk)
