@@ -19,7 +19,6 @@
 #include "cf_common.h"
 
 #include <cstdlib>
-#include <type_traits>
 
 void cf_free_edges(cf_ctx* c);
 int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
@@ -83,32 +82,17 @@ cf_unit_rend_kernel(const int64_t* __restrict__ unit_ptr, const int64_t* __restr
     }
 }
 
-// The word of a cloud entry that the sketch sweep of the narrow layout reads INSTEAD of the entry: hash(b) with the unit
-// index (mod 256, times an odd constant) added to its top byte.  Subtracting the same term of the posting's unit leaves
-// hash(b) + ((d * DIST_SK_DMUL) mod 256 << 24): a function of (b, d mod 256) whose low 24 bits are those of hash(b), so
-// the sweep gets its counter index with one subtraction and one shift and the bitmap bit of b without knowing b.
-#define DIST_SK_DMUL 0x9Du
-__host__ __device__ __forceinline__ uint32_t cf_sk_word(uint32_t b, uint32_t unit_index) {
-    return (b & 0xFFFFFFu) * 0x9E3779u + ((unit_index * DIST_SK_DMUL) << 24);
-}
-
 // per cloud entry the index of its unit inside its read (one wave per unit): as a 16-bit side array (wide table
 // layout) or, mod 256, packed above the 24-bit rank (narrow layout: one 4-byte load per pair emission)
 __global__ void __launch_bounds__(256)
 cf_entry_unit_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ rbeg, const int32_t* __restrict__ entries, int64_t n_units,
-                     uint16_t* __restrict__ entry_i, uint32_t* __restrict__ packed, uint32_t* __restrict__ sk_words) {
+                     uint16_t* __restrict__ entry_i, uint32_t* __restrict__ packed) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t u = wave; u < n_units; u += n_waves) {
         const uint32_t i = (uint32_t)(u - rbeg[u]);
-        if (packed) {
-            for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) {
-                const uint32_t b = (uint32_t)entries[e];
-                packed[e] = ((i & 0xFFu) << 24) | b;
-                sk_words[e] = cf_sk_word(b, i);
-            }
-        }
+        if (packed) { for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) packed[e] = ((i & 0xFFu) << 24) | (uint32_t)entries[e]; }
         else { for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) entry_i[e] = (uint16_t)i; }
     }
 }
@@ -149,7 +133,6 @@ struct cf_dist_args {
     const cf_dist_rec* urange;     // per unit: the partner range of a posting at this unit
     const uint16_t* entry_i;       // wide layout: per cloud entry the index of its unit inside its read
     const uint32_t* packed;        // narrow layout: per cloud entry [unit index inside its read mod 256 : 8 | rank : 24]
-    const uint32_t* sk_words;      // narrow layout: per cloud entry cf_sk_word(rank, unit index), read by the sketch sweep
     int64_t n_kmers;
     int32_t part, n_parts;
     int32_t min_d, max_d;       // min_d already clamped to >= 1
@@ -192,7 +175,6 @@ template <int DB>
 struct cf_tab_wide_t {
     static constexpr uint32_t kCntBits = 31 - DB, kCntMask = (1u << kCntBits) - 1u, kDMask = (1u << DB) - 1u, kDShift = 32 - DB;
     static constexpr uint32_t kSlotBytes = 8, kPerBucket = 4;
-    static constexpr bool kSketchWords = false;
     struct bucket { cf_u64x2 lo, hi; };
     struct raw { uint32_t b, i; };
     typedef unsigned long long qitem;   // deferred insert: [b:32 | d:8 | bucket to look at next:24]
@@ -281,7 +263,6 @@ typedef cf_tab_wide_t<16> cf_tab_wide16;
 
 struct cf_tab_narrow {
     static constexpr uint32_t kSlotBytes = 6, kPerBucket = 8;
-    static constexpr bool kSketchWords = true;      // the sketch sweep reads cf_sk_word()s
     static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
     struct bucket { cf_u32x4 lo, hi; };
     struct raw { uint32_t v; };
@@ -304,16 +285,11 @@ struct cf_tab_narrow {
         const run4 r = *(const run4*)(A.packed + (ok ? e : 0));
         out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
     }
-    static __device__ __forceinline__ void load_words(const uint32_t* arr, int64_t e, uint32_t ok, raw (&out)[DIST_UNROLL]) {
-        const run4 r = *(const run4*)(arr + (ok ? e : 0));
-        out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
-    }
     // the unit index is kept mod 256 and 1 <= d <= max_d <= 255, so the 8-bit difference IS d; no borrow reaches b
     static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { const uint32_t q = r.v - (ig << 24); b = q & 0xFFFFFFu; dd = q >> 24; }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }               // 24 x 24 -> low 32 bits
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return ((h >> 16) * (n_buckets & 0xFFFFu)) >> 16; }
-    static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 9) & (DIST_BM_BITS - 1u); }       // below the top byte: cf_sk_word() keeps these bits
-    static_assert(DIST_BM_BITS == 32768u, "bm_bit takes bits 9..23 of the hash");
+    static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
     __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u32x4*)&keys[8 * bk], *(const cf_u32x4*)&keys[8 * bk + 4]}; }
     static __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) { return (dd << 24) | b; }
     // branch-free: one bit per slot, then find-first-set (nested ?: chains compile to a cascade of exec-mask branches)
@@ -491,8 +467,7 @@ __device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0,
 #ifndef CF_DIST_DYN_B
 #define CF_DIST_DYN_B 0
 #endif
-// Words = true: the lanes load from A.sk_words and body(words, ig, ok) gets them as they are (sketch sweep, narrow layout).
-template <class Tab, bool Dyn, bool Words, class Body>
+template <class Tab, bool Dyn, class Body>
 __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, uint32_t a, const cf_dist_rec* rec, const uint32_t* ipx, uint32_t* cursor, int np, Body&& body) {
     const int lane = threadIdx.x & 63;
     const uint32_t n_items = ipx[4 + np - 1];
@@ -514,8 +489,7 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, uint32_t a,
             nok = 0;                                                                                          \
             _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) nok |= (uint32_t)(off + (uint32_t)u < len) << u; \
         }                                                                                                     \
-        if constexpr (Words) Tab::load_words(A.sk_words, r.e0 + (int64_t)off, nok, nx_);                      \
-        else Tab::load_run(A, r.e0 + (int64_t)off, nok, nx_);                                                 \
+        Tab::load_run(A, r.e0 + (int64_t)off, nok, nx_);                                                      \
     }
 #define CF_DIST_GRAB(VAR) { if (Dyn) { uint32_t g_ = 0; if (lane == 0) g_ = atomicAdd(cursor, 1u); VAR = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_); } else { VAR = nxt_static; nxt_static += (uint32_t)(blockDim.x >> 6); } }
     uint32_t nxt_static = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -530,18 +504,14 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, uint32_t a,
         CF_DIST_GRAB(i1)
         if (i1 < n_items) CF_DIST_FETCH(i1)
         i0 = i1;
-        if constexpr (Words) {
-            if (body(cx_, cig, cok)) break;
-        } else {
-            uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
+        uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
 #pragma unroll
-            for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cig, bb[u], dd_[u]);
-            if (__any(cok != (1u << DIST_UNROLL) - 1u)) {      // (wave-uniform) only the last item of a posting has lanes past its end
+        for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cig, bb[u], dd_[u]);
+        if (__any(cok != (1u << DIST_UNROLL) - 1u)) {      // (wave-uniform) only the last item of a posting has lanes past its end
 #pragma unroll
-                for (int u = 0; u < DIST_UNROLL; ++u) if (!((cok >> u) & 1u)) bb[u] = a;
-            }
-            if (body(bb, dd_)) break;
+            for (int u = 0; u < DIST_UNROLL; ++u) if (!((cok >> u) & 1u)) bb[u] = a;
         }
+        if (body(bb, dd_)) break;
     }
 #undef CF_DIST_FETCH
 #undef CF_DIST_GRAB
@@ -647,39 +617,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                 if (!one_chunk) cf_dist_setup(A, c0, np, rec, ipx, sh);
                 if (t == 0) sh[11] = 0;
                 __syncthreads();
-                if constexpr (Tab::kSketchWords) {
-                    // narrow layout: the word of an entry minus the posting's unit term is hash(b) + (d-term << 24).  The
-                    // first k-mer's own entries are counted too (a counter may only be too high) and lanes past the end
-                    // of a posting add 0.
-                    const uint32_t need = A.min_cov - 1u;
-                    auto step = [&](const typename Tab::raw (&w)[DIST_UNROLL], uint32_t ig, uint32_t ok, auto tail) {
-                        const uint32_t igt = (ig * DIST_SK_DMUL) << 24;
-                        uint32_t old_[DIST_UNROLL], x_[DIST_UNROLL];
-#pragma unroll
-                        for (int u = 0; u < DIST_UNROLL; ++u) {     // all counter adds of the step back to back
-                            x_[u] = w[u].v - igt;
-                            const uint32_t idx = x_[u] >> A.sk_shift;
-                            uint32_t inc = 1u << ((idx << 3) & 31u);
-                            if (decltype(tail)::value) inc = ((ok >> u) & 1u) ? inc : 0u;
-                            old_[u] = atomicAdd(&sk[idx >> 2], inc);
-                        }
-#pragma unroll
-                        for (int u = 0; u < DIST_UNROLL; ++u) {
-                            const uint32_t seen = __builtin_amdgcn_ubfe(old_[u], (x_[u] >> A.sk_shift) << 3, 8u);     // occurrences before this one (the offset is taken mod 32)
-                            if (seen >= need && (!decltype(tail)::value || ((ok >> u) & 1u))) {
-                                const uint32_t hbit = (x_[u] >> 9) & (DIST_BM_BITS - 1u);      // == Tab::bm_bit(b)
-                                atomicOr(&bm[hbit >> 5], 1u << (hbit & 31u));
-                                if (seen == 255u) sh[13] = 1u;
-                            }
-                        }
-                    };
-                    cf_dist_sweep<Tab, CF_DIST_DYN_A != 0, true>(A, a, rec, ipx, &sh[11], np, [&](const typename Tab::raw (&w)[DIST_UNROLL], uint32_t ig, uint32_t ok) -> bool {
-                        if (__any(ok != (1u << DIST_UNROLL) - 1u)) step(w, ig, ok, std::true_type{});      // (wave-uniform) the last item of a posting
-                        else step(w, ig, ok, std::false_type{});
-                        return false;
-                    });
-                } else
-                cf_dist_sweep<Tab, CF_DIST_DYN_A != 0, false>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
+                cf_dist_sweep<Tab, CF_DIST_DYN_A != 0>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
                     uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {     // all counter adds of the step back to back
@@ -757,7 +695,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     __builtin_amdgcn_wave_barrier();                                                          \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                 }
-                cf_dist_sweep<Tab, CF_DIST_DYN_B != 0, false>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
+                cf_dist_sweep<Tab, CF_DIST_DYN_B != 0>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
                     if (sh[0] > A.fill_limit) return true;     // too full (or physically full): the pass will be split
                     uint32_t w_[DIST_UNROLL], hbit_[DIST_UNROLL], live = 0, cand = 0;
 #pragma unroll
@@ -917,7 +855,6 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     int32_t *d_post = nullptr, *d_rend = nullptr, *d_rbeg = nullptr;
     uint16_t* d_entry_i = nullptr;
     uint32_t* d_packed = nullptr;
-    uint32_t* d_sk_words = nullptr;
     cf_dist_rec* d_urange = nullptr;
     bool narrow = false, wide16 = false;
     unsigned long long* d_cnt = nullptr;
@@ -971,20 +908,17 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         wide16 = max_d > 255;          // 16-bit distance field: [b:32 | d:16 | sel:1 | cnt:15]
         narrow = !wide16 && !ctx->dist_wide && K < ((int64_t)1 << 24) - 1 && max_post <= 32767u;
         if (max_post >= (1u << 23) || (wide16 && max_post > 32767u)) { rc = cf_fail(ctx, -34, wide16 ? "cf_dist_edges: max_d > 255 with a k-mer of more than 32767 postings" : "cf_dist_edges: a k-mer has more than 2^23 postings"); break; }
-        if (narrow) {
-            if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)v_n_entries + DIST_ITEM, "packed cloud entries"))) break;
-            if ((rc = cf_alloc_t(ctx, &d_sk_words, (size_t)v_n_entries + DIST_ITEM, "sketch words of the cloud entries"))) break;
-        }
+        if (narrow) { if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)v_n_entries + DIST_ITEM, "packed cloud entries"))) break; }
         else if ((rc = cf_alloc_t(ctx, &d_entry_i, (size_t)v_n_entries + 1, "entry unit indices"))) break;
         if (U && v_n_entries)
             hipLaunchKernelGGL(cf_entry_unit_kernel, dim3((unsigned)cf_grid_for(U * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               v_cloud_ptr, (const int32_t*)d_rbeg, v_entries, U, d_entry_i, d_packed, d_sk_words);
+                               v_cloud_ptr, (const int32_t*)d_rbeg, v_entries, U, d_entry_i, d_packed);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("postings: ") + hipGetErrorString(e)); break; }
 
         cf_dist_args A;
-        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = v_cloud_ptr; A.entries = v_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.urange = d_urange; A.entry_i = d_entry_i; A.packed = d_packed; A.sk_words = d_sk_words;
+        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = v_cloud_ptr; A.entries = v_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.urange = d_urange; A.entry_i = d_entry_i; A.packed = d_packed;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
         A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
         const uint32_t slot_bytes = narrow ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
@@ -1018,7 +952,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.sketch = (ctx->dist_sketch && min_cov >= 2 && min_cov <= 200) ? 1 : 0;
         A.sk_shift = 32; A.sk_counters = 1;
         while (A.sk_shift > 8 && (size_t)A.sk_counters * 2 <= (size_t)A.slots * slot_bytes) { A.sk_counters *= 2; --A.sk_shift; }
-        if (A.sk_counters < 256) A.sketch = 0;        // (the distance term of a sketch word sits in the top byte of the counter index)
+        if (A.sk_counters < 16) A.sketch = 0;
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / block));
         // locality order of the first k-mers: sort (first posting unit, a); k-mers without postings drop out
         n_a_alloc = (K > part) ? (K - part + n_parts - 1) / n_parts : 0;
@@ -1078,7 +1012,6 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     if (d_cnt) cf_release_t(ctx, d_cnt, n_cnt);
     if (d_entry_i) cf_release_t(ctx, d_entry_i, (size_t)v_n_entries + 1);
     if (d_packed) cf_release_t(ctx, d_packed, (size_t)v_n_entries + DIST_ITEM);
-    if (d_sk_words) cf_release_t(ctx, d_sk_words, (size_t)v_n_entries + DIST_ITEM);
     if (d_urange) cf_release_t(ctx, d_urange, (size_t)U + 1);
     if (d_rbeg) cf_release_t(ctx, d_rbeg, (size_t)U + 1);
     if (d_rend) cf_release_t(ctx, d_rend, (size_t)U + 1);
