@@ -272,6 +272,20 @@ int cf_get_edges(cf_ctx* ctx, uint32_t* out, int64_t cap) {
     return 0;
 }
 
+int cf_sort_edges(cf_ctx* ctx) {
+    if (!ctx) return -22;
+    const int64_t n = ctx->n_edges_stored;
+    if (n <= 1) return 0;
+    uint32_t* d_tmp = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &d_tmp, (size_t)n * 4, "edge sort scratch"));
+    int kbits = 1;
+    while (kbits < 32 && ((int64_t)1 << kbits) < std::max<int64_t>(ctx->n_kmers, 2)) ++kbits;
+    const int words[3] = {2, 1, 0}, bits[3] = {kbits, kbits, 16};      // b, then a, then d (<= 65535)
+    const int rc = cf_radix_sort_rec16(ctx, ctx->d_edges, d_tmp, n, words, bits, 3);
+    cf_release_t(ctx, d_tmp, (size_t)n * 4);
+    return rc;
+}
+
 int cf_get_stats(cf_ctx* ctx, cf_stats* out) {
     if (!ctx || !out) return -22;
     ctx->stats.hbm_bytes_live = (int64_t)ctx->live;

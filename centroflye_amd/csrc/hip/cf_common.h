@@ -186,3 +186,4 @@ int cf_scan_exclusive_i64(cf_ctx* ctx, const int64_t* d_in, int64_t* d_out, int6
 int cf_scan_exclusive_u32_to_i64(cf_ctx* ctx, const uint32_t* d_in, int64_t* d_out, int64_t n, int64_t* total);
 // LSD radix sort of 64-bit keys on `bits` low bits; result lands in d_keys (d_tmp is scratch)
 int cf_radix_sort_u64(cf_ctx* ctx, unsigned long long* d_keys, unsigned long long* d_tmp, int64_t n, int bits);
+int cf_radix_sort_rec16(cf_ctx* ctx, void* d_recs, void* d_tmp, int64_t n, const int* words, const int* bits, int n_fields);

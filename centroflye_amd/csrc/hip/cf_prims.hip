@@ -191,3 +191,100 @@ int cf_radix_sort_u64(cf_ctx* ctx, unsigned long long* d_keys, unsigned long lon
     cf_release_t(ctx, d_hist, (size_t)nh);
     return rc;
 }
+
+// ------------------------------------------------------------------ radix sort of 16-byte records by 32-bit fields
+// LSD passes of 8 bits over the fields the caller lists (least significant first): the same histogram / scan / stable
+// ballot-ranked scatter as above, with a record = four 32-bit words and the digit taken from word `word`.
+struct __attribute__((aligned(16))) cf_rec16 { uint32_t w[4]; };
+
+__global__ void __launch_bounds__(RS_THREADS)
+cf_rec16_hist(const cf_rec16* __restrict__ in, uint32_t* __restrict__ hist, int64_t n, int word, int shift, int ntiles) {
+    uint32_t* h = (uint32_t*)cf_lds;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const int64_t idx = base + (int64_t)i * RS_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(((const uint32_t*)(in + idx))[word] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(RS_THREADS)
+cf_rec16_scatter(const cf_rec16* __restrict__ in, cf_rec16* __restrict__ out, const int64_t* __restrict__ offs, int64_t n, int word, int shift, int ntiles) {
+    int64_t* run = (int64_t*)cf_lds;                       // 256 running offsets, one per digit
+    uint32_t* wcount = (uint32_t*)(cf_lds + 256 * 8);      // [4][256] per-wave digit counts
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    run[t] = offs[(int64_t)t * ntiles + blockIdx.x];
+    for (int w = 0; w < 4; ++w) wcount[w * 256 + t] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    for (int round = 0; round < RS_ITEMS; ++round) {
+        const int64_t idx = base + (int64_t)round * RS_THREADS + t;
+        const bool valid = idx < n;
+        cf_rec16 rec{{0u, 0u, 0u, 0u}};
+        if (valid) rec = in[idx];
+        const uint32_t digit = (rec.w[word] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int bit = (digit >> b) & 1;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) wcount[wave * 256 + digit] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        int64_t pos = 0;
+        if (valid) {
+            pos = run[digit] + rank;
+            for (int w = 0; w < wave; ++w) pos += wcount[w * 256 + digit];
+        }
+        __syncthreads();
+        {
+            uint32_t sum = 0;
+            for (int w = 0; w < 4; ++w) { sum += wcount[w * 256 + t]; wcount[w * 256 + t] = 0; }
+            run[t] += sum;
+        }
+        __syncthreads();
+        if (valid) out[pos] = rec;
+    }
+}
+
+// d_recs: n records of 16 bytes; d_tmp: scratch of the same size; fields: n_fields (word index, significant bits), least
+// significant field first.  The sorted records end in d_recs.
+int cf_radix_sort_rec16(cf_ctx* ctx, void* d_recs, void* d_tmp, int64_t n, const int* words, const int* bits, int n_fields) {
+    if (n <= 1) return 0;
+    const int ntiles = (int)((n + RS_TILE - 1) / RS_TILE);
+    const int64_t nh = (int64_t)ntiles * 256;
+    uint32_t* d_hist = nullptr;
+    int64_t* d_offs = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &d_hist, (size_t)nh, "radix histogram"));
+    int rc = cf_alloc_t(ctx, &d_offs, (size_t)nh, "radix offsets");
+    cf_rec16* src = (cf_rec16*)d_recs;
+    cf_rec16* dst = (cf_rec16*)d_tmp;
+    for (int f = 0; rc == 0 && f < n_fields; ++f) {
+        for (int shift = 0; rc == 0 && shift < bits[f]; shift += 8) {
+            hipLaunchKernelGGL(cf_rec16_hist, dim3((unsigned)ntiles), dim3(RS_THREADS), 256 * 4, ctx->stream, (const cf_rec16*)src, d_hist, n, words[f], shift, ntiles);
+            rc = cf_scan_exclusive_u32_to_i64(ctx, d_hist, d_offs, nh, nullptr);
+            if (rc) break;
+            hipLaunchKernelGGL(cf_rec16_scatter, dim3((unsigned)ntiles), dim3(RS_THREADS), 256 * 8 + 4 * 256 * 4, ctx->stream, (const cf_rec16*)src, dst, (const int64_t*)d_offs, n, words[f], shift, ntiles);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("record sort launch: ") + hipGetErrorString(e)); break; }
+            std::swap(src, dst);
+        }
+    }
+    if (rc == 0 && src != (cf_rec16*)d_recs) {
+        hipError_t e = hipMemcpyAsync(d_recs, src, (size_t)n * 16, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e != hipSuccess) rc = cf_fail(ctx, -5, std::string("record sort copy back: ") + hipGetErrorString(e));
+    }
+    if (rc == 0) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = cf_fail(ctx, -5, std::string("record sort sync: ") + hipGetErrorString(e));
+    }
+    if (d_offs) cf_release_t(ctx, d_offs, (size_t)nh);
+    cf_release_t(ctx, d_hist, (size_t)nh);
+    return rc;
+}

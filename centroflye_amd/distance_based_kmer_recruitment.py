@@ -136,8 +136,8 @@ def _run_dist(dist_cnt, min_coverage, rel_threshold, edge_sink=None):
                     edge_sink(None)
                     ok = False
                     break
-                ed = e.edges(n)
-                edge_sink(ed[np.lexsort((ed[:, 2], ed[:, 1], ed[:, 0]))])
+                e.sort_edges()          # by (d, a, b), on the device
+                edge_sink(e.edges(n))
         if ok:
             break
     dist_cnt.stats = e.stats()

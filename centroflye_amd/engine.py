@@ -250,6 +250,10 @@ class Engine:
         self._check(self._lib.cf_get_edges(self._ctx, _ptr(out), n), "cf_get_edges")
         return out
 
+    def sort_edges(self):
+        """Sort the stored edges by (d, a, b) on the device."""
+        self._check(self._lib.cf_sort_edges(self._ctx), "cf_sort_edges")
+
     def unique_mask(self):
         n = self.stats()["n_kmers"]
         out = np.zeros(n, np.uint8)

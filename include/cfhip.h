@@ -118,6 +118,10 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                   uint32_t min_cov, double rel_threshold, int32_t part, int32_t n_parts,
                   int64_t edge_cap, int64_t* n_edges);
 int cf_get_edges(cf_ctx* ctx, uint32_t* out /* n x 4: d, a, b, cnt */, int64_t cap);   /* the first min(cap, stored) edges */
+/* Sort the stored edges by (d, a, b) on the device (they are written in the order workgroups finish; the reference's file
+ * order, distance_based_kmer_recruitment.py:165-171, is the insertion order of its dicts and is not reproduced).  Only
+ * meaningful when every selected edge was stored (edge_cap >= n_edges of the last cf_dist_edges call). */
+int cf_sort_edges(cf_ctx* ctx);
 int cf_get_unique_mask(cf_ctx* ctx, uint8_t* mask /* n_kmers bytes of 0/1 */);
 int cf_or_unique_mask(cf_ctx* ctx, const uint8_t* mask);
 int cf_reset_unique(cf_ctx* ctx);
