@@ -315,6 +315,9 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
         ctx->dist_slots = (int)value;
     } else if (n == "dist_wide") {
         ctx->dist_wide = value != 0;
+    } else if (n == "dist_dbits") {
+        if (value != 0 && (value < 5 || value > 8)) return cf_fail(ctx, -22, "dist_dbits must be 0 (auto) or 5 .. 8");
+        ctx->dist_dbits = (int)value;
     } else if (n == "dist_fill_pct") {
         if (value < 10 || value > 90) return cf_fail(ctx, -22, "dist_fill_pct out of range (10 .. 90)");
         ctx->dist_fill_pct = (int)value;

@@ -83,16 +83,16 @@ cf_unit_rend_kernel(const int64_t* __restrict__ unit_ptr, const int64_t* __restr
 }
 
 // per cloud entry the index of its unit inside its read (one wave per unit): as a 16-bit side array (wide table
-// layout) or, mod 256, packed above the 24-bit rank (narrow layout: one 4-byte load per pair emission)
+// layout) or, mod 2^(32 - b_bits), packed above the rank (narrow layouts: one 4-byte load per pair emission)
 __global__ void __launch_bounds__(256)
 cf_entry_unit_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ rbeg, const int32_t* __restrict__ entries, int64_t n_units,
-                     uint16_t* __restrict__ entry_i, uint32_t* __restrict__ packed) {
+                     uint16_t* __restrict__ entry_i, uint32_t* __restrict__ packed, int b_bits) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t u = wave; u < n_units; u += n_waves) {
         const uint32_t i = (uint32_t)(u - rbeg[u]);
-        if (packed) { for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) packed[e] = ((i & 0xFFu) << 24) | (uint32_t)entries[e]; }
+        if (packed) { for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) packed[e] = (i << b_bits) | (uint32_t)entries[e]; }      // (the shift drops all but the low 32 - b_bits bits of i)
         else { for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) entry_i[e] = (uint16_t)i; }
     }
 }
@@ -188,13 +188,24 @@ struct cf_tab_wide_t {
     }
     // streaming side: one cloud entry -> (b, d)
     // DIST_UNROLL consecutive entries from e on; entries whose bit in ok is clear are not touched in memory
+    struct __attribute__((packed, aligned(4))) run4 { uint32_t x, y, z, w; };
+    struct __attribute__((packed, aligned(2))) run4h { uint16_t x, y, z, w; };
     static __device__ __forceinline__ void load_run(const cf_dist_args& A, int64_t e, uint32_t ok, raw (&out)[DIST_UNROLL]) {
+        static_assert(DIST_UNROLL == 4, "one 16-byte and one 8-byte load per lane");
+        if (ok == (1u << DIST_UNROLL) - 1u) {      // the whole run lies inside the posting's range (all items but the last of a posting)
+            const run4 r = *(const run4*)(A.entries + e);
+            const run4h h = *(const run4h*)(A.entry_i + e);
+            out[0] = raw{r.x, h.x}; out[1] = raw{r.y, h.y}; out[2] = raw{r.z, h.z}; out[3] = raw{r.w, h.w};
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < DIST_UNROLL; ++u) { const int64_t x = ((ok >> u) & 1u) ? e + u : 0; out[u] = raw{(uint32_t)A.entries[x], (uint32_t)A.entry_i[x]}; }
     }
     static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { b = r.b; dd = (r.i - ig) & 0xFFFFu; }   // unit indices are kept mod 65536 and d <= max_d < 65536: the 16-bit difference IS d
-    static __device__ __forceinline__ uint32_t hash(uint32_t b) { return b * 0x9E3779B1u; }
-    static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return (uint32_t)(((unsigned long long)h * (unsigned long long)n_buckets) >> 32); }
+    // 24 x 24-bit multiplies only (full rate; a 32-bit multiply or a multiply-high is quarter rate): the low 24 bits of b as in
+    // the narrow layout, the high 8 bits through a second multiplier
+    static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u + (b >> 24) * 0x85EBCBu; }
+    static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return ((h >> 16) * (n_buckets & 0xFFFFu)) >> 16; }
     static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
     __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u64x2*)&tab[4 * bk], *(const cf_u64x2*)&tab[4 * bk + 2]}; }
     static __device__ __forceinline__ bool is(unsigned long long v, uint32_t b, uint32_t dd) { return (uint32_t)(v >> 32) == b && ((uint32_t)v >> kDShift) == dd; }
@@ -261,14 +272,19 @@ struct cf_tab_wide_t {
 typedef cf_tab_wide_t<8> cf_tab_wide;
 typedef cf_tab_wide_t<16> cf_tab_wide16;
 
-struct cf_tab_narrow {
+// DB = bits of the distance field (5 .. 8): the key is [d : DB | b : 32 - DB].  d never exceeds min(max_d, units of the longest
+// read - 1), so sets of up to 2^27 - 2 k-mers keep the 6-byte slots when the reads are short enough in units (multi-GPU
+// runs sweep the union of all ranks' k-mers: 6e7 at 8 x 50 000 reads).  Hashes use the low 24 bits of b only.
+template <int DB>
+struct cf_tab_narrow_t {
+    static constexpr uint32_t kBBits = 32 - DB, kBMask = (1u << kBBits) - 1u;
     static constexpr uint32_t kSlotBytes = 6, kPerBucket = 8;
     static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
     struct bucket { cf_u32x4 lo, hi; };
     struct raw { uint32_t v; };
     typedef uint32_t qitem;             // deferred insert: the key; probing restarts at the home bucket
     static __device__ __forceinline__ qitem q_make(uint32_t b, uint32_t dd, uint32_t) { return key_of(b, dd); }
-    static __device__ __forceinline__ void q_take(qitem q, uint32_t n_buckets, uint32_t& b, uint32_t& dd, uint32_t& bk) { b = q & 0xFFFFFFu; dd = q >> 24; bk = home(hash(b), n_buckets); }
+    static __device__ __forceinline__ void q_take(qitem q, uint32_t n_buckets, uint32_t& b, uint32_t& dd, uint32_t& bk) { b = q & kBMask; dd = q >> kBBits; bk = home(hash(b), n_buckets); }
     uint32_t* keys;     // slots x 32-bit [d:8 | b:24]
     uint32_t* cnt32;    // slots x 16-bit [sel:1 | count - 1 : 15], two per word
     __device__ __forceinline__ void init(unsigned char* lds, uint32_t slots) { keys = (uint32_t*)lds; cnt32 = keys + slots; }
@@ -286,12 +302,12 @@ struct cf_tab_narrow {
         out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
     }
     // the unit index is kept mod 256 and 1 <= d <= max_d <= 255, so the 8-bit difference IS d; no borrow reaches b
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { const uint32_t q = r.v - (ig << 24); b = q & 0xFFFFFFu; dd = q >> 24; }
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { const uint32_t q = r.v - (ig << kBBits); b = q & kBMask; dd = q >> kBBits; }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }               // 24 x 24 -> low 32 bits
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return ((h >> 16) * (n_buckets & 0xFFFFu)) >> 16; }
     static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
     __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u32x4*)&keys[8 * bk], *(const cf_u32x4*)&keys[8 * bk + 4]}; }
-    static __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) { return (dd << 24) | b; }
+    static __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) { return (dd << kBBits) | b; }
     // branch-free: one bit per slot, then find-first-set (nested ?: chains compile to a cascade of exec-mask branches)
     static __device__ __forceinline__ uint32_t ne_bit(uint32_t k, uint32_t q) { return min(k ^ q, 1u); }
     static __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) {
@@ -315,7 +331,7 @@ struct cf_tab_narrow {
     }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
         const uint32_t q = keys[s];
-        b = q & 0xFFFFFFu; dd = q >> 24; cnt = ((cnt32[s >> 1] >> ((s & 1u) * 16u)) & 0x7FFFu) + 1u;
+        b = q & kBMask; dd = q >> kBBits; cnt = ((cnt32[s >> 1] >> ((s & 1u) * 16u)) & 0x7FFFu) + 1u;
         return q != kEmpty;
     }
     __device__ __forceinline__ unsigned long long total_of(uint32_t b, uint32_t n_buckets) const {
@@ -324,14 +340,14 @@ struct cf_tab_narrow {
         for (uint32_t probe = 0; probe < n_buckets; ++probe) {
             const bucket k = read(bk);
             const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];   // the 8 count fields of the bucket
-            if ((k.lo.x & 0xFFFFFFu) == b && k.lo.x != kEmpty) total += (c.x & 0x7FFFu) + 1u;
-            if ((k.lo.y & 0xFFFFFFu) == b && k.lo.y != kEmpty) total += ((c.x >> 16) & 0x7FFFu) + 1u;
-            if ((k.lo.z & 0xFFFFFFu) == b && k.lo.z != kEmpty) total += (c.y & 0x7FFFu) + 1u;
-            if ((k.lo.w & 0xFFFFFFu) == b && k.lo.w != kEmpty) total += ((c.y >> 16) & 0x7FFFu) + 1u;
-            if ((k.hi.x & 0xFFFFFFu) == b && k.hi.x != kEmpty) total += (c.z & 0x7FFFu) + 1u;
-            if ((k.hi.y & 0xFFFFFFu) == b && k.hi.y != kEmpty) total += ((c.z >> 16) & 0x7FFFu) + 1u;
-            if ((k.hi.z & 0xFFFFFFu) == b && k.hi.z != kEmpty) total += (c.w & 0x7FFFu) + 1u;
-            if ((k.hi.w & 0xFFFFFFu) == b && k.hi.w != kEmpty) total += ((c.w >> 16) & 0x7FFFu) + 1u;
+            if ((k.lo.x & kBMask) == b && k.lo.x != kEmpty) total += (c.x & 0x7FFFu) + 1u;
+            if ((k.lo.y & kBMask) == b && k.lo.y != kEmpty) total += ((c.x >> 16) & 0x7FFFu) + 1u;
+            if ((k.lo.z & kBMask) == b && k.lo.z != kEmpty) total += (c.y & 0x7FFFu) + 1u;
+            if ((k.lo.w & kBMask) == b && k.lo.w != kEmpty) total += ((c.y >> 16) & 0x7FFFu) + 1u;
+            if ((k.hi.x & kBMask) == b && k.hi.x != kEmpty) total += (c.z & 0x7FFFu) + 1u;
+            if ((k.hi.y & kBMask) == b && k.hi.y != kEmpty) total += ((c.z >> 16) & 0x7FFFu) + 1u;
+            if ((k.hi.z & kBMask) == b && k.hi.z != kEmpty) total += (c.w & 0x7FFFu) + 1u;
+            if ((k.hi.w & kBMask) == b && k.hi.w != kEmpty) total += ((c.w >> 16) & 0x7FFFu) + 1u;
             if (empty(k) >= 0) break;
             bk = bk + 1 == n_buckets ? 0u : bk + 1;
         }
@@ -353,18 +369,18 @@ struct cf_tab_narrow {
         for (int i = 0; i < 8; ++i) {
             const uint32_t cnt = ((w[i >> 1] >> ((i & 1) * 16)) & 0x7FFFu) + 1u;
             if (cnt >= min_cov && key[i] != kEmpty) {
-                const uint32_t b = key[i] & 0xFFFFFFu;
+                const uint32_t b = key[i] & kBMask;
                 // usual case: b lives in its home bucket and the bucket is not full, so all (b, .) keys are in the
                 // registers already — no chain walk through LDS
                 unsigned long long total = 0;
                 if (open_bucket && home(hash(b), n_buckets) == bk) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        if ((key[j] & 0xFFFFFFu) == b && key[j] != kEmpty) total += ((w[j >> 1] >> ((j & 1) * 16)) & 0x7FFFu) + 1u;
+                        if ((key[j] & kBMask) == b && key[j] != kEmpty) total += ((w[j >> 1] >> ((j & 1) * 16)) & 0x7FFFu) + 1u;
                 } else {
                     total = total_of(b, n_buckets);
                 }
-                f(8u * bk + (uint32_t)i, b, key[i] >> 24, cnt, total);
+                f(8u * bk + (uint32_t)i, b, key[i] >> kBBits, cnt, total);
             }
         }
     }
@@ -378,11 +394,13 @@ struct cf_tab_narrow {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint32_t h = w[i >> 1] >> ((i & 1) * 16);
-            if (h & 0x8000u) f(8u * bk + (uint32_t)i, key[i] & 0xFFFFFFu, key[i] >> 24, (h & 0x7FFFu) + 1u);
+            if (h & 0x8000u) f(8u * bk + (uint32_t)i, key[i] & kBMask, key[i] >> kBBits, (h & 0x7FFFu) + 1u);
         }
     }
     __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&cnt32[s >> 1], 0x8000u << ((s & 1u) * 16u)); }
 };
+typedef cf_tab_narrow_t<8> cf_tab_narrow;
+
 
 #define DIST_QCAP 128                    /* deferred inserts per wave (pushes come in batches of <= 64, drains take 64) */
 #define DIST_FULL_BIT 0x80000000u        /* sh[0]: the table is physically full (the pass is void and will be split) */
@@ -521,19 +539,23 @@ template <class Tab>
 __global__ void cf_dist_kernel(cf_dist_args A) {
     Tab T;
     T.init(cf_lds, (uint32_t)A.slots);
-    uint32_t* sk = (uint32_t*)cf_lds;                          // phase A: 8-bit counters over the table's LDS
-    cf_dist_rec* rec = (cf_dist_rec*)(cf_lds + (size_t)A.slots * Tab::kSlotBytes);   // partner range of each posting of the chunk
-    uint32_t* ipx = (uint32_t*)(rec + DIST_NP_CAP);            // 4 zeros, then the inclusive prefix of item counts
-    uint32_t* stack = ipx + 4 + DIST_NP_CAP;                   // (P, idx) pairs
-    uint32_t* sh = stack + 2 * DIST_STACK;                     // [0] keys in table | DIST_FULL_BIT [1] first k-mer [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] item cursor [12] entries of the chunk [13] a counter of the sketch wrapped [14,15] its first posting
-    uint16_t* stage = (uint16_t*)(sh + 16);                    // slot indices of the selected edges of a pass
-    uint32_t* bm = (uint32_t*)(stage + DIST_STAGE_CAP + 8);    // DIST_BM_BITS bits: hash(b) of the k-mers b that may have a selected edge
+    // LDS: [table | edge stage | insert queues | partition stack] [posting ranges | item prefixes | sh | bitmap].  The first
+    // group is dead while the sketch sweep runs, so its 8-bit counters (sk) lie over ALL of it: the 8-byte-slot layouts,
+    // whose table is smaller than 64 KiB next to their 8-byte queue items, keep 65 536 counters that way.
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
+    uint32_t* sk = (uint32_t*)cf_lds;
+    uint16_t* stage = (uint16_t*)(cf_lds + (size_t)A.slots * Tab::kSlotBytes);   // slot indices of the selected edges of a pass
     // per-wave queue of pending inserts: candidates are compacted here and inserted 64 at a time by a full wave.
     // Only its own wave touches it: LDS operations of one wave execute in order, and wavefront-scope fences (no
     // instructions) keep the compiler from moving the queue accesses across the drain; a volatile pointer would turn
     // every push into a FLAT store followed by a full vmcnt wait (it did: 4 per step in the first version).
-    typename Tab::qitem* wq = (typename Tab::qitem*)(bm + DIST_BM_BITS / 32) + (size_t)(t >> 6) * DIST_QCAP;
+    typename Tab::qitem* wq0 = (typename Tab::qitem*)(stage + DIST_STAGE_CAP + 8);
+    typename Tab::qitem* wq = wq0 + (size_t)(t >> 6) * DIST_QCAP;
+    uint32_t* stack = (uint32_t*)(wq0 + (size_t)(nt >> 6) * DIST_QCAP);          // (P, idx) pairs
+    cf_dist_rec* rec = (cf_dist_rec*)(stack + 2 * DIST_STACK);                   // partner range of each posting of the chunk
+    uint32_t* ipx = (uint32_t*)(rec + DIST_NP_CAP);            // 4 zeros, then the inclusive prefix of item counts
+    uint32_t* sh = ipx + 4 + DIST_NP_CAP;                      // [0] keys in table | DIST_FULL_BIT [1] first k-mer [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] item cursor [12] entries of the chunk [13] a counter of the sketch wrapped [14,15] its first posting
+    uint32_t* bm = sh + 16;                                    // DIST_BM_BITS bits: hash(b) of the k-mers b that may have a selected edge
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
 #if defined(CF_DIST_STAMPS)
@@ -857,6 +879,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     uint32_t* d_packed = nullptr;
     cf_dist_rec* d_urange = nullptr;
     bool narrow = false, wide16 = false;
+    int narrow_db = 8;
     unsigned long long* d_cnt = nullptr;
     int64_t n_post = 0;
     int rc = 0;
@@ -905,14 +928,24 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                                (const uint32_t*)d_pcnt, K, (uint32_t*)(d_cnt + 7));
             if (hipMemcpy(&max_post, d_cnt + 7, 4, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "max postings"); break; }
         }
-        wide16 = max_d > 255;          // 16-bit distance field: [b:32 | d:16 | sel:1 | cnt:15]
-        narrow = !wide16 && !ctx->dist_wide && K < ((int64_t)1 << 24) - 1 && max_post <= 32767u;
-        if (max_post >= (1u << 23) || (wide16 && max_post > 32767u)) { rc = cf_fail(ctx, -34, wide16 ? "cf_dist_edges: max_d > 255 with a k-mer of more than 32767 postings" : "cf_dist_edges: a k-mer has more than 2^23 postings"); break; }
+        // 6-byte slots [d : DB | b : 32 - DB] need the k-mer ranks in 32 - DB bits and every distance that can occur in DB
+        // bits: d <= min(max_d, units of the longest read - 1)
+        int64_t u_max = 0;
+        for (int64_t r = min_n; r < max_n; ++r) u_max = std::max(u_max, v_h_unit_ptr[(size_t)r + 1] - v_h_unit_ptr[(size_t)r]);
+        const int64_t d_need = std::max<int64_t>(1, std::min<int64_t>(max_d, u_max - 1));
+        int need_bits = 1; while (((int64_t)1 << need_bits) <= d_need) ++need_bits;
+        wide16 = d_need > 255;         // 16-bit distance field: [b:32 | d:16 | sel:1 | cnt:15]
+        int kb = 24; while (kb < 32 && K >= ((int64_t)1 << kb) - 1) ++kb;       // ranks 0 .. K - 1 and the all-ones key stays free
+        narrow_db = 32 - kb;                                                       // the widest distance field the ranks leave
+        if (ctx->dist_dbits) narrow_db = std::min(narrow_db, ctx->dist_dbits);
+        narrow = !wide16 && !ctx->dist_wide && narrow_db >= 5 && narrow_db >= need_bits && max_post <= 32767u;
+        if (ctx->dist_dbits && !narrow) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_dbits does not fit this input (distances or k-mer ranks need more bits)"); break; }
+        if (max_post >= (1u << 23) || (wide16 && max_post > 32767u)) { rc = cf_fail(ctx, -34, wide16 ? "cf_dist_edges: distances above 255 with a k-mer of more than 32767 postings" : "cf_dist_edges: a k-mer has more than 2^23 postings"); break; }
         if (narrow) { if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)v_n_entries + DIST_ITEM, "packed cloud entries"))) break; }
         else if ((rc = cf_alloc_t(ctx, &d_entry_i, (size_t)v_n_entries + 1, "entry unit indices"))) break;
         if (U && v_n_entries)
             hipLaunchKernelGGL(cf_entry_unit_kernel, dim3((unsigned)cf_grid_for(U * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               v_cloud_ptr, (const int32_t*)d_rbeg, v_entries, U, d_entry_i, d_packed);
+                               v_cloud_ptr, (const int32_t*)d_rbeg, v_entries, U, d_entry_i, d_packed, 32 - narrow_db);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("postings: ") + hipGetErrorString(e)); break; }
@@ -938,8 +971,9 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (wgs == 0) wgs = (block > 512 || per_first > 32768.0) ? 1 : 2;
         if (block == 0) block = wgs == 1 ? 1024 : 512;
         // LDS: everything but the table is fixed; dist_slots (the table budget in 8-byte units) defaults to all the rest
+        const size_t qitem_bytes = narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem);
         const size_t lds_fixed = sizeof(cf_dist_rec) * DIST_NP_CAP + (size_t)(4 + DIST_NP_CAP + 2 * DIST_STACK + 16) * 4 + DIST_STAGE_CAP * 2 + 16
-                               + DIST_BM_BITS / 8 + (size_t)(block / 64) * DIST_QCAP * (narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem));
+                               + DIST_BM_BITS / 8 + (size_t)(block / 64) * DIST_QCAP * qitem_bytes;
         const int64_t budget8 = ((int64_t)160 * 1024 / wgs - (int64_t)lds_fixed) / 8;
         if (budget8 < 256) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_wgs leaves no LDS for the table"); break; }
         if (ctx->dist_slots > budget8) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_slots does not fit the 160 KiB LDS next to the work lists"); break; }
@@ -951,7 +985,8 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         const size_t lds = (size_t)A.slots * slot_bytes + lds_fixed;
         A.sketch = (ctx->dist_sketch && min_cov >= 2 && min_cov <= 200) ? 1 : 0;
         A.sk_shift = 32; A.sk_counters = 1;
-        while (A.sk_shift > 8 && (size_t)A.sk_counters * 2 <= (size_t)A.slots * slot_bytes) { A.sk_counters *= 2; --A.sk_shift; }
+        const size_t sk_room = (size_t)A.slots * slot_bytes + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * DIST_QCAP * qitem_bytes + 2 * DIST_STACK * 4;   // table + stage + queues + stack
+        while (A.sk_shift > 8 && (size_t)A.sk_counters * 2 <= sk_room) { A.sk_counters *= 2; --A.sk_shift; }
         if (A.sk_counters < 16) A.sketch = 0;
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / block));
         // locality order of the first k-mers: sort (first posting unit, a); k-mers without postings drop out
@@ -976,14 +1011,13 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("order: ") + hipGetErrorString(e)); break; }
-        e = narrow ? hipFuncSetAttribute((const void*)cf_dist_kernel<cf_tab_narrow>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                   : wide16 ? hipFuncSetAttribute((const void*)cf_dist_kernel<cf_tab_wide16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                   : hipFuncSetAttribute((const void*)cf_dist_kernel<cf_tab_wide>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        void (*kern)(cf_dist_args) = !narrow ? (wide16 ? cf_dist_kernel<cf_tab_wide16> : cf_dist_kernel<cf_tab_wide>)
+                                   : narrow_db == 8 ? cf_dist_kernel<cf_tab_narrow_t<8>> : narrow_db == 7 ? cf_dist_kernel<cf_tab_narrow_t<7>>
+                                   : narrow_db == 6 ? cf_dist_kernel<cf_tab_narrow_t<6>> : cf_dist_kernel<cf_tab_narrow_t<5>>;
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("dist LDS attribute: ") + hipGetErrorString(e)); break; }
         if (n_a > 0 && max_d >= min_d_eff && n_post > 0) {
-            if (narrow) hipLaunchKernelGGL((cf_dist_kernel<cf_tab_narrow>), dim3((unsigned)grid), dim3((unsigned)block), lds, ctx->stream, A);
-            else if (wide16) hipLaunchKernelGGL((cf_dist_kernel<cf_tab_wide16>), dim3((unsigned)grid), dim3((unsigned)block), lds, ctx->stream, A);
-            else hipLaunchKernelGGL((cf_dist_kernel<cf_tab_wide>), dim3((unsigned)grid), dim3((unsigned)block), lds, ctx->stream, A);
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)block), lds, ctx->stream, A);
             e = hipGetLastError();
             if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_dist_kernel: ") + hipGetErrorString(e)); break; }
         }

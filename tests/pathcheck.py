@@ -80,9 +80,10 @@ def check_stage3(engine, pk, records, alns, lens, genomic_kmers, p3, expect_line
     return lines
 
 
-def check_synthetic_clouds(engine, n_reads=3, n_units=100, cloud=6, n_kmers=40, seed=0, min_d=1, max_d=150, min_cov=2):
+def check_synthetic_clouds(engine, n_reads=3, n_units=100, cloud=6, n_kmers=40, seed=0, min_d=1, max_d=150, min_cov=2, kmer_base=0):
     """Distance stage on hand-made clouds (cf_set_clouds): k-mer 0 sits in EVERY unit, so its posting list
-    (n_reads * n_units entries) exceeds the kernel's per-chunk posting capacity and the multi-chunk path runs."""
+    (n_reads * n_units entries) exceeds the kernel's per-chunk posting capacity and the multi-chunk path runs.
+    kmer_base > 0: the other k-mers get the ranks kmer_base + 1 .. (a set of kmer_base + n_kmers k-mers: ranks beyond 24 bits)."""
     rng = np.random.default_rng(seed)
     unit_ptr = np.arange(n_reads + 1, dtype=np.int64) * n_units
     U = n_reads * n_units
@@ -92,6 +93,9 @@ def check_synthetic_clouds(engine, n_reads=3, n_units=100, cloud=6, n_kmers=40, 
         ent.append(c)
         cp.append(cp[-1] + c.size)
     entries, cloud_ptr = np.concatenate(ent), np.array(cp, np.int64)
+    if kmer_base:
+        entries = np.where(entries > 0, entries + kmer_base, 0).astype(np.int32)
+        n_kmers += kmer_base
     a, b, d, cnt, E = recruit.dist_histogram(unit_ptr, cloud_ptr, entries, n_kmers, 0, n_reads, min_d, max_d)
     edges, uniq = recruit.filter_edges(a, b, d, cnt, min_cov)
     zeros = np.zeros(U, np.int64)

@@ -92,6 +92,23 @@ def test_max_distance_beyond_255_takes_the_16_bit_distance_layout(engine):
         engine.set_param("dist_block", 0)
 
 
+@pytest.mark.parametrize("dbits,n_units", [(5, 30), (6, 60), (7, 100)])
+def test_narrow_slots_with_fewer_distance_bits(engine, dbits, n_units):
+    """6-byte slots [d : DB | b : 32 - DB]: k-mer sets beyond 2^24 keep them when the reads are short enough in units;
+    here the split is forced on small sets, the longest read makes distances up to n_units - 1 (just inside DB bits)."""
+    engine.set_param("dist_slots", 4096)
+    engine.set_param("dist_block", 128)
+    engine.set_param("dist_dbits", dbits)
+    try:
+        pathcheck.check_synthetic_clouds(engine, n_reads=3, n_units=n_units, cloud=4, n_kmers=50, max_d=150, seed=dbits)
+        with pytest.raises(DeviceError, match="dist_dbits"):      # one unit more than DB bits can tell apart
+            pathcheck.check_synthetic_clouds(engine, n_reads=1, n_units=(1 << dbits) + 1, cloud=2, n_kmers=20, max_d=150, seed=1)
+    finally:
+        engine.set_param("dist_dbits", 0)
+        engine.set_param("dist_slots", 0)
+        engine.set_param("dist_block", 0)
+
+
 def test_stage3_against_reference_golden(engine, report, golden):
     from centroflye_amd import _host
     from oracle import ncrf

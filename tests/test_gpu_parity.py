@@ -114,6 +114,24 @@ def test_max_distance_beyond_255_and_reads_of_many_units(engine):
     pathcheck.check_synthetic_clouds(engine, n_reads=1, n_units=70000, cloud=3, n_kmers=2000, max_d=3, seed=4)
 
 
+def test_kmer_sets_beyond_2_pow_24_keep_the_six_byte_slots(engine):
+    """[d : DB | b : 32 - DB] with DB < 8: 2^24 + 40 and 2^26 + 40 k-mers (ranks in the keys pass 24 / 26 bits) with reads of
+    100 / 30 units; the same clouds through the 8-byte layout give the same edges (pathcheck compares both with the oracle)."""
+    pathcheck.check_synthetic_clouds(engine, n_reads=3, n_units=100, cloud=4, n_kmers=40, seed=7, kmer_base=1 << 24)      # DB = 7
+    pathcheck.check_synthetic_clouds(engine, n_reads=3, n_units=30, cloud=4, n_kmers=40, seed=8, kmer_base=1 << 26)       # DB = 5
+    engine.set_param("dist_wide", 1)
+    try:
+        pathcheck.check_synthetic_clouds(engine, n_reads=3, n_units=100, cloud=4, n_kmers=40, seed=7, kmer_base=1 << 24)
+    finally:
+        engine.set_param("dist_wide", 0)
+    for dbits in (5, 6, 7):
+        engine.set_param("dist_dbits", dbits)
+        try:
+            pathcheck.check_synthetic_clouds(engine, n_reads=3, n_units=min(100, (1 << dbits) - 2), cloud=4, n_kmers=50, seed=dbits)
+        finally:
+            engine.set_param("dist_dbits", 0)
+
+
 def test_against_c_oracle_on_bench_like_sample(engine):
     """Same generator and parameters as the benchmark workload, at a size the C oracle finishes in
     ~20 s: every counter and the order-independent checksums of rare set, clouds and edges."""
