@@ -153,12 +153,15 @@ static int load_units(cf_ctx* ctx, const int64_t* unit_ptr, const int64_t* unit_
         if (unit_ptr[r + 1] < unit_ptr[r]) return cf_fail(ctx, -22, "unit_ptr must be non-decreasing");
     const int64_t U = unit_ptr[R];
     if (U >= (int64_t)1 << 31) return cf_fail(ctx, -22, "more than 2^31 units");
+    int64_t longest = 0;
     for (int64_t r = 0; r < R; ++r) {
         for (int64_t u = unit_ptr[r]; u < unit_ptr[r + 1]; ++u) {
             if (unit_start[u] < ctx->h_read_off[(size_t)r] || unit_end[u] > ctx->h_read_off[(size_t)r + 1] || unit_end[u] < unit_start[u])
                 return cf_fail(ctx, -22, "unit " + std::to_string(u) + " lies outside its read");
+            longest = std::max(longest, unit_end[u] - unit_start[u]);
         }
     }
+    ctx->max_unit_len = longest;
     cf_free_clouds(ctx);
     free_units(ctx);
     ctx->n_units = U;

@@ -221,7 +221,7 @@ int cf_install_kmers(cf_ctx* ctx, int32_t k) {
     CF_HIP(hipMemsetAsync(ctx->d_unique_bits, 0, (size_t)ctx->unique_words * 4, ctx->stream));
     ctx->stats.n_unique = 0;
     unsigned int* d_flags = nullptr;
-    CF_TRY(cf_alloc_t(ctx, &d_flags, 4, "lut flags"));
+    CF_TRY(cf_alloc_t(ctx, &d_flags, 4, "lut flags"));      // (the last early return: everything below releases it)
     unsigned int flags = 0;
     int rc = 0;
     hipError_t e = hipMemsetAsync(d_flags, 0, 16, ctx->stream);
@@ -302,7 +302,7 @@ static int build_clouds_attempt(cf_ctx* ctx, int set_slots, int64_t* n_entries) 
     int rc = cf_alloc_t(ctx, &d_flags, 4, "cloud flags");
     const size_t lds = (size_t)set_slots * 8 + CL_THREADS * CL_TILE_W + 64 + 16;
     const int grid = (int)std::min<int64_t>(std::max<int64_t>(U, 1), (int64_t)std::max(1, ctx->n_cu) * 32);
-    int64_t total = 0;
+    int64_t total = 0, row_stride = 0;
     unsigned int flags = 0;
     do {
         if (rc) break;
@@ -312,7 +312,8 @@ static int build_clouds_attempt(cf_ctx* ctx, int set_slots, int64_t* n_entries) 
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_build_clouds setup: ") + hipGetErrorString(e)); break; }
         // one pass: every unit's sorted cloud goes to a fixed-stride row of a scratch buffer (a cloud that fits the LDS set
         // has at most 3/4 of its slots), sizes are scanned, rows are compacted into the CSR
-        const int64_t row_stride = (int64_t)set_slots * 3 / 4;
+        // (nor more entries than the longest unit has windows: the retry with the 64 KiB set does not quadruple the scratch)
+        row_stride = std::min<int64_t>((int64_t)set_slots * 3 / 4, std::max<int64_t>(1, ctx->max_unit_len - ctx->set_k + 1));
         if ((rc = cf_alloc_t(ctx, &d_rows, (size_t)(U * row_stride + 1), "cloud rows scratch"))) break;
         if (U) {
             hipLaunchKernelGGL(cf_cloud_kernel, dim3((unsigned)grid), dim3(CL_THREADS), lds, ctx->stream, (const uint8_t*)ctx->d_bases,
@@ -339,7 +340,7 @@ static int build_clouds_attempt(cf_ctx* ctx, int set_slots, int64_t* n_entries) 
         (void)hipEventElapsedTime(&ctx->times.clouds_ms, ctx->ev0, ctx->ev1);
     } while (0);
     if (d_flags) cf_release_t(ctx, d_flags, 4);
-    if (d_rows) cf_release_t(ctx, d_rows, (size_t)(U * ((int64_t)set_slots * 3 / 4) + 1));
+    if (d_rows) cf_release_t(ctx, d_rows, (size_t)(U * row_stride + 1));
     cf_release_t(ctx, d_sizes, (size_t)U + 1);
     if (rc) { cf_free_clouds(ctx); return rc; }
     ctx->have_clouds = true;

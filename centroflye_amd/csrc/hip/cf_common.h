@@ -74,6 +74,7 @@ struct cf_ctx {
     int64_t* d_unit_start = nullptr;
     int64_t* d_unit_end = nullptr;
     std::vector<int64_t> h_read_off, h_unit_ptr;
+    int64_t max_unit_len = 0;     // bases of the longest unit (bounds the entries of a cloud)
     int64_t n_reads = 0, n_bases = 0, n_units = 0;
     bool has_exotic = false;     // some base is not upper-case A, C, G, T
 
