@@ -142,7 +142,7 @@ struct cf_dist_args {
     uint32_t fill_limit;
     uint32_t est_limit;            // emissions one partition is expected to hold (fill_limit / expected distinct share)
     int32_t sketch;                // 1: count first in 8-bit counters, build the exact table only for k-mers that can pass min_cov
-    uint32_t sk_counters, sk_shift;   // counters (a power of two that fits the table's LDS) and 32 - log2 of it
+    uint32_t sk_counters, sk_shift;   // counters (a power of two that fits the LDS that is dead during the sketch sweep) and 32 - log2 of it
     uint32_t stage_cap;            // <= DIST_STAGE_CAP
     uint32_t* edges;
     unsigned long long edge_cap;
@@ -258,6 +258,22 @@ struct cf_tab_wide_t {
             const uint32_t cnt = (uint32_t)v[i] & kCntMask;
             if (v[i] != 0ull && cnt >= min_cov) f(4u * bk + (uint32_t)i, (uint32_t)(v[i] >> 32), ((uint32_t)v[i] >> kDShift) & kDMask, cnt, total_of((uint32_t)(v[i] >> 32), n_buckets));
         }
+    }
+    // filter, two steps: the slots of bucket bk whose count reaches min_cov as a bit mask ...
+    __device__ __forceinline__ uint32_t hot_mask(uint32_t bk, uint32_t min_cov) const {
+        const bucket k = read(bk);
+        const unsigned long long v[4] = {k.lo.x, k.lo.y, k.hi.x, k.hi.y};
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m |= (uint32_t)(v[i] != 0ull && ((uint32_t)v[i] & kCntMask) >= min_cov) << i;
+        return m;
+    }
+    // ... and one such slot evaluated: f(slot, b, dd, cnt, sum over d of cnt(b, .))
+    template <class F>
+    __device__ __forceinline__ void eval_slot(uint32_t s, uint32_t n_buckets, uint32_t min_cov, F&& f) const {
+        const unsigned long long v = tab[s];
+        const uint32_t cnt = (uint32_t)v & kCntMask;
+        if (v != 0ull && cnt >= min_cov) f(s, (uint32_t)(v >> 32), ((uint32_t)v >> kDShift) & kDMask, cnt, total_of((uint32_t)(v >> 32), n_buckets));
     }
     template <class F>
     __device__ __forceinline__ void for_marked(uint32_t bk, F&& f) const {
@@ -384,6 +400,42 @@ struct cf_tab_narrow_t {
             }
         }
     }
+    // filter, two steps: the slots of bucket bk whose count field reaches min_cov - 1 as a bit mask (an empty slot has the
+    // field 0: with min_cov <= 1 it is in the mask and eval_slot drops it) ...
+    __device__ __forceinline__ uint32_t hot_mask(uint32_t bk, uint32_t min_cov) const {
+        const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];
+        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+        const uint32_t need = min_cov ? min_cov - 1u : 0u;
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m |= ((uint32_t)((w[j] & 0x7FFFu) >= need) << (2 * j)) | ((uint32_t)(((w[j] >> 16) & 0x7FFFu) >= need) << (2 * j + 1));
+        return m;
+    }
+    // ... and one such slot evaluated: f(slot, b, dd, cnt, sum over d of cnt(b, .)).  Usual case: b lives in its home bucket
+    // and the bucket is not full, so all (b, .) keys are in the 8 keys just read — no chain walk through LDS.
+    template <class F>
+    __device__ __forceinline__ void eval_slot(uint32_t s, uint32_t n_buckets, uint32_t min_cov, F&& f) const {
+        const uint32_t bk = s >> 3, i = s & 7u;
+        const bucket k = read(bk);
+        const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];
+        const uint32_t key[8] = {k.lo.x, k.lo.y, k.lo.z, k.lo.w, k.hi.x, k.hi.y, k.hi.z, k.hi.w};
+        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+        uint32_t mine = key[0], mine_w = w[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) { if (i == (uint32_t)j) { mine = key[j]; mine_w = w[j >> 1]; } }
+        const uint32_t cnt = ((mine_w >> ((i & 1u) * 16u)) & 0x7FFFu) + 1u;
+        if (mine == kEmpty || cnt < min_cov) return;
+        const uint32_t b = mine & kBMask;
+        unsigned long long total = 0;
+        if (key[7] == kEmpty && home(hash(b), n_buckets) == bk) {      // slots fill in ascending order: an empty last slot = the chain ends here
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if ((key[j] & kBMask) == b && key[j] != kEmpty) total += ((w[j >> 1] >> ((j & 1) * 16)) & 0x7FFFu) + 1u;
+        } else {
+            total = total_of(b, n_buckets);
+        }
+        f(s, b, mine >> kBBits, cnt, total);
+    }
     template <class F>
     __device__ __forceinline__ void for_marked(uint32_t bk, F&& f) const {
         const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];
@@ -470,6 +522,9 @@ __device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0,
 // 16-byte load in the narrow layout).  Software pipeline: the global load of step i+1 is issued before the body of
 // step i runs; what a load returns is only touched one step later (ig travels in an SGPR, validity in a bit mask).
 // body(bb, dd) gets the decoded entries of a step (bb[u] == a: nothing to count) and returns true to stop the wave.
+// Round 2, edge output: copying the selected (b, d, cnt) of a pass into LDS, issuing the range-reserving global atomic and
+// going on with the next first k-mer (the copies written out right before its table sweep) takes the write phase from 57 to
+// 45 G cycles, but the two extra barriers and the LDS round trip give it back elsewhere: 458.6 vs 453.5 ms.  Not in the source.
 // Item hand-out of the two sweeps: 0 = dealt round robin to the waves (default), 1 = pulled from a shared LDS cursor
 // (round 1).  Measured at 50 000 reads (profiles/r02_dist_ab.log): cursor in both sweeps 480.8 ms, round robin in the sketch
 // sweep only 472.2, in the table sweep only 476.9, in both 465.5.  Other round-2 experiments on this kernel that LOST and
@@ -539,7 +594,7 @@ template <class Tab>
 __global__ void cf_dist_kernel(cf_dist_args A) {
     Tab T;
     T.init(cf_lds, (uint32_t)A.slots);
-    // LDS: [table | edge stage | insert queues | partition stack] [posting ranges | item prefixes | sh | bitmap].  The first
+    // LDS: [table | edge stage | partition stack | insert queues] [posting ranges | item prefixes | sh | bitmap].  The first
     // group is dead while the sketch sweep runs, so its 8-bit counters (sk) lie over ALL of it: the 8-byte-slot layouts,
     // whose table is smaller than 64 KiB next to their 8-byte queue items, keep 65 536 counters that way.
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
@@ -549,10 +604,10 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
     // Only its own wave touches it: LDS operations of one wave execute in order, and wavefront-scope fences (no
     // instructions) keep the compiler from moving the queue accesses across the drain; a volatile pointer would turn
     // every push into a FLAT store followed by a full vmcnt wait (it did: 4 per step in the first version).
-    typename Tab::qitem* wq0 = (typename Tab::qitem*)(stage + DIST_STAGE_CAP + 8);
+    uint32_t* stack = (uint32_t*)(stage + DIST_STAGE_CAP + 8);                   // (P, idx) pairs
+    typename Tab::qitem* wq0 = (typename Tab::qitem*)(stack + 2 * DIST_STACK);
     typename Tab::qitem* wq = wq0 + (size_t)(t >> 6) * DIST_QCAP;
-    uint32_t* stack = (uint32_t*)(wq0 + (size_t)(nt >> 6) * DIST_QCAP);          // (P, idx) pairs
-    cf_dist_rec* rec = (cf_dist_rec*)(stack + 2 * DIST_STACK);                   // partner range of each posting of the chunk
+    cf_dist_rec* rec = (cf_dist_rec*)(wq0 + (size_t)(nt >> 6) * DIST_QCAP);      // partner range of each posting of the chunk
     uint32_t* ipx = (uint32_t*)(rec + DIST_NP_CAP);            // 4 zeros, then the inclusive prefix of item counts
     uint32_t* sh = ipx + 4 + DIST_NP_CAP;                      // [0] keys in table | DIST_FULL_BIT [1] first k-mer [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] item cursor [12] entries of the chunk [13] a counter of the sketch wrapped [14,15] its first posting
     uint32_t* bm = sh + 16;                                    // DIST_BM_BITS bits: hash(b) of the k-mers b that may have a selected edge
@@ -765,17 +820,70 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             // staged), reserve the edge range with ONE global atomic, then write
             for (int d = 32; d >= 1; d >>= 1) my_e += __shfl_down(my_e, (unsigned)d);
             if (lane == 0 && my_e) atomicAdd(&sh[7], my_e);
-            // one bucket per thread and round: the counts decide first (one 16-byte read rejects 8 slots at once —
-            // the table is sparse and few pairs reach min_cov); only then keys are read and the chain of b is walked
-            for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt) {
-                T.for_counts_at_least(bk, n_buckets, A.min_cov, [&](uint32_t s, uint32_t b, uint32_t dd, uint32_t cnt, unsigned long long total) {
-                    (void)dd; (void)b;
-                    if (((double)cnt / (double)total) >= A.thr) {
-                        T.mark(s);
-                        const uint32_t pos = atomicAdd(&sh[8], 1u);
-                        if (pos < A.stage_cap) stage[pos] = (uint16_t)s;
+            // Filter in two steps.  (1) One bucket per thread and round: the slots whose count reaches min_cov (few: the
+            // table is sparse and most pairs stay below) are compacted into a list that lies over the insert queues, dead
+            // by now.  (2) The list is evaluated one slot per thread with all lanes busy: sum over d from the bucket's
+            // registers or a chain walk, the double division, mark + stage.  (Evaluating inside the bucket scan ran the
+            // division code at 8 unrolled sites per round with 4 % of the lanes active: 9 100 cycles per first k-mer.)
+            if (CF_DIST_DYN_B) { __syncthreads(); if (t == 0) sh[11] = 0; __syncthreads(); }      // (the item cursor of that build; round robin leaves the word 0)
+            uint16_t* hot = (uint16_t*)wq0;
+            const uint32_t hot_cap = (uint32_t)((size_t)(nt >> 6) * DIST_QCAP * sizeof(typename Tab::qitem) / 2);
+            // (every position comes from ONE LDS atomic per wave: 64 returning adds on one address serialise — 570 of them
+            // per first k-mer were the cost of this phase, not the arithmetic)
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            for (uint32_t bk0 = 0; bk0 < n_buckets; bk0 += (uint32_t)nt) {      // (uniform trip count: ballots inside)
+                const uint32_t bk = bk0 + (uint32_t)t;
+                const uint32_t m = bk < n_buckets ? T.hot_mask(bk, A.min_cov) : 0u;
+                if (__ballot(m != 0u)) {
+                    uint32_t before = 0, total = 0;      // hot slots of lower lanes (any slot index) / of the wave
+#pragma unroll
+                    for (int i = 0; i < (int)Tab::kPerBucket; ++i) {
+                        const unsigned long long mi = __ballot((m >> i) & 1u);
+                        before += (uint32_t)__popcll(mi & lt);
+                        total += (uint32_t)__popcll(mi);
                     }
-                });
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&sh[11], total);
+                    uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + before;
+                    uint32_t mm = m;
+                    while (mm) {
+                        const uint32_t i = (uint32_t)__ffs((int)mm) - 1u;
+                        mm &= mm - 1u;
+                        if (pos < hot_cap) hot[pos] = (uint16_t)(Tab::kPerBucket * bk + i);
+                        ++pos;
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t n_hot = sh[11];
+            auto keep = [&](bool sel, uint32_t s) {       // called by all lanes of a wave together
+                const unsigned long long m = __ballot(sel);
+                if (!m) return;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&sh[8], (uint32_t)__popcll(m));
+                const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + (uint32_t)__popcll(m & lt);
+                if (sel) { T.mark(s); if (pos < A.stage_cap) stage[pos] = (uint16_t)s; }
+            };
+            if (n_hot <= hot_cap) {
+                for (uint32_t i0 = 0; i0 < n_hot; i0 += (uint32_t)nt) {
+                    const uint32_t i = i0 + (uint32_t)t;
+                    bool sel = false;
+                    uint32_t s = 0;
+                    if (i < n_hot) {
+                        s = hot[i];
+                        T.eval_slot(s, n_buckets, A.min_cov, [&](uint32_t, uint32_t, uint32_t, uint32_t cnt, unsigned long long total) { sel = ((double)cnt / (double)total) >= A.thr; });
+                    }
+                    keep(sel, s);
+                }
+            } else {        // more than the list holds (never seen with the sketch): evaluate inside the bucket scan
+                for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt)
+                    T.for_counts_at_least(bk, n_buckets, A.min_cov, [&](uint32_t s, uint32_t, uint32_t, uint32_t cnt, unsigned long long total) {
+                        if (((double)cnt / (double)total) >= A.thr) {
+                            T.mark(s);
+                            const uint32_t pos = atomicAdd(&sh[8], 1u);
+                            if (pos < A.stage_cap) stage[pos] = (uint16_t)s;
+                        }
+                    });
             }
             __syncthreads();
             CF_STAMP(4);   // filter
