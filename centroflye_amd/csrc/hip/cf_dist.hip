@@ -260,6 +260,7 @@ struct cf_tab_wide_t {
         }
     }
     // filter, two steps: the slots of bucket bk whose count reaches min_cov as a bit mask ...
+    static constexpr uint32_t kScanGroup = 4;      // slots per step of the scan (one bucket)
     __device__ __forceinline__ uint32_t hot_mask(uint32_t bk, uint32_t min_cov) const {
         const bucket k = read(bk);
         const unsigned long long v[4] = {k.lo.x, k.lo.y, k.hi.x, k.hi.y};
@@ -291,17 +292,22 @@ typedef cf_tab_wide_t<16> cf_tab_wide16;
 // DB = bits of the distance field (5 .. 8): the key is [d : DB | b : 32 - DB].  d never exceeds min(max_d, units of the longest
 // read - 1), so sets of up to 2^27 - 2 k-mers keep the 6-byte slots when the reads are short enough in units (multi-GPU
 // runs sweep the union of all ranks' k-mers: 6e7 at 8 x 50 000 reads).  Hashes use the low 24 bits of b only.
-template <int DB>
+#ifndef CF_NARROW_PB
+#define CF_NARROW_PB 4      /* keys per bucket of the 6-byte-slot layout: 4 (one 16-byte read of keys; 453 -> 441 ms) or 8 */
+#endif
+template <int DB, int PB = CF_NARROW_PB>
 struct cf_tab_narrow_t {
+    static_assert(PB == 4 || PB == 8, "a bucket is one or two 16-byte reads of keys");
     static constexpr uint32_t kBBits = 32 - DB, kBMask = (1u << kBBits) - 1u;
-    static constexpr uint32_t kSlotBytes = 6, kPerBucket = 8;
+    static constexpr uint32_t kSlotBytes = 6, kPerBucket = PB, kAll = (1u << PB) - 1u;
     static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
-    struct bucket { cf_u32x4 lo, hi; };
+    struct bucket { uint32_t k[PB]; };
+    struct counts { uint32_t w[PB / 2]; };      // PB x 16-bit [sel:1 | count - 1 : 15]
     struct raw { uint32_t v; };
     typedef uint32_t qitem;             // deferred insert: the key; probing restarts at the home bucket
     static __device__ __forceinline__ qitem q_make(uint32_t b, uint32_t dd, uint32_t) { return key_of(b, dd); }
     static __device__ __forceinline__ void q_take(qitem q, uint32_t n_buckets, uint32_t& b, uint32_t& dd, uint32_t& bk) { b = q & kBMask; dd = q >> kBBits; bk = home(hash(b), n_buckets); }
-    uint32_t* keys;     // slots x 32-bit [d:8 | b:24]
+    uint32_t* keys;     // slots x 32-bit [d : DB | b : 32 - DB]
     uint32_t* cnt32;    // slots x 16-bit [sel:1 | count - 1 : 15], two per word
     __device__ __forceinline__ void init(unsigned char* lds, uint32_t slots) { keys = (uint32_t*)lds; cnt32 = keys + slots; }
     __device__ __forceinline__ void clear(uint32_t slots, uint32_t t, uint32_t nt) const {
@@ -317,29 +323,37 @@ struct cf_tab_narrow_t {
         const run4 r = *(const run4*)(A.packed + (ok ? e : 0));
         out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
     }
-    // the unit index is kept mod 256 and 1 <= d <= max_d <= 255, so the 8-bit difference IS d; no borrow reaches b
+    // the unit index is kept mod 2^DB and 1 <= d < 2^DB, so the DB-bit difference IS d; no borrow reaches b
     static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { const uint32_t q = r.v - (ig << kBBits); b = q & kBMask; dd = q >> kBBits; }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }               // 24 x 24 -> low 32 bits
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return ((h >> 16) * (n_buckets & 0xFFFFu)) >> 16; }
     static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
-    __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u32x4*)&keys[8 * bk], *(const cf_u32x4*)&keys[8 * bk + 4]}; }
+    __device__ __forceinline__ bucket read(uint32_t bk) const {
+        bucket r;
+#pragma unroll
+        for (int q = 0; q < PB / 4; ++q) { const cf_u32x4 v = *(const cf_u32x4*)&keys[PB * bk + 4 * q]; r.k[4 * q] = v.x; r.k[4 * q + 1] = v.y; r.k[4 * q + 2] = v.z; r.k[4 * q + 3] = v.w; }
+        return r;
+    }
+    __device__ __forceinline__ counts read_counts(uint32_t bk) const {
+        counts c;
+        if constexpr (PB == 8) { const cf_u32x4 v = *(const cf_u32x4*)&cnt32[4 * bk]; c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w; }
+        else { const unsigned long long v = *(const unsigned long long*)&cnt32[2 * bk]; c.w[0] = (uint32_t)v; c.w[1] = (uint32_t)(v >> 32); }
+        return c;
+    }
+    static __device__ __forceinline__ uint32_t field(const counts& c, int j) { return (c.w[j >> 1] >> ((j & 1) * 16)) & 0x7FFFu; }      // count - 1 of slot j
     static __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) { return (dd << kBBits) | b; }
     // branch-free: one bit per slot, then find-first-set (nested ?: chains compile to a cascade of exec-mask branches)
     static __device__ __forceinline__ uint32_t ne_bit(uint32_t k, uint32_t q) { return min(k ^ q, 1u); }
-    static __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) {
-        const uint32_t q = key_of(b, dd);
-        const uint32_t ne = ne_bit(k.lo.x, q) | (ne_bit(k.lo.y, q) << 1) | (ne_bit(k.lo.z, q) << 2) | (ne_bit(k.lo.w, q) << 3)
-                          | (ne_bit(k.hi.x, q) << 4) | (ne_bit(k.hi.y, q) << 5) | (ne_bit(k.hi.z, q) << 6) | (ne_bit(k.hi.w, q) << 7);
-        return __ffs((int)(ne ^ 0xFFu)) - 1;
+    static __device__ __forceinline__ int first_equal(const bucket& k, uint32_t q) {
+        uint32_t ne = 0;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) ne |= ne_bit(k.k[j], q) << j;
+        return __ffs((int)(ne ^ kAll)) - 1;
     }
-    static __device__ __forceinline__ int empty(const bucket& k) {
-        const uint32_t q = kEmpty;
-        const uint32_t ne = ne_bit(k.lo.x, q) | (ne_bit(k.lo.y, q) << 1) | (ne_bit(k.lo.z, q) << 2) | (ne_bit(k.lo.w, q) << 3)
-                          | (ne_bit(k.hi.x, q) << 4) | (ne_bit(k.hi.y, q) << 5) | (ne_bit(k.hi.z, q) << 6) | (ne_bit(k.hi.w, q) << 7);
-        return __ffs((int)(ne ^ 0xFFu)) - 1;
-    }
-    __device__ __forceinline__ void add(uint32_t bk, int i) const { const uint32_t s = 8 * bk + (uint32_t)i; atomicAdd(&cnt32[s >> 1], 1u << ((s & 1u) * 16u)); }
-    __device__ __forceinline__ uint32_t claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const { return atomicCAS(&keys[8 * bk + i], kEmpty, key_of(b, dd)); }
+    static __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) { return first_equal(k, key_of(b, dd)); }
+    static __device__ __forceinline__ int empty(const bucket& k) { return first_equal(k, kEmpty); }
+    __device__ __forceinline__ void add(uint32_t bk, int i) const { const uint32_t s = PB * bk + (uint32_t)i; atomicAdd(&cnt32[s >> 1], 1u << ((s & 1u) * 16u)); }
+    __device__ __forceinline__ uint32_t claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const { return atomicCAS(&keys[PB * bk + i], kEmpty, key_of(b, dd)); }
     __device__ __forceinline__ int claim_finish(uint32_t old, uint32_t bk, int i, uint32_t b, uint32_t dd) const {
         if (old == kEmpty) return 0;                        // claimed: the zero count field already means "seen once"
         if (old == key_of(b, dd)) { add(bk, i); return 1; }  // the same key was claimed by someone else: count it
@@ -350,103 +364,87 @@ struct cf_tab_narrow_t {
         b = q & kBMask; dd = q >> kBBits; cnt = ((cnt32[s >> 1] >> ((s & 1u) * 16u)) & 0x7FFFu) + 1u;
         return q != kEmpty;
     }
+    // sum of the counts of the keys (b, .) among the PB keys of a bucket
+    static __device__ __forceinline__ uint32_t sum_of(const bucket& k, const counts& c, uint32_t b) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            if ((k.k[j] & kBMask) == b && k.k[j] != kEmpty) total += field(c, j) + 1u;
+        return total;
+    }
     __device__ __forceinline__ unsigned long long total_of(uint32_t b, uint32_t n_buckets) const {
         unsigned long long total = 0;
         uint32_t bk = home(hash(b), n_buckets);
         for (uint32_t probe = 0; probe < n_buckets; ++probe) {
             const bucket k = read(bk);
-            const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];   // the 8 count fields of the bucket
-            if ((k.lo.x & kBMask) == b && k.lo.x != kEmpty) total += (c.x & 0x7FFFu) + 1u;
-            if ((k.lo.y & kBMask) == b && k.lo.y != kEmpty) total += ((c.x >> 16) & 0x7FFFu) + 1u;
-            if ((k.lo.z & kBMask) == b && k.lo.z != kEmpty) total += (c.y & 0x7FFFu) + 1u;
-            if ((k.lo.w & kBMask) == b && k.lo.w != kEmpty) total += ((c.y >> 16) & 0x7FFFu) + 1u;
-            if ((k.hi.x & kBMask) == b && k.hi.x != kEmpty) total += (c.z & 0x7FFFu) + 1u;
-            if ((k.hi.y & kBMask) == b && k.hi.y != kEmpty) total += ((c.z >> 16) & 0x7FFFu) + 1u;
-            if ((k.hi.z & kBMask) == b && k.hi.z != kEmpty) total += (c.w & 0x7FFFu) + 1u;
-            if ((k.hi.w & kBMask) == b && k.hi.w != kEmpty) total += ((c.w >> 16) & 0x7FFFu) + 1u;
-            if (empty(k) >= 0) break;
+            total += sum_of(k, read_counts(bk), b);
+            if (k.k[PB - 1] == kEmpty) break;       // slots fill in ascending order: an empty last slot = the chain ends here
             bk = bk + 1 == n_buckets ? 0u : bk + 1;
         }
         return total;
     }
     template <class F>
     __device__ __forceinline__ void for_counts_at_least(uint32_t bk, uint32_t n_buckets, uint32_t min_cov, F&& f) const {
-        const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];
-        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+        const counts c = read_counts(bk);
         const uint32_t need = min_cov ? min_cov - 1u : 0u;     // on the stored field (count - 1)
         bool any = false;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) any |= ((w[j] & 0x7FFFu) >= need) | (((w[j] >> 16) & 0x7FFFu) >= need);
+        for (int j = 0; j < PB; ++j) any |= field(c, j) >= need;
         if (!any) return;
         const bucket k = read(bk);
-        const uint32_t key[8] = {k.lo.x, k.lo.y, k.lo.z, k.lo.w, k.hi.x, k.hi.y, k.hi.z, k.hi.w};
-        const bool open_bucket = key[7] == kEmpty;     // slots fill in ascending order: an empty last slot = a chain ends here
+        const bool open_bucket = k.k[PB - 1] == kEmpty;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t cnt = ((w[i >> 1] >> ((i & 1) * 16)) & 0x7FFFu) + 1u;
-            if (cnt >= min_cov && key[i] != kEmpty) {
-                const uint32_t b = key[i] & kBMask;
+        for (int i = 0; i < PB; ++i) {
+            const uint32_t cnt = field(c, i) + 1u;
+            if (cnt >= min_cov && k.k[i] != kEmpty) {
+                const uint32_t b = k.k[i] & kBMask;
                 // usual case: b lives in its home bucket and the bucket is not full, so all (b, .) keys are in the
                 // registers already — no chain walk through LDS
-                unsigned long long total = 0;
-                if (open_bucket && home(hash(b), n_buckets) == bk) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if ((key[j] & kBMask) == b && key[j] != kEmpty) total += ((w[j >> 1] >> ((j & 1) * 16)) & 0x7FFFu) + 1u;
-                } else {
-                    total = total_of(b, n_buckets);
-                }
-                f(8u * bk + (uint32_t)i, b, key[i] >> kBBits, cnt, total);
+                const unsigned long long total = (open_bucket && home(hash(b), n_buckets) == bk) ? (unsigned long long)sum_of(k, c, b) : total_of(b, n_buckets);
+                f((uint32_t)PB * bk + (uint32_t)i, b, k.k[i] >> kBBits, cnt, total);
             }
         }
     }
     // filter, two steps: the slots of bucket bk whose count field reaches min_cov - 1 as a bit mask (an empty slot has the
     // field 0: with min_cov <= 1 it is in the mask and eval_slot drops it) ...
-    __device__ __forceinline__ uint32_t hot_mask(uint32_t bk, uint32_t min_cov) const {
-        const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];
-        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
+    static constexpr uint32_t kScanGroup = 8;      // slots per step of the scan: 16 bytes of count fields, whatever the bucket size
+    __device__ __forceinline__ uint32_t hot_mask(uint32_t g, uint32_t min_cov) const {
+        const cf_u32x4 v = *(const cf_u32x4*)&cnt32[4 * g];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         const uint32_t need = min_cov ? min_cov - 1u : 0u;
         uint32_t m = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) m |= ((uint32_t)((w[j] & 0x7FFFu) >= need) << (2 * j)) | ((uint32_t)(((w[j] >> 16) & 0x7FFFu) >= need) << (2 * j + 1));
+        for (int j = 0; j < 8; ++j) m |= (uint32_t)(((w[j >> 1] >> ((j & 1) * 16)) & 0x7FFFu) >= need) << j;
         return m;
     }
     // ... and one such slot evaluated: f(slot, b, dd, cnt, sum over d of cnt(b, .)).  Usual case: b lives in its home bucket
-    // and the bucket is not full, so all (b, .) keys are in the 8 keys just read — no chain walk through LDS.
+    // and the bucket is not full, so all (b, .) keys are among the keys just read — no chain walk through LDS.
     template <class F>
     __device__ __forceinline__ void eval_slot(uint32_t s, uint32_t n_buckets, uint32_t min_cov, F&& f) const {
-        const uint32_t bk = s >> 3, i = s & 7u;
+        const uint32_t bk = s / (uint32_t)PB, i = s % (uint32_t)PB;
         const bucket k = read(bk);
-        const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];
-        const uint32_t key[8] = {k.lo.x, k.lo.y, k.lo.z, k.lo.w, k.hi.x, k.hi.y, k.hi.z, k.hi.w};
-        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
-        uint32_t mine = key[0], mine_w = w[0];
+        const counts c = read_counts(bk);
+        uint32_t mine = k.k[0], mine_f = field(c, 0);
 #pragma unroll
-        for (int j = 1; j < 8; ++j) { if (i == (uint32_t)j) { mine = key[j]; mine_w = w[j >> 1]; } }
-        const uint32_t cnt = ((mine_w >> ((i & 1u) * 16u)) & 0x7FFFu) + 1u;
+        for (int j = 1; j < PB; ++j) { if (i == (uint32_t)j) { mine = k.k[j]; mine_f = field(c, j); } }
+        const uint32_t cnt = mine_f + 1u;
         if (mine == kEmpty || cnt < min_cov) return;
         const uint32_t b = mine & kBMask;
-        unsigned long long total = 0;
-        if (key[7] == kEmpty && home(hash(b), n_buckets) == bk) {      // slots fill in ascending order: an empty last slot = the chain ends here
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if ((key[j] & kBMask) == b && key[j] != kEmpty) total += ((w[j >> 1] >> ((j & 1) * 16)) & 0x7FFFu) + 1u;
-        } else {
-            total = total_of(b, n_buckets);
-        }
+        const unsigned long long total = (k.k[PB - 1] == kEmpty && home(hash(b), n_buckets) == bk) ? (unsigned long long)sum_of(k, c, b) : total_of(b, n_buckets);
         f(s, b, mine >> kBBits, cnt, total);
     }
     template <class F>
     __device__ __forceinline__ void for_marked(uint32_t bk, F&& f) const {
-        const cf_u32x4 c = *(const cf_u32x4*)&cnt32[4 * bk];
-        if (!((c.x | c.y | c.z | c.w) & 0x80008000u)) return;       // no selected slot among the 8
-        const uint32_t w[4] = {c.x, c.y, c.z, c.w};
-        const bucket k = read(bk);
-        const uint32_t key[8] = {k.lo.x, k.lo.y, k.lo.z, k.lo.w, k.hi.x, k.hi.y, k.hi.z, k.hi.w};
+        const counts c = read_counts(bk);
+        uint32_t any = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t h = w[i >> 1] >> ((i & 1) * 16);
-            if (h & 0x8000u) f(8u * bk + (uint32_t)i, key[i] & kBMask, key[i] >> kBBits, (h & 0x7FFFu) + 1u);
+        for (int j = 0; j < PB / 2; ++j) any |= c.w[j];
+        if (!(any & 0x80008000u)) return;       // no selected slot in the bucket
+        const bucket k = read(bk);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const uint32_t h = c.w[i >> 1] >> ((i & 1) * 16);
+            if (h & 0x8000u) f((uint32_t)PB * bk + (uint32_t)i, k.k[i] & kBMask, k.k[i] >> kBBits, (h & 0x7FFFu) + 1u);
         }
     }
     __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&cnt32[s >> 1], 0x8000u << ((s & 1u) * 16u)); }
@@ -820,7 +818,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             // staged), reserve the edge range with ONE global atomic, then write
             for (int d = 32; d >= 1; d >>= 1) my_e += __shfl_down(my_e, (unsigned)d);
             if (lane == 0 && my_e) atomicAdd(&sh[7], my_e);
-            // Filter in two steps.  (1) One bucket per thread and round: the slots whose count reaches min_cov (few: the
+            // Filter in two steps.  (1) A group of slots per thread and round: the slots whose count reaches min_cov (few: the
             // table is sparse and most pairs stay below) are compacted into a list that lies over the insert queues, dead
             // by now.  (2) The list is evaluated one slot per thread with all lanes busy: sum over d from the bucket's
             // registers or a chain walk, the double division, mark + stage.  (Evaluating inside the bucket scan ran the
@@ -831,13 +829,14 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             // (every position comes from ONE LDS atomic per wave: 64 returning adds on one address serialise — 570 of them
             // per first k-mer were the cost of this phase, not the arithmetic)
             const unsigned long long lt = (1ull << lane) - 1ull;
-            for (uint32_t bk0 = 0; bk0 < n_buckets; bk0 += (uint32_t)nt) {      // (uniform trip count: ballots inside)
-                const uint32_t bk = bk0 + (uint32_t)t;
-                const uint32_t m = bk < n_buckets ? T.hot_mask(bk, A.min_cov) : 0u;
+            const uint32_t n_groups = slots / Tab::kScanGroup;
+            for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)nt) {      // (uniform trip count: ballots inside)
+                const uint32_t bk = g0 + (uint32_t)t;                       // a group of kScanGroup consecutive slots
+                const uint32_t m = bk < n_groups ? T.hot_mask(bk, A.min_cov) : 0u;
                 if (__ballot(m != 0u)) {
                     uint32_t before = 0, total = 0;      // hot slots of lower lanes (any slot index) / of the wave
 #pragma unroll
-                    for (int i = 0; i < (int)Tab::kPerBucket; ++i) {
+                    for (int i = 0; i < (int)Tab::kScanGroup; ++i) {
                         const unsigned long long mi = __ballot((m >> i) & 1u);
                         before += (uint32_t)__popcll(mi & lt);
                         total += (uint32_t)__popcll(mi);
@@ -849,7 +848,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     while (mm) {
                         const uint32_t i = (uint32_t)__ffs((int)mm) - 1u;
                         mm &= mm - 1u;
-                        if (pos < hot_cap) hot[pos] = (uint16_t)(Tab::kPerBucket * bk + i);
+                        if (pos < hot_cap) hot[pos] = (uint16_t)(Tab::kScanGroup * bk + i);
                         ++pos;
                     }
                 }
