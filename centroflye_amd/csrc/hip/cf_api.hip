@@ -332,6 +332,14 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "dist_stage") {
         if (value < 0 || value > 2048) return cf_fail(ctx, -22, "dist_stage out of range (0 .. 2048)");
         ctx->dist_stage = (int)value;
+    } else if (n == "place_fused") {
+        ctx->place_fused = value != 0;
+    } else if (n == "place_chunk") {
+        if (value < 1 || value > 64) return cf_fail(ctx, -22, "place_chunk out of range (1 .. 64)");
+        ctx->place_chunk = (int)value;
+    } else if (n == "place_grid") {
+        if (value < 0 || value > 4096) return cf_fail(ctx, -22, "place_grid out of range (0 = auto, 1 .. 4096)");
+        ctx->place_grid = (int)value;
     } else if (n == "count_mode") {
         ctx->count_mode = value != 0;
     } else if (n == "count_bits") {

@@ -91,6 +91,24 @@ __device__ __forceinline__ void cf_contig_add(const cf_place_state& S, uint32_t 
     atomicOr(&S.ctl[2], 1u);
 }
 
+// The same add for the fused iteration kernel: returns true when (x, q) just became frequent instead of queueing an event.
+__device__ __forceinline__ bool cf_contig_add_hit(const cf_place_state& S, uint32_t x, uint32_t q) {
+    const unsigned long long want = (((unsigned long long)q << 32) | x) | CF_OCC;
+    uint64_t h = cf_mix64(want) & S.cmask;
+    for (uint64_t probe = 0; probe <= S.cmask; ++probe) {
+        unsigned long long cur = S.ckeys[h];
+        if (cur == 0ull) cur = atomicCAS(&S.ckeys[h], 0ull, want);
+        if (cur == 0ull || cur == want) {
+            const uint32_t c = atomicAdd(&S.ccnt[h], 1u) + 1u;
+            if (c == S.thr) { S.freq_flag[x] = 1; return true; }
+            return false;
+        }
+        h = (h + 1) & S.cmask;
+    }
+    atomicOr(&S.ctl[2], 1u);
+    return false;
+}
+
 // mode 0: add read `fixed_read` at position 0 (prefix reads); mode 1: add the read in S.best
 __global__ void __launch_bounds__(PL_THREADS)
 cf_place_add_kernel(cf_place_state S, int mode, int64_t fixed_read) {
@@ -276,6 +294,60 @@ cf_place_pick_add_kernel(cf_place_state S, int n_cand) {
     }
 }
 
+// pick + add + score updates in ONE kernel: the wave whose add makes a (k-mer, position) pair frequent applies that event
+// to the scores itself (all 64 lanes over the k-mer's postings) instead of queueing it for a separate update kernel — one
+// kernel boundary less in the dependent chain of a greedy iteration.  The read's cloud entries are one contiguous CSR
+// range; a wave takes PL_CHUNK (ctx->place_chunk, default 2) of them at a time, so that the events of a read spread over a
+// thousand waves: what a wave does per event is a chain of dependent HBM round trips, and the iteration takes as long as the
+// wave with the most events (50 000 reads: 8 entries per wave and 128 workgroups 1.36 s, 2 and 256: 1.22 s; three kernels 1.61 s).
+__global__ void __launch_bounds__(PL_THREADS)
+cf_place_pick_add_update_kernel(cf_place_state S, int n_cand, int PL_CHUNK) {
+    if (S.ctl[0]) return;
+    cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
+    for (int i = threadIdx.x; i < n_cand; i += blockDim.x) if (cf_cand_better(S.block_best[i], mine)) mine = S.block_best[i];
+    const cf_cand b = cf_block_best(mine);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *S.best = b;
+        if (!b.valid) S.ctl[0] = 1;
+        else {
+            const unsigned int o = S.ctl[1]++;
+            S.out_read[o] = (int64_t)b.read; S.out_pos[o] = (int64_t)b.off; S.out_s0[o] = (int32_t)b.s0; S.out_s1[o] = (int32_t)b.s1;
+            S.used[b.read] = 1;
+        }
+    }
+    if (!b.valid) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t u0 = S.unit_ptr[b.read], u1 = S.unit_ptr[b.read + 1];
+    const int64_t e0 = S.cloud_ptr[u0], e1 = S.cloud_ptr[u1];
+    const int64_t n_chunks = (e1 - e0 + PL_CHUNK - 1) / PL_CHUNK;
+    for (int64_t c = wave; c < n_chunks; c += n_waves) {
+        const int64_t e = e0 + c * PL_CHUNK + lane;
+        const bool act = lane < PL_CHUNK && e < e1;
+        uint32_t x = 0, q = 0;
+        bool hit = false;
+        if (act) {
+            int64_t lo = u0, hi = u1 - 1;          // the unit of entry e: the last u with cloud_ptr[u] <= e (a ballot over the unit starts held by the lanes instead of this search changed nothing)
+            while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (S.cloud_ptr[mid] <= e) lo = mid; else hi = mid - 1; }
+            x = (uint32_t)S.entries[e];
+            q = b.off + (uint32_t)(lo - u0);
+            hit = cf_contig_add_hit(S, x, q);
+        }
+        unsigned long long m = __ballot(hit);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const uint32_t xx = (uint32_t)__shfl((int)x, l), qq = (uint32_t)__shfl((int)q, l);
+            const int64_t p0 = S.post_ptr[xx], p1 = S.post_ptr[xx + 1];
+            for (int64_t pp = p0 + lane; pp < p1; pp += 64) {
+                const unsigned long long ri = S.post_ri[pp];
+                cf_score_hit(S, (uint32_t)(ri >> 32), (uint32_t)ri, qq);
+            }
+        }
+    }
+}
+
 
 // (Round 2 tried the greedy loop of a stage as ONE persistent launch — flag scan per workgroup, grid barrier, pick + add +
 // score updates by the waves that raise the events, grid barrier: 58 us per placed read against 32 us for the three
@@ -420,10 +492,13 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         CF_KERNEL_CHECK("cf_place_seed_kernel");
         unsigned int h_ctl[4] = {0, 0, 0, 0};
         const int64_t n_iter = (int64_t)stage_reads.size();
+        const bool fused = ctx->place_fused != 0;
+        if (fused) hipLaunchKernelGGL(cf_place_update_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);      // the seed events; later ones are applied by the waves that raise them
         for (int64_t it = 0; it < n_iter; ++it) {
-            hipLaunchKernelGGL(cf_place_update_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
+            if (!fused) hipLaunchKernelGGL(cf_place_update_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
             hipLaunchKernelGGL(cf_place_argmax_kernel, dim3((unsigned)n_am), dim3(PL_THREADS), 8 * sizeof(cf_cand) + 16, st, S);
-            hipLaunchKernelGGL(cf_place_pick_add_kernel, dim3(8), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S, n_am);
+            if (fused) hipLaunchKernelGGL(cf_place_pick_add_update_kernel, dim3((unsigned)(ctx->place_grid > 0 ? ctx->place_grid : std::max(8, ctx->n_cu))), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S, n_am, ctx->place_chunk);
+            else hipLaunchKernelGGL(cf_place_pick_add_kernel, dim3(8), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S, n_am);
             if ((it & 255) == 255 || it + 1 == n_iter) {
                 CF_KERNEL_CHECK("placement iteration");
                 CF_HIP(hipMemcpyAsync(h_ctl, S.ctl, 16, hipMemcpyDeviceToHost, st));

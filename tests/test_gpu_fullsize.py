@@ -100,3 +100,13 @@ def test_placement_3k_reads_vs_c_placer(engine):
     gl = lines_from_placement(pk.ids, *[x.tolist() for x in got])
     assert sum(1 for x in gl if not x.endswith("None")) > 2500
     assert gl == wl
+    # the greedy iteration as three kernels with an event list (round 1) and with other chunk / grid shapes of the fused
+    # kernel: the same placement
+    for knobs in ({"place_fused": 0}, {"place_chunk": 7, "place_grid": 13}, {"place_chunk": 64, "place_grid": 512}):
+        try:
+            for k, v in knobs.items():
+                engine.set_param(k, v)
+            again = engine.place_reads(cls, rank, 2, 2, 10, 3)
+        finally:
+            engine.set_param("place_fused", 1); engine.set_param("place_chunk", 2); engine.set_param("place_grid", 0)
+        assert all(np.array_equal(a, b) for a, b in zip(again, got)), knobs
