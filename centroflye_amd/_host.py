@@ -5,6 +5,7 @@ Host-side only; no GPU involved.  The library is built in-tree by
 is no pure-Python fallback.
 """
 import ctypes as C
+import hashlib
 import os
 
 import numpy as np
@@ -46,6 +47,8 @@ def lib():
     L.cfh_synth_defaults.restype = None
     L.cfh_synth.argtypes = [C.POINTER(SynthParams), C.c_char_p, C.c_int, C.POINTER(P), C.c_char_p, C.c_int]
     L.cfh_parse_report.argtypes = [C.c_char_p, i64, C.c_int, C.c_int, C.POINTER(P), C.c_char_p, C.c_int]
+    L.cfh_pack_save.argtypes = [P, C.c_char_p, C.POINTER(C.c_int64), C.c_char_p, C.c_int]
+    L.cfh_pack_load.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(P), C.c_char_p, C.c_int]
     L.cfh_pack_free.argtypes = [P]
     L.cfh_pack_free.restype = None
     for name in ("cfh_n_reads", "cfh_n_bases", "cfh_n_seen"):
@@ -181,13 +184,38 @@ class PackedReads:
         return C.string_at(p, n.value).decode()
 
 
-def parse_report(path, min_record_len=5000, keep_rows=True, n_threads=0):
+def parse_report(path, min_record_len=5000, keep_rows=True, n_threads=0, cache_dir=None):
+    """Parse an NCRF report into packed arrays.  cache_dir (default: $CF_PACK_CACHE, unset = no cache): directory of binary
+    packs keyed by the report's path, size, mtime and the two options — the second stage script that reads the same report
+    loads the arrays instead of parsing the text again."""
     L = lib()
     err = C.create_string_buffer(512)
     h = C.c_void_p()
+    cache_dir = os.environ.get("CF_PACK_CACHE") if cache_dir is None else cache_dir
+    cache_fn = src = None
+    if cache_dir:
+        try:
+            st = os.stat(path)
+            src = (C.c_int64 * 4)(st.st_size, st.st_mtime_ns, int(min_record_len), int(bool(keep_rows)))
+            key = hashlib.sha1(f"{os.path.abspath(path)}|{st.st_size}|{st.st_mtime_ns}|{int(min_record_len)}|{int(bool(keep_rows))}".encode()).hexdigest()
+            cache_fn = os.path.join(cache_dir, key + ".cfpack")
+            if os.path.exists(cache_fn) and L.cfh_pack_load(os.fsencode(cache_fn), src, C.byref(h), err, 512) == 0:
+                pk = PackedReads(h)
+                pk.from_cache = True
+                return pk
+        except OSError:
+            cache_fn = None
     _check(L.cfh_parse_report(os.fsencode(path), min_record_len, int(keep_rows), n_threads,
                               C.byref(h), err, 512), err)
-    return PackedReads(h)
+    pk = PackedReads(h)
+    pk.from_cache = False
+    if cache_fn:
+        try:
+            os.makedirs(cache_dir, exist_ok=True)
+            L.cfh_pack_save(h, os.fsencode(cache_fn), src, err, 512)      # best effort: a cache that cannot be written is no error
+        except OSError:
+            pass
+    return pk
 
 
 def synth_params(**kw):

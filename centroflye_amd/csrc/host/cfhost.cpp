@@ -728,6 +728,56 @@ static inline char* put_u32(char* p, uint32_t v) {      // decimal, no padding
     return p;
 }
 
+namespace {
+const char kPackMagic[8] = {'C', 'F', 'P', 'A', 'C', 'K', '0', '2'};
+struct PackWriter {
+    FILE* f; bool ok = true;
+    void raw(const void* p, size_t n) { if (ok && n && std::fwrite(p, 1, n, f) != n) ok = false; }
+    void u64(uint64_t v) { raw(&v, 8); }
+    template <class T> void vec(const std::vector<T>& v) { u64(v.size()); raw(v.data(), v.size() * sizeof(T)); }
+    void str(const std::string& v) { u64(v.size()); raw(v.data(), v.size()); }
+    void strs(const std::vector<std::string>& v) { u64(v.size()); for (auto& x : v) str(x); }
+};
+struct PackReader {
+    const unsigned char* p; const unsigned char* e; bool ok = true;
+    bool raw(void* d, size_t n) { if (!ok || (size_t)(e - p) < n) { ok = false; return false; } std::memcpy(d, p, n); p += n; return true; }
+    uint64_t u64() { uint64_t v = 0; raw(&v, 8); return v; }
+    template <class T> void vec(std::vector<T>& v) { const uint64_t n = u64(); if (!ok || n > (uint64_t)(e - p) / sizeof(T)) { ok = false; return; } v.resize((size_t)n); raw(v.data(), (size_t)n * sizeof(T)); }
+    void str(std::string& v) { const uint64_t n = u64(); if (!ok || n > (uint64_t)(e - p)) { ok = false; return; } v.assign((const char*)p, (size_t)n); p += n; }
+    void strs(std::vector<std::string>& v) { const uint64_t n = u64(); if (!ok || n > (uint64_t)(e - p)) { ok = false; return; } v.resize((size_t)n); for (auto& x : v) str(x); }
+};
+struct SeenFlat { int64_t read_len, f_st, f_en, l_st, l_en, n_aln, rec; int64_t f_strand, l_strand; };
+// checksum of a byte range by all threads: 1 MiB blocks, a multiplicative hash over the 8-byte words of each, block hashes
+// combined with their index (a flipped bit anywhere in a gigabyte of bases must not pass for a valid cache)
+uint64_t pack_checksum(const unsigned char* p, size_t n) {
+    const size_t B = (size_t)1 << 20, nb = (n + B - 1) / B;
+    const int T = (int)std::max<size_t>(1, std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), nb));
+    std::vector<uint64_t> part((size_t)T, 0);
+    std::atomic<size_t> next{0};
+    auto work = [&](int t) {
+        uint64_t acc = 0;
+        while (true) {
+            const size_t b = next.fetch_add(1);
+            if (b >= nb) break;
+            const size_t lo = b * B, hi = std::min(n, lo + B);
+            uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)b;
+            size_t i = lo;
+            for (; i + 8 <= hi; i += 8) { uint64_t w; std::memcpy(&w, p + i, 8); h = (h ^ w) * 0x100000001B3ull; h ^= h >> 29; }
+            for (; i < hi; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
+            acc += h * (2 * (uint64_t)b + 1);
+        }
+        part[(size_t)t] = acc;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    uint64_t sum = 0;
+    for (uint64_t v : part) sum += v;
+    return sum;
+}
+}  // namespace
+
 extern "C" {
 
 void cfh_synth_defaults(cfh_synth_params* p) {
@@ -952,6 +1002,133 @@ int cfh_parse_report(const char* path, int64_t min_record_len, int keep_rows, in
 }
 
 void cfh_pack_free(cfh_pack* p) { delete p; }
+
+// ---------------------------------------------------------------- binary cache of a pack
+// Both stage scripts parse the same report; the second one can load what the first one packed.  One file: a header with
+// the identity of the source report as the caller states it (size, mtime, min_record_len, keep_rows), then every array of
+// the pack as (count, bytes).  A file that does not match, is truncated or was written by another version is refused
+// (-61): the caller parses the report instead.
+
+int cfh_pack_save(const cfh_pack* p, const char* path, const int64_t* source_id, char* err, int errlen) {
+    try {
+        const std::string tmp = std::string(path) + ".tmp" + std::to_string((long long)getpid());
+        FILE* f = std::fopen(tmp.c_str(), "wb");
+        if (!f) { set_err(err, errlen, std::string("cannot open ") + tmp); return -2; }
+        PackWriter w{f};
+        w.raw(kPackMagic, 8);
+        for (int i = 0; i < 4; ++i) w.u64((uint64_t)source_id[i]);
+        w.u64(p->keep_rows ? 1 : 0); w.u64(p->non_acgt ? 1 : 0);
+        w.vec(p->meta); w.str(p->ids); w.vec(p->id_off); w.vec(p->read_off);
+        w.u64(p->bases.size()); w.raw(p->bases.data(), p->bases.size());
+        w.strs(p->motifs);
+        w.vec(p->u1_ptr); w.vec(p->u1_start); w.vec(p->u1_end); w.vec(p->u1_col);
+        std::vector<SeenFlat> sf(p->seen.size());
+        for (size_t i = 0; i < sf.size(); ++i) {
+            const SeenRead& s = p->seen[i];
+            sf[i] = SeenFlat{s.read_len, s.first.st, s.first.en, s.last.st, s.last.en, s.n_aln, s.rec, (int64_t)s.first.strand, (int64_t)s.last.strand};
+        }
+        w.vec(sf); w.vec(p->rec_seen); w.str(p->discarded);
+        if (p->keep_rows) { w.strs(p->rows_r); w.strs(p->rows_m); }
+        bool ok = w.ok;
+        if (std::fclose(f) != 0 || !ok) { std::remove(tmp.c_str()); set_err(err, errlen, std::string("write failed: ") + tmp); return -5; }
+        {       // checksum of what was written (from the page cache, by all threads), then the end marker: a truncated file is not a cache
+            const int fd = ::open(tmp.c_str(), O_RDWR);
+            struct stat st;
+            ok = fd >= 0 && fstat(fd, &st) == 0;
+            if (ok) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                ok = m != MAP_FAILED;
+                if (ok) {
+                    const uint64_t sum = pack_checksum((const unsigned char*)m, (size_t)st.st_size);
+                    munmap(m, (size_t)st.st_size);
+                    unsigned char tail[16];
+                    std::memcpy(tail, &sum, 8); std::memcpy(tail + 8, kPackMagic, 8);
+                    ok = ::lseek(fd, 0, SEEK_END) >= 0 && ::write(fd, tail, 16) == 16;
+                }
+            }
+            if (fd >= 0 && ::close(fd) != 0) ok = false;
+            if (!ok) { std::remove(tmp.c_str()); set_err(err, errlen, std::string("write failed: ") + tmp); return -5; }
+        }
+        if (std::rename(tmp.c_str(), path) != 0) { std::remove(tmp.c_str()); set_err(err, errlen, std::string("cannot rename to ") + path); return -5; }
+        return 0;
+    } catch (const std::exception& e) { set_err(err, errlen, std::string("cfh_pack_save: ") + e.what()); return -12; }
+}
+
+int cfh_pack_load(const char* path, const int64_t* source_id, cfh_pack** out, char* err, int errlen) {
+    int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { set_err(err, errlen, std::string("cannot open ") + path); return -2; }
+    struct stat st;
+    void* m = MAP_FAILED;
+    size_t size = 0;
+    if (fstat(fd, &st) == 0 && st.st_size >= 32) { size = (size_t)st.st_size; m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0); }
+    ::close(fd);
+    if (m == MAP_FAILED) { set_err(err, errlen, std::string("not a pack cache: ") + path); return -61; }
+    int rc = -61;
+    try {
+        PackReader r{(const unsigned char*)m, (const unsigned char*)m + size};
+        char magic[8];
+        std::unique_ptr<cfh_pack> P(new cfh_pack());
+        bool good = r.raw(magic, 8) && std::memcmp(magic, kPackMagic, 8) == 0 && std::memcmp((const char*)m + size - 8, kPackMagic, 8) == 0;
+        for (int i = 0; good && i < 4; ++i) good = (int64_t)r.u64() == source_id[i];
+        if (good) { uint64_t want; std::memcpy(&want, (const char*)m + size - 16, 8); good = pack_checksum((const unsigned char*)m, size - 16) == want; }
+        if (good) {
+            P->keep_rows = r.u64() != 0; P->non_acgt = r.u64() != 0;
+            r.vec(P->meta); r.str(P->ids); r.vec(P->id_off); r.vec(P->read_off);
+            const uint64_t nb = r.u64();
+            if (r.ok && nb <= (uint64_t)(r.e - r.p)) {
+                P->bases.resize((size_t)nb);
+                // the gigabyte of bases: copied by all threads (each the first to touch its part of the new pages)
+                const int T = (int)std::max<size_t>(1, std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), (size_t)nb / (8 << 20) + 1));
+                std::vector<std::thread> th;
+                const unsigned char* src = r.p;
+                for (int t = 0; t < T; ++t) {
+                    const size_t lo = (size_t)nb * (size_t)t / (size_t)T, hi = (size_t)nb * (size_t)(t + 1) / (size_t)T;
+                    th.emplace_back([=, &P]() { if (hi > lo) std::memcpy(P->bases.data() + lo, src + lo, hi - lo); });
+                }
+                for (auto& x : th) x.join();
+                r.p += nb;
+            } else r.ok = false;
+            r.strs(P->motifs);
+            r.vec(P->u1_ptr); r.vec(P->u1_start); r.vec(P->u1_end); r.vec(P->u1_col);
+            std::vector<SeenFlat> sf;
+            r.vec(sf); r.vec(P->rec_seen); r.str(P->discarded);
+            if (P->keep_rows) { r.strs(P->rows_r); r.strs(P->rows_m); }
+            const int64_t R = (int64_t)P->read_off.size() - 1;
+            good = r.ok && (size_t)(r.e - r.p) == 16 && R >= 0 && (int64_t)P->meta.size() == R * 8 && (int64_t)P->id_off.size() == R + 1 &&
+                   (int64_t)P->u1_ptr.size() == R + 1 && (int64_t)P->rec_seen.size() == R && (!P->keep_rows || ((int64_t)P->rows_r.size() == R && (int64_t)P->rows_m.size() == R)) &&
+                   (R == 0 || ((uint64_t)P->read_off[(size_t)R] == nb && (uint64_t)P->id_off[(size_t)R] == P->ids.size())) &&
+                   P->u1_start.size() == P->u1_end.size() && P->u1_col.size() == 2 * P->u1_start.size() && (P->u1_ptr.empty() || (uint64_t)P->u1_ptr.back() == P->u1_start.size());
+            if (good) {
+                P->seen.resize(sf.size());
+                for (size_t i = 0; i < sf.size(); ++i) {
+                    SeenRead& s = P->seen[i];
+                    s.read_len = sf[i].read_len; s.first = AlnKey{sf[i].f_st, sf[i].f_en, (char)sf[i].f_strand}; s.last = AlnKey{sf[i].l_st, sf[i].l_en, (char)sf[i].l_strand};
+                    s.n_aln = sf[i].n_aln; s.rec = sf[i].rec;
+                }
+                for (int64_t i = 0; good && i < R; ++i) good = P->rec_seen[(size_t)i] >= 0 && P->rec_seen[(size_t)i] < (int64_t)P->seen.size() && P->meta[(size_t)i * 8 + 7] >= 0 && P->meta[(size_t)i * 8 + 7] < (int64_t)P->motifs.size();
+                // offsets ascend and stay inside their arrays (a damaged file must not turn into reads out of bounds later)
+                auto ascending = [](const std::vector<int64_t>& v, int64_t last) {
+                    if (v.empty() || v[0] != 0 || v.back() != last) return false;
+                    for (size_t i = 1; i < v.size(); ++i) if (v[i] < v[i - 1]) return false;
+                    return true;
+                };
+                good = good && ascending(P->read_off, (int64_t)nb) && ascending(P->id_off, (int64_t)P->ids.size()) && ascending(P->u1_ptr, (int64_t)P->u1_start.size());
+                for (int64_t i = 0; good && i < R; ++i) {
+                    const int64_t b0 = P->read_off[(size_t)i], b1 = P->read_off[(size_t)i + 1], ncols = P->meta[(size_t)i * 8 + 6];
+                    for (int64_t u = P->u1_ptr[(size_t)i]; good && u < P->u1_ptr[(size_t)i + 1]; ++u)
+                        good = P->u1_start[(size_t)u] >= b0 && P->u1_end[(size_t)u] >= P->u1_start[(size_t)u] && P->u1_end[(size_t)u] <= b1 &&
+                               P->u1_col[(size_t)u * 2] >= 0 && P->u1_col[(size_t)u * 2 + 1] >= P->u1_col[(size_t)u * 2] && P->u1_col[(size_t)u * 2 + 1] <= ncols;
+                    if (good && P->keep_rows) good = (int64_t)P->rows_r[(size_t)i].size() == ncols && (int64_t)P->rows_m[(size_t)i].size() == ncols;
+                }
+                for (size_t i = 0; i < P->motifs.size(); ++i) P->motif_ids.emplace(P->motifs[i], (int32_t)i);
+            }
+        }
+        if (good) { *out = P.release(); rc = 0; }
+        else set_err(err, errlen, std::string("pack cache does not match its report or is damaged: ") + path);
+    } catch (const std::exception& e) { set_err(err, errlen, std::string("cfh_pack_load: ") + e.what()); rc = -12; }
+    munmap(m, size);
+    return rc;
+}
 
 int64_t cfh_n_reads(const cfh_pack* p) { return p->n_reads(); }
 int64_t cfh_n_bases(const cfh_pack* p) { return (int64_t)p->bases.size(); }

@@ -65,6 +65,12 @@ int cfh_parse_report(const char* path, int64_t min_record_len, int keep_rows, in
 
 void cfh_pack_free(cfh_pack* p);
 
+/* Binary cache of a pack (both stage scripts read the same report).  source_id[4] identifies what
+ * the pack was made from, as the caller sees it — by convention {size of the report, its mtime in ns, min_record_len,
+ * keep_rows}; cfh_pack_load refuses (-61) a file whose four numbers differ, that is truncated or damaged. */
+int cfh_pack_save(const cfh_pack* p, const char* path, const int64_t* source_id, char* err, int errlen);
+int cfh_pack_load(const char* path, const int64_t* source_id, cfh_pack** out, char* err, int errlen);
+
 /* Shape. */
 int64_t cfh_n_reads(const cfh_pack* p);      /* kept records, in first-insertion order */
 int64_t cfh_n_bases(const cfh_pack* p);      /* N_b = sum of de-gapped aligned lengths */

@@ -177,3 +177,45 @@ def test_text_writers_keep_record_order_across_tasks(tmp_path):
     assert got[-1] == "" and len(got) == kk.size + 1
     assert got[0] == word(kk[0]) and got[131072] == word(kk[131072]) and got[-2] == word(kk[-1])
     assert np.array_equal(_host.read_kmers(p, k), kk)
+
+
+def test_pack_cache_round_trip_and_refusals(tmp_path, monkeypatch):
+    """SURVEY §8(f) rank 1: the binary cache of a pack.  A loaded pack equals the parsed one in every array the stages use;
+    a cache whose report changed, that is truncated or has a damaged offset is refused and the report is parsed again."""
+    kw = dict(fixtures.FIXTURES["tiny"]["synth"])
+    path = str(tmp_path / "r.ncrf")
+    _host.synth(report_path=path, pack=False, **kw)
+    cache = str(tmp_path / "cache")
+    for keep_rows in (True, False):
+        a = _host.parse_report(path, keep_rows=keep_rows, cache_dir=cache)
+        b = _host.parse_report(path, keep_rows=keep_rows, cache_dir=cache)
+        assert not a.from_cache and b.from_cache
+        assert a.ids == b.ids and np.array_equal(a.bases, b.bases) and np.array_equal(a.meta, b.meta) and np.array_equal(a.read_off, b.read_off)
+        assert a.motifs == b.motifs and sorted(a.discarded_reads) == sorted(b.discarded_reads) and a.non_acgt == b.non_acgt
+        for n in ((1, 2) if keep_rows else (1,)):
+            for x, y in zip(a.units(n), b.units(n)):
+                assert np.array_equal(x, y)
+        assert np.array_equal(a.classify(50000), b.classify(50000))
+        if keep_rows:
+            assert all(a.row(i, w) == b.row(i, w) for i in range(a.n_reads) for w in (0, 1))
+    files = sorted(os.listdir(cache))
+    assert len(files) == 2
+    # another min_record_len is another cache entry; a touched report invalidates its entries
+    c = _host.parse_report(path, min_record_len=6500, cache_dir=cache)
+    assert not c.from_cache and len(os.listdir(cache)) == 3
+    st = os.stat(path)
+    os.utime(path, ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000))
+    assert not _host.parse_report(path, cache_dir=cache).from_cache
+    # damaged files under the right name are refused (the header still matches): truncation, a flipped offset
+    st = os.stat(path)
+    good = [f for f in os.listdir(cache)]
+    d = _host.parse_report(path, keep_rows=False, cache_dir=cache)
+    new = [f for f in os.listdir(cache) if f not in good]
+    assert len(new) == 1 and not d.from_cache
+    fn = os.path.join(cache, new[0])
+    blob = open(fn, "rb").read()
+    for bad in (blob[: len(blob) // 2], blob[:-8] + b"XXXXXXXX", blob[:200] + bytes([blob[200] ^ 0x40]) + blob[201:]):
+        open(fn, "wb").write(bad)
+        e = _host.parse_report(path, keep_rows=False, cache_dir=cache)      # falls back to parsing, rewrites the cache
+        assert not e.from_cache and np.array_equal(e.bases, d.bases)
+        assert open(fn, "rb").read() == blob

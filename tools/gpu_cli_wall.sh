@@ -22,6 +22,12 @@ for rep in 1 2; do
   echo "rc=$?"; cp $W/out50k/stage2_metrics.json $OUT/metrics_noedges_$rep.json
   python -c "import time,sys; print(\"wall\", round(time.time() - float(sys.argv[1]), 2), \"s\")" $T0 | tee $OUT/time_noedges_$rep.txt
 done
+# the binary pack cache (CF_PACK_CACHE): the first run writes it, the second loads it instead of parsing
+for rep in 1 2; do
+  CF_PACK_CACHE=$W/cache python -m centroflye_amd.distance_based_kmer_recruitment --ncrf $W/r50000.ncrf --coverage 32 --outdir $W/out50k --no-edges --metrics > $OUT/cli_cache_$rep.log 2>&1
+  cp $W/out50k/stage2_metrics.json $OUT/metrics_cache_$rep.json
+done
+ls -l $W/cache
 T0=$(date +%s.%N); CFH_TIMING=1 python -m centroflye_amd.distance_based_kmer_recruitment --ncrf $W/r5000.ncrf --coverage 32 \
       --outdir $W/out5k --metrics > $OUT/cli_edges.log 2>&1
 echo "rc=$?"; cp $W/out5k/stage2_metrics.json $OUT/metrics_edges.json
@@ -30,7 +36,7 @@ ls -l $W/out5k $W/out50k > $OUT/ls.txt; cat $OUT/ls.txt
 grep cfhost $OUT/cli_noedges_2.log
 python - <<PY
 import json
-for f in ("metrics_noedges_1", "metrics_noedges_2", "metrics_edges"):
+for f in ("metrics_noedges_1", "metrics_noedges_2", "metrics_cache_1", "metrics_cache_2", "metrics_edges"):
     m = json.load(open(f"$OUT/{f}.json"))
     print(f, {k: m[k] for k in ("parse_s", "dist_wall_s", "total_s")}, m["times_ms"])
 PY
