@@ -24,10 +24,18 @@ void cf_free_table(cf_ctx* c);
 #define C2_ITEMS 16                         /* windows (pass 1) / records (later passes) per thread and tile */
 #define C2_TILE (C2_THREADS * C2_ITEMS)
 #define C2_MAXBITS 9                        /* radix bits per pass */
+#ifndef C2_RTHREADS
 #define C2_RTHREADS 512                     /* threads of a reduce workgroup */
+#endif
+#ifndef C2_RTILE
 #define C2_RTILE 2048                       /* records per reduce tile */
+#endif
+#ifndef C2_SET
 #define C2_SET 4096                         /* (k-mer, read) set slots: twice the tile */
+#endif
+#ifndef C2_TAB
 #define C2_TAB 2048                         /* k-mers per bucket table */
+#endif
 #define C2_DUP (1ull << 63)
 
 struct cf_c2_tile { int32_t read; int32_t chunk; };      // pass-1 tile: windows [chunk * C2_TILE, ...) of a read
