@@ -45,6 +45,25 @@ for i in range(300):
     except _host.HostError:
         bad += 1
 print("FUZZ", ok, bad)
+# the binary pack cache: damaged cache files are refused (checksum, end marker, shapes) and the report is parsed again
+cache = os.path.join(d, "cache")
+a = _host.parse_report(src, keep_rows=True, cache_dir=cache)
+fn = os.path.join(cache, os.listdir(cache)[0])
+blob = open(fn, "rb").read()
+hits = 0
+for i in range(60):
+    b = bytearray(blob)
+    what = rng.randrange(3)
+    if what == 0: b = b[: rng.randrange(0, len(b))]
+    elif what == 1: b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+    else:
+        pos = rng.randrange(len(b)); b[pos:pos + 8] = bytes(rng.randrange(256) for _ in range(8))
+    open(fn, "wb").write(bytes(b))
+    pk = _host.parse_report(src, keep_rows=True, cache_dir=cache)
+    hits += pk.from_cache
+    assert pk.ids == a.ids and bytes(pk.bases) == bytes(a.bases)
+    pk.units(2); pk.classify(50000)
+print("CACHE", hits)
 '''
 
 
@@ -70,3 +89,4 @@ def test_corrupted_reports_never_trip_the_sanitizers(asan_env, tmp_path):
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("FUZZ ")][0].split()
     assert int(line[1]) + int(line[2]) == 300 and int(line[2]) > 20 and int(line[1]) > 20
+    assert [ln for ln in p.stdout.splitlines() if ln.startswith("CACHE ")] == ["CACHE 0"]      # no damaged cache was taken for a good one
