@@ -6,7 +6,9 @@ int cf_fail(cf_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
-static const size_t CF_POOL_MAX = (size_t)128 << 30;  // bytes kept for reuse per context (the edge list of a full-size step alone is 51 GB)
+// Work buffers are pooled per context, up to ctx->pool_max bytes (85 % of the device's memory: at 8 Gb of reads the two
+// record arrays of A1 alone are 128 GB, and giving them back to the driver after every step cost 1.5 s per step).  A
+// hipMalloc that fails flushes the pool and tries again, so a large pool never causes an out-of-memory error by itself.
 
 static void cf_pool_flush(cf_ctx* ctx) {
     for (auto& kv : ctx->pool) { ctx->block_bytes.erase(kv.second); (void)hipFree(kv.second); }
@@ -47,7 +49,7 @@ void cf_release(cf_ctx* ctx, void* p, size_t bytes) {
     if (bytes == 0) bytes = 16;
     ctx->live -= bytes < ctx->live ? bytes : ctx->live;
     auto it = ctx->block_bytes.find(p);
-    if (it == ctx->block_bytes.end() || ctx->pooled + it->second > CF_POOL_MAX) {
+    if (it == ctx->block_bytes.end() || ctx->pooled + it->second > ctx->pool_max) {
         if (it != ctx->block_bytes.end()) ctx->block_bytes.erase(it);
         (void)hipFree(p);
         return;
@@ -106,6 +108,7 @@ int cf_create(int device, cf_ctx** out) {
     hipDeviceProp_t prop;
     CF_HIP(hipGetDeviceProperties(&prop, device));
     ctx->n_cu = prop.multiProcessorCount;
+    ctx->pool_max = std::max<size_t>((size_t)1 << 30, (size_t)((double)prop.totalGlobalMem * 0.85));
     ctx->hbm_total = (int64_t)prop.totalGlobalMem;
     CF_HIP(hipStreamCreate(&ctx->stream));
     CF_HIP(hipEventCreate(&ctx->ev0));

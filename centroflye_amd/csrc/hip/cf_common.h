@@ -66,6 +66,7 @@ struct cf_ctx {
     std::multimap<size_t, void*> pool;
     std::unordered_map<void*, size_t> block_bytes;
     size_t pooled = 0;
+    size_t pool_max = (size_t)128 << 30;      // bytes kept for reuse (cf_create: 85 % of the device's memory)
 
     // reads / units
     uint8_t* d_bases = nullptr;
