@@ -86,13 +86,14 @@ cf_unit_rend_kernel(const int64_t* __restrict__ unit_ptr, const int64_t* __restr
 // layout) or, mod 2^(32 - b_bits), packed above the rank (narrow layouts: one 4-byte load per pair emission)
 __global__ void __launch_bounds__(256)
 cf_entry_unit_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ rbeg, const int32_t* __restrict__ entries, int64_t n_units,
-                     uint16_t* __restrict__ entry_i, uint32_t* __restrict__ packed, int b_bits) {
+                     uint16_t* __restrict__ entry_i, uint32_t* __restrict__ packed, int b_bits, uint8_t* __restrict__ entry_i8) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t u = wave; u < n_units; u += n_waves) {
         const uint32_t i = (uint32_t)(u - rbeg[u]);
         if (packed) { for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) packed[e] = (i << b_bits) | (uint32_t)entries[e]; }      // (the shift drops all but the low 32 - b_bits bits of i)
+        else if (entry_i8) { for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) entry_i8[e] = (uint8_t)i; }
         else { for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) entry_i[e] = (uint16_t)i; }
     }
 }
@@ -132,6 +133,8 @@ struct cf_dist_args {
     const int32_t* unit_rbeg;      // first unit of the unit's read
     const cf_dist_rec* urange;     // per unit: the partner range of a posting at this unit
     const uint16_t* entry_i;       // wide layout: per cloud entry the index of its unit inside its read
+    const uint8_t* entry_i8;       // region layout: the same index mod 256
+    uint32_t reg_shift;            // region layout: log2 of the number of table regions
     const uint32_t* packed;        // narrow layout: per cloud entry [unit index inside its read mod 256 : 8 | rank : 24]
     int64_t n_kmers;
     int32_t part, n_parts;
@@ -180,6 +183,9 @@ struct cf_tab_wide_t {
     typedef unsigned long long qitem;   // deferred insert: [b:32 | d:8 | bucket to look at next:24]
     static __device__ __forceinline__ qitem q_make(uint32_t b, uint32_t dd, uint32_t bk) { return ((unsigned long long)b << 32) | ((unsigned long long)dd << kDShift) | bk; }
     static __device__ __forceinline__ void q_take(qitem q, uint32_t n_buckets, uint32_t& b, uint32_t& dd, uint32_t& bk) { b = (uint32_t)(q >> 32); dd = ((uint32_t)q >> kDShift) & kDMask; bk = (uint32_t)q & ((1u << kDShift) - 1u); }
+    __device__ __forceinline__ qitem q_of(uint32_t b, uint32_t dd, uint32_t n_buckets) const { return q_make(b, dd, home(hash(b), n_buckets)); }
+    static __device__ __forceinline__ uint32_t next(uint32_t bk, uint32_t, uint32_t n_buckets) { return bk + 1 == n_buckets ? 0u : bk + 1; }
+    __device__ __forceinline__ void configure(const cf_dist_args&, uint32_t) {}
     unsigned long long* tab;
     __device__ __forceinline__ void init(unsigned char* lds, uint32_t) { tab = (unsigned long long*)lds; }
     __device__ __forceinline__ void clear(uint32_t slots, uint32_t t, uint32_t nt) const {
@@ -307,6 +313,9 @@ struct cf_tab_narrow_t {
     typedef uint32_t qitem;             // deferred insert: the key; probing restarts at the home bucket
     static __device__ __forceinline__ qitem q_make(uint32_t b, uint32_t dd, uint32_t) { return key_of(b, dd); }
     static __device__ __forceinline__ void q_take(qitem q, uint32_t n_buckets, uint32_t& b, uint32_t& dd, uint32_t& bk) { b = q & kBMask; dd = q >> kBBits; bk = home(hash(b), n_buckets); }
+    __device__ __forceinline__ qitem q_of(uint32_t b, uint32_t dd, uint32_t) const { return key_of(b, dd); }
+    static __device__ __forceinline__ uint32_t next(uint32_t bk, uint32_t, uint32_t n_buckets) { return bk + 1 == n_buckets ? 0u : bk + 1; }
+    __device__ __forceinline__ void configure(const cf_dist_args&, uint32_t) {}
     uint32_t* keys;     // slots x 32-bit [d : DB | b : 32 - DB]
     uint32_t* cnt32;    // slots x 16-bit [sel:1 | count - 1 : 15], two per word
     __device__ __forceinline__ void init(unsigned char* lds, uint32_t slots) { keys = (uint32_t*)lds; cnt32 = keys + slots; }
@@ -451,6 +460,174 @@ struct cf_tab_narrow_t {
 };
 typedef cf_tab_narrow_t<8> cf_tab_narrow;
 
+// The 6-byte slots for k-mer sets of up to 2^27 - 16 k-mers whatever the reads' lengths (distances up to 255): the 32-bit key
+// [d : 8 | b >> S : 24] leaves out the low S <= 3 bits of the rank, and the table is cut into 2^S REGIONS of equal size —
+// a key lives in the region of its rank's low bits (home bucket, probe chain and the chain walk for the totals all stay
+// inside the region), so (region, key) identifies (b, d).  Ranks are dense, so the regions fill evenly.  The cloud entries
+// are read as they are (the CSR's 32-bit ranks) plus one byte per entry for the unit index mod 256; a queued insert is
+// 64 bits (b, d).  Everything else — 4 keys per bucket, 16-bit count fields, the filter — is the 6-byte layout's.
+struct cf_tab_region {
+    static constexpr int PB = 4;
+    static constexpr uint32_t kBBits = 24, kBMask = (1u << kBBits) - 1u;
+    static constexpr uint32_t kSlotBytes = 6, kPerBucket = PB, kAll = (1u << PB) - 1u;
+    static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+    struct bucket { uint32_t k[PB]; };
+    struct counts { uint32_t w[PB / 2]; };
+    struct raw { uint32_t b, i; };
+    typedef unsigned long long qitem;   // deferred insert: [b : 32 | d : 32]
+    uint32_t* keys;
+    uint32_t* cnt32;
+    uint32_t S, nb_r;                   // log2(regions), buckets per region
+    __device__ __forceinline__ void init(unsigned char* lds, uint32_t slots) { keys = (uint32_t*)lds; cnt32 = keys + slots; S = 0; nb_r = slots / PB; }
+    __device__ __forceinline__ void configure(const cf_dist_args& A, uint32_t n_buckets) { S = A.reg_shift; nb_r = n_buckets >> A.reg_shift; }
+    __device__ __forceinline__ void clear(uint32_t slots, uint32_t t, uint32_t nt) const {
+        const cf_u32x4 e{kEmpty, kEmpty, kEmpty, kEmpty}, z{0u, 0u, 0u, 0u};
+        for (uint32_t s = t; s < (slots >> 2); s += nt) ((cf_u32x4*)keys)[s] = e;
+        for (uint32_t s = t; s < (slots >> 3); s += nt) ((cf_u32x4*)cnt32)[s] = z;
+    }
+    struct __attribute__((packed, aligned(4))) run4 { uint32_t x, y, z, w; };
+    static __device__ __forceinline__ void load_run(const cf_dist_args& A, int64_t e, uint32_t ok, raw (&out)[DIST_UNROLL]) {
+        static_assert(DIST_UNROLL == 4, "one 16-byte and one 4-byte load per lane");
+        if (ok == (1u << DIST_UNROLL) - 1u) {      // the whole run lies inside the posting's range
+            const run4 r = *(const run4*)(A.entries + e);
+            // the 4 index bytes start at any byte address: two ALIGNED dwords around them and a funnel shift (a dword load
+            // from a misaligned address takes the slow path of the memory pipeline: the sketch sweep ran 39 % longer with it)
+            struct __attribute__((packed, aligned(4))) pair2 { uint32_t lo, hi; };
+            const pair2 w = *(const pair2*)(A.entry_i8 + (e & ~(int64_t)3));
+            const uint32_t sh = ((uint32_t)e & 3u) * 8u;
+            const uint32_t iw = (uint32_t)((((unsigned long long)w.hi << 32) | w.lo) >> sh);
+            out[0] = raw{r.x, iw & 0xFFu}; out[1] = raw{r.y, (iw >> 8) & 0xFFu}; out[2] = raw{r.z, (iw >> 16) & 0xFFu}; out[3] = raw{r.w, iw >> 24};
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < DIST_UNROLL; ++u) { const int64_t x = ((ok >> u) & 1u) ? e + u : 0; out[u] = raw{(uint32_t)A.entries[x], (uint32_t)A.entry_i8[x]}; }
+    }
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { b = r.b; dd = (r.i - ig) & 0xFFu; }      // unit indices mod 256, d <= 255
+    static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }      // sketch and bitmap: any function of b will do (ranks that differ above bit 23 share counters and bits)
+    static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
+    __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) const { return (dd << kBBits) | (b >> S); }
+    __device__ __forceinline__ uint32_t region_base(uint32_t b) const { return (b & ((1u << S) - 1u)) * nb_r; }
+    __device__ __forceinline__ uint32_t home_of(uint32_t b) const { return region_base(b) + (((((b >> S) * 0x9E3779u) >> 16) * (nb_r & 0xFFFFu)) >> 16); }
+    __device__ __forceinline__ uint32_t next(uint32_t bk, uint32_t b, uint32_t) const { const uint32_t r0 = region_base(b); return bk + 1 == r0 + nb_r ? r0 : bk + 1; }
+    __device__ __forceinline__ uint32_t region_of(uint32_t bk) const {      // bk / nb_r for at most 8 regions
+        uint32_t r = 0;
+        for (uint32_t x = nb_r; x <= bk; x += nb_r) ++r;
+        return r;
+    }
+    __device__ __forceinline__ uint32_t b_of(uint32_t key, uint32_t bk) const { return ((key & kBMask) << S) | region_of(bk); }
+    __device__ __forceinline__ qitem q_of(uint32_t b, uint32_t dd, uint32_t) const { return ((unsigned long long)b << 32) | dd; }
+    __device__ __forceinline__ void q_take(qitem q, uint32_t, uint32_t& b, uint32_t& dd, uint32_t& bk) const { b = (uint32_t)(q >> 32); dd = (uint32_t)q; bk = home_of(b); }
+    __device__ __forceinline__ bucket read(uint32_t bk) const {
+        bucket r;
+        const cf_u32x4 v = *(const cf_u32x4*)&keys[PB * bk];
+        r.k[0] = v.x; r.k[1] = v.y; r.k[2] = v.z; r.k[3] = v.w;
+        return r;
+    }
+    __device__ __forceinline__ counts read_counts(uint32_t bk) const {
+        counts c;
+        const unsigned long long v = *(const unsigned long long*)&cnt32[2 * bk];
+        c.w[0] = (uint32_t)v; c.w[1] = (uint32_t)(v >> 32);
+        return c;
+    }
+    static __device__ __forceinline__ uint32_t field(const counts& c, int j) { return (c.w[j >> 1] >> ((j & 1) * 16)) & 0x7FFFu; }
+    static __device__ __forceinline__ uint32_t ne_bit(uint32_t k, uint32_t q) { return min(k ^ q, 1u); }
+    static __device__ __forceinline__ int first_equal(const bucket& k, uint32_t q) {
+        uint32_t ne = 0;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) ne |= ne_bit(k.k[j], q) << j;
+        return __ffs((int)(ne ^ kAll)) - 1;
+    }
+    __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) const { return first_equal(k, key_of(b, dd)); }
+    static __device__ __forceinline__ int empty(const bucket& k) { return first_equal(k, kEmpty); }
+    __device__ __forceinline__ void add(uint32_t bk, int i) const { const uint32_t s = PB * bk + (uint32_t)i; atomicAdd(&cnt32[s >> 1], 1u << ((s & 1u) * 16u)); }
+    __device__ __forceinline__ uint32_t claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const { return atomicCAS(&keys[PB * bk + i], kEmpty, key_of(b, dd)); }
+    __device__ __forceinline__ int claim_finish(uint32_t old, uint32_t bk, int i, uint32_t b, uint32_t dd) const {
+        if (old == kEmpty) return 0;
+        if (old == key_of(b, dd)) { add(bk, i); return 1; }
+        return 2;
+    }
+    __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
+        const uint32_t q = keys[s];
+        b = b_of(q, s / (uint32_t)PB); dd = q >> kBBits; cnt = ((cnt32[s >> 1] >> ((s & 1u) * 16u)) & 0x7FFFu) + 1u;
+        return q != kEmpty;
+    }
+    // sum of the counts of the keys (b, .) among the keys of a bucket of b's region
+    __device__ __forceinline__ uint32_t sum_of(const bucket& k, const counts& c, uint32_t b) const {
+        const uint32_t bq = b >> S;
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            if ((k.k[j] & kBMask) == bq && k.k[j] != kEmpty) total += field(c, j) + 1u;
+        return total;
+    }
+    __device__ __forceinline__ unsigned long long total_of(uint32_t b, uint32_t n_buckets) const {
+        unsigned long long total = 0;
+        uint32_t bk = home_of(b);
+        for (uint32_t probe = 0; probe < nb_r; ++probe) {
+            const bucket k = read(bk);
+            total += sum_of(k, read_counts(bk), b);
+            if (k.k[PB - 1] == kEmpty) break;
+            bk = next(bk, b, n_buckets);
+        }
+        return total;
+    }
+    template <class F>
+    __device__ __forceinline__ void for_counts_at_least(uint32_t bk, uint32_t n_buckets, uint32_t min_cov, F&& f) const {
+        const counts c = read_counts(bk);
+        const uint32_t need = min_cov ? min_cov - 1u : 0u;
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) any |= field(c, j) >= need;
+        if (!any) return;
+        const bucket k = read(bk);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const uint32_t cnt = field(c, i) + 1u;
+            if (cnt >= min_cov && k.k[i] != kEmpty) {
+                const uint32_t b = b_of(k.k[i], bk);
+                const unsigned long long total = (k.k[PB - 1] == kEmpty && home_of(b) == bk) ? (unsigned long long)sum_of(k, c, b) : total_of(b, n_buckets);
+                f((uint32_t)PB * bk + (uint32_t)i, b, k.k[i] >> kBBits, cnt, total);
+            }
+        }
+    }
+    static constexpr uint32_t kScanGroup = 8;
+    __device__ __forceinline__ uint32_t hot_mask(uint32_t g, uint32_t min_cov) const {
+        const cf_u32x4 v = *(const cf_u32x4*)&cnt32[4 * g];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t need = min_cov ? min_cov - 1u : 0u;
+        uint32_t m = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m |= (uint32_t)(((w[j >> 1] >> ((j & 1) * 16)) & 0x7FFFu) >= need) << j;
+        return m;
+    }
+    template <class F>
+    __device__ __forceinline__ void eval_slot(uint32_t s, uint32_t n_buckets, uint32_t min_cov, F&& f) const {
+        const uint32_t bk = s / (uint32_t)PB, i = s % (uint32_t)PB;
+        const bucket k = read(bk);
+        const counts c = read_counts(bk);
+        uint32_t mine = k.k[0], mine_f = field(c, 0);
+#pragma unroll
+        for (int j = 1; j < PB; ++j) { if (i == (uint32_t)j) { mine = k.k[j]; mine_f = field(c, j); } }
+        const uint32_t cnt = mine_f + 1u;
+        if (mine == kEmpty || cnt < min_cov) return;
+        const uint32_t b = b_of(mine, bk);
+        const unsigned long long total = (k.k[PB - 1] == kEmpty && home_of(b) == bk) ? (unsigned long long)sum_of(k, c, b) : total_of(b, n_buckets);
+        f(s, b, mine >> kBBits, cnt, total);
+    }
+    template <class F>
+    __device__ __forceinline__ void for_marked(uint32_t bk, F&& f) const {
+        const counts c = read_counts(bk);
+        if (!((c.w[0] | c.w[1]) & 0x80008000u)) return;
+        const bucket k = read(bk);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const uint32_t h = c.w[i >> 1] >> ((i & 1) * 16);
+            if (h & 0x8000u) f((uint32_t)PB * bk + (uint32_t)i, b_of(k.k[i], bk), k.k[i] >> kBBits, (h & 0x7FFFu) + 1u);
+        }
+    }
+    __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&cnt32[s >> 1], 0x8000u << ((s & 1u) * 16u)); }
+};
+
 
 #define DIST_QCAP 128                    /* deferred inserts per wave (pushes come in batches of <= 64, drains take 64) */
 #define DIST_FULL_BIT 0x80000000u        /* sh[0]: the table is physically full (the pass is void and will be split) */
@@ -461,7 +638,7 @@ template <class Tab>
 __device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buckets, uint32_t bk, uint32_t b, uint32_t dd, uint32_t* sh) {
     for (uint32_t tries = 0; tries < 9 * n_buckets; ++tries) {
         const typename Tab::bucket k = T.read(bk);
-        const int m = Tab::match(k, b, dd);
+        const int m = T.match(k, b, dd);
         if (m >= 0) { T.add(bk, m); return 0u; }
         const int e = Tab::empty(k);
         if (e >= 0) {
@@ -470,7 +647,7 @@ __device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buck
             if (st == 1) return 0u;
             continue;   // another key took the slot: look at the same bucket again
         }
-        bk = bk + 1 == n_buckets ? 0u : bk + 1;
+        bk = T.next(bk, b, n_buckets);
     }
     atomicOr(&sh[0], DIST_FULL_BIT);
     return 0u;
@@ -592,6 +769,7 @@ template <class Tab>
 __global__ void cf_dist_kernel(cf_dist_args A) {
     Tab T;
     T.init(cf_lds, (uint32_t)A.slots);
+    T.configure(A, (uint32_t)A.slots / Tab::kPerBucket);
     // LDS: [table | edge stage | partition stack | insert queues] [posting ranges | item prefixes | sh | bitmap].  The first
     // group is dead while the sketch sweep runs, so its 8-bit counters (sk) lie over ALL of it: the 8-byte-slot layouts,
     // whose table is smaller than 64 KiB next to their 8-byte queue items, keep 65 536 counters that way.
@@ -762,7 +940,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     uint32_t made_ = 0;                                                                       \
                     if ((uint32_t)lane < n_) {                                                                \
                         uint32_t xb, xd, xk;                                                                  \
-                        Tab::q_take(wq[qtail + (uint32_t)lane], n_buckets, xb, xd, xk);                       \
+                        T.q_take(wq[qtail + (uint32_t)lane], n_buckets, xb, xd, xk);                         \
                         made_ = cf_dist_insert(T, n_buckets, xk, xb, xd, sh);                                 \
                     }                                                                                         \
                     const uint32_t new_ = (uint32_t)__popcll(__ballot(made_ != 0u));                          \
@@ -794,7 +972,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                         const unsigned long long cm = __ballot((cand >> u) & 1u);
                         if (cm) {
                             if (qtail >= 64u) { CF_DIST_DRAIN(64u) }
-                            if ((cand >> u) & 1u) wq[qtail + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = Tab::q_make(bb[u], dd_[u], Tab::home(Tab::hash(bb[u]), n_buckets));
+                            if ((cand >> u) & 1u) wq[qtail + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = T.q_of(bb[u], dd_[u], n_buckets);
                             qtail += (uint32_t)__popcll(cm);
                         }
                     }
@@ -985,8 +1163,9 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     uint16_t* d_entry_i = nullptr;
     uint32_t* d_packed = nullptr;
     cf_dist_rec* d_urange = nullptr;
-    bool narrow = false, wide16 = false;
-    int narrow_db = 8;
+    bool narrow = false, wide16 = false, region = false;
+    int narrow_db = 8, reg_shift = 0;
+    uint8_t* d_entry_i8 = nullptr;
     unsigned long long* d_cnt = nullptr;
     int64_t n_post = 0;
     int rc = 0;
@@ -1047,21 +1226,31 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (ctx->dist_dbits) narrow_db = std::min(narrow_db, ctx->dist_dbits);
         narrow = !wide16 && !ctx->dist_wide && narrow_db >= 5 && narrow_db >= need_bits && max_post <= 32767u;
         if (ctx->dist_dbits && !narrow) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_dbits does not fit this input (distances or k-mer ranks need more bits)"); break; }
+        // ranks that do not fit next to the distance: the 6-byte slots in 2^S table regions (the key drops the rank's low S bits)
+        if (!narrow || ctx->dist_regions) {
+            reg_shift = 0;
+            while (reg_shift < 3 && ((K - 1) >> reg_shift) > ((int64_t)1 << 24) - 2) ++reg_shift;
+            if (ctx->dist_regions) { int want = 0; while ((1 << want) < ctx->dist_regions) ++want; reg_shift = std::max(reg_shift, want); }
+            region = !wide16 && !ctx->dist_wide && !ctx->dist_dbits && reg_shift <= 3 && ((K - 1) >> reg_shift) <= ((int64_t)1 << 24) - 2 && max_post <= 32767u && K < ((int64_t)1 << 31);
+            if (ctx->dist_regions && !region) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_regions does not fit this input"); break; }
+            if (region) narrow = false;
+        }
         if (max_post >= (1u << 23) || (wide16 && max_post > 32767u)) { rc = cf_fail(ctx, -34, wide16 ? "cf_dist_edges: distances above 255 with a k-mer of more than 32767 postings" : "cf_dist_edges: a k-mer has more than 2^23 postings"); break; }
         if (narrow) { if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)v_n_entries + DIST_ITEM, "packed cloud entries"))) break; }
+        else if (region) { if ((rc = cf_alloc_t(ctx, &d_entry_i8, (size_t)v_n_entries + 4 * DIST_ITEM, "entry unit indices (bytes)"))) break; }
         else if ((rc = cf_alloc_t(ctx, &d_entry_i, (size_t)v_n_entries + 1, "entry unit indices"))) break;
         if (U && v_n_entries)
             hipLaunchKernelGGL(cf_entry_unit_kernel, dim3((unsigned)cf_grid_for(U * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               v_cloud_ptr, (const int32_t*)d_rbeg, v_entries, U, d_entry_i, d_packed, 32 - narrow_db);
+                               v_cloud_ptr, (const int32_t*)d_rbeg, v_entries, U, d_entry_i, d_packed, 32 - narrow_db, d_entry_i8);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("postings: ") + hipGetErrorString(e)); break; }
 
         cf_dist_args A;
-        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = v_cloud_ptr; A.entries = v_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.urange = d_urange; A.entry_i = d_entry_i; A.packed = d_packed;
+        A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = v_cloud_ptr; A.entries = v_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.urange = d_urange; A.entry_i = d_entry_i; A.packed = d_packed; A.entry_i8 = d_entry_i8; A.reg_shift = (uint32_t)reg_shift;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
         A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
-        const uint32_t slot_bytes = narrow ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
+        const uint32_t slot_bytes = (narrow || region) ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
         // launch shape: two 512-thread workgroups per CU (80 KiB of LDS each) overlap each other's latency-bound phases
         // and win when a first k-mer has few pair emissions; with many (long reads, high coverage) the halved table and
         // sketch cost more than the overlap gains, and one 1024-thread workgroup with the whole LDS wins (measured:
@@ -1085,7 +1274,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (budget8 < 256) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_wgs leaves no LDS for the table"); break; }
         if (ctx->dist_slots > budget8) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_slots does not fit the 160 KiB LDS next to the work lists"); break; }
         const int64_t slots8 = ctx->dist_slots ? ctx->dist_slots : budget8;
-        A.slots = (int32_t)((slots8 * 8 / slot_bytes) & ~7ll);
+        A.slots = (int32_t)((slots8 * 8 / slot_bytes) & ~(region ? (int64_t)(32 << reg_shift) - 1 : 7ll));      // (regions: equal parts of whole 8-slot groups)
         A.fill_limit = (uint32_t)((int64_t)A.slots * ctx->dist_fill_pct / 100);   // checked once per wave step: leave slack below the physical size
         A.est_limit = (uint32_t)((int64_t)A.fill_limit * 100 / ctx->dist_est_pct);
         A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
@@ -1118,7 +1307,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("order: ") + hipGetErrorString(e)); break; }
-        void (*kern)(cf_dist_args) = !narrow ? (wide16 ? cf_dist_kernel<cf_tab_wide16> : cf_dist_kernel<cf_tab_wide>)
+        void (*kern)(cf_dist_args) = region ? cf_dist_kernel<cf_tab_region> : !narrow ? (wide16 ? cf_dist_kernel<cf_tab_wide16> : cf_dist_kernel<cf_tab_wide>)
                                    : narrow_db == 8 ? cf_dist_kernel<cf_tab_narrow_t<8>> : narrow_db == 7 ? cf_dist_kernel<cf_tab_narrow_t<7>>
                                    : narrow_db == 6 ? cf_dist_kernel<cf_tab_narrow_t<6>> : cf_dist_kernel<cf_tab_narrow_t<5>>;
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1153,6 +1342,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     if (d_cnt) cf_release_t(ctx, d_cnt, n_cnt);
     if (d_entry_i) cf_release_t(ctx, d_entry_i, (size_t)v_n_entries + 1);
     if (d_packed) cf_release_t(ctx, d_packed, (size_t)v_n_entries + DIST_ITEM);
+    if (d_entry_i8) cf_release_t(ctx, d_entry_i8, (size_t)v_n_entries + 4 * DIST_ITEM);
     if (d_urange) cf_release_t(ctx, d_urange, (size_t)U + 1);
     if (d_rbeg) cf_release_t(ctx, d_rbeg, (size_t)U + 1);
     if (d_rend) cf_release_t(ctx, d_rend, (size_t)U + 1);

@@ -109,6 +109,28 @@ def test_narrow_slots_with_fewer_distance_bits(engine, dbits, n_units):
         engine.set_param("dist_block", 0)
 
 
+@pytest.mark.parametrize("regions", [1, 2, 8])
+def test_region_layout_of_the_six_byte_slots(engine, report, oracle_stage2, regions):
+    """Key [d : 8 | rank >> S : 24] in 2^S table regions (k-mer sets of 2^24 .. 2^27 ranks): forced here on small sets, whole
+    stage 2 of a fixture and the synthetic clouds with long posting lists and tiny tables (chains that wrap inside a region)."""
+    engine.set_param("dist_regions", regions)
+    engine.set_param("dist_block", 128)
+    try:
+        engine.set_param("dist_slots", 2048)
+        pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov", max_distance=2), check_table=False)
+        engine.set_param("dist_slots", 256)
+        engine.set_param("dist_sketch", 0)        # every pair in the exact table: full buckets, chains, partition splits
+        pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=40, cloud=6, n_kmers=60, max_d=7, min_d=1, seed=regions)
+        engine.set_param("dist_sketch", 1)
+        engine.set_param("dist_slots", 4096)
+        pathcheck.check_synthetic_clouds(engine, n_reads=1, n_units=250, cloud=3, n_kmers=25, max_d=240, seed=3)      # distances up to 240
+    finally:
+        engine.set_param("dist_regions", 0)
+        engine.set_param("dist_sketch", 1)
+        engine.set_param("dist_slots", 0)
+        engine.set_param("dist_block", 0)
+
+
 def test_stage3_against_reference_golden(engine, report, golden):
     from centroflye_amd import _host
     from oracle import ncrf

@@ -124,6 +124,15 @@ def test_kmer_sets_beyond_2_pow_24_keep_the_six_byte_slots(engine):
         pathcheck.check_synthetic_clouds(engine, n_reads=3, n_units=100, cloud=4, n_kmers=40, seed=7, kmer_base=1 << 24)
     finally:
         engine.set_param("dist_wide", 0)
+    # long reads (200 units: distances need 8 bits) with 2^24 + 40 and 2^26 + 40 k-mers: the region layout (2 and 8 regions)
+    pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=200, cloud=4, n_kmers=40, seed=9, kmer_base=1 << 24)
+    pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=200, cloud=4, n_kmers=40, seed=10, kmer_base=1 << 26)
+    for regions in (1, 4):
+        engine.set_param("dist_regions", regions)
+        try:
+            pathcheck.check_synthetic_clouds(engine, n_reads=3, n_units=100, cloud=4, n_kmers=50, seed=regions)
+        finally:
+            engine.set_param("dist_regions", 0)
     for dbits in (5, 6, 7):
         engine.set_param("dist_dbits", dbits)
         try:
