@@ -128,6 +128,7 @@ def parse_args():
     ap.add_argument("--place", action="store_true", help="also run stage 3 (A4 + A8/A9 placement) once and report it (N = 1)")
     ap.add_argument("--rr", action="store_true", help="also time read recruitment (SURVEY 8(f) rank 4) on the same reads + as many random ones (N = 1)")
     ap.add_argument("--param", action="append", default=[], help="library knob name=value (cf_set_param)")
+    ap.add_argument("--force-exchange", action="store_true", help="N = 1 only: run the multi-GPU exchange path (bucketing, all-to-all, all-gathers, gathered view) through a one-rank RCCL communicator, to price it without wire time")
     ap.add_argument("--lib", default=None, help="test hook: another build of libcfhip (the CPU suite passes the host-emulated one to check this harness)")
     return ap.parse_args()
 
@@ -171,7 +172,7 @@ def main():
     if a.lib:
         from centroflye_amd import _lib
         lib = _lib.load(a.lib)
-    sr = ShardedRecruiter(local_rank if not a.lib else 0, lib=lib, rank=rank, world=world)
+    sr = ShardedRecruiter(local_rank if not a.lib else 0, lib=lib, rank=rank, world=world, force_exchange=a.force_exchange and world == 1)
     E = sr.engine
     for p in a.param:
         name, val = p.split("=")

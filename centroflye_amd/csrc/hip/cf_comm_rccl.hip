@@ -128,6 +128,13 @@ cf_comm* cf_comm_open(int device, int rank, int world, const char* rendezvous, s
     c->rank = rank; c->world = world;
     if (!load_rccl(c->api, err)) { delete c; return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { err = "cf_comm_init: hipSetDevice"; delete c; return nullptr; }
+    // RCCL prints a version banner on stdout when a communicator comes up; the caller's stdout belongs to the caller (the
+    // benchmark prints ONE line there): while RCCL initialises, file descriptor 1 points at stderr.
+    struct StdoutToStderr {
+        int saved = -1;
+        StdoutToStderr() { std::fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+        ~StdoutToStderr() { std::fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
+    } quiet;
     ncclUniqueId id;
     std::memset(&id, 0, sizeof id);
     if (rank == 0) {
