@@ -72,6 +72,20 @@ def test_config0_1k_reads_full_stage2_vs_cpu(engine):
     assert (st["n_windows"], st["n_read_kmers"], st["n_distinct"], st["n_kept"]) == (c["n_windows"], c["n_read_kmers"], c["n_distinct"], c["n_kept"])
     assert cport.edge_checksum(engine.edges(ne)) == c["edge_checksum"]
     assert np.array_equal(engine.unique_mask(), a["unique"])
+    # every layout of the (b, d) table on the same clouds: 6-byte slots with a 7-bit distance field, the region layout
+    # (2 and 8 regions), the 8-byte slots, and one 1 024-thread workgroup per CU — the same edges and unique set
+    for knobs in ({"dist_dbits": 7}, {"dist_regions": 2}, {"dist_regions": 8}, {"dist_wide": 1}, {"dist_wgs": 1, "dist_block": 1024}):
+        try:
+            for name, v in knobs.items():
+                engine.set_param(name, v)
+            engine.reset_unique()
+            ne2 = engine.dist_edges(0, 2 ** 62, P["min_d"], P["max_d"], P["min_cov"], P["rel_threshold"], 0, 1, edge_cap=c["n_edges"])
+            assert (ne2, engine.stats()["n_emissions"]) == (c["n_edges"], c["n_emissions"]), knobs
+            assert cport.edge_checksum(engine.edges(ne2)) == c["edge_checksum"], knobs
+            assert np.array_equal(engine.unique_mask(), a["unique"]), knobs
+        finally:
+            for name in knobs:
+                engine.set_param(name, 0)
 
 
 @pytest.mark.timeout(900)
