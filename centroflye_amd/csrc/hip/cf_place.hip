@@ -349,6 +349,9 @@ cf_place_pick_add_update_kernel(cf_place_state S, int n_cand, int PL_CHUNK) {
 }
 
 
+// (Also measured and not kept: the score-entry probe and the seen-set probe of a hit in lockstep — the seen key made of
+// (read, offset, unit) instead of the score slot, so that both slot loads and both claims are in flight together: 1.203 vs
+// 1.207 s per 50 000 reads, and it limits reads, units and units per read to 24, 24 and 15 bits.)
 // (Round 2 tried the greedy loop of a stage as ONE persistent launch — flag scan per workgroup, grid barrier, pick + add +
 // score updates by the waves that raise the events, grid barrier: 58 us per placed read against 32 us for the three
 // kernels below at 50 000 reads (two agent-scope barriers under load cost more than three dependent launches whose
