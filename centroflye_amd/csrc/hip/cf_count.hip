@@ -335,7 +335,7 @@ static int table_compact(cf_ctx* ctx, uint32_t max_nonuniq, uint32_t lo, uint32_
     return rc;
 }
 
-int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, int64_t n_w);   // cf_count2.hip
+int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, int64_t n_w, int occ);   // cf_count2.hip
 
 int cf_table_ensure(cf_ctx* ctx, uint64_t want_cap) {
     ctx->table_dense = false;
@@ -369,8 +369,10 @@ static int count_impl(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, 
     if (2 * k < 62 && cap > (2ull << (2 * k))) cap = cf_pow2_ceil(2ull << (2 * k));
     ctx->k = k;
     ctx->stats.n_windows = n_w;
-    if (mode == 0 && ctx->count_mode) {      // A1 by sort and reduce; 1 = does not apply here (long k, too many reads, a crowded bucket)
-        const int rc2 = cf_count_sorted(ctx, k, read_lo, read_hi, n_w);
+    if (mode == 1 && ctx->has_exotic)
+        return cf_fail(ctx, -22, "cf_count_occurrences: reads with symbols other than upper-case A, C, G, T are not supported");
+    if (ctx->count_mode) {      // by sort and reduce; 1 = does not apply here (long k, too many reads, a crowded bucket)
+        const int rc2 = cf_count_sorted(ctx, k, read_lo, read_hi, n_w, mode);
         if (rc2 <= 0) return rc2;
     }
     if (ctx->has_exotic)

@@ -15,7 +15,8 @@
 //   4. the result is a DENSE array of table slots {key | OCC, pres | multi << 32}: every consumer that scans the table
 //      (A2 select, cf_get_table, the multi-GPU bucketing) reads it like a table without holes.
 // All traffic is streamed: N_b x 2 + 8 N_w x 5 + 16 K_dist bytes (~45 GB per Gbase).  Needs 2k + bits(reads) <= 64 and
-// reads < 2^27; otherwise (and for the occurrence counts of cf_count_occurrences) the table path of cf_count.hip runs.
+// reads < 2^27; otherwise the table path of cf_count.hip runs.  cf_count_occurrences takes the same passes with records that
+// are the k-mer alone and its own reduce kernel (cf_c2_reduce_occ_kernel below).
 #include "cf_common.h"
 
 void cf_free_table(cf_ctx* c);
@@ -96,7 +97,7 @@ __device__ __forceinline__ void cf_c2_tile_records(const uint8_t* __restrict__ b
         const int s2 = 2 * (46 - j - k);                 // bits to drop behind the window [j, j + k): 0 .. 90
         unsigned long long code = s2 >= 64 ? hi >> (s2 - 64) : (s2 ? (lo >> s2) | (hi << (64 - s2)) : lo);
         code &= kmask;
-        f(j, (code << rb) | (unsigned long long)(uint32_t)tl.read, valid);
+        f(j, (code << rb) | ((unsigned long long)(uint32_t)tl.read & ((1ull << rb) - 1ull)), valid);      // (rb = 0: occurrence mode, the record is the k-mer alone)
     }
 }
 
@@ -498,6 +499,121 @@ cf_c2_reduce_kernel(const unsigned long long* __restrict__ recs, int64_t n, int 
 #endif
 }
 
+// Occurrence counts (reference better_consensus_unit_reconstruction.py:129-137: counts[kmer] += 1 for every
+// window): the same bucketed record stream with records that are the k-mer alone (rb = 0), reduced by a per-bucket LDS table
+// k-mer -> 64-bit count.  No (k-mer, read) set, no per-read state.  A round of 64 records that are all the same k-mer — the
+// HOR's consensus k-mers fill whole tiles — is ONE add of 64 by the first lane (64 adds to one LDS word would serialise).
+__global__ void __launch_bounds__(C2_RTHREADS)
+cf_c2_reduce_occ_kernel(const unsigned long long* __restrict__ recs, int64_t n, int bits, cf_slot* __restrict__ out, unsigned long long out_cap,
+                        unsigned long long chunk, int64_t per, int64_t n_chunks, const int64_t* __restrict__ starts, unsigned long long* __restrict__ counters) {
+    unsigned long long* tkey = (unsigned long long*)cf_lds;                    // C2_TAB x (k-mer + 1); 0 = empty
+    unsigned long long* tcnt = tkey + C2_TAB;
+    unsigned long long* sh64 = tcnt + C2_TAB;                                   // [0] position / flush base [1] next free slot of the chunk [2] end of the chunk
+    uint32_t* sh = (uint32_t*)(sh64 + 3);                                       // [0] records of the tile in the bucket [1] k-mers in the table
+    const int t = threadIdx.x, lane = t & 63;
+    const int64_t n_buckets = (int64_t)1 << bits;
+    constexpr int RJ = C2_RTILE / C2_RTHREADS;
+    if (t == 0) { sh64[1] = 0; sh64[2] = 0; }
+    unsigned long long n_dist = 0;
+    while (true) {
+        __syncthreads();
+        if (t == 0) sh64[0] = atomicAdd(&counters[4], 1ull);
+        __syncthreads();
+        const int64_t ck = (int64_t)sh64[0];
+        if (ck >= n_chunks) break;
+        const int64_t b0 = ck * per, b1 = min(n_buckets, b0 + per);
+        int64_t pos = starts[ck];
+        for (int64_t b = b0; b < b1; ++b) {
+            for (int s = t; s < C2_TAB; s += C2_RTHREADS) { tkey[s] = 0ull; tcnt[s] = 0ull; }
+            if (t == 0) sh[1] = 0;
+            __syncthreads();
+            bool more = true;
+            while (more) {
+                if (t == 0) sh[0] = 0;
+                __syncthreads();
+                unsigned long long rec[RJ];
+                uint32_t th[RJ], act = 0, mine = 0, made = 0;
+#pragma unroll
+                for (int j = 0; j < RJ; ++j) {
+                    const int64_t i = pos + (int64_t)j * C2_RTHREADS + t;
+                    const unsigned long long v = i < n ? recs[i] : ~0ull;
+                    rec[j] = v; th[j] = 0;
+                    if (i < n && (int64_t)cf_c2_bucket(v, bits) == b) { ++mine; act |= 1u << j; th[j] = cf_c2_hash_tab(v) & (C2_TAB - 1); }
+                }
+                const uint32_t in_bucket = act;
+                for (int probe = 0; probe < C2_TAB && __any(act != 0u); ++probe) {      // the k-mer's table entry, probe chains in lockstep
+                    unsigned long long cur[RJ];
+#pragma unroll
+                    for (int j = 0; j < RJ; ++j) cur[j] = ((act >> j) & 1u) ? tkey[th[j]] : 1ull;
+#pragma unroll
+                    for (int j = 0; j < RJ; ++j)
+                        if (((act >> j) & 1u) && cur[j] == 0ull) { cur[j] = atomicCAS(&tkey[th[j]], 0ull, rec[j] + 1ull); if (cur[j] == 0ull) { ++made; cur[j] = rec[j] + 1ull; } }
+#pragma unroll
+                    for (int j = 0; j < RJ; ++j) {
+                        if (!((act >> j) & 1u)) continue;
+                        if (cur[j] == rec[j] + 1ull) act &= ~(1u << j);
+                        else th[j] = (th[j] + 1) & (C2_TAB - 1);
+                    }
+                }
+                if (act) atomicOr(&counters[2], 1ull);       // the bucket holds more k-mers than the table: the caller falls back
+#pragma unroll
+                for (int j = 0; j < RJ; ++j) {                // (uniform loop: the ballots inside see the whole wave)
+                    const bool have = ((in_bucket >> j) & 1u) && !((act >> j) & 1u);
+                    const unsigned long long m = __ballot(have);
+                    if (!m) continue;
+                    const int leader = __ffsll((long long)m) - 1;
+                    const unsigned long long k0 = (unsigned long long)__shfl((long long)rec[j], leader);
+                    if (m == ~0ull && __all(rec[j] == k0)) { if (lane == 0) atomicAdd(&tcnt[th[j]], 64ull); }
+                    else if (have) atomicAdd(&tcnt[th[j]], 1ull);
+                }
+                for (int d = 32; d >= 1; d >>= 1) { mine += __shfl_down(mine, (unsigned)d); made += __shfl_down(made, (unsigned)d); }
+                if (lane == 0) { if (mine) atomicAdd(&sh[0], mine); if (made) atomicAdd(&sh[1], made); }
+                __syncthreads();
+                const uint32_t got = sh[0];
+                pos += got;
+                more = got == C2_RTILE && pos < n;                  // a full tile: the bucket may go on
+                __syncthreads();
+            }
+            // ---- bucket done: its k-mers go to the table, into the workgroup's current chunk or a fresh one (as in cf_c2_reduce_kernel)
+            const uint32_t n_k = sh[1];
+            const unsigned long long c_free = sh64[1], c_end = sh64[2];
+            __syncthreads();
+            const bool fresh = n_k > c_end - c_free;
+            if (fresh) for (unsigned long long o = c_free + t; o < c_end; o += C2_RTHREADS) if (o < out_cap) { cf_slot z; z.key = 0ull; z.val = 0ull; out[o] = z; }
+            if (t == 0) {
+                unsigned long long at = c_free;
+                if (fresh) { at = atomicAdd(&counters[0], chunk); sh64[2] = at + chunk; }
+                sh64[1] = at + n_k;
+                sh64[0] = at;
+                sh[1] = 0;
+                n_dist += n_k;
+            }
+            __syncthreads();
+            if (n_k) {
+                const unsigned long long base = sh64[0];
+                for (int s0 = 0; s0 < C2_TAB; s0 += C2_RTHREADS) {
+                    const int s = s0 + t;
+                    const bool occ = tkey[s] != 0ull;
+                    const unsigned long long m = __ballot(occ);
+                    uint32_t off = 0;
+                    if (m) {
+                        const int leader = __ffsll((long long)m) - 1;
+                        if (lane == leader) off = atomicAdd(&sh[1], (uint32_t)__popcll(m));
+                        off = (uint32_t)__shfl((int)off, leader);
+                    }
+                    if (occ) {
+                        const unsigned long long o = base + off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        if (o < out_cap) { cf_slot sl; sl.key = (tkey[s] - 1ull) | CF_OCC; sl.val = tcnt[s]; out[o] = sl; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (unsigned long long o = sh64[1] + t; o < sh64[2]; o += C2_RTHREADS) if (o < out_cap) { cf_slot z; z.key = 0ull; z.val = 0ull; out[o] = z; }
+    if (t == 0 && n_dist) atomicAdd(&counters[3], n_dist);
+}
+
 namespace {
 struct Bufs2 {
     cf_ctx* ctx;
@@ -526,10 +642,12 @@ int launch_nb(int nb, K&& k) {      // radix bits of a pass -> template instance
 }  // namespace
 
 // Returns 0 on success, 1 when the sort-and-reduce path does not apply (caller falls back to the table path), < 0 on error.
-int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, int64_t n_w) {
+// occ = 0: presence / multi table (A1); occ = 1: occurrence counts (records without the read id)
+int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, int64_t n_w, int occ) {
     const int64_t R = ctx->n_reads;
     int rb = 1;
     while (((int64_t)1 << rb) < std::max<int64_t>(R, 2)) ++rb;
+    if (occ) rb = 0;
     if (2 * k + rb > 62 || rb > 26) return 1;
     // tiles of pass 1
     std::vector<cf_c2_tile> tiles;
@@ -624,8 +742,12 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
         CF_HIP(hipMemsetAsync(d_cnt, 0, 128, ctx->stream));
         const int grid = (int)std::min<int64_t>(n_chunks, (int64_t)std::max(1, ctx->n_cu) * 2);
         const unsigned long long chunk = (unsigned long long)std::min<int64_t>(32768, std::max<int64_t>(C2_TAB, n_w / grid / 4));
-        hipLaunchKernelGGL(cf_c2_reduce_kernel, dim3((unsigned)grid), dim3(C2_RTHREADS), lds_r, ctx->stream, (const unsigned long long*)src, n_rec, rb, bits, d_out,
-                           out_cap, chunk, per, n_chunks, (const int64_t*)d_starts, d_cnt);
+        if (occ)
+            hipLaunchKernelGGL(cf_c2_reduce_occ_kernel, dim3((unsigned)grid), dim3(C2_RTHREADS), (size_t)C2_TAB * 16 + 24 + 16, ctx->stream, (const unsigned long long*)src, n_rec, bits, d_out,
+                               out_cap, chunk, per, n_chunks, (const int64_t*)d_starts, d_cnt);
+        else
+            hipLaunchKernelGGL(cf_c2_reduce_kernel, dim3((unsigned)grid), dim3(C2_RTHREADS), lds_r, ctx->stream, (const unsigned long long*)src, n_rec, rb, bits, d_out,
+                               out_cap, chunk, per, n_chunks, (const int64_t*)d_starts, d_cnt);
         CF_KERNEL_CHECK("cf_c2_reduce_kernel");
         CF_HIP(hipMemcpy(h_cnt, d_cnt, 32, hipMemcpyDeviceToHost));
 #if defined(CF_C2_STAMPS)
@@ -654,7 +776,7 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
     ctx->table_dense = true;
     ctx->k = k;
     ctx->stats.n_windows = n_w;
-    ctx->stats.n_read_kmers = (int64_t)h_cnt[1];
+    ctx->stats.n_read_kmers = occ ? (int64_t)h_cnt[3] : (int64_t)h_cnt[1];      // (occurrence mode: the distinct k-mers)
     CF_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     CF_HIP(hipEventSynchronize(ctx->ev1));
     (void)hipEventElapsedTime(&ctx->times.count_ms, ctx->ev0, ctx->ev1);

@@ -148,7 +148,13 @@ def test_unit_kmer_occurrences_and_top_n(engine, report):
     import json
     with open(os.path.join(ROOT, "tests", "golden", "lowcov.unit_kmers.json")) as f:
         g = json.load(f)
-    pathcheck.check_unit_kmers(engine, report("lowcov"), g, 30)
+    pathcheck.check_unit_kmers(engine, report("lowcov"), g, 30)      # by sort and reduce (records without the read id)
+    for mode, bits in ((1, 3), (0, 0)):                                     # few buckets (tiles of one k-mer, tables that fill up); the atomic table
+        engine.set_param("count_mode", mode); engine.set_param("count_bits", bits)
+        try:
+            pathcheck.check_unit_kmers(engine, report("lowcov"), g, 19)
+        finally:
+            engine.set_param("count_mode", 1); engine.set_param("count_bits", 0)
 
 
 def test_errors(engine):

@@ -99,6 +99,11 @@ def test_unit_kmer_occurrences_and_top_n(engine, report, name, k):
     with open(os.path.join(ROOT, "tests", "golden", f"{name}.unit_kmers.json")) as f:
         g = json.load(f)
     pathcheck.check_unit_kmers(engine, report(name), g, k)
+    engine.set_param("count_mode", 0)      # the atomic table of round 1 instead of sort and reduce: the same table and top n
+    try:
+        pathcheck.check_unit_kmers(engine, report(name), g, k)
+    finally:
+        engine.set_param("count_mode", 1)
 
 
 def test_long_posting_lists_take_the_multi_chunk_path(engine):
