@@ -28,7 +28,7 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 #define DIST_STACK 112
 #define DIST_UNROLL 4
 #define DIST_ITEM (64u * DIST_UNROLL)    /* cloud entries one wave takes per step: DIST_UNROLL consecutive ones per lane */
-#define DIST_BM_BITS 32768u              /* bitmap over hash(b): k-mers that may have a selected edge */
+#define DIST_BM_BITS 65536u              /* bitmap over hash(b): k-mers that may have a selected edge */
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
 #define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
 
