@@ -147,6 +147,7 @@ struct cf_dist_args {
     int32_t sketch;                // 1: count first in 8-bit counters, build the exact table only for k-mers that can pass min_cov
     uint32_t sk_counters, sk_shift;   // counters (a power of two that fits the LDS that is dead during the sketch sweep) and 32 - log2 of it
     uint32_t stage_cap;            // <= DIST_STAGE_CAP
+    uint32_t hot_cap;              // cap on the filter's list of hot slots (tests: a small one forces the in-scan evaluation)
     uint32_t* edges;
     unsigned long long edge_cap;
     const int32_t* order;          // first k-mers of this partition, sorted by their first posting (locality)
@@ -1003,7 +1004,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             // division code at 8 unrolled sites per round with 4 % of the lanes active: 9 100 cycles per first k-mer.)
             if (CF_DIST_DYN_B) { __syncthreads(); if (t == 0) sh[11] = 0; __syncthreads(); }      // (the item cursor of that build; round robin leaves the word 0)
             uint16_t* hot = (uint16_t*)wq0;
-            const uint32_t hot_cap = (uint32_t)((size_t)(nt >> 6) * DIST_QCAP * sizeof(typename Tab::qitem) / 2);
+            const uint32_t hot_cap = min(A.hot_cap, (uint32_t)((size_t)(nt >> 6) * DIST_QCAP * sizeof(typename Tab::qitem) / 2));
             // (every position comes from ONE LDS atomic per wave: 64 returning adds on one address serialise — 570 of them
             // per first k-mer were the cost of this phase, not the arithmetic)
             const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1250,6 +1251,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = v_cloud_ptr; A.entries = v_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.urange = d_urange; A.entry_i = d_entry_i; A.packed = d_packed; A.entry_i8 = d_entry_i8; A.reg_shift = (uint32_t)reg_shift;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
         A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
+        A.hot_cap = ctx->dist_hot_cap > 0 ? (uint32_t)ctx->dist_hot_cap : 0xFFFFFFFFu;
         const uint32_t slot_bytes = (narrow || region) ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
         // launch shape: two 512-thread workgroups per CU (80 KiB of LDS each) overlap each other's latency-bound phases
         // and win when a first k-mer has few pair emissions; with many (long reads, high coverage) the halved table and

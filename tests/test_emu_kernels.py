@@ -59,6 +59,22 @@ def test_stage2_wide_table_layout(engine, report, oracle_stage2):
         engine.set_param("dist_sketch", 1)
 
 
+def test_filter_falls_back_when_its_hot_list_is_full(engine, report, oracle_stage2):
+    """The filter compacts the slots that reach min_cov into an LDS list and evaluates the list; more such slots than the
+    list holds are evaluated inside the bucket scan instead (never seen with the sketch at real sizes: forced here)."""
+    tup = oracle_stage2("lowcov", max_distance=2)
+    engine.set_param("dist_slots", 2048)
+    engine.set_param("dist_block", 128)
+    engine.set_param("dist_hot_cap", 3)
+    try:
+        pathcheck.check_stage2(engine, report("lowcov"), tup, check_table=False)
+        engine.set_param("dist_wide", 1)
+        pathcheck.check_stage2(engine, report("lowcov"), tup, check_table=False)
+    finally:
+        engine.set_param("dist_wide", 0)
+        engine.set_param("dist_hot_cap", 0)
+
+
 def test_stage2_spill_and_partition(engine, report, oracle_stage2):
     tup = oracle_stage2("lowcov", max_distance=2)
     engine.set_param("dist_slots", 256)   # forces the (b, d) table to be split by a second hash of b
