@@ -24,8 +24,12 @@ Rank 0 prints ONE JSON line (contract in the task brief) with these extra object
                         whole_step_frac = SURVEY §8(d)'s B_alg of the whole step / ms_per_step / 8 TB/s
   value_incl_transfers  the same step with the H2D of the packed reads and the D2H of the rare set,
                         the unique mask and stored edges inside the timed region
-  cpu_baseline          oracle/c (plain-C port of the reference's stage 2) timed on this host on
-                        bounded samples of the same workload: one thread, and all cores (OpenMP)
+  cpu_baseline          oracle/c (plain-C port of the reference's stage 2) timed on this host on the
+                        benchmark's own reads: A1-A3 whole + A5/A6 for one first-k-mer partition of 64
+                        (x 64), all cores (OpenMP); second leg: the partitioned A5/A6 on one thread
+  parity_vs_committed_oracle   counters + device-side checksum of every stored edge against the 64/64
+                        CPU run of the oracle on the same reads (profiles/r03_full_parity.json)
+  end_to_end            stage 2 + A4 + greedy placement of the same reads (BASELINE configs[2])
 """
 import argparse
 import json
@@ -52,34 +56,66 @@ def synth_kwargs(total_reads, seed):
     return dict(seed=seed, n_units=max(24, int(round(0.3 * total_reads))), var_len=VAR_LEN)
 
 
-def cpu_leg(sample_reads, seed, threads):
-    from centroflye_amd import _host
+def cpu_baseline(a, pk, engine):
+    """The CPU path (oracle/c/cf_oracle_mt.c, the C restatement of the reference's stage 2) timed on THIS host on the
+    benchmark's own reads.  A1-A3 run whole on every core; A5 + A6 (98 % of the CPU time) run for ONE partition of the
+    first k-mers (a % n_parts == part — dist_cnt[d][a] is a's own dict in the reference, so a partition is an independent
+    1 / n_parts of the same work) and are scaled by n_parts: a bounded sample of the same workload, same reads, same
+    emissions per base.  The GPU runs the same partition and must give the same numbers (sample_matches_gpu).
+    Second leg: the same partitioned A5 + A6 on ONE thread (distance stage only)."""
     from oracle import cport
-    pk = _host.synth(n_reads=sample_reads, **synth_kwargs(sample_reads, seed))
     up, us, ue, _ = pk.units(1)
-    t0 = time.time()
-    c, _ = cport.stage2(pk.bases, pk.read_off, up, us, ue, K, PARAMS["max_nonuniq"], PARAMS["lo"], PARAMS["hi"], 0, 2 ** 62,
-                        PARAMS["min_d"], PARAMS["max_d"], PARAMS["min_cov"], PARAMS["rel_threshold"], threads=threads)
-    dt = time.time() - t0
-    cores = 1 if threads is None else (os.cpu_count() if threads == 0 else threads)
+    ncpu = os.cpu_count()
     try:
-        cores = min(cores, len(os.sched_getaffinity(0))) if threads == 0 else cores
+        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
     except AttributeError:
         pass
-    return dict(value=pk.n_bases / dt, unit="bases/s", cores=cores, kind="port",
-                sample=f"{pk.n_reads} reads / {pk.n_bases} bases of the same generator (var_len {VAR_LEN}) at coverage {COVERAGE} "
-                       f"({c['n_emissions']} pair emissions, {dt:.1f} s, "
-                       + ("oracle/c/cf_oracle.c single thread)" if threads is None else f"oracle/c/cf_oracle_mt.c OpenMP, {cores} threads)"),
-                emissions_per_s=c["n_emissions"] / dt)
-
-
-def cpu_baseline(a):
-    one = cpu_leg(a.cpu_sample_reads, a.seed, None)
-    allc = cpu_leg(a.cpu_sample_reads_all, a.seed, 0)
+    n_parts, part = a.cpu_parts, a.cpu_parts // 3
+    with cport.Stage2State(pk.bases, pk.read_off, up, us, ue, K, PARAMS["max_nonuniq"], PARAMS["lo"], PARAMS["hi"], threads=0) as st:
+        w = st.dist_part(part, n_parts, 0, 2 ** 62, PARAMS["min_d"], PARAMS["max_d"], PARAMS["min_cov"], PARAMS["rel_threshold"], threads=0)
+        t_a13 = st.secs_count_select + st.secs_clouds + w["secs_postings"]
+        t_all = t_a13 + n_parts * w["secs"]
+        # the same partition on the GPU (clouds of the last step are still resident)
+        engine.reset_unique()
+        ne = engine.dist_edges(0, 2 ** 62, PARAMS["min_d"], PARAMS["max_d"], PARAMS["min_cov"], PARAMS["rel_threshold"], part, n_parts, edge_cap=w["n_edges"] + 16)
+        gs = engine.stats()
+        match = (ne, gs["n_emissions"], gs["n_unique"], engine.edges_checksum()) == (w["n_edges"], w["n_emissions"], w["n_unique"], w["edge_checksum"]) \
+            and (gs["n_kmers"], gs["n_cloud_entries"]) == (st.counters["n_rare"], st.counters["n_cloud_entries"])
+        allc = dict(value=pk.n_bases / t_all, unit="bases/s", cores=ncpu, kind="port",
+                    sample=f"the benchmark's own {pk.n_reads} reads / {pk.n_bases} bases: A1-A3 whole ({t_a13:.1f} s) + A5/A6 for the first k-mers a % {n_parts} == {part} "
+                           f"({w['n_emissions']} pair emissions, {w['secs']:.1f} s) x {n_parts}; oracle/c/cf_oracle_mt.c OpenMP, {ncpu} threads",
+                    emissions_per_s=w["n_emissions"] / w["secs"], secs=dict(count_select=st.secs_count_select, clouds=st.secs_clouds,
+                                                                           postings=w["secs_postings"], dist_part=w["secs"]),
+                    sample_matches_gpu=bool(match))
+        n1 = a.cpu_parts_1t
+        w1 = st.dist_part(n1 // 3, n1, 0, 2 ** 62, PARAMS["min_d"], PARAMS["max_d"], PARAMS["min_cov"], PARAMS["rel_threshold"], threads=1)
+        one = dict(value=pk.n_bases / (n1 * w1["secs"]), unit="bases/s", cores=1, kind="port",
+                   sample=f"the same reads, distance stage only (A5/A6; A1-A3 of 1 Gb on one thread do not fit a bounded sample): first k-mers a % {n1} == {n1 // 3} "
+                          f"({w1['n_emissions']} pair emissions, {w1['secs']:.1f} s) x {n1}; oracle/c/cf_oracle_mt.c, 1 thread",
+                   emissions_per_s=w1["n_emissions"] / w1["secs"])
     out = dict(allc)                 # the headline leg: every core of the host
     out["host_cpus"] = os.cpu_count()
     out["legs"] = [one, allc]
     return out
+
+
+def committed_parity(out, engine, a, world):
+    """The result of this run against profiles/r03_full_parity.json: the 64 / 64 CPU run of the oracle on the same reads
+    (tools/full_parity.py), i.e. every pair emission and every selected edge of BASELINE configs[2]."""
+    path = os.path.join(ROOT, "profiles", "r03_full_parity.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        fp = json.load(f)
+    wl = fp["workload"]
+    if (wl["reads"], wl["seed"], wl["params"]) != (a.reads, a.seed, PARAMS) or fp["n_bases"] != out["n_bases"]:
+        return None
+    got = dict(n_rare=out["n_rare"], n_cloud_entries=out["n_cloud_entries"], n_emissions=out["n_emissions"], n_edges=out["n_edges"],
+               n_unique=out["n_unique"], n_distinct=out["n_distinct"], n_kept=out["n_kept"], n_windows=out["n_windows"], n_read_kmers=out["n_read_kmers"])
+    if a.edge_cap < 0:
+        got["edge_checksum"] = engine.edges_checksum()       # all selected edges are stored: device-side checksum of the rows
+    return dict(against="profiles/r03_full_parity.json (oracle/c/cf_oracle_mt.c over all 64 first-k-mer partitions of these reads)",
+                checked=sorted(got), match=bool(all(got[k] == fp[k] for k in got)))
 
 
 def rr_leg(engine, pk, no_cpu):
@@ -120,12 +156,13 @@ def parse_args():
     ap.add_argument("--reads", type=int, default=50000, help="reads per GPU")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--edge-cap", type=int, default=-1, help="edges stored per GPU (all are counted); -1 = every selected edge")
-    ap.add_argument("--cpu-sample-reads", type=int, default=150, help="reads of the single-thread CPU leg")
-    ap.add_argument("--cpu-sample-reads-all", type=int, default=1200, help="reads of the all-core CPU leg")
+    ap.add_argument("--cpu-parts", type=int, default=64, help="all-core CPU leg: A5/A6 run for 1 of this many first-k-mer partitions of the bench's reads")
+    ap.add_argument("--cpu-parts-1t", type=int, default=1024, help="one-thread CPU leg: the same with this many partitions")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--transfer-steps", type=int, default=1, help="extra steps timed with H2D / D2H inside (0 = skip)")
     ap.add_argument("--d2h-edge-bytes", type=int, default=4 << 30, help="stored edges copied back in the transfer-inclusive steps, in bytes")
-    ap.add_argument("--place", action="store_true", help="also run stage 3 (A4 + A8/A9 placement) once and report it (N = 1)")
+    ap.add_argument("--place", action="store_true", help="(default at N = 1) also run stage 3 (A4 + A8/A9 placement) once and report it with the end-to-end rate")
+    ap.add_argument("--no-place", action="store_true", help="skip stage 3")
     ap.add_argument("--rr", action="store_true", help="also time read recruitment (SURVEY 8(f) rank 4) on the same reads + as many random ones (N = 1)")
     ap.add_argument("--param", action="append", default=[], help="library knob name=value (cf_set_param)")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1 only: run the multi-GPU exchange path (bucketing, all-to-all, all-gathers, gathered view) through a one-rank RCCL communicator, to price it without wire time")
@@ -140,9 +177,27 @@ def launch_ranks(a):
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), CF_COMM_ID_FILE=idf)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # fail fast: a rank that dies leaves the others waiting in a collective — end them, exit non-zero (this process never
+    # touches a GPU, so it may kill its children)
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                rc = max(rc, abs(code))
+    if rc:
+        for p in live:
+            p.terminate()
+        t_end = time.time() + 10
+        for p in live:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print(f"bench.py: a rank exited with code {rc}; the other ranks were stopped", file=sys.stderr)
     if os.path.isdir(idf):          # (the emulator's file transport of --lib uses a directory)
         import shutil
         shutil.rmtree(idf, ignore_errors=True)
@@ -274,7 +329,8 @@ def main():
             "steps_identical": bool(same),
             "device": E.device_info()["name"].strip(),
         }
-        if world == 1 and a.place:
+        res["parity_vs_committed_oracle"] = committed_parity(out, E, a, world)
+        if world == 1 and not a.no_place:
             # BASELINE configs[2]: cloud_contig extension on the same reads with the k-mers selected above
             t1 = time.perf_counter()
             gk = sr.rare[sr.unique_mask]
@@ -290,17 +346,19 @@ def main():
                                 "classes": np.bincount(cls, minlength=3).tolist(), "clouds_filter_s": t2 - t1, "place_s": t3 - t2,
                                 "place_device_ms": E.times()["place_ms"],
                                 "end_to_end_bases_per_s": n_bases / (ms_per_step * 1e-3 + (t3 - t1))}
+            res["end_to_end"] = {"value": res["placement"]["end_to_end_bases_per_s"], "unit": "bases/s",
+                                 "what": "one stage-2 step (ms_per_step) + A3/A4 on the selected k-mers + greedy placement of all reads (BASELINE configs[2]), reads resident"}
         if world == 1 and a.rr:
             res["read_recruitment"] = rr_leg(E, pk, a.no_cpu_baseline)
-        res["cpu_baseline"] = cpu_baseline(a) if (world == 1 and not a.no_cpu_baseline) else None
+        if world == 1 and not a.no_cpu_baseline:
+            sr.load(pk, 1)       # (stage 3 installed the placer's k-mer set and clouds)
+            sr.run(edge_cap=0, **PARAMS)
+            res["cpu_baseline"] = cpu_baseline(a, pk, E)
+        else:
+            res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
     sr.barrier()
     sr.close()
-    if world > 1 and rank == 0 and "CF_COMM_ID_FILE" not in os.environ:
-        try:
-            os.remove(default_rendezvous())
-        except OSError:
-            pass
 
 
 if __name__ == "__main__":

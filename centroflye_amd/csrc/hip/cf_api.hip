@@ -91,6 +91,8 @@ void cf_free_edges(cf_ctx* c) {
     c->edge_cap = 0; c->n_edges_stored = 0;
 }
 
+void cf_comm_apply_params(cf_ctx* ctx);   // cf_exchange.hip
+
 extern "C" {
 
 int cf_create(int device, cf_ctx** out) {
@@ -360,6 +362,13 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "count_tile") {
         if (value < 1 || value > 64) return cf_fail(ctx, -22, "count_tile out of range");
         ctx->count_tile = (int)value;
+    } else if (n == "comm_round_bytes") {
+        if (value < 16 || value > ((int64_t)1 << 30) || value % 16) return cf_fail(ctx, -22, "comm_round_bytes must be a multiple of 16 in [16, 2^30]");
+        ctx->comm_round_bytes = value;
+        cf_comm_apply_params(ctx);
+    } else if (n == "comm_self_p2p") {
+        ctx->comm_self_p2p = value != 0;
+        cf_comm_apply_params(ctx);
     } else return cf_fail(ctx, -22, "unknown parameter " + n);
     return 0;
 }

@@ -3,20 +3,18 @@
 // New design (the reference has no collective).  xGMI is point to point (7 links per GPU), so the two
 // variable-size exchanges — the owner-bucketed k-mer table (all-to-all) and the rare lists / clouds (all-gather of
 // different sizes) — are ncclSend / ncclRecv pairs inside one ncclGroup: every peer's link carries its own message at the
-// same time, nothing funnels through a ring.  Messages are cut into rounds of at most CF_COMM_ROUND bytes per pair
-// (round 1 finding: a 1.26 GB all_to_all lost rows on this RCCL build while 480 MB arrived whole; both sides of a pair
-// derive the rounds from the pair's byte count alone, so no agreement between ranks is needed).
+// same time, nothing funnels through a ring.  Messages are cut into rounds of at most round_bytes per pair by the
+// loop in cf_comm.h (shared with the CPU suite's file transport); one round = one ncclGroup here.
 // RCCL is loaded with dlopen at cf_comm_init: a single-GPU process never maps it.
 #include "cf_comm.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <chrono>
 #include <thread>
-
-static const int64_t CF_COMM_ROUND = (int64_t)256 << 20;
 
 namespace {
 
@@ -72,30 +70,17 @@ struct rccl_comm : cf_comm {
         return 0;
     }
 
-    int alltoallv(const void* send, const int64_t* soff, const int64_t* sbytes, void* recv, const int64_t* roff,
-                  const int64_t* rbytes, hipStream_t stream, std::string& err) override {
-        if (sbytes[rank] != rbytes[rank]) { err = "alltoallv: self message sizes differ"; return -22; }
-        if (sbytes[rank]) {
-            const hipError_t e = hipMemcpyAsync((char*)recv + roff[rank], (const char*)send + soff[rank], (size_t)sbytes[rank], hipMemcpyDeviceToDevice, stream);
-            if (e != hipSuccess) { err = std::string("alltoallv self copy: ") + hipGetErrorString(e); return -5; }
+    int exchange_round(const char* const* sp, const int64_t* ns, char* const* rp, const int64_t* nr, hipStream_t stream, std::string& err) override {
+        ncclResult_t r = api.GroupStart();
+        if (r != ncclSuccess) return fail(r, "ncclGroupStart", err);
+        for (int p = 0; p < world && r == ncclSuccess; ++p) {      // (p == rank: only with self_p2p — a send to and a receive from the calling rank)
+            if (ns[p]) r = api.Send(sp[p], (size_t)ns[p], ncclUint8, p, comm, stream);
+            if (nr[p] && r == ncclSuccess) r = api.Recv(rp[p], (size_t)nr[p], ncclUint8, p, comm, stream);
         }
-        int64_t most = 0;
-        for (int p = 0; p < world; ++p) if (p != rank) most = std::max(most, std::max(sbytes[p], rbytes[p]));
-        for (int64_t r0 = 0; r0 < most; r0 += CF_COMM_ROUND) {
-            ncclResult_t r = api.GroupStart();
-            if (r != ncclSuccess) return fail(r, "ncclGroupStart", err);
-            for (int p = 0; p < world && r == ncclSuccess; ++p) {
-                if (p == rank) continue;
-                const int64_t ns = std::min(std::max<int64_t>(sbytes[p] - r0, 0), CF_COMM_ROUND);
-                const int64_t nr = std::min(std::max<int64_t>(rbytes[p] - r0, 0), CF_COMM_ROUND);
-                if (ns) r = api.Send((const char*)send + soff[p] + r0, (size_t)ns, ncclUint8, p, comm, stream);
-                if (nr && r == ncclSuccess) r = api.Recv((char*)recv + roff[p] + r0, (size_t)nr, ncclUint8, p, comm, stream);
-            }
-            const ncclResult_t r2 = api.GroupEnd();
-            if (r != ncclSuccess) return fail(r, "ncclSend/ncclRecv", err);
-            if (r2 != ncclSuccess) return fail(r2, "ncclGroupEnd", err);
-        }
-        return sync(stream, "alltoallv", err);
+        const ncclResult_t r2 = api.GroupEnd();
+        if (r != ncclSuccess) return fail(r, "ncclSend/ncclRecv", err);
+        if (r2 != ncclSuccess) return fail(r2, "ncclGroupEnd", err);
+        return 0;
     }
 
     int allgather(const void* send, void* recv, int64_t bytes, hipStream_t stream, std::string& err) override {
@@ -107,7 +92,7 @@ struct rccl_comm : cf_comm {
     int allreduce(void* buf, int64_t count, cf_comm_dtype dt, cf_comm_op op, hipStream_t stream, std::string& err) override {
         const ncclDataType_t t = dt == CF_COMM_U8 ? ncclUint8 : ncclInt64;
         const ncclRedOp_t o = op == CF_COMM_SUM ? ncclSum : ncclMax;
-        const int64_t per = dt == CF_COMM_U8 ? CF_COMM_ROUND : CF_COMM_ROUND / 8;
+        const int64_t per = std::max<int64_t>(1, dt == CF_COMM_U8 ? round_bytes : round_bytes / 8);
         for (int64_t c0 = 0; c0 < count; c0 += per) {
             char* p = (char*)buf + c0 * (dt == CF_COMM_U8 ? 1 : 8);
             const ncclResult_t r = api.AllReduce(p, p, (size_t)std::min(per, count - c0), t, o, comm, stream);
@@ -119,8 +104,41 @@ struct rccl_comm : cf_comm {
 
 }  // namespace
 
-// rank 0 writes the ncclUniqueId to `rendezvous` (tmp + rename), the others poll for it (2 minutes)
+// What rank 0 publishes: a magic word, the time it was written (ns since the epoch) and the id.
+struct rdv_record { uint64_t magic, written_ns; ncclUniqueId id; };
+static const uint64_t RDV_MAGIC = 0x63666364763033ull;      // "cfcdv03"
+static uint64_t wall_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count(); }
+// when this process started (ns since the epoch), from /proc/self/stat; 0 when it cannot be told
+static uint64_t process_start_ns() {
+    FILE* f = std::fopen("/proc/self/stat", "r");
+    if (!f) return 0;
+    char buf[2048];
+    const size_t n = std::fread(buf, 1, sizeof buf - 1, f);
+    std::fclose(f);
+    buf[n] = 0;
+    const char* p = std::strrchr(buf, ')');
+    if (!p) return 0;
+    unsigned long long ticks = 0;
+    int field = 2;      // the field after ") " is number 3 (state); starttime is number 22
+    for (++p; *p && field < 22; ++p) if (*p == ' ') { ++field; if (field == 22) { ticks = std::strtoull(p + 1, nullptr, 10); break; } }
+    f = std::fopen("/proc/uptime", "r");
+    double up = 0;
+    if (!f || std::fscanf(f, "%lf", &up) != 1) { if (f) std::fclose(f); return 0; }
+    std::fclose(f);
+    const long hz = sysconf(_SC_CLK_TCK);
+    if (hz <= 0 || ticks == 0) return 0;
+    const double age = up - (double)ticks / (double)hz;      // seconds since this process started
+    return wall_ns() - (uint64_t)(std::max(age, 0.0) * 1e9);
+}
+
+// rank 0 writes {magic, time, ncclUniqueId} to `<rendezvous>.<n>` for the n-th communicator of this process (tmp + rename;
+// a leftover of that name is removed first), the others poll for it (2 minutes) and ignore a file written more than
+// CF_RDV_SLACK_S before they started (a leftover of a crashed launch under a reused name); rank 0 removes the file once
+// ncclCommInitRank has returned (every rank has joined by then).
+static const double CF_RDV_SLACK_S = 120.0;
 cf_comm* cf_comm_open(int device, int rank, int world, const char* rendezvous, std::string& err) {
+    static int generation = 0;      // ranks open their communicators in the same order
+    const int gen = generation++;
     if (world < 1 || rank < 0 || rank >= world) { err = "cf_comm_init: bad rank / world"; return nullptr; }
     if (world > 1 && (!rendezvous || !*rendezvous)) { err = "cf_comm_init: a rendezvous path is needed for world > 1"; return nullptr; }
     rccl_comm* c = new (std::nothrow) rccl_comm();
@@ -135,28 +153,37 @@ cf_comm* cf_comm_open(int device, int rank, int world, const char* rendezvous, s
         StdoutToStderr() { std::fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
         ~StdoutToStderr() { std::fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
     } quiet;
-    ncclUniqueId id;
-    std::memset(&id, 0, sizeof id);
+    const std::string path = (rendezvous ? std::string(rendezvous) : std::string()) + "." + std::to_string(gen);
+    rdv_record rec;
+    std::memset(&rec, 0, sizeof rec);
     if (rank == 0) {
-        const ncclResult_t r = c->api.GetUniqueId(&id);
+        if (world > 1) (void)std::remove(path.c_str());      // a leftover of an earlier launch under the same name
+        const ncclResult_t r = c->api.GetUniqueId(&rec.id);
         if (r != ncclSuccess) { c->fail(r, "ncclGetUniqueId", err); delete c; return nullptr; }
         if (world > 1) {
-            const std::string tmp = std::string(rendezvous) + ".tmp" + std::to_string((long)getpid());
+            rec.magic = RDV_MAGIC; rec.written_ns = wall_ns();
+            const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
             FILE* f = std::fopen(tmp.c_str(), "wb");
-            const bool ok = f && std::fwrite(&id, sizeof id, 1, f) == 1;
+            const bool ok = f && std::fwrite(&rec, sizeof rec, 1, f) == 1;
             if (f) std::fclose(f);
-            if (!ok || std::rename(tmp.c_str(), rendezvous) != 0) { err = std::string("cf_comm_init: cannot write ") + rendezvous; delete c; return nullptr; }
+            if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) { err = std::string("cf_comm_init: cannot write ") + path; delete c; return nullptr; }
         }
     } else {
-        bool got = false;
+        const uint64_t born = process_start_ns();
+        bool got = false, stale = false;
         for (int i = 0; i < 2400 && !got; ++i) {
-            FILE* f = std::fopen(rendezvous, "rb");
-            if (f) { got = std::fread(&id, sizeof id, 1, f) == 1; std::fclose(f); }
+            FILE* f = std::fopen(path.c_str(), "rb");
+            if (f) {
+                got = std::fread(&rec, sizeof rec, 1, f) == 1 && rec.magic == RDV_MAGIC;
+                std::fclose(f);
+                if (got && born && rec.written_ns + (uint64_t)(CF_RDV_SLACK_S * 1e9) < born) { got = false; stale = true; }      // older than this launch: wait for rank 0 to replace it
+            }
             if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(50));
         }
-        if (!got) { err = std::string("cf_comm_init: timed out waiting for ") + rendezvous; delete c; return nullptr; }
+        if (!got) { err = std::string("cf_comm_init: timed out waiting for ") + path + (stale ? " (only a stale file of an earlier launch was there)" : ""); delete c; return nullptr; }
     }
-    const ncclResult_t r = c->api.CommInitRank(&c->comm, world, id, rank);
+    const ncclResult_t r = c->api.CommInitRank(&c->comm, world, rec.id, rank);
+    if (rank == 0 && world > 1) (void)std::remove(path.c_str());      // every rank has read it
     if (r != ncclSuccess) { c->fail(r, "ncclCommInitRank", err); c->comm = nullptr; delete c; return nullptr; }
     return c;
 }

@@ -140,6 +140,8 @@ struct cf_ctx {
     int count_bits = 0;          // bucket bits of the sort-and-reduce path; 0 = from the number of windows (tests force small / large values)
     int count_slots = 4096;
     int count_tile = 16;
+    int64_t comm_round_bytes = (int64_t)256 << 20;   // bytes per pair and round of the multi-GPU exchanges (tests force small rounds)
+    int comm_self_p2p = 0;       // 1: a rank's message to itself goes through ncclSend / ncclRecv too (tests: the p2p path on one GPU)
 };
 
 int cf_fail(cf_ctx* ctx, int code, const std::string& msg);

@@ -1127,7 +1127,43 @@ cf_max_u32_kernel(const uint32_t* __restrict__ v, int64_t n, uint32_t* __restric
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
+// order-independent checksum of stored edges: sum over rows of mix(d, a, b, cnt) mod 2^64 (the oracle's edge checksum:
+// tests compare all 3e9 edges of a full-size run without copying 50 GB to the host)
+__global__ void __launch_bounds__(256)
+cf_edge_checksum_kernel(const uint32_t* __restrict__ edges, int64_t n, unsigned long long* __restrict__ out) {
+    unsigned long long s = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const cf_u32x4 e = *(const cf_u32x4*)(edges + 4 * i);
+        s += cf_mix64(cf_mix64(cf_mix64(cf_mix64((unsigned long long)e.x + 0x9E37ull) ^ (unsigned long long)e.y) ^ ((unsigned long long)e.z << 1)) ^ ((unsigned long long)e.w << 2));
+    }
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, (unsigned)d);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
 extern "C" {
+
+int cf_edges_checksum(cf_ctx* ctx, int64_t n, uint64_t* out) {
+    if (!ctx || !out) return -22;
+    *out = 0;
+    n = std::min(n, ctx->n_edges_stored);
+    if (n <= 0) return 0;
+    CF_HIP(hipSetDevice(ctx->device));
+    unsigned long long* d_sum = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &d_sum, 1, "edge checksum"));
+    int rc = 0;
+    unsigned long long h = 0;
+    if (hipMemsetAsync(d_sum, 0, 8, ctx->stream) != hipSuccess) rc = cf_fail(ctx, -5, "edge checksum memset");
+    if (!rc) {
+        hipLaunchKernelGGL(cf_edge_checksum_kernel, dim3((unsigned)cf_grid_for(n, 256, std::max(1, ctx->n_cu) * 16)), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)ctx->d_edges, n, d_sum);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) rc = cf_fail(ctx, -5, "edge checksum kernel");
+    }
+    cf_release_t(ctx, d_sum, 1);
+    if (!rc) *out = (uint64_t)h;
+    return rc;
+}
 
 int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int32_t max_d, uint32_t min_cov,
                   double rel_threshold, int32_t part, int32_t n_parts, int64_t edge_cap, int64_t* n_edges) {

@@ -173,6 +173,12 @@ int allgatherv(cf_ctx* ctx, Bufs& keep, const void* d_mine, int64_t my_bytes, ch
 
 }  // namespace
 
+void cf_comm_apply_params(cf_ctx* ctx) {
+    if (!ctx->comm) return;
+    ctx->comm->round_bytes = ctx->comm_round_bytes;
+    ctx->comm->self_p2p = ctx->comm_self_p2p != 0;
+}
+
 extern "C" {
 
 int cf_comm_init(cf_ctx* ctx, int32_t rank, int32_t world, const char* rendezvous) {
@@ -183,6 +189,7 @@ int cf_comm_init(cf_ctx* ctx, int32_t rank, int32_t world, const char* rendezvou
     cf_comm* c = cf_comm_open(ctx->device, rank, world, rendezvous, err);
     if (!c) return cf_fail(ctx, -5, err);
     ctx->comm = c;
+    cf_comm_apply_params(ctx);
     return 0;
 }
 

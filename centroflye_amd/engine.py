@@ -254,6 +254,12 @@ class Engine:
         """Sort the stored edges by (d, a, b) on the device."""
         self._check(self._lib.cf_sort_edges(self._ctx), "cf_sort_edges")
 
+    def edges_checksum(self, n=2 ** 62):
+        """Order-independent checksum of the first n stored edges, computed on the device (see cfhip.h)."""
+        out = C.c_uint64()
+        self._check(self._lib.cf_edges_checksum(self._ctx, int(n), C.byref(out)), "cf_edges_checksum")
+        return int(out.value)
+
     def unique_mask(self):
         n = self.stats()["n_kmers"]
         out = np.zeros(n, np.uint8)

@@ -122,6 +122,11 @@ int cf_get_edges(cf_ctx* ctx, uint32_t* out /* n x 4: d, a, b, cnt */, int64_t c
  * order, distance_based_kmer_recruitment.py:165-171, is the insertion order of its dicts and is not reproduced).  Only
  * meaningful when every selected edge was stored (edge_cap >= n_edges of the last cf_dist_edges call). */
 int cf_sort_edges(cf_ctx* ctx);
+/* Order-independent checksum of the first min(n, stored) edges, computed on the device: the sum over rows (d, a, b, cnt) of
+ * mix(mix(mix(mix(d + 0x9E37) ^ a) ^ (b << 1)) ^ (cnt << 2)) mod 2^64 with the 64-bit finaliser of MurmurHash3 as mix (the
+ * same figure the oracle reports; full-size parity checks compare every selected edge of
+ * distance_based_kmer_recruitment.py:131-149 without copying tens of GB to the host). */
+int cf_edges_checksum(cf_ctx* ctx, int64_t n, uint64_t* out);
 int cf_get_unique_mask(cf_ctx* ctx, uint8_t* mask /* n_kmers bytes of 0/1 */);
 int cf_or_unique_mask(cf_ctx* ctx, const uint8_t* mask);
 int cf_reset_unique(cf_ctx* ctx);
@@ -171,7 +176,7 @@ int cf_allreduce_unique(cf_ctx* ctx, int64_t* n_unique);
 /* Tuning knobs (defaults are chosen for gfx950): name in {"dist_block" (threads per workgroup, 0 = auto), "dist_wgs"
  * (workgroups per CU the LDS is split between, 0 = auto: by the pair emissions per first k-mer), "dist_slots" (LDS budget of the (b,d) table in 8-byte units, 0 = all that
  * is left), "dist_sketch" (0: every pair goes to the exact table), "dist_fill_pct", "dist_est_pct", "dist_stage",
- * "dist_wide", "dist_hot_cap" (tests: a small cap on the filter's hot-slot list forces the evaluation inside the bucket scan), "dist_regions" (1, 2, 4, 8: force the region layout of the 6-byte slots, which k-mer sets of 2^24 .. 2^27 ranks with long reads take by themselves), "dist_dbits" (5 .. 8: cap on the distance-field bits of the 6-byte table slots [d | b]; 0 = 32 minus the bits the k-mer ranks need), "place_chunk", "place_grid" (cloud entries per wave step and workgroups of the fused placement kernel), "place_fused" (1: score updates applied by the waves that lay a read onto the contig, 0: through an event list and a third kernel per greedy iteration), "count_mode" (1: A1 by sort and reduce, 0: the atomic table), "count_bits" (bucket bits of the former, 0 = auto), "count_slots", "count_tile"}.  Results never depend on them (tests/test_gpu_parity.py). */
+ * "dist_wide", "dist_hot_cap" (tests: a small cap on the filter's hot-slot list forces the evaluation inside the bucket scan), "dist_regions" (1, 2, 4, 8: force the region layout of the 6-byte slots, which k-mer sets of 2^24 .. 2^27 ranks with long reads take by themselves), "dist_dbits" (5 .. 8: cap on the distance-field bits of the 6-byte table slots [d | b]; 0 = 32 minus the bits the k-mer ranks need), "place_chunk", "place_grid" (cloud entries per wave step and workgroups of the fused placement kernel), "place_fused" (1: score updates applied by the waves that lay a read onto the contig, 0: through an event list and a third kernel per greedy iteration), "count_mode" (1: A1 by sort and reduce, 0: the atomic table), "count_bits" (bucket bits of the former, 0 = auto), "count_slots", "count_tile", "comm_round_bytes" (bytes per pair of ranks and round of the multi-GPU exchanges, default 2^28; tests force many rounds), "comm_self_p2p" (1: the message a rank sends to itself goes through ncclSend / ncclRecv like every other one, so that a one-GPU box runs the whole p2p path)}.  Results never depend on them (tests/test_gpu_parity.py). */
 int cf_set_param(cf_ctx* ctx, const char* name, int64_t value);
 
 /* Self-tests of the device primitives against host results (used by tests/ only). */

@@ -84,20 +84,47 @@ static int push64(vec64* a, uint64_t x) {
 }
 
 /*
- * Whole stage 2 on n_threads threads (<= 0: all).  stop_after = 1 ends after A2 (BASELINE configs[1]: count + rare filter).
- * Optional outputs as in cfo_stage2, plus table_checksum (sum of cfo_table_mix over every distinct k-mer).
- * Returns 0, or -1 (non-ACGT), -2 (out of memory), -3 (an output buffer is too small).
+ * State kept between the two halves of stage 2: cfo_mt_prepare runs A1-A3 once (all threads), cfo_mt_dist_part runs
+ * A5 + A6 for the first k-mers a with a % n_parts == part (dist_cnt[d][a] is a's own dict in the reference,
+ * distance_based_kmer_recruitment.py:108-113, so any subset of the a's is an independent piece of the same result).
+ * The full-size parity test and bench.py's cpu_baseline use the partitioned form on the benchmark's own reads.
  */
-int cfo_stage2_mt(const uint8_t* bases, const int64_t* read_off, int64_t n_reads, const int64_t* unit_ptr,
-                  const int64_t* unit_start, const int64_t* unit_end, int k, int max_nonuniq, uint32_t lo, uint32_t hi,
-                  int64_t min_n, int64_t max_n, int min_d, int max_d, uint32_t min_cov, double rel_threshold,
-                  cfo_result* res, uint64_t* rare_out, int64_t rare_cap, int64_t* cloud_ptr_out, int32_t* entries_out,
-                  int64_t entries_cap, uint32_t* edges_out, int64_t edges_cap, uint8_t* unique_out,
-                  int n_threads, int stop_after, uint64_t* table_checksum) {
+typedef struct {
+    int64_t n_reads, n_rare, U, n_ent;
+    int64_t* unit_ptr;       /* copy, n_reads + 1 */
+    uint64_t* rare;
+    int64_t* cptr;
+    int32_t* ent;
+    /* postings of the reads [post_min_n, post_max_n), built on first use */
+    int64_t post_min_n, post_max_n;
+    int64_t* pptr; int32_t* post; int32_t* rend;
+} cfo_mt_state;
+
+static double now_s(void) { return omp_get_wtime(); }
+
+void cfo_mt_free(void* h) {
+    cfo_mt_state* st = (cfo_mt_state*)h;
+    if (!st) return;
+    free(st->unit_ptr); free(st->rare); free(st->cptr); free(st->ent); free(st->pptr); free(st->post); free(st->rend);
+    free(st);
+}
+
+/*
+ * A1 + A2 (+ A3 unless stop_after == 1) on n_threads threads (<= 0: all).  secs (optional, 2 doubles): A1 + A2, A3.
+ * Returns the state (NULL on failure, *rc_out = -1 non-ACGT, -2 out of memory).
+ */
+void* cfo_mt_prepare(const uint8_t* bases, const int64_t* read_off, int64_t n_reads, const int64_t* unit_ptr,
+                     const int64_t* unit_start, const int64_t* unit_end, int k, int max_nonuniq, uint32_t lo, uint32_t hi,
+                     int n_threads, int stop_after, cfo_result* res, uint64_t* table_checksum, double* secs, int* rc_out) {
     int rc = 0;
     int64_t r, max_len = 0, n_w = 0;
+    const double t_begin = now_s();
     memset(res, 0, sizeof *res);
     if (n_threads <= 0) n_threads = omp_get_max_threads();
+    cfo_mt_state* st = (cfo_mt_state*)calloc(1, sizeof *st);
+    if (!st) { *rc_out = -2; return NULL; }
+    st->n_reads = n_reads;
+    st->post_min_n = st->post_max_n = -1;
     for (r = 0; r < n_reads; ++r) {
         int64_t len = read_off[r + 1] - read_off[r];
         if (len > max_len) max_len = len;
@@ -215,20 +242,24 @@ int cfo_stage2_mt(const uint8_t* bases, const int64_t* read_off, int64_t n_reads
     qsort(rare, (size_t)n_rare, 8, cmp_u64);
     res->n_rare = n_rare;
     for (int64_t i = 0; i < n_rare; ++i) res->rare_checksum += cfo_key_mix(rare[i]);
-    if (rare_out) {
-        if (rare_cap < n_rare) { rc = -3; goto done; }
-        memcpy(rare_out, rare, 8 * (size_t)n_rare);
-    }
+    st->rare = rare; st->n_rare = n_rare; rare = NULL;
+    /* the A1 work arrays are not needed any more */
+    for (int t = 0; t < T; ++t) { free(parts[t]); parts[t] = NULL; }
+    if (secs) secs[0] = now_s() - t_begin;
     if (stop_after == 1) goto done;
     /* ---- A3: units in parallel, each cloud in its own block, then one CSR */
     {
+        const double t_a3 = now_s();
         const int64_t U = unit_ptr[n_reads];
+        const uint64_t* rk = st->rare;
         res->n_units = U;
+        st->U = U;
         int32_t** uc = (int32_t**)calloc((size_t)U + 1, sizeof(int32_t*));
         int64_t* cptr = (int64_t*)calloc((size_t)U + 1, 8);
         int32_t* ent = NULL;
-        int64_t* pptr = NULL; int32_t* post = NULL; int32_t* rend = NULL; uint8_t* uniq = NULL;
-        if (!uc || !cptr) { rc = -2; goto done3; }
+        st->unit_ptr = (int64_t*)malloc(8 * (size_t)(n_reads + 1));
+        if (!uc || !cptr || !st->unit_ptr) { rc = -2; goto done3; }
+        memcpy(st->unit_ptr, unit_ptr, 8 * (size_t)(n_reads + 1));
 #pragma omp parallel num_threads(T)
         {
             uint64_t* buf = (uint64_t*)malloc(8 * (size_t)(max_len + 1));
@@ -241,8 +272,8 @@ int cfo_stage2_mt(const uint8_t* bases, const int64_t* read_off, int64_t n_reads
                 int32_t* e = (int32_t*)malloc(4 * (size_t)(n + 1));
                 if (!e) { bad = -2; continue; }
                 for (i = 0; i < n; ++i) {
-                    int64_t p = lower_bound(rare, n_rare, buf[i]);
-                    if (p < n_rare && rare[p] == buf[i]) e[m++] = (int32_t)p;
+                    int64_t p = lower_bound(rk, n_rare, buf[i]);
+                    if (p < n_rare && rk[p] == buf[i]) e[m++] = (int32_t)p;
                 }
                 qsort(e, (size_t)m, 4, cmp_i32);
                 int64_t w = 0;
@@ -272,121 +303,213 @@ int cfo_stage2_mt(const uint8_t* bases, const int64_t* read_off, int64_t n_reads
             res->cloud_checksum = cchk;
         }
         res->n_cloud_entries = n_ent;
-        if (cloud_ptr_out) memcpy(cloud_ptr_out, cptr, 8 * (size_t)(U + 1));
-        if (entries_out) {
-            if (entries_cap < n_ent) { rc = -3; goto done3; }
-            memcpy(entries_out, ent, 4 * (size_t)n_ent);
-        }
-        if (stop_after == 2) goto done3;
-        /* ---- A5 + A6 */
-        if (min_n < 0) min_n = 0;
-        if (max_n > n_reads) max_n = n_reads;
-        if (max_n < min_n) max_n = min_n;
-        if (min_d < 1) min_d = 1;
-        {
-            const int64_t u_lo = unit_ptr[min_n], u_hi = unit_ptr[max_n];
-            pptr = (int64_t*)calloc((size_t)n_rare + 2, 8);
-            post = (int32_t*)malloc(4 * (size_t)(cptr[u_hi] - cptr[u_lo] + 1));
-            rend = (int32_t*)malloc(4 * (size_t)(U + 1));
-            uniq = (uint8_t*)calloc((size_t)n_rare + 1, 1);
-            if (!pptr || !post || !rend || !uniq) { rc = -2; goto done3; }
-            for (int64_t e = cptr[u_lo]; e < cptr[u_hi]; ++e) pptr[ent[e] + 2]++;
-            for (int64_t i = 0; i < n_rare; ++i) pptr[i + 2] += pptr[i + 1];
-            for (int64_t u = u_lo; u < u_hi; ++u)
-                for (int64_t e = cptr[u]; e < cptr[u + 1]; ++e) post[pptr[ent[e] + 1]++] = (int32_t)u;
-            for (r = 0; r < n_reads; ++r)
-                for (int64_t u = unit_ptr[r]; u < unit_ptr[r + 1]; ++u) rend[u] = (int32_t)unit_ptr[r + 1];
-            int64_t n_em = 0, n_edges = 0;
-            uint64_t echk = 0;
-#pragma omp parallel num_threads(T) reduction(+ : n_em, echk)
-            {
-                uint64_t hcap = 1 << 12;
-                uint64_t* hk = (uint64_t*)malloc(8 * hcap);
-                uint32_t* hv = (uint32_t*)malloc(4 * hcap);
-                int bad = (hk && hv) ? 0 : -2;
-#pragma omp for schedule(dynamic, 64)
-                for (int64_t a = 0; a < n_rare; ++a) {
-                    if (bad) continue;
-                    const int64_t p0 = pptr[a], p1 = pptr[a + 1];
-                    if (p0 == p1) continue;
-                    int64_t em = 0;
-                    for (int64_t p = p0; p < p1; ++p) {
-                        int32_t g = post[p], jlo = g + min_d, jhi = rend[g] - 1 < g + max_d ? rend[g] - 1 : g + max_d;
-                        if (jhi >= jlo) em += cptr[jhi + 1] - cptr[jlo];
-                    }
-                    if (!em) continue;
-                    uint64_t need = 16;
-                    while (need < (uint64_t)em * 2) need <<= 1;
-                    if (need > hcap) {
-                        free(hk); free(hv);
-                        hcap = need;
-                        hk = (uint64_t*)malloc(8 * hcap); hv = (uint32_t*)malloc(4 * hcap);
-                        if (!hk || !hv) { bad = -2; continue; }
-                    }
-                    memset(hk, 0, 8 * need);
-                    for (int64_t p = p0; p < p1; ++p) {
-                        int32_t g = post[p], jlo = g + min_d, jhi = rend[g] - 1 < g + max_d ? rend[g] - 1 : g + max_d;
-                        for (int32_t j = jlo; j <= jhi; ++j) {
-                            const uint64_t d = (uint64_t)(j - g);
-                            for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
-                                const uint64_t b = (uint64_t)ent[e];
-                                if ((int64_t)b == a) continue;
-                                ++n_em;
-                                const uint64_t key = ((b << 9) | d) + 1;
-                                uint64_t h = mix64(key) & (need - 1);
-                                while (hk[h] && hk[h] != key) h = (h + 1) & (need - 1);
-                                if (!hk[h]) { hk[h] = key; hv[h] = 0; }
-                                hv[h]++;
-                            }
-                        }
-                    }
-                    for (uint64_t s = 0; s < need; ++s) {
-                        if (!hk[s] || hv[s] < min_cov) continue;
-                        const uint64_t b = (hk[s] - 1) >> 9, d = (hk[s] - 1) & 511;
-                        uint64_t total = 0;
-                        for (int dd = min_d; dd <= max_d; ++dd) {
-                            const uint64_t key = ((b << 9) | (uint64_t)dd) + 1;
-                            uint64_t h = mix64(key) & (need - 1);
-                            while (hk[h] && hk[h] != key) h = (h + 1) & (need - 1);
-                            if (hk[h]) total += hv[h];
-                        }
-                        if ((double)hv[s] / (double)total >= rel_threshold) {
-                            int64_t at;
-#pragma omp atomic capture
-                            at = n_edges++;
-                            if (edges_out) {
-                                if (at >= edges_cap) { bad = -3; break; }
-                                uint32_t* E = edges_out + 4 * at;
-                                E[0] = (uint32_t)d; E[1] = (uint32_t)a; E[2] = (uint32_t)b; E[3] = hv[s];
-                            }
-                            echk += cfo_edge_mix(d, (uint64_t)a, b, hv[s]);
-#pragma omp atomic write
-                            uniq[a] = 1;
-#pragma omp atomic write
-                            uniq[b] = 1;
-                        }
-                    }
-                }
-                free(hk); free(hv);
-                if (bad) {
-#pragma omp critical
-                    rc = bad;
-                }
-            }
-            res->n_emissions = n_em;
-            res->n_edges = n_edges;
-            res->edge_checksum = echk;
-            for (int64_t i = 0; i < n_rare; ++i) res->n_unique += uniq[i];
-            if (unique_out && !rc) memcpy(unique_out, uniq, (size_t)n_rare);
-        }
+        st->cptr = cptr; st->ent = ent; st->n_ent = n_ent;
+        cptr = NULL; ent = NULL;
+        if (secs) secs[1] = now_s() - t_a3;
     done3:
         if (uc) for (int64_t u = 0; u < U; ++u) free(uc[u]);
-        free(uc); free(cptr); free(ent); free(pptr); free(post); free(rend); free(uniq);
+        free(uc); free(cptr); free(ent);
     }
 done:
     if (recs) for (int t = 0; t < T; ++t) free(recs[t].v);
     if (parts) for (int t = 0; t < T; ++t) free(parts[t]);
     if (rare_parts) for (int b = 0; b < NB; ++b) free(rare_parts[b].v);
     free(recs); free(cnt); free(offs); free(parts); free(rare_parts); free(rare);
+    *rc_out = rc;
+    if (rc) { cfo_mt_free(st); return NULL; }
+    return st;
+}
+
+/* counters of one A5 + A6 run over a partition of the first k-mers */
+typedef struct {
+    int64_t n_emissions, n_edges, n_unique, n_first_kmers;
+    uint64_t edge_checksum;
+    double secs;             /* A5 + A6 alone (postings excluded: they are built once per read range) */
+    double secs_postings;    /* 0 when the postings of this read range were already there */
+} cfo_part_result;
+
+/*
+ * A5 + A6 for the first k-mers a % n_parts == part on n_threads threads (<= 0: all).  unique_out (optional, n_rare
+ * bytes, ZEROED by the caller or carrying earlier partitions): the k-mers a, b of this partition's edges are set to 1.
+ * edges_out (optional): (d, a, b, cnt) rows in no particular order.  Returns 0, -2 (memory), -3 (edges_cap too small).
+ */
+int cfo_mt_dist_part(void* h, int64_t min_n, int64_t max_n, int min_d, int max_d, uint32_t min_cov, double rel_threshold,
+                     int part, int n_parts, int n_threads, cfo_part_result* out, uint8_t* unique_out, uint32_t* edges_out,
+                     int64_t edges_cap) {
+    cfo_mt_state* st = (cfo_mt_state*)h;
+    int rc = 0;
+    memset(out, 0, sizeof *out);
+    if (!st || !st->cptr || n_parts < 1 || part < 0 || part >= n_parts) return -22;
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+    const int T = n_threads;
+    const int64_t n_reads = st->n_reads, n_rare = st->n_rare, U = st->U;
+    const int64_t* cptr = st->cptr;
+    const int32_t* ent = st->ent;
+    if (min_n < 0) min_n = 0;
+    if (max_n > n_reads) max_n = n_reads;
+    if (max_n < min_n) max_n = min_n;
+    if (min_d < 1) min_d = 1;
+    if (st->post_min_n != min_n || st->post_max_n != max_n) {
+        const double t0 = now_s();
+        const int64_t u_lo = st->unit_ptr[min_n], u_hi = st->unit_ptr[max_n];
+        free(st->pptr); free(st->post); free(st->rend);
+        st->pptr = (int64_t*)calloc((size_t)n_rare + 2, 8);
+        st->post = (int32_t*)malloc(4 * (size_t)(cptr[u_hi] - cptr[u_lo] + 1));
+        st->rend = (int32_t*)malloc(4 * (size_t)(U + 1));
+        st->post_min_n = st->post_max_n = -1;
+        if (!st->pptr || !st->post || !st->rend) return -2;
+        int64_t* pptr = st->pptr;
+        for (int64_t e = cptr[u_lo]; e < cptr[u_hi]; ++e) pptr[ent[e] + 2]++;
+        for (int64_t i = 0; i < n_rare; ++i) pptr[i + 2] += pptr[i + 1];
+        for (int64_t u = u_lo; u < u_hi; ++u)
+            for (int64_t e = cptr[u]; e < cptr[u + 1]; ++e) st->post[pptr[ent[e] + 1]++] = (int32_t)u;
+        for (int64_t r = 0; r < n_reads; ++r)
+            for (int64_t u = st->unit_ptr[r]; u < st->unit_ptr[r + 1]; ++u) st->rend[u] = (int32_t)st->unit_ptr[r + 1];
+        st->post_min_n = min_n; st->post_max_n = max_n;
+        out->secs_postings = now_s() - t0;
+    }
+    const int64_t* pptr = st->pptr;
+    const int32_t* post = st->post;
+    const int32_t* rend = st->rend;
+    uint8_t* uniq = (uint8_t*)calloc((size_t)n_rare + 1, 1);
+    if (!uniq) return -2;
+    const double t1 = now_s();
+    int64_t n_em = 0, n_edges = 0, n_first = 0;
+    uint64_t echk = 0;
+#pragma omp parallel num_threads(T) reduction(+ : n_em, echk, n_first)
+    {
+        uint64_t hcap = 1 << 12;
+        uint64_t* hk = (uint64_t*)malloc(8 * hcap);
+        uint32_t* hv = (uint32_t*)malloc(4 * hcap);
+        int bad = (hk && hv) ? 0 : -2;
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t a = part; a < n_rare; a += n_parts) {
+            if (bad) continue;
+            const int64_t p0 = pptr[a], p1 = pptr[a + 1];
+            if (p0 == p1) continue;
+            int64_t em = 0;
+            for (int64_t p = p0; p < p1; ++p) {
+                int32_t g = post[p], jlo = g + min_d, jhi = rend[g] - 1 < g + max_d ? rend[g] - 1 : g + max_d;
+                if (jhi >= jlo) em += cptr[jhi + 1] - cptr[jlo];
+            }
+            if (!em) continue;
+            ++n_first;
+            uint64_t need = 16;
+            while (need < (uint64_t)em * 2) need <<= 1;
+            if (need > hcap) {
+                free(hk); free(hv);
+                hcap = need;
+                hk = (uint64_t*)malloc(8 * hcap); hv = (uint32_t*)malloc(4 * hcap);
+                if (!hk || !hv) { bad = -2; continue; }
+            }
+            memset(hk, 0, 8 * need);
+            for (int64_t p = p0; p < p1; ++p) {
+                int32_t g = post[p], jlo = g + min_d, jhi = rend[g] - 1 < g + max_d ? rend[g] - 1 : g + max_d;
+                for (int32_t j = jlo; j <= jhi; ++j) {
+                    const uint64_t d = (uint64_t)(j - g);
+                    for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) {
+                        const uint64_t b = (uint64_t)ent[e];
+                        if ((int64_t)b == a) continue;
+                        ++n_em;
+                        const uint64_t key = ((b << 17) | d) + 1;
+                        uint64_t hh = mix64(key) & (need - 1);
+                        while (hk[hh] && hk[hh] != key) hh = (hh + 1) & (need - 1);
+                        if (!hk[hh]) { hk[hh] = key; hv[hh] = 0; }
+                        hv[hh]++;
+                    }
+                }
+            }
+            for (uint64_t s = 0; s < need; ++s) {
+                if (!hk[s] || hv[s] < min_cov) continue;
+                const uint64_t b = (hk[s] - 1) >> 17, d = (hk[s] - 1) & 0x1FFFF;
+                uint64_t total = 0;
+                for (int dd = min_d; dd <= max_d; ++dd) {
+                    const uint64_t key = ((b << 17) | (uint64_t)dd) + 1;
+                    uint64_t hh = mix64(key) & (need - 1);
+                    while (hk[hh] && hk[hh] != key) hh = (hh + 1) & (need - 1);
+                    if (hk[hh]) total += hv[hh];
+                }
+                if ((double)hv[s] / (double)total >= rel_threshold) {
+                    int64_t at;
+#pragma omp atomic capture
+                    at = n_edges++;
+                    if (edges_out) {
+                        if (at >= edges_cap) { bad = -3; break; }
+                        uint32_t* E = edges_out + 4 * at;
+                        E[0] = (uint32_t)d; E[1] = (uint32_t)a; E[2] = (uint32_t)b; E[3] = hv[s];
+                    }
+                    echk += cfo_edge_mix(d, (uint64_t)a, b, hv[s]);
+#pragma omp atomic write
+                    uniq[a] = 1;
+#pragma omp atomic write
+                    uniq[b] = 1;
+                }
+            }
+        }
+        free(hk); free(hv);
+        if (bad) {
+#pragma omp critical
+            rc = bad;
+        }
+    }
+    out->secs = now_s() - t1;
+    out->n_emissions = n_em;
+    out->n_edges = n_edges;
+    out->edge_checksum = echk;
+    out->n_first_kmers = n_first;
+    for (int64_t i = 0; i < n_rare; ++i) out->n_unique += uniq[i];
+    if (unique_out && !rc)
+        for (int64_t i = 0; i < n_rare; ++i) unique_out[i] |= uniq[i];
+    free(uniq);
+    return rc;
+}
+
+/* read-only views of the state (tests compare them with the device's arrays) */
+int64_t cfo_mt_n_rare(const void* h) { return ((const cfo_mt_state*)h)->n_rare; }
+int cfo_mt_get(const void* h, uint64_t* rare_out, int64_t* cloud_ptr_out, int32_t* entries_out) {
+    const cfo_mt_state* st = (const cfo_mt_state*)h;
+    if (rare_out) memcpy(rare_out, st->rare, 8 * (size_t)st->n_rare);
+    if (cloud_ptr_out) { if (!st->cptr) return -22; memcpy(cloud_ptr_out, st->cptr, 8 * (size_t)(st->U + 1)); }
+    if (entries_out) { if (!st->ent) return -22; memcpy(entries_out, st->ent, 4 * (size_t)st->n_ent); }
+    return 0;
+}
+
+/*
+ * Whole stage 2 on n_threads threads (<= 0: all).  stop_after = 1 ends after A2 (BASELINE configs[1]: count + rare filter).
+ * Optional outputs as in cfo_stage2, plus table_checksum (sum of cfo_table_mix over every distinct k-mer).
+ * Returns 0, or -1 (non-ACGT), -2 (out of memory), -3 (an output buffer is too small).
+ */
+int cfo_stage2_mt(const uint8_t* bases, const int64_t* read_off, int64_t n_reads, const int64_t* unit_ptr,
+                  const int64_t* unit_start, const int64_t* unit_end, int k, int max_nonuniq, uint32_t lo, uint32_t hi,
+                  int64_t min_n, int64_t max_n, int min_d, int max_d, uint32_t min_cov, double rel_threshold,
+                  cfo_result* res, uint64_t* rare_out, int64_t rare_cap, int64_t* cloud_ptr_out, int32_t* entries_out,
+                  int64_t entries_cap, uint32_t* edges_out, int64_t edges_cap, uint8_t* unique_out,
+                  int n_threads, int stop_after, uint64_t* table_checksum) {
+    int rc = 0;
+    cfo_mt_state* st = (cfo_mt_state*)cfo_mt_prepare(bases, read_off, n_reads, unit_ptr, unit_start, unit_end, k, max_nonuniq, lo, hi,
+                                                     n_threads, stop_after, res, table_checksum, NULL, &rc);
+    if (!st) return rc;
+    if (rare_out) {
+        if (rare_cap < st->n_rare) { rc = -3; goto done; }
+        memcpy(rare_out, st->rare, 8 * (size_t)st->n_rare);
+    }
+    if (stop_after == 1) goto done;
+    if (cloud_ptr_out) memcpy(cloud_ptr_out, st->cptr, 8 * (size_t)(st->U + 1));
+    if (entries_out) {
+        if (entries_cap < st->n_ent) { rc = -3; goto done; }
+        memcpy(entries_out, st->ent, 4 * (size_t)st->n_ent);
+    }
+    if (stop_after == 2) goto done;
+    {
+        cfo_part_result pr;
+        if (unique_out) memset(unique_out, 0, (size_t)st->n_rare);
+        rc = cfo_mt_dist_part(st, min_n, max_n, min_d, max_d, min_cov, rel_threshold, 0, 1, n_threads, &pr, unique_out, edges_out, edges_cap);
+        res->n_emissions = pr.n_emissions;
+        res->n_edges = pr.n_edges;
+        res->edge_checksum = pr.edge_checksum;
+        res->n_unique = pr.n_unique;
+    }
+done:
+    cfo_mt_free(st);
     return rc;
 }

@@ -15,6 +15,7 @@
  *                                                         none qualifies -> the rest are "None" (:79-84)
  *   ReadPlacer.run                read_placer.py:96-128   prefix reads, internal stage, suffix stage
  */
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -99,6 +100,12 @@ static int contig_add(contig_t* c, int64_t r, int64_t position, const int64_t* u
     return 0;
 }
 
+/* read_placer.py:63-78: larger (s0, s1, offset) wins, then the smaller read id */
+static int entry_better(int64_t en, int64_t best, const int64_t* s0, const int64_t* s1, const int64_t* s_off, const int64_t* s_read, const int32_t* id_rank) {
+    const int64_t v0 = s0[en], v1 = s1[en], b0 = s0[best], b1 = s1[best], bo = s_off[best], o = s_off[en];
+    return v0 != b0 ? v0 > b0 : v1 != b1 ? v1 > b1 : o != bo ? o > bo : id_rank[s_read[en]] < id_rank[s_read[best]];
+}
+
 /*
  * classes[r]: 0 prefix, 1 internal, 2 suffix; id_rank[r]: rank of the read id in ascending string order.
  * Outputs in the order the reference writes read_positions.csv (each stage's None block by id_rank):
@@ -178,15 +185,23 @@ int cfo_place_reads(int64_t n_reads, int64_t n_kmers, const uint8_t* classes, co
                 }
             }
             if (rc) break;
+            /* arg-max over the live entries; (s0, s1, offset, then smaller id rank) is a strict total order over entries of
+             * unused reads (two entries of one read differ in their offset), so the scan may be split over threads: every
+             * thread keeps its best, the bests are merged with the same comparison — the result does not depend on the split */
             int64_t best = -1;
-            for (int64_t en = 0; en < s1.n; ++en) {
-                const int64_t r = s_read.v[en];
-                if (!unused[r]) continue;
-                const int64_t v0 = s0.v[en], v1 = s1.v[en];
-                if (!(v0 >= min_unit && v0 * min_prop <= v1 && v1 >= min_inters)) continue;
-                if (best < 0) { best = en; continue; }
-                const int64_t b0 = s0.v[best], b1 = s1.v[best], bo = s_off.v[best], o = s_off.v[en];
-                if (v0 != b0 ? v0 > b0 : v1 != b1 ? v1 > b1 : o != bo ? o > bo : id_rank[r] < id_rank[s_read.v[best]]) best = en;
+#pragma omp parallel if (s1.n > 200000) num_threads(omp_get_max_threads() > 32 ? 32 : omp_get_max_threads())
+            {
+                int64_t lb = -1;
+#pragma omp for schedule(static) nowait
+                for (int64_t en = 0; en < s1.n; ++en) {
+                    const int64_t r = s_read.v[en];
+                    if (!unused[r]) continue;
+                    const int64_t v0 = s0.v[en], v1 = s1.v[en];
+                    if (!(v0 >= min_unit && v0 * min_prop <= v1 && v1 >= min_inters)) continue;
+                    if (lb < 0 || entry_better(en, lb, s0.v, s1.v, s_off.v, s_read.v, id_rank)) lb = en;
+                }
+#pragma omp critical
+                if (lb >= 0 && (best < 0 || entry_better(lb, best, s0.v, s1.v, s_off.v, s_read.v, id_rank))) best = lb;
             }
             if (best < 0) break;
             const int64_t r = s_read.v[best];

@@ -20,6 +20,14 @@ class Result(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class PartResult(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_emissions", "n_edges", "n_unique", "n_first_kmers")] + [
+        ("edge_checksum", C.c_uint64), ("secs", C.c_double), ("secs_postings", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 _lib = None
 
 
@@ -39,6 +47,14 @@ def lib():
                                  C.c_int, C.c_int, C.c_uint32, C.c_double, C.POINTER(Result), P, C.c_int64, P, P, C.c_int64,
                                  P, C.c_int64, P]
         L.cfo_stage2_mt.argtypes = L.cfo_stage2.argtypes + [C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        L.cfo_mt_prepare.restype = C.c_void_p
+        L.cfo_mt_prepare.argtypes = [P, P, C.c_int64, P, P, P, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int,
+                                     C.POINTER(Result), C.POINTER(C.c_uint64), P, C.POINTER(C.c_int)]
+        L.cfo_mt_dist_part.argtypes = [P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_uint32, C.c_double, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(PartResult), P, P, C.c_int64]
+        L.cfo_mt_free.argtypes = [P]
+        L.cfo_mt_free.restype = None
+        L.cfo_mt_get.argtypes = [P, P, P, P]
         L.cfo_place_reads.argtypes = [C.c_int64, C.c_int64, P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P]
         L.cfo_table_mix.restype = C.c_uint64
         L.cfo_table_mix.argtypes = [C.c_uint64] * 3
@@ -173,3 +189,58 @@ def _stage2_mt(bases, read_off, unit_ptr, unit_start, unit_end, k, max_nonuniq, 
     out = res.as_dict()
     out["table_checksum"] = int(tchk.value)
     return out, arrays
+
+
+class Stage2State:
+    """A1-A3 of the OpenMP oracle run once and kept (cfo_mt_prepare); dist_part() then runs A5 + A6 for the first k-mers
+    a % n_parts == part (cfo_mt_dist_part) — the checker of the 50 000-read distance stage and bench.py's same-data CPU
+    baseline.  Reference: distance_based_kmer_recruitment.py:39-149 (dist_cnt[d][a] is a's own dict, :108-113)."""
+
+    def __init__(self, bases, read_off, unit_ptr, unit_start, unit_end, k=19, max_nonuniq=3, lo=10, hi=32, threads=0):
+        self._keep = [np.ascontiguousarray(bases, np.uint8), np.ascontiguousarray(read_off, np.int64), np.ascontiguousarray(unit_ptr, np.int64),
+                      np.ascontiguousarray(unit_start, np.int64), np.ascontiguousarray(unit_end, np.int64)]
+        b, ro, up, us, ue = self._keep
+        res, tchk, rc = Result(), C.c_uint64(), C.c_int()
+        secs = (C.c_double * 2)()
+        self._h = lib().cfo_mt_prepare(b.ctypes.data, ro.ctypes.data, ro.size - 1, up.ctypes.data, us.ctypes.data, ue.ctypes.data, k,
+                                       max_nonuniq, lo, hi, int(threads), 0, C.byref(res), C.byref(tchk), secs, C.byref(rc))
+        if not self._h:
+            raise RuntimeError(f"cfo_mt_prepare failed ({rc.value})")
+        self.counters = res.as_dict()
+        self.counters["table_checksum"] = int(tchk.value)
+        self.secs_count_select, self.secs_clouds = float(secs[0]), float(secs[1])
+
+    def arrays(self):
+        c = self.counters
+        rare = np.zeros(c["n_rare"], np.uint64)
+        cptr = np.zeros(c["n_units"] + 1, np.int64)
+        ent = np.zeros(c["n_cloud_entries"], np.int32)
+        if lib().cfo_mt_get(self._h, rare.ctypes.data, cptr.ctypes.data, ent.ctypes.data):
+            raise RuntimeError("cfo_mt_get failed")
+        return dict(rare=rare, cloud_ptr=cptr, entries=ent)
+
+    def dist_part(self, part, n_parts, min_n=0, max_n=2 ** 62, min_d=1, max_d=150, min_cov=4, rel_threshold=0.8, threads=0,
+                  unique=None, want_edges=0):
+        """Returns the partition's counters (+ "edges" when want_edges = capacity > 0); `unique` (uint8[n_rare]) is OR-ed in place."""
+        pr = PartResult()
+        edges = np.zeros((want_edges, 4), np.uint32) if want_edges else None
+        rc = lib().cfo_mt_dist_part(self._h, min_n, min(max_n, 2 ** 62), min_d, max_d, min_cov, rel_threshold, part, n_parts, int(threads),
+                                    C.byref(pr), unique.ctypes.data if unique is not None else None,
+                                    edges.ctypes.data if edges is not None else None, want_edges)
+        if rc:
+            raise RuntimeError(f"cfo_mt_dist_part failed ({rc})")
+        out = pr.as_dict()
+        if edges is not None:
+            out["edges"] = edges[:out["n_edges"]]
+        return out
+
+    def close(self):
+        if self._h:
+            lib().cfo_mt_free(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -2,7 +2,7 @@
 // TEST INFRASTRUCTURE ONLY (tests/emu/build_emu.sh links it in place of centroflye_amd/csrc/hip/cf_comm_rccl.hip): the
 // world-size-2 CPU test runs two processes of the emulated library; "device" memory is host memory there, and every
 // message is a file `m<seq>_<from>_<to>` in the rendezvous DIRECTORY (written as tmp + rename, removed by its reader).
-// Ranks call the collectives in the same order, so a per-communicator sequence number pairs the messages.
+// Both ends of a pair derive the same messages from the pair's byte counts, so per-pair sequence numbers pair them up.
 #include "cf_comm.h"
 
 #include <sys/stat.h>
@@ -15,7 +15,7 @@ namespace {
 
 struct emu_comm : cf_comm {
     std::string dir;
-    uint64_t seq = 0;
+    std::vector<uint64_t> sseq, rseq;      // messages sent to / received from each peer so far: both ends of a pair count alike
 
     std::string name(uint64_t s, int from, int to) const { return dir + "/m" + std::to_string(s) + "_" + std::to_string(from) + "_" + std::to_string(to); }
 
@@ -47,15 +47,13 @@ struct emu_comm : cf_comm {
         return -5;
     }
 
-    int alltoallv(const void* send, const int64_t* soff, const int64_t* sbytes, void* recv, const int64_t* roff,
-                  const int64_t* rbytes, hipStream_t, std::string& err) override {
-        const uint64_t s = seq++;
+    // one round of the shared loop in cf_comm.h (p == rank appears only with self_p2p: the file goes to ourselves)
+    int exchange_round(const char* const* sp, const int64_t* ns, char* const* rp, const int64_t* nr, hipStream_t, std::string& err) override {
+        if (sseq.empty()) { sseq.assign((size_t)world, 0); rseq.assign((size_t)world, 0); }
         for (int p = 0; p < world; ++p)
-            if (p != rank) { int rc = put(name(s, rank, p), (const char*)send + soff[p], sbytes[p], err); if (rc) return rc; }
-        if (sbytes[rank] != rbytes[rank]) { err = "emu comm: self message sizes differ"; return -22; }
-        if (sbytes[rank]) std::memmove((char*)recv + roff[rank], (const char*)send + soff[rank], (size_t)sbytes[rank]);
+            if (ns[p]) { int rc = put(name(sseq[(size_t)p]++, rank, p), sp[p], ns[p], err); if (rc) return rc; }
         for (int p = 0; p < world; ++p)
-            if (p != rank) { int rc = get(name(s, p, rank), (char*)recv + roff[p], rbytes[p], err); if (rc) return rc; }
+            if (nr[p]) { int rc = get(name(rseq[(size_t)p]++, p, rank), rp[p], nr[p], err); if (rc) return rc; }
         return 0;
     }
     int allgather(const void* send, void* recv, int64_t bytes, hipStream_t st, std::string& err) override {

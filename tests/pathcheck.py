@@ -43,6 +43,9 @@ def check_stage2(engine, report_path, oracle_tuple, n_parts=1, check_table=True)
         ne = engine.dist_edges(p2["min_nreads"], p2["max_nreads"], p2["min_distance"], p2["max_distance"],
                                p2["min_coverage"], 0.8, part, n_parts, edge_cap=res["edges"].shape[0] + 8)
         parts.append(engine.edges(ne))
+        from oracle import cport
+        assert engine.edges_checksum() == cport.edge_checksum(parts[-1]), "cf_edges_checksum (device) vs the rows"
+        assert engine.edges_checksum(ne // 2) == cport.edge_checksum(parts[-1][:ne // 2])
         engine.sort_edges()                  # the device's own (d, a, b) order = numpy's lexsort of the same rows
         assert np.array_equal(engine.edges(ne), sorted_edges(parts[-1])), "cf_sort_edges"
         E += engine.stats()["n_emissions"]

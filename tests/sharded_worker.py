@@ -2,7 +2,7 @@
 talking to its peer through the emulator's file transport (tests/emu/cf_comm_emu.cpp) behind the same C entry points
 the RCCL build exports.  Rank 0 checks the result against the C oracle run on the union of all shards.
 
-    python sharded_worker.py RANK WORLD RENDEZVOUS_DIR
+    python sharded_worker.py RANK WORLD RENDEZVOUS_DIR [COMM_ROUND_BYTES [SELF_P2P]]
 """
 import json
 import os
@@ -30,6 +30,10 @@ def main():
     pk = _host.synth(n_reads=READS_PER_RANK, cand_offset=rank, cand_stride=world, **SYNTH)
     sr = ShardedRecruiter(0, lib=lib, rank=rank, world=world, rendezvous=rdv)
     sr.engine.set_param("dist_slots", 2048); sr.engine.set_param("dist_block", 128)
+    if len(sys.argv) > 4:       # many small rounds per pair of ranks (the loop of cf_comm.h that RCCL runs in 256 MB rounds)
+        sr.engine.set_param("comm_round_bytes", int(sys.argv[4]))
+    if len(sys.argv) > 5:
+        sr.engine.set_param("comm_self_p2p", int(sys.argv[5]))
     sr.load(pk, 1)
     outs = [sr.run(edge_cap=200000, **PARAMS) for _ in range(2)]       # two steps: the local table is rebuilt from the shard
     out = outs[-1]

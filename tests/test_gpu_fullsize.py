@@ -3,7 +3,13 @@
     (k-mer, pres, multi) table through an order-independent checksum, the rare set element by element;
   * BASELINE configs[0] — 1 000 reads: the whole stage 2 (A1-A6, ~3e9 pair emissions) vs the CPU path: counters, rare set,
     clouds, every selected edge (checksum + count), the unique mask;
-  * placement (A4 + A8/A9) of 3 000 reads vs the C restatement of the greedy loop: identical lines.
+  * BASELINE configs[2] — the same 50 000 reads: the distance stage (A5 + A6, 1.5e11 pair emissions) vs the CPU path by
+    first-k-mer partition (a % 64 == p for two p: dist_cnt[d][a] is a's own dict, so a partition is an independent
+    piece of the same result): emission count, edge count, edge checksum (device-side and on the copied rows), the
+    unique bits of the partition; the full 64/64 CPU run is committed under profiles/r03_full_parity.json and asserted
+    against a full GPU launch here and by bench.py every run;
+  * placement (A4 + A8/A9) of 3 000 reads vs the C restatement of the greedy loop: identical lines; and of the 50 000
+    reads of configs[2] vs the same C placer (the arg-max scan threaded).
 The oracle side is pinned on CPU (tests/test_oracle_golden.py).  Reference: distance_based_kmer_recruitment.py:39-149,
 read_placer.py:42-94."""
 import os
@@ -50,6 +56,79 @@ def test_config1_50k_reads_count_and_rare_filter_vs_cpu(engine):
     assert got_tchk == c["table_checksum"]
     assert cport.rare_checksum(rare) == c["rare_checksum"] and np.array_equal(rare, a["rare"])
     assert n_rare > 5_000_000 and c["n_distinct"] > 100_000_000
+
+
+def _full_parity():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_full_parity.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.timeout(1500)
+def test_config2_50k_reads_distance_partitions_vs_cpu(engine):
+    pk = synth(50000, 2)                      # the bench workload itself
+    up, us, ue, _ = pk.units(1)
+    engine.load(pk, 1)
+    engine.count_kmers(P["k"])
+    n_rare = engine.select_rare(P["max_nonuniq"], P["lo"], P["hi"])
+    n_ce = engine.build_clouds()
+    with cport.Stage2State(pk.bases, pk.read_off, up, us, ue, P["k"], P["max_nonuniq"], P["lo"], P["hi"], threads=0) as st:
+        c = st.counters
+        assert (n_rare, n_ce) == (c["n_rare"], c["n_cloud_entries"])
+        a = st.arrays()
+        assert np.array_equal(engine.kmers(), a["rare"])
+        cp, ent = engine.clouds()
+        assert np.array_equal(cp, a["cloud_ptr"]) and np.array_equal(ent, a["entries"])
+        del cp, ent, a
+        n_parts = 64
+        for part in (5, 42):
+            uq = np.zeros(n_rare, np.uint8)
+            w = st.dist_part(part, n_parts, 0, 2 ** 62, P["min_d"], P["max_d"], P["min_cov"], P["rel_threshold"], threads=0, unique=uq)
+            assert w["n_emissions"] > 2_000_000_000 and w["n_edges"] > 30_000_000
+            engine.reset_unique()
+            ne = engine.dist_edges(0, 2 ** 62, P["min_d"], P["max_d"], P["min_cov"], P["rel_threshold"], part, n_parts, edge_cap=w["n_edges"] + 16)
+            s2 = engine.stats()
+            assert (ne, s2["n_emissions"], s2["n_unique"]) == (w["n_edges"], w["n_emissions"], w["n_unique"]), part
+            assert engine.edges_checksum() == w["edge_checksum"], part
+            rows = engine.edges(ne)
+            assert cport.edge_checksum(rows) == w["edge_checksum"] and bool(np.all(rows[:, 1] % n_parts == part)), part
+            del rows
+            assert np.array_equal(engine.unique_mask(), uq.astype(bool)), part
+    # the whole launch (all first k-mers, every selected edge stored) against the committed result of the 64 / 64 CPU run
+    fp = _full_parity()
+    assert fp["workload"]["reads"] == 50000 and fp["workload"]["seed"] == 2 and fp["n_bases"] == pk.n_bases
+    engine.reset_unique()
+    ne = engine.dist_edges(0, 2 ** 62, P["min_d"], P["max_d"], P["min_cov"], P["rel_threshold"], 0, 1, edge_cap=fp["n_edges"] + 16)
+    s2 = engine.stats()
+    assert (ne, s2["n_emissions"], s2["n_unique"]) == (fp["n_edges"], fp["n_emissions"], fp["n_unique"])
+    assert engine.edges_checksum() == fp["edge_checksum"]
+    assert cport.rare_checksum(engine.kmers()[engine.unique_mask()]) == fp["unique_kmers_checksum"]
+
+
+@pytest.mark.timeout(1500)
+def test_config2_50k_reads_placement_vs_c_placer(engine):
+    from conftest import lines_from_placement
+    pk = synth(50000, 2)
+    engine.load(pk, 1)
+    engine.count_kmers(P["k"])
+    engine.select_rare(P["max_nonuniq"], P["lo"], P["hi"])
+    engine.build_clouds()
+    engine.reset_unique()
+    engine.dist_edges(0, 2 ** 62, P["min_d"], P["max_d"], P["min_cov"], P["rel_threshold"], 0, 1, edge_cap=0)
+    gk = engine.kmers()[engine.unique_mask()]
+    engine.set_kmers(gk, P["k"])
+    engine.build_clouds()
+    engine.filter_clouds(2)
+    cp, ent = engine.clouds()
+    up, _, _, _ = pk.units(1)
+    cls = pk.classify(50000)
+    rank = np.argsort(np.argsort(np.array(pk.ids, dtype=object), kind="stable"), kind="stable").astype(np.int32)
+    got = engine.place_reads(cls, rank, 2, 2, 10, 3)
+    want = cport.place_reads(cls, rank, up, cp, ent, gk.size, 2, 2, 10, 3)
+    gl = lines_from_placement(pk.ids, *[x.tolist() for x in got])
+    wl = lines_from_placement(pk.ids, *[x.tolist() for x in want])
+    assert sum(1 for x in gl if not x.endswith("None")) > 45000
+    assert gl == wl
 
 
 @pytest.mark.timeout(900)

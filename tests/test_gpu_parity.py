@@ -261,3 +261,34 @@ def test_exchange_path_on_one_rank_rccl():
     assert ra["n_edges"] > 1000 and a.exchange and not b.exchange
     assert {k: ra[k] for k in keys} == {k: rb[k] for k in keys}
     assert np.array_equal(ka, kb) and np.array_equal(ua, ub) and np.array_equal(srt(ea), srt(eb))
+
+
+@pytest.mark.timeout(900)
+def test_p2p_rounds_execute_on_one_gpu_through_self_send_recv():
+    """ncclSend / ncclRecv on real hardware: with comm_self_p2p the message a rank sends to itself goes through
+    ncclSend(rank -> rank) / ncclRecv inside the same ncclGroup rounds every other pair uses, so the rounds loop of the
+    all-to-all (table records) and of the variable-size all-gathers (rare lists, clouds) runs on the one GPU there is:
+    (1) many small rounds (64 KiB) on a small read set, (2) the production round size (256 MB) on a read set whose table
+    exchange is > 600 MB, i.e. several rounds — both against the plain path.  (N > 1 remains unmeasured: only the
+    driver has a multi-GPU node.)"""
+    from centroflye_amd.sharded import ShardedRecruiter
+    P = dict(k=19, max_nonuniq=3, lo=10, hi=32, min_d=1, max_d=150, min_cov=4, rel_threshold=0.8)
+    keys = ("n_edges", "n_emissions", "n_bases", "n_windows", "n_read_kmers", "n_distinct", "n_kept", "n_cloud_entries", "n_rare", "n_unique")
+    for reads, units, round_bytes, cap in ((200, 60, 65536, 1 << 24), (12000, 3600, 0, 1 << 20)):
+        pk = _host.synth(seed=31, n_units=units, n_reads=reads, var_len=8)
+        res = []
+        for self_p2p in (0, 1):
+            sr = ShardedRecruiter(0, force_exchange=bool(self_p2p))
+            if self_p2p:
+                sr.engine.set_param("comm_self_p2p", 1)
+                if round_bytes:
+                    sr.engine.set_param("comm_round_bytes", round_bytes)
+            sr.load(pk, 1)
+            r = sr.run(edge_cap=cap, **P)
+            res.append((r, sr.rare.copy(), sr.unique_mask.copy(), sr.engine.edges_checksum() if r["local_edges"] <= cap else None, sr.exchange_bytes))
+            sr.close()
+        (ra, ka, ua, ca, _), (rb, kb, ub, cb, xb) = res
+        assert {k: ra[k] for k in keys} == {k: rb[k] for k in keys}, reads
+        assert np.array_equal(ka, kb) and np.array_equal(ua, ub) and ca == cb, reads
+        if not round_bytes:
+            assert 16 * rb["n_distinct"] > 600e6, "the table exchange must span several 256 MB rounds"

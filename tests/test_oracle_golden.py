@@ -149,6 +149,23 @@ def test_openmp_c_oracle_equals_single_thread_c_oracle(name, report):
     c3, _ = cport.stage2(*args, threads=2, stop_after=1)
     assert (c3["n_rare"], c3["rare_checksum"], c3["n_distinct"], c3["n_kept"], c3["table_checksum"]) == (c1["n_rare"], c1["rare_checksum"], c1["n_distinct"], c1["n_kept"], c2["table_checksum"])
     assert c3["n_cloud_entries"] == 0 and c3["n_emissions"] == 0
+    # the partitioned form (the checker of the 50 000-read distance stage, bench.py's same-data CPU baseline): the first
+    # k-mers a % n == p for every p give disjoint pieces that add up to the whole result, with any thread count
+    with cport.Stage2State(pk.bases, pk.read_off, up, us, ue, p2["k"], p2["max_nonuniq"], lo, hi, threads=3) as st:
+        assert {k: st.counters[k] for k in ("n_rare", "n_cloud_entries", "rare_checksum", "cloud_checksum", "table_checksum")} == \
+            {k: c2[k] for k in ("n_rare", "n_cloud_entries", "rare_checksum", "cloud_checksum", "table_checksum")}
+        arr = st.arrays()
+        assert np.array_equal(arr["rare"], a1["rare"]) and np.array_equal(arr["cloud_ptr"], a1["cloud_ptr"]) and np.array_equal(arr["entries"], a1["entries"])
+        for n_parts in (1, 3):
+            uq = np.zeros(c1["n_rare"], np.uint8)
+            rows, em, chk = [], 0, 0
+            for part in range(n_parts):
+                w = st.dist_part(part, n_parts, 0, 2 ** 62, p2["min_distance"], min(p2["max_distance"], 6), p2["min_coverage"], 0.8,
+                                 threads=1 + part, unique=uq, want_edges=c1["n_edges"])
+                assert np.all(w["edges"][:, 1] % n_parts == part) and cport.edge_checksum(w["edges"]) == w["edge_checksum"]
+                rows.append(w["edges"]); em += w["n_emissions"]; chk = (chk + w["edge_checksum"]) % 2 ** 64
+            assert (em, chk) == (c1["n_emissions"], c1["edge_checksum"])
+            assert np.array_equal(srt(np.concatenate(rows)), srt(a1["edges"])) and np.array_equal(uq.astype(bool), a1["unique"])
 
 
 @pytest.mark.parametrize("name", NAMES)

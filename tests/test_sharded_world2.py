@@ -12,12 +12,15 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_equals_single_process_oracle(emu_lib, tmp_path, world):
+@pytest.mark.parametrize("world,extra", [(2, []), (3, []), (2, ["4096"]), (3, ["1008", "1"])])
+def test_sharded_equals_single_process_oracle(emu_lib, tmp_path, world, extra):
+    """extra = [comm_round_bytes [, comm_self_p2p]]: every pair's messages cut into many small rounds (ranks then run
+    DIFFERENT numbers of rounds per exchange: the rounds of a pair follow from the pair's byte count alone), and a rank's
+    message to itself sent through the transport as well."""
     env = dict(os.environ, OMP_NUM_THREADS="1")
     rdv = tmp_path / "rdv"
     rdv.mkdir()
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"), str(r), str(world), str(rdv)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"), str(r), str(world), str(rdv)] + extra,
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = []
     try:
