@@ -1,6 +1,9 @@
 // cf_api.hip — context management, hand-over of the packed reads, getters (C ABI: include/cfhip.h).
 #include "cf_common.h"
 
+#include <atomic>
+#include <thread>
+
 int cf_fail(cf_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return code;
@@ -57,6 +60,84 @@ void cf_release(cf_ctx* ctx, void* p, size_t bytes) {
     ctx->pool.emplace(it->second, p);
     ctx->pooled += it->second;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Host hand-over.  The C ABI borrows plain host pointers (numpy arrays: pageable memory); a hipMemcpy from / to pageable
+// memory runs at 10 - 25 GB/s on this platform (the runtime stages it through one bounce buffer on one thread: round 2
+// measured 22 GB/s for 5.4 GB).  Here kCopyThreads threads each own a pinned slot and a stream: DMA into / out of the slot
+// at PCIe speed, memcpy between the slot and the caller's buffer by the same thread, the threads overlapping each other
+// (the first touch of a fresh output buffer — page faults — spreads over the threads as well).
+static const size_t CF_PIN_SLOT = (size_t)8 << 20;
+static const size_t CF_PIN_MIN = (size_t)4 << 20;      // below this a plain copy is as fast
+
+static bool cf_pin_ready(cf_ctx* ctx) {
+    if (ctx->pin_bytes) return true;
+    for (int i = 0; i < cf_ctx::kCopyThreads; ++i) {
+        if (hipHostMalloc(&ctx->pin_slot[i], CF_PIN_SLOT, 0) != hipSuccess || hipStreamCreate(&ctx->pin_stream[i]) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int j = 0; j <= i; ++j) {
+                if (ctx->pin_slot[j]) { (void)hipHostFree(ctx->pin_slot[j]); ctx->pin_slot[j] = nullptr; }
+                if (ctx->pin_stream[j]) { (void)hipStreamDestroy(ctx->pin_stream[j]); ctx->pin_stream[j] = nullptr; }
+            }
+            return false;
+        }
+    }
+    ctx->pin_bytes = CF_PIN_SLOT;
+    return true;
+}
+static void cf_pin_free(cf_ctx* ctx) {
+    for (int i = 0; i < cf_ctx::kCopyThreads; ++i) {
+        if (ctx->pin_slot[i]) { (void)hipHostFree(ctx->pin_slot[i]); ctx->pin_slot[i] = nullptr; }
+        if (ctx->pin_stream[i]) { (void)hipStreamDestroy(ctx->pin_stream[i]); ctx->pin_stream[i] = nullptr; }
+    }
+    ctx->pin_bytes = 0;
+}
+static bool cf_is_host_pointer(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return true; }      // unknown to the runtime: ordinary host memory
+    return at.type != hipMemoryTypeDevice;
+}
+static int cf_copy_staged(cf_ctx* ctx, void* dst, const void* src, size_t bytes, bool to_device) {
+    const void* host = to_device ? src : dst;
+    if (bytes < CF_PIN_MIN || !cf_is_host_pointer(host) || !cf_pin_ready(ctx)) {
+        CF_HIP(hipStreamSynchronize(ctx->stream));
+        CF_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
+        return 0;
+    }
+    CF_HIP(hipStreamSynchronize(ctx->stream));      // what the copy reads / overwrites is settled
+    const size_t n_chunks = (bytes + CF_PIN_SLOT - 1) / CF_PIN_SLOT;
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&](int t) {
+        if (hipSetDevice(ctx->device) != hipSuccess) { bad = 1; return; }
+        char* slot = (char*)ctx->pin_slot[t];
+        for (;;) {
+            const size_t c = next.fetch_add(1);
+            if (c >= n_chunks || bad.load()) return;
+            const size_t off = c * CF_PIN_SLOT, n = std::min(CF_PIN_SLOT, bytes - off);
+            if (to_device) {
+                std::memcpy(slot, (const char*)src + off, n);
+                if (hipMemcpyAsync((char*)dst + off, slot, n, hipMemcpyHostToDevice, ctx->pin_stream[t]) != hipSuccess ||
+                    hipStreamSynchronize(ctx->pin_stream[t]) != hipSuccess) { bad = 1; return; }
+            } else {
+                if (hipMemcpyAsync(slot, (const char*)src + off, n, hipMemcpyDeviceToHost, ctx->pin_stream[t]) != hipSuccess ||
+                    hipStreamSynchronize(ctx->pin_stream[t]) != hipSuccess) { bad = 1; return; }
+                std::memcpy((char*)dst + off, slot, n);
+            }
+        }
+    };
+    const int nt = (int)std::min<size_t>(cf_ctx::kCopyThreads, n_chunks);
+    std::vector<std::thread> th;
+    try {
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    } catch (...) { /* fewer threads: the others take the chunks */ }
+    work(0);
+    for (auto& x : th) x.join();
+    if (bad.load()) { (void)hipGetLastError(); return cf_fail(ctx, -5, "staged host copy failed"); }
+    return 0;
+}
+int cf_copy_h2d(cf_ctx* ctx, void* dev, const void* host, size_t bytes) { return bytes ? cf_copy_staged(ctx, dev, host, bytes, true) : 0; }
+int cf_copy_d2h(cf_ctx* ctx, void* host, const void* dev, size_t bytes) { return bytes ? cf_copy_staged(ctx, host, dev, bytes, false) : 0; }
 
 static void free_reads(cf_ctx* c) {
     cf_release_t(c, c->d_bases, (size_t)c->n_bases);
@@ -131,6 +212,7 @@ void cf_destroy(cf_ctx* ctx) {
     free_units(ctx);
     free_reads(ctx);
     cf_pool_flush(ctx);
+    cf_pin_free(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
@@ -221,7 +303,7 @@ int cf_load_reads(cf_ctx* ctx, const uint8_t* bases, const int64_t* read_off, in
     CF_TRY(cf_alloc_t(ctx, &ctx->d_read_off, (size_t)n_reads + 1, "read_off"));
     // note: d_bases was allocated with +64 slack; account it under n_bases for release
     ctx->live -= 64;
-    if (nb) CF_HIP(hipMemcpyAsync(ctx->d_bases, bases, (size_t)nb, hipMemcpyHostToDevice, ctx->stream));
+    CF_TRY(cf_copy_h2d(ctx, ctx->d_bases, bases, (size_t)nb));
     CF_HIP(hipMemcpyAsync(ctx->d_read_off, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     CF_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stats = cf_stats{};
@@ -244,7 +326,7 @@ int cf_load_units(cf_ctx* ctx, const int64_t* unit_ptr, const int64_t* unit_star
 int cf_get_kmers(cf_ctx* ctx, uint64_t* out, int64_t cap) {
     if (!ctx) return -22;
     if (cap < ctx->n_kmers) return cf_fail(ctx, -22, "cf_get_kmers: buffer too small");
-    if (ctx->n_kmers) CF_HIP(hipMemcpy(out, ctx->d_kmers, (size_t)ctx->n_kmers * 8, hipMemcpyDefault));
+    CF_TRY(cf_copy_d2h(ctx, out, ctx->d_kmers, (size_t)ctx->n_kmers * 8));
     return 0;
 }
 
@@ -252,8 +334,8 @@ int cf_get_clouds(cf_ctx* ctx, int64_t* cloud_ptr, int32_t* entries, int64_t cap
     if (!ctx) return -22;
     if (!ctx->have_clouds) return cf_fail(ctx, -22, "cf_get_clouds: no clouds built");
     if (cap < ctx->n_entries) return cf_fail(ctx, -22, "cf_get_clouds: buffer too small");
-    CF_HIP(hipMemcpy(cloud_ptr, ctx->d_cloud_ptr, (size_t)(ctx->n_units + 1) * 8, hipMemcpyDefault));
-    if (ctx->n_entries) CF_HIP(hipMemcpy(entries, ctx->d_entries, (size_t)ctx->n_entries * 4, hipMemcpyDefault));
+    CF_TRY(cf_copy_d2h(ctx, cloud_ptr, ctx->d_cloud_ptr, (size_t)(ctx->n_units + 1) * 8));
+    CF_TRY(cf_copy_d2h(ctx, entries, ctx->d_entries, (size_t)ctx->n_entries * 4));
     return 0;
 }
 
@@ -265,8 +347,8 @@ int cf_set_clouds(cf_ctx* ctx, const int64_t* cloud_ptr, const int32_t* entries,
     CF_TRY(cf_alloc_t(ctx, &ctx->d_cloud_ptr, (size_t)ctx->n_units + 1, "cloud_ptr"));
     ctx->n_entries = n_entries;
     CF_TRY(cf_alloc_t(ctx, &ctx->d_entries, (size_t)n_entries, "cloud entries"));
-    CF_HIP(hipMemcpy(ctx->d_cloud_ptr, cloud_ptr, (size_t)(ctx->n_units + 1) * 8, hipMemcpyDefault));
-    if (n_entries) CF_HIP(hipMemcpy(ctx->d_entries, entries, (size_t)n_entries * 4, hipMemcpyDefault));
+    CF_TRY(cf_copy_h2d(ctx, ctx->d_cloud_ptr, cloud_ptr, (size_t)(ctx->n_units + 1) * 8));
+    CF_TRY(cf_copy_h2d(ctx, ctx->d_entries, entries, (size_t)n_entries * 4));
     ctx->have_clouds = true;
     ctx->stats.n_cloud_entries = n_entries;
     return 0;
@@ -276,7 +358,8 @@ int cf_get_edges(cf_ctx* ctx, uint32_t* out, int64_t cap) {
     if (!ctx) return -22;
     const int64_t n = std::min(cap, ctx->n_edges_stored);      // the first min(cap, stored) edges
     if (n < 0 || (n && !out)) return cf_fail(ctx, -22, "cf_get_edges: bad buffer");
-    if (n) CF_HIP(hipMemcpy(out, ctx->d_edges, (size_t)n * 16, hipMemcpyDefault));
+    CF_HIP(hipSetDevice(ctx->device));
+    CF_TRY(cf_copy_d2h(ctx, out, ctx->d_edges, (size_t)n * 16));
     return 0;
 }
 

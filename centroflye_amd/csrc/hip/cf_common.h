@@ -119,6 +119,13 @@ struct cf_ctx {
     uint32_t* d_unique_bits = nullptr;
     int64_t unique_words = 0;
 
+    // host <-> device copies of the caller's (pageable) buffers go through pinned staging slots, one per copy thread
+    // (cf_api.hip: cf_copy_h2d / cf_copy_d2h)
+    static constexpr int kCopyThreads = 8;
+    void* pin_slot[kCopyThreads] = {nullptr};
+    hipStream_t pin_stream[kCopyThreads] = {nullptr};
+    size_t pin_bytes = 0;
+
     cf_stats stats{};
     cf_times times{};
 
@@ -145,6 +152,10 @@ struct cf_ctx {
 };
 
 int cf_fail(cf_ctx* ctx, int code, const std::string& msg);
+// copies between device memory and memory of the CALLER (pageable): staged through pinned slots by several threads; `host`
+// may also be a device pointer (the multi-GPU exchange hands device buffers to some getters): then one plain copy
+int cf_copy_h2d(cf_ctx* ctx, void* dev, const void* host, size_t bytes);
+int cf_copy_d2h(cf_ctx* ctx, void* host, const void* dev, size_t bytes);
 int cf_alloc(cf_ctx* ctx, void** p, size_t bytes, const char* what);
 void cf_release(cf_ctx* ctx, void* p, size_t bytes);
 

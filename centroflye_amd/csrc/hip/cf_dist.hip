@@ -29,6 +29,7 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 #define DIST_UNROLL 4
 #define DIST_ITEM (64u * DIST_UNROLL)    /* cloud entries one wave takes per step: DIST_UNROLL consecutive ones per lane */
 #define DIST_BM_BITS 65536u              /* bitmap over hash(b): k-mers that may have a selected edge */
+#define DIST_OVQ 96u                     /* per-wave list of inserts whose first probe did not finish (drained with the probe loop at >= 32) */
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
 #define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
 
@@ -146,6 +147,7 @@ struct cf_dist_args {
     uint32_t est_limit;            // emissions one partition is expected to hold (fill_limit / expected distinct share)
     int32_t sketch;                // 1: count first in 8-bit counters, build the exact table only for k-mers that can pass min_cov
     uint32_t sk_counters, sk_shift;   // counters (a power of two that fits the LDS that is dead during the sketch sweep) and 32 - log2 of it
+    uint32_t it_cap;               // item records the LDS list holds (a multiple of 64, >= 64)
     uint32_t stage_cap;            // <= DIST_STAGE_CAP
     uint32_t hot_cap;              // cap on the filter's list of hot slots (tests: a small one forces the in-scan evaluation)
     uint32_t* edges;
@@ -197,16 +199,19 @@ struct cf_tab_wide_t {
     // DIST_UNROLL consecutive entries from e on; entries whose bit in ok is clear are not touched in memory
     struct __attribute__((packed, aligned(4))) run4 { uint32_t x, y, z, w; };
     struct __attribute__((packed, aligned(2))) run4h { uint16_t x, y, z, w; };
-    static __device__ __forceinline__ void load_run(const cf_dist_args& A, int64_t e, uint32_t ok, raw (&out)[DIST_UNROLL]) {
+    // s_e: index of the item's first entry (wave-uniform: the base address is scalar), l4 = 4 * lane
+    static __device__ __forceinline__ void load_run(const cf_dist_args& A, uint32_t s_e, uint32_t l4, uint32_t ok, raw (&out)[DIST_UNROLL]) {
         static_assert(DIST_UNROLL == 4, "one 16-byte and one 8-byte load per lane");
+        const int32_t* pe = A.entries + s_e;
+        const uint16_t* pi = A.entry_i + s_e;
         if (ok == (1u << DIST_UNROLL) - 1u) {      // the whole run lies inside the posting's range (all items but the last of a posting)
-            const run4 r = *(const run4*)(A.entries + e);
-            const run4h h = *(const run4h*)(A.entry_i + e);
+            const run4 r = *(const run4*)(pe + l4);
+            const run4h h = *(const run4h*)(pi + l4);
             out[0] = raw{r.x, h.x}; out[1] = raw{r.y, h.y}; out[2] = raw{r.z, h.z}; out[3] = raw{r.w, h.w};
             return;
         }
 #pragma unroll
-        for (int u = 0; u < DIST_UNROLL; ++u) { const int64_t x = ((ok >> u) & 1u) ? e + u : 0; out[u] = raw{(uint32_t)A.entries[x], (uint32_t)A.entry_i[x]}; }
+        for (int u = 0; u < DIST_UNROLL; ++u) { const uint32_t x = ((ok >> u) & 1u) ? l4 + (uint32_t)u : 0u; out[u] = raw{(uint32_t)pe[x], (uint32_t)pi[x]}; }
     }
     static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { b = r.b; dd = (r.i - ig) & 0xFFFFu; }   // unit indices are kept mod 65536 and d <= max_d < 65536: the 16-bit difference IS d
     // 24 x 24-bit multiplies only (full rate; a 32-bit multiply or a multiply-high is quarter rate): the low 24 bits of b as in
@@ -328,9 +333,10 @@ struct cf_tab_narrow_t {
     // DIST_UNROLL (= 4) consecutive entries from e on with ONE 16-byte load (4-byte aligned); the packed array is
     // padded by DIST_ITEM entries, so a run that starts inside the array may be read whole whatever ok says
     struct __attribute__((packed, aligned(4))) run4 { uint32_t x, y, z, w; };
-    static __device__ __forceinline__ void load_run(const cf_dist_args& A, int64_t e, uint32_t ok, raw (&out)[DIST_UNROLL]) {
+    static __device__ __forceinline__ void load_run(const cf_dist_args& A, uint32_t s_e, uint32_t l4, uint32_t, raw (&out)[DIST_UNROLL]) {
         static_assert(DIST_UNROLL == 4, "one 16-byte load per lane");
-        const run4 r = *(const run4*)(A.packed + (ok ? e : 0));
+        const uint32_t* p = A.packed + s_e;         // scalar base + 32-bit lane offset: global_load_dwordx4 v, v_off, s[base]
+        const run4 r = *(const run4*)(p + l4);
         out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
     }
     // the unit index is kept mod 2^DB and 1 <= d < 2^DB, so the DB-bit difference IS d; no borrow reaches b
@@ -487,21 +493,25 @@ struct cf_tab_region {
         for (uint32_t s = t; s < (slots >> 3); s += nt) ((cf_u32x4*)cnt32)[s] = z;
     }
     struct __attribute__((packed, aligned(4))) run4 { uint32_t x, y, z, w; };
-    static __device__ __forceinline__ void load_run(const cf_dist_args& A, int64_t e, uint32_t ok, raw (&out)[DIST_UNROLL]) {
-        static_assert(DIST_UNROLL == 4, "one 16-byte and one 4-byte load per lane");
+    static __device__ __forceinline__ void load_run(const cf_dist_args& A, uint32_t s_e, uint32_t l4, uint32_t ok, raw (&out)[DIST_UNROLL]) {
+        static_assert(DIST_UNROLL == 4, "one 16-byte and one 8-byte load per lane");
+        const int32_t* pe = A.entries + s_e;
         if (ok == (1u << DIST_UNROLL) - 1u) {      // the whole run lies inside the posting's range
-            const run4 r = *(const run4*)(A.entries + e);
+            const run4 r = *(const run4*)(pe + l4);
             // the 4 index bytes start at any byte address: two ALIGNED dwords around them and a funnel shift (a dword load
-            // from a misaligned address takes the slow path of the memory pipeline: the sketch sweep ran 39 % longer with it)
+            // from a misaligned address takes the slow path of the memory pipeline: the sketch sweep ran 39 % longer with it);
+            // the misalignment is the item's (wave-uniform)
             struct __attribute__((packed, aligned(4))) pair2 { uint32_t lo, hi; };
-            const pair2 w = *(const pair2*)(A.entry_i8 + (e & ~(int64_t)3));
-            const uint32_t sh = ((uint32_t)e & 3u) * 8u;
+            const uint8_t* pb = A.entry_i8 + (s_e & ~3u);
+            const pair2 w = *(const pair2*)(pb + l4);
+            const uint32_t sh = (s_e & 3u) * 8u;
             const uint32_t iw = (uint32_t)((((unsigned long long)w.hi << 32) | w.lo) >> sh);
             out[0] = raw{r.x, iw & 0xFFu}; out[1] = raw{r.y, (iw >> 8) & 0xFFu}; out[2] = raw{r.z, (iw >> 16) & 0xFFu}; out[3] = raw{r.w, iw >> 24};
             return;
         }
+        const uint8_t* pi = A.entry_i8 + s_e;
 #pragma unroll
-        for (int u = 0; u < DIST_UNROLL; ++u) { const int64_t x = ((ok >> u) & 1u) ? e + u : 0; out[u] = raw{(uint32_t)A.entries[x], (uint32_t)A.entry_i8[x]}; }
+        for (int u = 0; u < DIST_UNROLL; ++u) { const uint32_t x = ((ok >> u) & 1u) ? l4 + (uint32_t)u : 0u; out[u] = raw{(uint32_t)pe[x], (uint32_t)pi[x]}; }
     }
     static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { b = r.b; dd = (r.i - ig) & 0xFFu; }      // unit indices mod 256, d <= 255
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }      // sketch and bitmap: any function of b will do (ranks that differ above bit 23 share counters and bits)
@@ -630,7 +640,7 @@ struct cf_tab_region {
 };
 
 
-#define DIST_QCAP 128                    /* deferred inserts per wave (pushes come in batches of <= 64, drains take 64) */
+#define DIST_QCAP 320                    /* deferred inserts per wave: fewer than 64 left by the drains before a step + at most 4 x 64 pushed by it */
 #define DIST_FULL_BIT 0x80000000u        /* sh[0]: the table is physically full (the pass is void and will be split) */
 
 // general insert: walk buckets from bk; claims the first empty slot with a CAS when the key is absent.
@@ -690,80 +700,74 @@ __device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0,
 #define CF_STAMP(i) do { } while (0)
 #endif
 
-// Sweeps the partner entries of one chunk of postings.  The units g+min_d .. min(read end, g+max_d) of a posting are
-// ONE contiguous range of the CSR, cut into items of DIST_ITEM = 64 x DIST_UNROLL entries; the items of all postings of
-// the chunk are numbered consecutively and waves pull one item at a time from a shared LDS cursor (dynamic balance).
-// The posting of an item is found per WAVE, not per lane: every lane keeps 4 of the 256 inclusive item prefixes in
-// registers and 4 ballots count the prefixes <= item.  A lane takes DIST_UNROLL consecutive entries of the item (one
-// 16-byte load in the narrow layout).  Software pipeline: the global load of step i+1 is issued before the body of
-// step i runs; what a load returns is only touched one step later (ig travels in an SGPR, validity in a bit mask).
-// body(bb, dd) gets the decoded entries of a step (bb[u] == a: nothing to count) and returns true to stop the wave.
-// Round 2, edge output: copying the selected (b, d, cnt) of a pass into LDS, issuing the range-reserving global atomic and
-// going on with the next first k-mer (the copies written out right before its table sweep) takes the write phase from 57 to
-// 45 G cycles, but the two extra barriers and the LDS round trip give it back elsewhere: 458.6 vs 453.5 ms.  Not in the source.
-// Item hand-out of the two sweeps: 0 = dealt round robin to the waves (default), 1 = pulled from a shared LDS cursor
-// (round 1).  Measured at 50 000 reads (profiles/r02_dist_ab.log): cursor in both sweeps 480.8 ms, round robin in the sketch
-// sweep only 472.2, in the table sweep only 476.9, in both 465.5.  Other round-2 experiments on this kernel that LOST and
-// are not in the source (same log): byte counters on hash(b) alone with fire-and-forget ds_add and a counter bitmap made
-// by a pass over the counters (sketch sweep 186 -> 127 G cycles, but the pass costs 69 and the table sweep grows: 504 ms);
-// the next first k-mer's partner ranges fetched during filter/write, edge data and unique words read before the edge
-// range is reserved (465.8 / 469.6 ms: those latencies already hide behind the CU's second workgroup; anything that adds
-// live registers spills — the kernel sits at 125 of the 128 VGPRs that four waves per SIMD allow, and 16 more bytes of
-// LDS take the table below the 64 KiB its 65 536 sketch counters need).
-#ifndef CF_DIST_DYN_A
-#define CF_DIST_DYN_A 0
-#endif
-#ifndef CF_DIST_DYN_B
-#define CF_DIST_DYN_B 0
-#endif
-template <class Tab, bool Dyn, class Body>
-__device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, uint32_t a, const cf_dist_rec* rec, const uint32_t* ipx, uint32_t* cursor, int np, Body&& body) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t n_items = ipx[4 + np - 1];
-    if (n_items == 0u) return;
-    const cf_u32x4 iv = *(const cf_u32x4*)&ipx[4 + 4 * lane];
-    typename Tab::raw nx_[DIST_UNROLL];
-    uint32_t nig = 0, nok = 0;
-#define CF_DIST_FETCH(I0) {                                                                                   \
-        const uint32_t item = (I0);                                                                           \
-        const uint32_t p = (uint32_t)(__popcll(__ballot(iv.x <= item)) + __popcll(__ballot(iv.y <= item))     \
-                                    + __popcll(__ballot(iv.z <= item)) + __popcll(__ballot(iv.w <= item)));   \
-        const cf_dist_rec r = rec[p];                                                                         \
-        const uint32_t base = (item - (uint32_t)__builtin_amdgcn_readfirstlane((int)ipx[3 + p])) * DIST_ITEM; \
-        const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.len);                            \
-        const uint32_t off = base + (uint32_t)lane * DIST_UNROLL;                                             \
-        nig = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.ig);                                            \
-        nok = (1u << DIST_UNROLL) - 1u;                                                                       \
-        if (base + DIST_ITEM > len) {      /* (wave-uniform) only the last item of a posting runs past its end */ \
-            nok = 0;                                                                                          \
-            _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) nok |= (uint32_t)(off + (uint32_t)u < len) << u; \
-        }                                                                                                     \
-        Tab::load_run(A, r.e0 + (int64_t)off, nok, nx_);                                                      \
+// One item = up to DIST_ITEM consecutive partner entries of one posting: what one wave takes per step.
+//   e  index of its first entry in the cloud-entry arrays (32 bits: cf_dist_edges refuses more than 2^32 - DIST_ITEM entries)
+//   m  [entries of the item (1 .. DIST_ITEM) : 16 | unit index of the posting inside its read, mod 65536 : 16]
+struct alignas(8) cf_dist_item { uint32_t e, m; };
+
+// Item records of the items [i0, i0 + n) of the current posting chunk (rec / ipx as cf_dist_setup left them) -> LDS, once per
+// first k-mer in the usual case; both sweeps then run on them.  Called by all threads; ends with a barrier.
+// Round 3: before, every wave found the posting of each item it took with 4 ballots + 4 popcounts + an LDS read of the
+// posting's record + 3 readfirstlanes + 64-bit address arithmetic, in both sweeps: about 25 vector and 40 scalar
+// instructions per step of 256 entries, on the dependency chain in front of the step's global load.
+__device__ __forceinline__ void cf_dist_build_items(const cf_dist_rec* rec, const uint32_t* ipx, int np, uint32_t i0, uint32_t n, cf_dist_item* items) {
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        const uint32_t item = i0 + j;
+        int lo = 0, hi = np - 1;                 // the posting of the item: the first p with inclusive prefix ipx[4 + p] > item
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (ipx[4 + mid] > item) hi = mid; else lo = mid + 1; }
+        const cf_dist_rec r = rec[lo];
+        const uint32_t off = (item - ipx[3 + lo]) * DIST_ITEM;
+        items[j] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | (r.ig & 0xFFFFu)};
     }
-#define CF_DIST_GRAB(VAR) { if (Dyn) { uint32_t g_ = 0; if (lane == 0) g_ = atomicAdd(cursor, 1u); VAR = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_); } else { VAR = nxt_static; nxt_static += (uint32_t)(blockDim.x >> 6); } }
-    uint32_t nxt_static = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t i0, i1;
-    CF_DIST_GRAB(i0)
-    if (i0 < n_items) CF_DIST_FETCH(i0)
-    while (i0 < n_items) {
-        typename Tab::raw cx_[DIST_UNROLL];
-        const uint32_t cok = nok, cig = nig;
-#pragma unroll
-        for (int u = 0; u < DIST_UNROLL; ++u) cx_[u] = nx_[u];
-        CF_DIST_GRAB(i1)
-        if (i1 < n_items) CF_DIST_FETCH(i1)
-        i0 = i1;
-        uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
-#pragma unroll
-        for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cig, bb[u], dd_[u]);
-        if (__any(cok != (1u << DIST_UNROLL) - 1u)) {      // (wave-uniform) only the last item of a posting has lanes past its end
-#pragma unroll
-            for (int u = 0; u < DIST_UNROLL; ++u) if (!((cok >> u) & 1u)) bb[u] = a;
+    __syncthreads();
+}
+
+// Sweeps the items [0, n_items) in LDS: wave w takes the items w, w + W, w + 2W, ... (W waves per workgroup; round 2 found
+// this static deal faster than a shared cursor).  Every lane first loads ONE of its wave's item records (lane j: the j-th item of
+// the wave); a step then gets its record with two v_readlane into SGPRs — the base address of the step's global load is scalar,
+// the per-lane offset is the constant 16 * lane.  Software pipeline: the load of step j + 1 is issued before the body of step j.
+// body(bb, dd, ok, partial): the decoded entries of a step; ok = per-lane bit mask of the entries that exist (only the last item
+// of a posting has lanes past its end: partial, wave-uniform, says whether ok needs looking at); returns true to stop the wave.
+// pre(final) runs at ONE site before every step and once more (final = true) after the wave's last step: the table sweep drains
+// its insert queue there (one copy of that code in the loop instead of one per push site: 42 -> 27 KB of code).
+template <class Tab, class Pre, class Body>
+__device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_dist_item* items, uint32_t n_items, Pre&& pre, Body&& body) {
+    const uint32_t lane = threadIdx.x & 63u, l4 = lane * DIST_UNROLL;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
+    if (wv >= n_items) return;
+    const uint32_t mine = (n_items - wv + nw - 1u) / nw;
+    for (uint32_t j0 = 0; j0 < mine; j0 += 64u) {      // (one round whenever the item list fits 64 per wave)
+        const uint32_t cnt = min(64u, mine - j0);
+        cf_dist_item my = cf_dist_item{0u, 0u};
+        if (lane < cnt) my = items[wv + (j0 + lane) * nw];
+        typename Tab::raw nx_[DIST_UNROLL];
+        uint32_t nm = 0, nok = 0;
+#define CF_DIST_FETCH(J) {                                                                                      \
+            const uint32_t s_e = (uint32_t)__builtin_amdgcn_readlane((int)my.e, (int)(J));                      \
+            nm = (uint32_t)__builtin_amdgcn_readlane((int)my.m, (int)(J));                                      \
+            nok = (1u << DIST_UNROLL) - 1u;                                                                     \
+            if ((nm >> 16) < DIST_ITEM) {      /* (wave-uniform) the last item of a posting */                  \
+                nok = 0;                                                                                        \
+                _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) nok |= (uint32_t)(l4 + (uint32_t)u < (nm >> 16)) << u; \
+            }                                                                                                   \
+            Tab::load_run(A, s_e, l4, nok, nx_);                                                                \
         }
-        if (body(bb, dd_)) break;
-    }
+        CF_DIST_FETCH(0u)
+        for (uint32_t j = 0;; ++j) {
+            pre(j == cnt && j0 + 64u >= mine);
+            if (j == cnt) break;
+            typename Tab::raw cx_[DIST_UNROLL];
+            const uint32_t cok = nok, cm = nm;
+#pragma unroll
+            for (int u = 0; u < DIST_UNROLL; ++u) cx_[u] = nx_[u];
+            if (j + 1u < cnt) CF_DIST_FETCH(j + 1u)
+            uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
+#pragma unroll
+            for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cm & 0xFFFFu, bb[u], dd_[u]);
+            if (body(bb, dd_, cok, (cm >> 16) < DIST_ITEM)) return;
+        }
 #undef CF_DIST_FETCH
-#undef CF_DIST_GRAB
+    }
 }
 
 template <class Tab>
@@ -784,10 +788,15 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
     uint32_t* stack = (uint32_t*)(stage + DIST_STAGE_CAP + 8);                   // (P, idx) pairs
     typename Tab::qitem* wq0 = (typename Tab::qitem*)(stack + 2 * DIST_STACK);
     typename Tab::qitem* wq = wq0 + (size_t)(t >> 6) * DIST_QCAP;
-    cf_dist_rec* rec = (cf_dist_rec*)(wq0 + (size_t)(nt >> 6) * DIST_QCAP);      // partner range of each posting of the chunk
+    // inserts whose FIRST probe did not finish (bucket full, or another key took the slot it wanted): parked here and run
+    // through the probe loop 32 .. 64 at a time (round 2 ran that loop inside every drain: most drains went around twice for
+    // one or two of their 64 lanes)
+    typename Tab::qitem* ovq = wq0 + (size_t)(nt >> 6) * DIST_QCAP + (size_t)(t >> 6) * DIST_OVQ;
+    cf_dist_rec* rec = (cf_dist_rec*)(wq0 + (size_t)(nt >> 6) * (DIST_QCAP + DIST_OVQ));      // partner range of each posting of the chunk
     uint32_t* ipx = (uint32_t*)(rec + DIST_NP_CAP);            // 4 zeros, then the inclusive prefix of item counts
-    uint32_t* sh = ipx + 4 + DIST_NP_CAP;                      // [0] keys in table | DIST_FULL_BIT [1] first k-mer [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] item cursor [12] entries of the chunk [13] a counter of the sketch wrapped [14,15] its first posting
+    uint32_t* sh = ipx + 4 + DIST_NP_CAP;                      // [0] keys in table | DIST_FULL_BIT [1] first k-mer [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] hot-list cursor [12] entries of the chunk [13] a counter of the sketch wrapped [14,15] its first posting
     uint32_t* bm = sh + 16;                                    // DIST_BM_BITS bits: hash(b) of the k-mers b that may have a selected edge
+    cf_dist_item* items = (cf_dist_item*)(bm + DIST_BM_BITS / 32);   // A.it_cap item records: the work list of the sweeps
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
 #if defined(CF_DIST_STAMPS)
@@ -836,14 +845,19 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             if (t == 0 && nx_idx >= 0) { nx_a = (uint32_t)A.order[nx_idx]; nx_pp0 = A.post_ptr[nx_a]; nx_pp1 = A.post_ptr[nx_a + 1]; }
             continue;
         }
-        // Usual case (<= DIST_NP_CAP postings): the partner ranges are set up ONCE and reused by every sweep.
-        const bool one_chunk = (pp1 - pp0) <= DIST_NP_CAP;
+        // Usual case: <= DIST_NP_CAP postings whose items fit the LDS list — records built ONCE, both sweeps run on them.
+        bool one_chunk = (pp1 - pp0) <= DIST_NP_CAP;
+        uint32_t n_items_all = 0;
         if (t == 0) { sh[7] = 0; sh[13] = 0; }
         __syncthreads();
         if (one_chunk) {
             cf_dist_setup(A, pp0, (int)(pp1 - pp0), rec, ipx, sh);
             if (t == 0) sh[7] = sh[12];
-        } else {
+            n_items_all = ipx[4 + (int)(pp1 - pp0) - 1];
+            one_chunk = n_items_all <= A.it_cap;
+            if (one_chunk) cf_dist_build_items(rec, ipx, (int)(pp1 - pp0), 0u, n_items_all, items);
+        }
+        if (!one_chunk && (pp1 - pp0) > DIST_NP_CAP) {
             unsigned long long em = 0;
             for (int64_t p = pp0 + t; p < pp1; p += nt) {
                 em += (unsigned long long)A.urange[A.post[p]].len;
@@ -851,7 +865,23 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             for (int d = 32; d >= 1; d >>= 1) em += __shfl_down(em, (unsigned)d);
             if (lane == 0 && em) atomicAdd(&sh[7], (uint32_t)min(em, 0x3FFFFFFFull));
         }
-        CF_STAMP(1);   // prologue: posting ranges, estimate
+        CF_STAMP(1);   // prologue: posting ranges, item records, estimate
+        // run(n) for every item list of the first k-mer: the one built above, or (many postings / more items than the list
+        // holds) chunk after chunk of postings, list after list
+        auto for_lists = [&](auto&& run) {
+            if (one_chunk) { run(n_items_all); __syncthreads(); return; }
+            for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
+                const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
+                cf_dist_setup(A, c0, np, rec, ipx, sh);
+                const uint32_t tot = ipx[4 + np - 1];
+                for (uint32_t i0 = 0; i0 < tot; i0 += A.it_cap) {
+                    const uint32_t n = min(A.it_cap, tot - i0);
+                    cf_dist_build_items(rec, ipx, np, i0, n, items);
+                    run(n);
+                    __syncthreads();      // every wave is done with the list before it is rebuilt
+                }
+            }
+        };
         // ---- phase A (min_cov >= 2): which k-mers b can have a selected edge at all?  Most (b, d) pairs of a are seen
         // once or twice and can never reach min_cov, but an exact table would have to hold them all.  So first every
         // pair is only COUNTED, in an array of 8-bit counters indexed by hash(b, d) that fills the table's LDS: a
@@ -861,39 +891,43 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
         // totals are exact too); unmarked b have no pair with cnt >= min_cov and cannot be selected.  A counter about
         // to wrap (255 -> 0) is seen by the add that wraps it: the first k-mer then falls back to "every b marked".
         bool mark_all = !A.sketch;
+        const uint32_t min_cov_m1 = A.min_cov - 1u;      // (the sketch runs with min_cov >= 2)
         if (A.sketch) {
             const cf_u32x4 z{0u, 0u, 0u, 0u};
             for (uint32_t s = (uint32_t)t; s < (A.sk_counters >> 4); s += (uint32_t)nt) ((cf_u32x4*)sk)[s] = z;
             for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = z;
             __syncthreads();
-            for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
-                const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
-                if (!one_chunk) cf_dist_setup(A, c0, np, rec, ipx, sh);
-                if (t == 0) sh[11] = 0;
-                __syncthreads();
-                cf_dist_sweep<Tab, CF_DIST_DYN_A != 0>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
-                    uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL];
-#pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) {     // all counter adds of the step back to back
-                        const uint32_t idx = (Tab::hash(bb[u]) + dd_[u] * 0x5BD1E9u) >> A.sk_shift;
-                        sft_[u] = (idx & 3u) << 3;
-                        old_[u] = 0;
-                        if (bb[u] != a) old_[u] = atomicAdd(&sk[idx >> 2], 1u << sft_[u]);
-                    }
+            for_lists([&](uint32_t n_list) {
+                cf_dist_sweep<Tab>(A, items, n_list, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, bool partial) -> bool {
+                    // (entries equal to a are counted too: the sketch may only over-count, and the table sweep drops them)
+                    uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL], inc_[DIST_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
-                        if (bb[u] == a) continue;
-                        const uint32_t seen = (old_[u] >> sft_[u]) & 0xFFu;     // occurrences before this one
-                        if (seen + 1u >= A.min_cov) {
-                            const uint32_t hbit = Tab::bm_bit(bb[u]);
-                            if (!((bm[hbit >> 5] >> (hbit & 31u)) & 1u)) atomicOr(&bm[hbit >> 5], 1u << (hbit & 31u));
-                            if (seen == 255u) sh[13] = 1u;
+                        const uint32_t idx = (Tab::hash(bb[u]) + dd_[u] * 0x5BD1E9u) >> A.sk_shift;
+                        sft_[u] = idx << 3;             // (only its low 5 bits are used: the shift and the bit-field extract take them mod 32)
+                        inc_[u] = 1u << (sft_[u] & 31u);
+                        old_[u] = idx >> 2;
+                    }
+                    if (partial) {      // (wave-uniform) lanes past the end of the posting's range add nothing
+#pragma unroll
+                        for (int u = 0; u < DIST_UNROLL; ++u) if (!((ok >> u) & 1u)) inc_[u] = 0u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < DIST_UNROLL; ++u) old_[u] = atomicAdd(&sk[old_[u]], inc_[u]);     // all counter adds of the step back to back
+#pragma unroll
+                    for (int u = 0; u < DIST_UNROLL; ++u) {
+                        const uint32_t seen = __builtin_amdgcn_ubfe(old_[u], sft_[u], 8u);     // occurrences before this one (v_bfe_u32 takes the offset mod 32)
+                        if (seen >= min_cov_m1) {
+                            if (inc_[u]) {
+                                const uint32_t hbit = Tab::bm_bit(bb[u]);
+                                if (!((bm[hbit >> 5] >> (hbit & 31u)) & 1u)) atomicOr(&bm[hbit >> 5], 1u << (hbit & 31u));
+                                if (seen == 255u) sh[13] = 1u;
+                            }
                         }
                     }
                     return false;
                 });
-                __syncthreads();
-            }
+            });
             if (sh[13]) mark_all = true;
             CF_STAMP(6);   // sketch sweep
         }
@@ -919,7 +953,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             const uint32_t sp_now = sh[2];
             __syncthreads();  // everyone has read the stack pointer before thread 0 pops
             if (sp_now == 0) break;
-            if (t == 0) { const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[7] = 0; sh[8] = 0; }
+            if (t == 0) { const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[7] = 0; sh[8] = 0; sh[11] = 0; }
             T.clear(slots, (uint32_t)t, (uint32_t)nt);
             __syncthreads();
             const uint32_t P = sh[3], pidx = sh[4], pmask = P - 1u;   // P is a power of two; P == 1: every b belongs to the pass
@@ -927,29 +961,66 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             CF_STAMP(2);   // pop partition + clear table
             // ---- phase B: sweep again; pairs of this partition whose b is marked go to the wave's queue and are
             // inserted into the exact table 64 at a time by a full wave
-            for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
-                const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
-                if (!one_chunk) cf_dist_setup(A, c0, np, rec, ipx, sh);
-                if (t == 0) sh[11] = 0;   // shared cursor over the items of this chunk
-                __syncthreads();
-                uint32_t qtail = 0;      // wave-uniform
-                // pops the last N (<= 64) queued inserts, one per lane; every lane runs the probe loop for its own
+            for_lists([&](uint32_t n_list) {
+                uint32_t qtail = 0, otail = 0;      // wave-uniform: queued inserts / parked inserts of this wave
+                const unsigned long long lt_ = (1ull << lane) - 1ull;
+                // pops the last N (<= 64) queued inserts, one per lane, and gives each ONE probe of its home bucket in
+                // straight-line code: match -> count it; empty slot -> claim it; bucket full or the slot lost to another key ->
+                // parked in the overflow list, which goes through the probe loop once it holds 32
+#define CF_DIST_OVERFLOW(N) {                                                                                 \
+                    const uint32_t m_ = (N); otail -= m_;                                                     \
+                    uint32_t omade_ = 0;                                                                      \
+                    if ((uint32_t)lane < m_) {                                                                \
+                        uint32_t xb, xd, xk;                                                                  \
+                        T.q_take(ovq[otail + (uint32_t)lane], n_buckets, xb, xd, xk);                        \
+                        omade_ = cf_dist_insert(T, n_buckets, xk, xb, xd, sh);                                \
+                    }                                                                                         \
+                    const uint32_t onew_ = (uint32_t)__popcll(__ballot(omade_ != 0u));                        \
+                    if (onew_ && lane == 0) atomicAdd(&sh[0], onew_);                                         \
+                }
 #define CF_DIST_DRAIN(N) {                                                                                    \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                     __builtin_amdgcn_wave_barrier();                                                          \
                     const uint32_t n_ = (N); qtail -= n_;                                                     \
-                    uint32_t made_ = 0;                                                                       \
+                    uint32_t made_ = 0, park_ = 0;                                                            \
+                    typename Tab::qitem it_ = 0;                                                              \
                     if ((uint32_t)lane < n_) {                                                                \
                         uint32_t xb, xd, xk;                                                                  \
-                        T.q_take(wq[qtail + (uint32_t)lane], n_buckets, xb, xd, xk);                         \
-                        made_ = cf_dist_insert(T, n_buckets, xk, xb, xd, sh);                                 \
+                        it_ = wq[qtail + (uint32_t)lane];                                                     \
+                        T.q_take(it_, n_buckets, xb, xd, xk);                                                 \
+                        const typename Tab::bucket k_ = T.read(xk);                                           \
+                        const int mt_ = T.match(k_, xb, xd);                                                  \
+                        if (mt_ >= 0) T.add(xk, mt_);                                                         \
+                        else {                                                                                \
+                            const int em_ = Tab::empty(k_);                                                   \
+                            park_ = 1u;                                                                       \
+                            if (em_ >= 0) {                                                                   \
+                                const int st_ = T.claim_finish(T.claim_issue(xk, em_, xb, xd), xk, em_, xb, xd); \
+                                made_ = (uint32_t)(st_ == 0); park_ = (uint32_t)(st_ == 2);                  \
+                            }                                                                                 \
+                        }                                                                                     \
                     }                                                                                         \
                     const uint32_t new_ = (uint32_t)__popcll(__ballot(made_ != 0u));                          \
                     if (new_ && lane == 0) atomicAdd(&sh[0], new_);                                           \
+                    const unsigned long long pm_ = __ballot(park_ != 0u);                                     \
+                    if (pm_) {                                                                                \
+                        if (park_) ovq[otail + (uint32_t)__popcll(pm_ & lt_)] = it_;                          \
+                        otail += (uint32_t)__popcll(pm_);                                                     \
+                    }                                                                                         \
                     __builtin_amdgcn_wave_barrier();                                                          \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                 }
-                cf_dist_sweep<Tab, CF_DIST_DYN_B != 0>(A, a, rec, ipx, &sh[11], np, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL]) -> bool {
+                cf_dist_sweep<Tab>(A, items, n_list, [&](bool final) {
+                    // a step pushes at most 4 x 64 inserts: the queue is brought below 64 first; after the wave's last step
+                    // both lists are emptied (a pass whose table got too full is void and drops them)
+                    const uint32_t lim = final ? 1u : 64u;
+                    for (;;) {
+                        if (sh[0] > A.fill_limit) break;
+                        if (qtail >= lim) { CF_DIST_DRAIN(min(qtail, 64u)) }
+                        else if (!(final && otail > 0u)) break;
+                        if (otail >= 32u || (final && qtail == 0u && otail > 0u)) { CF_DIST_OVERFLOW(min(otail, 64u)) }
+                    }
+                }, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, bool partial) -> bool {
                     if (sh[0] > A.fill_limit) return true;     // too full (or physically full): the pass will be split
                     uint32_t w_[DIST_UNROLL], hbit_[DIST_UNROLL], live = 0, cand = 0;
 #pragma unroll
@@ -958,6 +1029,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                         hbit_[u] = Tab::bm_bit(bb[u]);
                         w_[u] = bm[hbit_[u] >> 5];
                     }
+                    if (partial) live &= ok;      // (wave-uniform) only the last item of a posting has lanes past its end
                     if (pmask) {       // (wave-uniform) only a first k-mer whose table was split tests the partition of b
 #pragma unroll
                         for (int u = 0; u < DIST_UNROLL; ++u) {
@@ -972,17 +1044,15 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         const unsigned long long cm = __ballot((cand >> u) & 1u);
                         if (cm) {
-                            if (qtail >= 64u) { CF_DIST_DRAIN(64u) }
-                            if ((cand >> u) & 1u) wq[qtail + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull))] = T.q_of(bb[u], dd_[u], n_buckets);
+                            if ((cand >> u) & 1u) wq[qtail + (uint32_t)__popcll(cm & lt_)] = T.q_of(bb[u], dd_[u], n_buckets);
                             qtail += (uint32_t)__popcll(cm);
                         }
                     }
                     return false;
                 });
-                while (qtail > 0u && sh[0] <= A.fill_limit) { CF_DIST_DRAIN(min(qtail, 64u)) }   // (a void pass drops its queue)
 #undef CF_DIST_DRAIN
-                __syncthreads();
-            }
+#undef CF_DIST_OVERFLOW
+            });
             CF_STAMP(3);   // stream + insert
             if (sh[0] > A.fill_limit) {  // overflow: split this partition in two
                 if (t == 0) {
@@ -1002,7 +1072,6 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             // by now.  (2) The list is evaluated one slot per thread with all lanes busy: sum over d from the bucket's
             // registers or a chain walk, the double division, mark + stage.  (Evaluating inside the bucket scan ran the
             // division code at 8 unrolled sites per round with 4 % of the lanes active: 9 100 cycles per first k-mer.)
-            if (CF_DIST_DYN_B) { __syncthreads(); if (t == 0) sh[11] = 0; __syncthreads(); }      // (the item cursor of that build; round robin leaves the word 0)
             uint16_t* hot = (uint16_t*)wq0;
             const uint32_t hot_cap = min(A.hot_cap, (uint32_t)((size_t)(nt >> 6) * DIST_QCAP * sizeof(typename Tab::qitem) / 2));
             // (every position comes from ONE LDS atomic per wave: 64 returning adds on one address serialise — 570 of them
@@ -1178,6 +1247,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     const int64_t v_n_entries = gv ? ctx->g_entries : ctx->n_entries;
     if (n_parts < 1 || part < 0 || part >= n_parts) return cf_fail(ctx, -22, "cf_dist_edges: bad partition");
     if (max_d > 65535) return cf_fail(ctx, -22, "cf_dist_edges: max_d > 65535 does not fit the 16-bit distance field");
+    if (v_n_entries >= ((int64_t)1 << 32) - 8 * (int64_t)DIST_ITEM) return cf_fail(ctx, -34, "cf_dist_edges: more than 2^32 cloud entries (the sweeps address them with 32-bit indices)");
     if (edge_cap < 0) edge_cap = 0;
     const int64_t R = gv ? ctx->g_reads : ctx->n_reads, U = gv ? ctx->g_units : ctx->n_units, K = ctx->n_kmers;
     // (no limit on the units of a read: unit indices travel mod 256 / mod 65536 and a difference <= max_d is exact)
@@ -1287,6 +1357,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = v_cloud_ptr; A.entries = v_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.urange = d_urange; A.entry_i = d_entry_i; A.packed = d_packed; A.entry_i8 = d_entry_i8; A.reg_shift = (uint32_t)reg_shift;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
         A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
+        A.it_cap = 64;      // (set with the launch shape below)
         A.hot_cap = ctx->dist_hot_cap > 0 ? (uint32_t)ctx->dist_hot_cap : 0xFFFFFFFFu;
         const uint32_t slot_bytes = (narrow || region) ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
         // launch shape: two 512-thread workgroups per CU (80 KiB of LDS each) overlap each other's latency-bound phases
@@ -1306,11 +1377,14 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (block == 0) block = wgs == 1 ? 1024 : 512;
         // LDS: everything but the table is fixed; dist_slots (the table budget in 8-byte units) defaults to all the rest
         const size_t qitem_bytes = narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem);
+        // item records of a first k-mer's sweeps: 64 per wave (one v_readlane round); more with the whole LDS (long reads / high coverage)
+        const uint32_t it_cap = (uint32_t)(block / 64) * (wgs == 1 ? 128u : 64u);
         const size_t lds_fixed = sizeof(cf_dist_rec) * DIST_NP_CAP + (size_t)(4 + DIST_NP_CAP + 2 * DIST_STACK + 16) * 4 + DIST_STAGE_CAP * 2 + 16
-                               + DIST_BM_BITS / 8 + (size_t)(block / 64) * DIST_QCAP * qitem_bytes;
+                               + DIST_BM_BITS / 8 + (size_t)(block / 64) * (DIST_QCAP + DIST_OVQ) * qitem_bytes + (size_t)it_cap * sizeof(cf_dist_item);
         const int64_t budget8 = ((int64_t)160 * 1024 / wgs - (int64_t)lds_fixed) / 8;
         if (budget8 < 256) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_wgs leaves no LDS for the table"); break; }
         if (ctx->dist_slots > budget8) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_slots does not fit the 160 KiB LDS next to the work lists"); break; }
+        A.it_cap = it_cap;
         const int64_t slots8 = ctx->dist_slots ? ctx->dist_slots : budget8;
         A.slots = (int32_t)((slots8 * 8 / slot_bytes) & ~(region ? (int64_t)(32 << reg_shift) - 1 : 7ll));      // (regions: equal parts of whole 8-slot groups)
         A.fill_limit = (uint32_t)((int64_t)A.slots * ctx->dist_fill_pct / 100);   // checked once per wave step: leave slack below the physical size
@@ -1319,7 +1393,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         const size_t lds = (size_t)A.slots * slot_bytes + lds_fixed;
         A.sketch = (ctx->dist_sketch && min_cov >= 2 && min_cov <= 200) ? 1 : 0;
         A.sk_shift = 32; A.sk_counters = 1;
-        const size_t sk_room = (size_t)A.slots * slot_bytes + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * DIST_QCAP * qitem_bytes + 2 * DIST_STACK * 4;   // table + stage + queues + stack
+        const size_t sk_room = (size_t)A.slots * slot_bytes + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QCAP + DIST_OVQ) * qitem_bytes + 2 * DIST_STACK * 4;   // table + stage + queues + stack
         while (A.sk_shift > 8 && (size_t)A.sk_counters * 2 <= sk_room) { A.sk_counters *= 2; --A.sk_shift; }
         if (A.sk_counters < 16) A.sketch = 0;
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / block));

@@ -172,9 +172,15 @@ __device__ __forceinline__ void cf_score_hit(const cf_place_state& S, uint32_t r
     // add is the last one on the entry sees its final state, so a finally-qualifying entry is always flagged; flags can be
     // stale-true (the arg-max re-checks and clears them), never stale-false
     const unsigned long long inc = 1ull | ((unsigned long long)(fresh ? 1u : 0u) << 32);
-    const unsigned long long v = atomicAdd(&S.s01[h], inc) + inc;
-    const uint32_t v0 = (uint32_t)(v >> 32), v1 = (uint32_t)v;
-    if (v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters) { ((uint8_t*)S.qflag)[h] = 1; S.dirty[h >> S.slice_shift] = 1; }
+    const unsigned long long was = atomicAdd(&S.s01[h], inc), v = was + inc;
+    const uint32_t v0 = (uint32_t)(v >> 32), v1 = (uint32_t)v, w0 = (uint32_t)(was >> 32), w1 = (uint32_t)was;
+    const bool now_q = v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters;
+    const bool was_q = w0 >= S.min_unit && (unsigned long long)w0 * S.min_prop <= w1 && w1 >= S.min_inters;
+    if (now_q) ((uint8_t*)S.qflag)[h] = 1;
+    // the slice's cached candidate may be this entry with its OLD values: any change of an entry that qualified before or
+    // qualifies now makes the cache stale (s0 * min_prop <= s1 is not monotone: a first hit in a new unit can take an entry out
+    // of the candidates, and round 2 marked the slice only when the entry qualified AFTER the add)
+    if (now_q || was_q) S.dirty[h >> S.slice_shift] = 1;
 }
 
 // apply the pending events to the scores: one wave per event, lanes over the k-mer's postings
