@@ -78,6 +78,7 @@ PROTOTYPES = {
     "cf_allreduce_unique": (C.c_int, [_P, _PI64]),
     "cf_selftest_sort": (C.c_int, [_P, _P, _I64, _I32, _P]),
     "cf_selftest_scan": (C.c_int, [_P, _P, _I64, _P]),
+    "cf_selftest_argmax": (C.c_int, [_P, _P, _I64, _P]),
 }
 
 _cache = {}

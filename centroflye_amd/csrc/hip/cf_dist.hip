@@ -730,7 +730,7 @@ __device__ __forceinline__ void cf_dist_build_items(const cf_dist_rec* rec, cons
 // of a posting has lanes past its end: partial, wave-uniform, says whether ok needs looking at); returns true to stop the wave.
 // pre(final) runs at ONE site before every step and once more (final = true) after the wave's last step: the table sweep drains
 // its insert queue there (one copy of that code in the loop instead of one per push site: 42 -> 27 KB of code).
-template <class Tab, class Pre, class Body>
+template <class Tab, int D, class Pre, class Body>
 __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_dist_item* items, uint32_t n_items, Pre&& pre, Body&& body) {
     const uint32_t lane = threadIdx.x & 63u, l4 = lane * DIST_UNROLL;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
@@ -740,35 +740,58 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
         const uint32_t cnt = min(64u, mine - j0);
         cf_dist_item my = cf_dist_item{0u, 0u};
         if (lane < cnt) my = items[wv + (j0 + lane) * nw];
-        typename Tab::raw nx_[DIST_UNROLL];
-        uint32_t nm = 0, nok = 0;
-#define CF_DIST_FETCH(J) {                                                                                      \
+        // D loads in flight per lane: a ring of D register sets, the loop unrolled D times so that every set has fixed registers
+        typename Tab::raw ring[D][DIST_UNROLL];
+        auto ok_of = [&](uint32_t m) -> uint32_t {      // per-lane mask of the entries of an item that exist
+            uint32_t ok = (1u << DIST_UNROLL) - 1u;
+            if ((m >> 16) < DIST_ITEM) {      // (wave-uniform) the last item of a posting
+                ok = 0;
+#pragma unroll
+                for (int u = 0; u < DIST_UNROLL; ++u) ok |= (uint32_t)(l4 + (uint32_t)u < (m >> 16)) << u;
+            }
+            return ok;
+        };
+#define CF_DIST_FETCH(J, SET) {                                                                                 \
             const uint32_t s_e = (uint32_t)__builtin_amdgcn_readlane((int)my.e, (int)(J));                      \
-            nm = (uint32_t)__builtin_amdgcn_readlane((int)my.m, (int)(J));                                      \
-            nok = (1u << DIST_UNROLL) - 1u;                                                                     \
-            if ((nm >> 16) < DIST_ITEM) {      /* (wave-uniform) the last item of a posting */                  \
-                nok = 0;                                                                                        \
-                _Pragma("unroll") for (int u = 0; u < DIST_UNROLL; ++u) nok |= (uint32_t)(l4 + (uint32_t)u < (nm >> 16)) << u; \
-            }                                                                                                   \
-            Tab::load_run(A, s_e, l4, nok, nx_);                                                                \
+            const uint32_t fm_ = (uint32_t)__builtin_amdgcn_readlane((int)my.m, (int)(J));                      \
+            Tab::load_run(A, s_e, l4, ok_of(fm_), ring[SET]);                                                   \
         }
-        CF_DIST_FETCH(0u)
-        for (uint32_t j = 0;; ++j) {
-            pre(j == cnt && j0 + 64u >= mine);
-            if (j == cnt) break;
-            typename Tab::raw cx_[DIST_UNROLL];
-            const uint32_t cok = nok, cm = nm;
 #pragma unroll
-            for (int u = 0; u < DIST_UNROLL; ++u) cx_[u] = nx_[u];
-            if (j + 1u < cnt) CF_DIST_FETCH(j + 1u)
-            uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
+        for (int d = 0; d < D; ++d) CF_DIST_FETCH(min((uint32_t)d, cnt - 1u), d)      // (unconditional, see below)
+        uint32_t j = 0;
+        bool more = true;
+        while (more) {
 #pragma unroll
-            for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cm & 0xFFFFu, bb[u], dd_[u]);
-            if (body(bb, dd_, cok, (cm >> 16) < DIST_ITEM)) return;
+            for (int d = 0; d < D; ++d) {
+                if (!more) break;
+                pre(j == cnt && j0 + 64u >= mine);
+                if (j == cnt) { more = false; break; }
+                typename Tab::raw cx_[DIST_UNROLL];
+#pragma unroll
+                for (int u = 0; u < DIST_UNROLL; ++u) cx_[u] = ring[d][u];
+                const uint32_t cm = (uint32_t)__builtin_amdgcn_readlane((int)my.m, (int)j);
+                // unconditional: a wave past its last item fetches that one again — with a fetch under a condition the number of
+                // loads in flight differs between the paths into the loop head and the compiler waits for ALL of them there
+                // (s_waitcnt vmcnt(0) instead of vmcnt(D - 1))
+                CF_DIST_FETCH(min(j + (uint32_t)D, cnt - 1u), d)
+                uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
+#pragma unroll
+                for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cm & 0xFFFFu, bb[u], dd_[u]);
+                const bool partial = (cm >> 16) < DIST_ITEM;
+                if (body(bb, dd_, partial ? ok_of(cm) : (1u << DIST_UNROLL) - 1u, partial)) return;
+                ++j;
+            }
         }
 #undef CF_DIST_FETCH
     }
 }
+
+#ifndef CF_DIST_PF_A
+#define CF_DIST_PF_A 2      /* loads in flight per lane in the sketch sweep */
+#endif
+#ifndef CF_DIST_PF_B
+#define CF_DIST_PF_B 1      /* ... and in the table sweep (its body holds the drain code: every copy costs 15 KB of instructions) */
+#endif
 
 template <class Tab>
 __global__ void cf_dist_kernel(cf_dist_args A) {
@@ -898,7 +921,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = z;
             __syncthreads();
             for_lists([&](uint32_t n_list) {
-                cf_dist_sweep<Tab>(A, items, n_list, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, bool partial) -> bool {
+                cf_dist_sweep<Tab, CF_DIST_PF_A>(A, items, n_list, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, bool partial) -> bool {
                     // (entries equal to a are counted too: the sketch may only over-count, and the table sweep drops them)
                     uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL], inc_[DIST_UNROLL];
 #pragma unroll
@@ -1010,7 +1033,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     __builtin_amdgcn_wave_barrier();                                                          \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                 }
-                cf_dist_sweep<Tab>(A, items, n_list, [&](bool final) {
+                cf_dist_sweep<Tab, CF_DIST_PF_B>(A, items, n_list, [&](bool final) {
                     // a step pushes at most 4 x 64 inserts: the queue is brought below 64 first; after the wave's last step
                     // both lists are emptied (a pass whose table got too full is void and drops them)
                     const uint32_t lim = final ? 1u : 64u;

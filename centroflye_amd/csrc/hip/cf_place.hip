@@ -202,27 +202,55 @@ cf_place_update_kernel(cf_place_state S) {
     }
 }
 
-__device__ __forceinline__ cf_cand cf_cand_shfl_down(const cf_cand& c, unsigned d) {
-    cf_cand o;
-    o.s0 = __shfl_down(c.s0, d); o.s1 = __shfl_down(c.s1, d); o.off = __shfl_down(c.off, d);
-    o.rank = __shfl_down(c.rank, d); o.read = __shfl_down(c.read, d); o.valid = __shfl_down(c.valid, d);
-    return o;
+// A candidate as ONE lexicographic key: hi = (s0 << 32 | s1) + 1 (0 = no candidate), lo = offset << 32 | ~rank — larger is
+// better (read_placer.py:63-78: larger (s0, s1), then the larger offset, then the smaller read id), plus the read it names.
+// Every comparison-and-replace below is written as branch-free selects on these three scalars.  Round 3: the round-2 form —
+// `if (cf_cand_better(o, mine)) mine = o;` on the six-field struct inside the shuffle loop — was MISCOMPILED by hipcc 7.2 at
+// -O3 for gfx950: after the d = 32 step the wave's lane kept the OLD `read` next to the new (s0, s1, offset, rank) whenever it
+// took its partner's candidate there and none afterwards (the generated code parks (read, valid) of the not-taken side in a
+// register pair and copies it back over the taken one; profiles/r03_place_miscompile.md has the ISA).  The 50 000-read
+// placement test against the C placer caught it: a read was placed with another read's score.  tests/test_gpu_parity.py
+// (cf_selftest_argmax) pins the reduction against the host on adversarial candidate sets.
+struct cf_key { unsigned long long hi, lo; uint32_t read; };
+__device__ __forceinline__ cf_key cf_key_of(const cf_cand& c) {
+    cf_key k;
+    k.hi = c.valid ? ((((unsigned long long)c.s0 << 32) | c.s1) + 1ull) : 0ull;
+    k.lo = c.valid ? (((unsigned long long)c.off << 32) | (unsigned long long)(~c.rank)) : 0ull;
+    k.read = c.valid ? c.read : 0u;
+    return k;
+}
+__device__ __forceinline__ cf_cand cf_cand_of(const cf_key& k) {
+    cf_cand c;
+    c.valid = k.hi != 0ull ? 1u : 0u;
+    c.s0 = c.valid ? (uint32_t)((k.hi - 1ull) >> 32) : 0u; c.s1 = c.valid ? (uint32_t)(k.hi - 1ull) : 0u;
+    c.off = (uint32_t)(k.lo >> 32); c.rank = c.valid ? ~(uint32_t)k.lo : 0u; c.read = k.read;
+    return c;
+}
+// mine := the better of (mine, o), by selects
+__device__ __forceinline__ void cf_key_take(cf_key& mine, const cf_key& o) {
+    const bool bt = o.hi > mine.hi || (o.hi == mine.hi && o.lo > mine.lo);
+    mine.hi = bt ? o.hi : mine.hi;
+    mine.lo = bt ? o.lo : mine.lo;
+    mine.read = bt ? o.read : mine.read;
 }
 
-__device__ __forceinline__ cf_cand cf_block_best(cf_cand mine) {
-    cf_cand* sh = (cf_cand*)cf_lds;
+// best candidate of the workgroup (every thread gets it); uses the first 16 x 24 bytes of LDS
+__device__ __forceinline__ cf_key cf_block_best_key(cf_key mine) {
+    unsigned long long* shk = (unsigned long long*)cf_lds;      // per wave: hi, lo, read
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int d = 32; d >= 1; d >>= 1) {
-        cf_cand o = cf_cand_shfl_down(mine, (unsigned)d);
-        if (lane + d < 64 && cf_cand_better(o, mine)) mine = o;
+    for (int d = 32; d >= 1; d >>= 1) {      // butterfly: all lanes end up with the wave's best
+        cf_key o;
+        o.hi = __shfl_xor(mine.hi, d); o.lo = __shfl_xor(mine.lo, d); o.read = (uint32_t)__shfl_xor((int)mine.read, d);
+        cf_key_take(mine, o);
     }
-    if (lane == 0) sh[wave] = mine;
+    if (lane == 0) { shk[3 * wave] = mine.hi; shk[3 * wave + 1] = mine.lo; shk[3 * wave + 2] = (unsigned long long)mine.read; }
     __syncthreads();
-    cf_cand best = sh[0];
-    for (int w = 1; w < nw; ++w) if (cf_cand_better(sh[w], best)) best = sh[w];
+    cf_key best{shk[0], shk[1], (uint32_t)shk[2]};
+    for (int w = 1; w < nw; ++w) { const cf_key o{shk[3 * w], shk[3 * w + 1], (uint32_t)shk[3 * w + 2]}; cf_key_take(best, o); }
     __syncthreads();
     return best;
 }
+__device__ __forceinline__ cf_cand cf_block_best(const cf_key& mine) { return cf_cand_of(cf_block_best_key(mine)); }
 
 __global__ void __launch_bounds__(PL_THREADS)
 cf_place_argmax_kernel(cf_place_state S) {
@@ -231,7 +259,7 @@ cf_place_argmax_kernel(cf_place_state S) {
     // placed; only then is the slice scanned again — most slices are untouched by one greedy iteration.
     if (S.ctl[0]) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) S.n_events[0] = 0ull;   // consumed by the update kernel before this one; refilled by the next
-    uint32_t* rescan = (uint32_t*)(cf_lds + 8 * sizeof(cf_cand));
+    uint32_t* rescan = (uint32_t*)(cf_lds + 16 * sizeof(cf_cand));
     if (threadIdx.x == 0) {
         const cf_cand c = S.block_best[blockIdx.x];
         const bool r = S.dirty[blockIdx.x] || (c.valid && S.used[c.read]);
@@ -240,7 +268,7 @@ cf_place_argmax_kernel(cf_place_state S) {
     }
     __syncthreads();
     if (!*rescan) return;
-    cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
+    cf_key mine{0ull, 0ull, 0u};
     {
         const uint64_t per = (1ull << S.slice_shift) >> 4;   // 16-byte quads (16 flag bytes) per block
         const uint64_t q0 = (uint64_t)blockIdx.x * per;
@@ -262,7 +290,7 @@ cf_place_argmax_kernel(cf_place_state S) {
                     if (!(v0 >= S.min_unit && (unsigned long long)v0 * S.min_prop <= v1 && v1 >= S.min_inters)) { ((uint8_t*)S.qflag)[i] = 0; continue; }   // stale flag
                     if (S.used[r]) { ((uint8_t*)S.qflag)[i] = 0; continue; }   // a placed read is never a candidate again: drop its entry from later scans
                     cf_cand c; c.s0 = v0; c.s1 = v1; c.off = off; c.rank = (uint32_t)S.id_rank[r]; c.read = r; c.valid = 1;
-                    if (cf_cand_better(c, mine)) mine = c;
+                    cf_key_take(mine, cf_key_of(c));
                 }
             }
         }
@@ -277,8 +305,8 @@ cf_place_argmax_kernel(cf_place_state S) {
 __global__ void __launch_bounds__(PL_THREADS)
 cf_place_pick_add_kernel(cf_place_state S, int n_cand) {
     if (S.ctl[0]) return;
-    cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
-    for (int i = threadIdx.x; i < n_cand; i += blockDim.x) if (cf_cand_better(S.block_best[i], mine)) mine = S.block_best[i];
+    cf_key mine{0ull, 0ull, 0u};
+    for (int i = threadIdx.x; i < n_cand; i += blockDim.x) cf_key_take(mine, cf_key_of(S.block_best[i]));
     const cf_cand b = cf_block_best(mine);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *S.best = b;
@@ -309,8 +337,8 @@ cf_place_pick_add_kernel(cf_place_state S, int n_cand) {
 __global__ void __launch_bounds__(PL_THREADS)
 cf_place_pick_add_update_kernel(cf_place_state S, int n_cand, int PL_CHUNK) {
     if (S.ctl[0]) return;
-    cf_cand mine; mine.valid = 0; mine.s0 = mine.s1 = mine.off = mine.rank = mine.read = 0;
-    for (int i = threadIdx.x; i < n_cand; i += blockDim.x) if (cf_cand_better(S.block_best[i], mine)) mine = S.block_best[i];
+    cf_key mine{0ull, 0ull, 0u};
+    for (int i = threadIdx.x; i < n_cand; i += blockDim.x) cf_key_take(mine, cf_key_of(S.block_best[i]));
     const cf_cand b = cf_block_best(mine);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *S.best = b;
@@ -503,11 +531,40 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         const int64_t n_iter = (int64_t)stage_reads.size();
         const bool fused = ctx->place_fused != 0;
         if (fused) hipLaunchKernelGGL(cf_place_update_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);      // the seed events; later ones are applied by the waves that raise them
+        // Diagnostic (CF_PLACE_DEBUG="iteration,read,read"): before that greedy iteration of the first stage, print every score
+        // entry of the two reads and the cached slice candidates that name them
+        int64_t dbg_it = -1, dbg_r[2] = {-1, -1};
+        if (const char* dv = std::getenv("CF_PLACE_DEBUG")) { long long a_ = -1, b_ = -1, c_ = -1; if (std::sscanf(dv, "%lld,%lld,%lld", &a_, &b_, &c_) == 3 && stage_cls == 1) { dbg_it = a_; dbg_r[0] = b_; dbg_r[1] = c_; } }
         for (int64_t it = 0; it < n_iter; ++it) {
+            if (it == dbg_it || it == dbg_it + 1) {
+                CF_HIP(hipStreamSynchronize(st));
+                std::vector<unsigned long long> hk((size_t)score_cap), hv((size_t)score_cap);
+                std::vector<uint8_t> hf((size_t)score_cap);
+                std::vector<cf_cand> hb((size_t)n_am);
+                std::vector<uint8_t> hd((size_t)n_am), hu((size_t)R);
+                cf_cand hbest;
+                CF_HIP(hipMemcpy(hk.data(), S.skeys, (size_t)score_cap * 8, hipMemcpyDeviceToHost));
+                CF_HIP(hipMemcpy(hv.data(), S.s01, (size_t)score_cap * 8, hipMemcpyDeviceToHost));
+                CF_HIP(hipMemcpy(hf.data(), S.qflag, (size_t)score_cap, hipMemcpyDeviceToHost));
+                CF_HIP(hipMemcpy(hb.data(), S.block_best, (size_t)n_am * sizeof(cf_cand), hipMemcpyDeviceToHost));
+                CF_HIP(hipMemcpy(hd.data(), S.dirty, (size_t)n_am, hipMemcpyDeviceToHost));
+                CF_HIP(hipMemcpy(hu.data(), d_used, (size_t)R, hipMemcpyDeviceToHost));
+                CF_HIP(hipMemcpy(&hbest, S.best, sizeof hbest, hipMemcpyDeviceToHost));
+                std::fprintf(stderr, "[cf_place debug] before iteration %lld: score_cap=%llu n_am=%d slice_shift=%u last best: read=%u off=%u s0=%u s1=%u rank=%u valid=%u\n", (long long)it, (unsigned long long)score_cap, n_am, S.slice_shift, hbest.read, hbest.off, hbest.s0, hbest.s1, hbest.rank, hbest.valid);
+                for (uint64_t i = 0; i < score_cap; ++i) {
+                    if (!hk[i]) continue;
+                    const int64_t r = (int64_t)((hk[i] & ~CF_OCC) >> 32);
+                    if (r != dbg_r[0] && r != dbg_r[1]) continue;
+                    const uint32_t v0 = (uint32_t)(hv[i] >> 32), v1 = (uint32_t)hv[i];
+                    if (v1 >= 20) std::fprintf(stderr, "  slot %llu (slice %llu dirty %d) read %lld used %d off %u s0 %u s1 %u flag %d\n", (unsigned long long)i, (unsigned long long)(i >> S.slice_shift), (int)hd[i >> S.slice_shift], (long long)r, (int)hu[(size_t)r], (uint32_t)hk[i], v0, v1, (int)hf[i]);
+                }
+                for (int b = 0; b < n_am; ++b) if (hb[b].valid && ((int64_t)hb[b].read == dbg_r[0] || (int64_t)hb[b].read == dbg_r[1]))
+                    std::fprintf(stderr, "  cached slice %d: read %u off %u s0 %u s1 %u rank %u\n", b, hb[b].read, hb[b].off, hb[b].s0, hb[b].s1, hb[b].rank);
+            }
             if (!fused) hipLaunchKernelGGL(cf_place_update_kernel, dim3((unsigned)n_blocks), dim3(PL_THREADS), 0, st, S);
-            hipLaunchKernelGGL(cf_place_argmax_kernel, dim3((unsigned)n_am), dim3(PL_THREADS), 8 * sizeof(cf_cand) + 16, st, S);
-            if (fused) hipLaunchKernelGGL(cf_place_pick_add_update_kernel, dim3((unsigned)(ctx->place_grid > 0 ? ctx->place_grid : std::max(8, ctx->n_cu))), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S, n_am, ctx->place_chunk);
-            else hipLaunchKernelGGL(cf_place_pick_add_kernel, dim3(8), dim3(PL_THREADS), 8 * sizeof(cf_cand), st, S, n_am);
+            hipLaunchKernelGGL(cf_place_argmax_kernel, dim3((unsigned)n_am), dim3(PL_THREADS), 16 * sizeof(cf_cand) + 16, st, S);
+            if (fused) hipLaunchKernelGGL(cf_place_pick_add_update_kernel, dim3((unsigned)(ctx->place_grid > 0 ? ctx->place_grid : std::max(8, ctx->n_cu))), dim3(PL_THREADS), 16 * sizeof(cf_cand), st, S, n_am, ctx->place_chunk);
+            else hipLaunchKernelGGL(cf_place_pick_add_kernel, dim3(8), dim3(PL_THREADS), 16 * sizeof(cf_cand), st, S, n_am);
             if ((it & 255) == 255 || it + 1 == n_iter) {
                 CF_KERNEL_CHECK("placement iteration");
                 CF_HIP(hipMemcpyAsync(h_ctl, S.ctl, 16, hipMemcpyDeviceToHost, st));
@@ -543,7 +600,34 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     return 0;
 }
 
+// the placement's candidate reduction on n given candidates (tests): thread t takes the candidates t, t + 256, ...
+__global__ void __launch_bounds__(PL_THREADS)
+cf_selftest_argmax_kernel(const uint32_t* __restrict__ cands, int64_t n, uint32_t* __restrict__ out) {
+    cf_key mine{0ull, 0ull, 0u};
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        cf_cand c; c.s0 = cands[5 * i]; c.s1 = cands[5 * i + 1]; c.off = cands[5 * i + 2]; c.rank = cands[5 * i + 3]; c.valid = cands[5 * i + 4] ? 1u : 0u; c.read = (uint32_t)i;
+        cf_key_take(mine, cf_key_of(c));
+    }
+    const cf_cand b = cf_block_best(mine);
+    if (threadIdx.x == 0) { out[0] = b.s0; out[1] = b.s1; out[2] = b.off; out[3] = b.rank; out[4] = b.read; out[5] = b.valid; }
+}
+
 extern "C" {
+
+int cf_selftest_argmax(cf_ctx* ctx, const uint32_t* cands, int64_t n, uint32_t* out6) {
+    if (!ctx || !out6 || n < 0 || (n && !cands)) return -22;
+    CF_HIP(hipSetDevice(ctx->device));
+    Bufs B{ctx, {}};
+    uint32_t *d_c = nullptr, *d_o = nullptr;
+    CF_TRY(B.get(&d_c, (size_t)5 * (size_t)std::max<int64_t>(n, 1), "selftest candidates"));
+    CF_TRY(B.get(&d_o, 8, "selftest winner"));
+    if (n) CF_HIP(hipMemcpyAsync(d_c, cands, (size_t)n * 20, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(cf_selftest_argmax_kernel, dim3(1), dim3(PL_THREADS), 16 * sizeof(cf_cand), ctx->stream, (const uint32_t*)d_c, n, d_o);
+    CF_KERNEL_CHECK("cf_selftest_argmax_kernel");
+    CF_HIP(hipMemcpyAsync(out6, d_o, 24, hipMemcpyDeviceToHost, ctx->stream));
+    CF_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
 
 int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int32_t min_cloud_kmer_freq,
                    int32_t min_unit, int32_t min_inters, int32_t min_prop,

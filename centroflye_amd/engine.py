@@ -333,6 +333,13 @@ class Engine:
         self._check(self._lib.cf_selftest_sort(self._ctx, _ptr(keys), keys.size, int(bits), _ptr(out)), "cf_selftest_sort")
         return out
 
+    def selftest_argmax(self, cands):
+        """Winner (s0, s1, offset, rank, index, valid) of the placement's candidate reduction over rows (s0, s1, offset, rank, valid)."""
+        cands = np.ascontiguousarray(cands, np.uint32).reshape(-1, 5)
+        out = np.zeros(6, np.uint32)
+        self._check(self._lib.cf_selftest_argmax(self._ctx, _ptr(cands) if cands.size else None, cands.shape[0], _ptr(out)), "cf_selftest_argmax")
+        return out
+
     def selftest_scan(self, vals):
         vals = np.ascontiguousarray(vals, np.int64)
         out = np.zeros(vals.size + 1, np.int64)

@@ -182,6 +182,9 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value);
 /* Self-tests of the device primitives against host results (used by tests/ only). */
 int cf_selftest_sort(cf_ctx* ctx, const uint64_t* keys, int64_t n, int32_t bits, uint64_t* out);
 int cf_selftest_scan(cf_ctx* ctx, const int64_t* in, int64_t n, int64_t* out);
+/* the arg-max of the greedy placement (read_placer.py:63-78: larger (s0, s1), then the larger offset, then the smaller id rank)
+ * over n candidates given as rows (s0, s1, offset, rank, valid); out6 = (s0, s1, offset, rank, index of the winner, valid) */
+int cf_selftest_argmax(cf_ctx* ctx, const uint32_t* cands, int64_t n, uint32_t* out6);
 
 #ifdef __cplusplus
 }

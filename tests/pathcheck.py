@@ -140,3 +140,45 @@ def check_unit_kmers(engine, report_path, golden_entry, k):
     assert engine.top_kmers(0)[0].size == 0
     allk, allc = engine.top_kmers(10 ** 9)
     assert allk.size == okeys.size and int(allc.astype(np.int64).sum()) == g["total"]
+
+
+def check_argmax_selftest(engine):
+    """The placement's candidate reduction against the host (reference read_placer.py:63-78: larger (s0, s1), then the
+    larger offset, then the smaller id).  Layouts that decide which lane takes whose candidate at which shuffle step —
+    round 3 found the six-field struct form of this reduction miscompiled (a lane that took its partner's candidate at
+    distance 32 and none afterwards kept its OLD read id next to the new scores)."""
+    rng = np.random.default_rng(9)
+
+    def best(c):
+        idx = [i for i in range(c.shape[0]) if c[i, 4]]
+        if not idx:
+            return None
+        return max(idx, key=lambda i: (int(c[i, 0]), int(c[i, 1]), int(c[i, 2]), -int(c[i, 3])))
+
+    cases = []
+    # the failing pattern: a worse candidate in lane L, the best one in lane L + 32 of the same wave, nothing else
+    for wave in range(4):
+        for lane in (0, 5, 31):
+            c = np.zeros((256, 5), np.uint32)
+            c[64 * wave + lane] = (6, 476, 5210, 35727, 1)
+            c[64 * wave + lane + 32] = (8, 764, 5360, 31523, 1)
+            cases.append(c)
+    for d in (1, 2, 4, 8, 16, 32):      # ... and at every other shuffle distance, in both orders
+        for swap in (0, 1):
+            c = np.zeros((256, 5), np.uint32)
+            a, b = (70, 70 + d) if not swap else (70 + d, 70)
+            c[a] = (3, 90, 17, 5, 1); c[b] = (3, 90, 17, 4, 1)      # a tie down to the id rank
+            cases.append(c)
+    for n in (0, 1, 63, 64, 65, 255, 256, 257, 1000, 5000):      # random sets with heavy ties, some invalid rows
+        c = np.zeros((n, 5), np.uint32)
+        c[:, 0] = rng.integers(0, 3, n); c[:, 1] = rng.integers(0, 4, n); c[:, 2] = rng.integers(0, 3, n)
+        c[:, 3] = rng.permutation(n); c[:, 4] = rng.integers(0, 4, n) > 0
+        cases.append(c)
+    cases.append(np.zeros((300, 5), np.uint32))      # no valid candidate
+    for c in cases:
+        got = engine.selftest_argmax(c)
+        w = best(c)
+        if w is None:
+            assert got[5] == 0, got
+        else:
+            assert got.tolist() == [int(c[w, 0]), int(c[w, 1]), int(c[w, 2]), int(c[w, 3]), w, 1], (got.tolist(), w, c[w].tolist())

@@ -32,6 +32,10 @@ def test_scan_and_sort(engine):
     assert np.array_equal(engine.selftest_sort(k, 8), np.sort(k))
 
 
+def test_placement_argmax_reduction(engine):
+    pathcheck.check_argmax_selftest(engine)
+
+
 def test_stage2_small(engine, report, oracle_stage2):
     # max_distance 2 keeps the emulated dist kernel to a few 10^5 emissions
     tup = oracle_stage2("lowcov", max_distance=2)

@@ -30,6 +30,11 @@ def test_device_is_gfx950(engine):
     assert info["n_cu"] == 256
 
 
+def test_placement_argmax_reduction(engine):
+    """cf_selftest_argmax: the candidate reduction of the greedy placement on adversarial layouts (see pathcheck)."""
+    pathcheck.check_argmax_selftest(engine)
+
+
 def test_scan_and_sort(engine):
     rng = np.random.default_rng(1)
     for n in (0, 1, 63, 2048, 2049, 100003, 3_000_001):
