@@ -23,13 +23,14 @@
 void cf_free_edges(cf_ctx* c);
 int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 
-#define DIST_NP_CAP 256
+#define DIST_NP_CAP 128
 #define DIST_STAGE_CAP 1024              /* selected slots staged per table pass (u16 slot indices) */
 #define DIST_STACK 112
 #define DIST_UNROLL 4
 #define DIST_ITEM (64u * DIST_UNROLL)    /* cloud entries one wave takes per step: DIST_UNROLL consecutive ones per lane */
 #define DIST_BM_BITS 65536u              /* bitmap over hash(b): k-mers that may have a selected edge */
 #define DIST_OVQ 96u                     /* per-wave list of inserts whose first probe did not finish (drained with the probe loop at >= 32) */
+#define DIST_LDS_HEAD (DIST_BM_BITS / 8 + 16 * DIST_NP_CAP + 4 * (4 + DIST_NP_CAP) + 64)   /* bitmap + posting ranges + item prefixes + sh: the fixed head of the kernel's LDS */
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
 #define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
 
@@ -154,7 +155,7 @@ struct cf_dist_args {
     unsigned long long edge_cap;
     const int32_t* order;          // first k-mers of this partition, sorted by their first posting (locality)
     int64_t n_order;
-    unsigned long long* counters;  // [0] edges [1] emissions [2] spilled a [4] error flags [5] passes; [16 + 16 x] queue head x
+    unsigned long long* counters;  // [0] edges [1] partner entries swept [2] spilled a [3] (host: self pairs) [4] error flags [5] passes; [16 + 16 x] queue head x
     uint32_t* unique_bits;
 };
 
@@ -640,6 +641,9 @@ struct cf_tab_region {
 };
 
 
+// lanes below this one whose bit is set in a ballot: v_mbcnt_lo + v_mbcnt_hi (2 instructions; popcount(mask & lanemask_lt) is 4)
+__device__ __forceinline__ uint32_t cf_rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
 #define DIST_QCAP 320                    /* deferred inserts per wave: fewer than 64 left by the drains before a step + at most 4 x 64 pushed by it */
 #define DIST_FULL_BIT 0x80000000u        /* sh[0]: the table is physically full (the pass is void and will be split) */
 
@@ -726,8 +730,8 @@ __device__ __forceinline__ void cf_dist_build_items(const cf_dist_rec* rec, cons
 // this static deal faster than a shared cursor).  Every lane first loads ONE of its wave's item records (lane j: the j-th item of
 // the wave); a step then gets its record with two v_readlane into SGPRs — the base address of the step's global load is scalar,
 // the per-lane offset is the constant 16 * lane.  Software pipeline: the load of step j + 1 is issued before the body of step j.
-// body(bb, dd, ok, partial): the decoded entries of a step; ok = per-lane bit mask of the entries that exist (only the last item
-// of a posting has lanes past its end: partial, wave-uniform, says whether ok needs looking at); returns true to stop the wave.
+// body(bb, dd, ok, len): the decoded entries of a step; ok = per-lane bit mask of the entries that exist (only the last item of
+// a posting has lanes past its end: len < DIST_ITEM, wave-uniform, says whether ok needs looking at); returns true to stop the wave.
 // pre(final) runs at ONE site before every step and once more (final = true) after the wave's last step: the table sweep drains
 // its insert queue there (one copy of that code in the loop instead of one per push site: 42 -> 27 KB of code).
 template <class Tab, int D, class Pre, class Body>
@@ -777,8 +781,8 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
                 uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
 #pragma unroll
                 for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cm & 0xFFFFu, bb[u], dd_[u]);
-                const bool partial = (cm >> 16) < DIST_ITEM;
-                if (body(bb, dd_, partial ? ok_of(cm) : (1u << DIST_UNROLL) - 1u, partial)) return;
+                const uint32_t len = cm >> 16;      // entries of the item (wave-uniform); < DIST_ITEM only for the last item of a posting
+                if (body(bb, dd_, len < DIST_ITEM ? ok_of(cm) : (1u << DIST_UNROLL) - 1u, len)) return;
                 ++j;
             }
         }
@@ -793,17 +797,30 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
 #define CF_DIST_PF_B 1      /* ... and in the table sweep (its body holds the drain code: every copy costs 15 KB of instructions) */
 #endif
 
+// registers per lane: the default bound (1024 threads, one workgroup per CU) gives 128 = four waves per SIMD; diagnostic builds
+// ask for (640, 2) = five waves per SIMD (96 registers) or (768, 2) = six (80)
+#ifndef CF_DIST_LB_THREADS
+#define CF_DIST_LB_THREADS 1024
+#define CF_DIST_LB_BLOCKS 1
+#endif
 template <class Tab>
-__global__ void cf_dist_kernel(cf_dist_args A) {
-    Tab T;
-    T.init(cf_lds, (uint32_t)A.slots);
-    T.configure(A, (uint32_t)A.slots / Tab::kPerBucket);
-    // LDS: [table | edge stage | partition stack | insert queues] [posting ranges | item prefixes | sh | bitmap].  The first
-    // group is dead while the sketch sweep runs, so its 8-bit counters (sk) lie over ALL of it: the 8-byte-slot layouts,
-    // whose table is smaller than 64 KiB next to their 8-byte queue items, keep 65 536 counters that way.
+__global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist_kernel(cf_dist_args A) {
+    // LDS: [bitmap | posting ranges | item prefixes | sh] at FIXED offsets (the bitmap at 0: its word address is the hash bits
+    // themselves, no base to add; the offsets of the rest fold into the instructions' offset fields), then
+    // [table | edge stage | partition stack | insert queues], then the item records.  The table group is dead while the sketch
+    // sweep runs, so its 8-bit counters (sk) lie over ALL of it: the 8-byte-slot layouts, whose table is smaller than 64 KiB
+    // next to their 8-byte queue items, keep 65 536 counters that way.
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
-    uint32_t* sk = (uint32_t*)cf_lds;
-    uint16_t* stage = (uint16_t*)(cf_lds + (size_t)A.slots * Tab::kSlotBytes);   // slot indices of the selected edges of a pass
+    uint32_t* bm = (uint32_t*)cf_lds;                          // DIST_BM_BITS bits: hash(b) of the k-mers b that may have a selected edge
+    cf_dist_rec* rec = (cf_dist_rec*)(cf_lds + DIST_BM_BITS / 8);      // partner range of each posting of the chunk
+    uint32_t* ipx = (uint32_t*)(rec + DIST_NP_CAP);            // 4 zeros, then the inclusive prefix of item counts
+    uint32_t* sh = ipx + 4 + DIST_NP_CAP;                      // [0] keys in table | DIST_FULL_BIT [1] first k-mer [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] hot-list cursor [12] entries of the chunk [13] a counter of the sketch wrapped [14,15] its first posting
+    unsigned char* lds_tab = cf_lds + DIST_LDS_HEAD;
+    Tab T;
+    T.init(lds_tab, (uint32_t)A.slots);
+    T.configure(A, (uint32_t)A.slots / Tab::kPerBucket);
+    uint32_t* sk = (uint32_t*)lds_tab;
+    uint16_t* stage = (uint16_t*)(lds_tab + (size_t)A.slots * Tab::kSlotBytes);   // slot indices of the selected edges of a pass
     // per-wave queue of pending inserts: candidates are compacted here and inserted 64 at a time by a full wave.
     // Only its own wave touches it: LDS operations of one wave execute in order, and wavefront-scope fences (no
     // instructions) keep the compiler from moving the queue accesses across the drain; a volatile pointer would turn
@@ -815,11 +832,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
     // through the probe loop 32 .. 64 at a time (round 2 ran that loop inside every drain: most drains went around twice for
     // one or two of their 64 lanes)
     typename Tab::qitem* ovq = wq0 + (size_t)(nt >> 6) * DIST_QCAP + (size_t)(t >> 6) * DIST_OVQ;
-    cf_dist_rec* rec = (cf_dist_rec*)(wq0 + (size_t)(nt >> 6) * (DIST_QCAP + DIST_OVQ));      // partner range of each posting of the chunk
-    uint32_t* ipx = (uint32_t*)(rec + DIST_NP_CAP);            // 4 zeros, then the inclusive prefix of item counts
-    uint32_t* sh = ipx + 4 + DIST_NP_CAP;                      // [0] keys in table | DIST_FULL_BIT [1] first k-mer [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] hot-list cursor [12] entries of the chunk [13] a counter of the sketch wrapped [14,15] its first posting
-    uint32_t* bm = sh + 16;                                    // DIST_BM_BITS bits: hash(b) of the k-mers b that may have a selected edge
-    cf_dist_item* items = (cf_dist_item*)(bm + DIST_BM_BITS / 32);   // A.it_cap item records: the work list of the sweeps
+    cf_dist_item* items = (cf_dist_item*)(wq0 + (size_t)(nt >> 6) * (DIST_QCAP + DIST_OVQ));   // A.it_cap item records: the work list of the sweeps
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
 #if defined(CF_DIST_STAMPS)
@@ -921,7 +934,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = z;
             __syncthreads();
             for_lists([&](uint32_t n_list) {
-                cf_dist_sweep<Tab, CF_DIST_PF_A>(A, items, n_list, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, bool partial) -> bool {
+                cf_dist_sweep<Tab, CF_DIST_PF_A>(A, items, n_list, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
                     // (entries equal to a are counted too: the sketch may only over-count, and the table sweep drops them)
                     uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL], inc_[DIST_UNROLL];
 #pragma unroll
@@ -931,20 +944,25 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                         inc_[u] = 1u << (sft_[u] & 31u);
                         old_[u] = idx >> 2;
                     }
-                    if (partial) {      // (wave-uniform) lanes past the end of the posting's range add nothing
+                    if (len < DIST_ITEM) {      // (wave-uniform) lanes past the end of the posting's range add nothing
 #pragma unroll
                         for (int u = 0; u < DIST_UNROLL; ++u) if (!((ok >> u) & 1u)) inc_[u] = 0u;
                     }
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) old_[u] = atomicAdd(&sk[old_[u]], inc_[u]);     // all counter adds of the step back to back
+                    uint32_t seen_[DIST_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) {
-                        const uint32_t seen = __builtin_amdgcn_ubfe(old_[u], sft_[u], 8u);     // occurrences before this one (v_bfe_u32 takes the offset mod 32)
-                        if (seen >= min_cov_m1) {
-                            if (inc_[u]) {
+                    for (int u = 0; u < DIST_UNROLL; ++u) seen_[u] = __builtin_amdgcn_ubfe(old_[u], sft_[u], 8u);     // occurrences before this one (v_bfe_u32 takes the offset mod 32)
+                    // ONE test per step: few adds reach min_cov (each of the four branches of round 2 cost a compare, three scalar
+                    // exec-mask instructions and a jump)
+                    static_assert(DIST_UNROLL == 4, "max of four");
+                    if (max(max(seen_[0], seen_[1]), max(seen_[2], seen_[3])) >= min_cov_m1) {
+#pragma unroll
+                        for (int u = 0; u < DIST_UNROLL; ++u) {
+                            if (seen_[u] >= min_cov_m1 && inc_[u]) {
                                 const uint32_t hbit = Tab::bm_bit(bb[u]);
                                 if (!((bm[hbit >> 5] >> (hbit & 31u)) & 1u)) atomicOr(&bm[hbit >> 5], 1u << (hbit & 31u));
-                                if (seen == 255u) sh[13] = 1u;
+                                if (seen_[u] == 255u) sh[13] = 1u;
                             }
                         }
                     }
@@ -980,13 +998,13 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             T.clear(slots, (uint32_t)t, (uint32_t)nt);
             __syncthreads();
             const uint32_t P = sh[3], pidx = sh[4], pmask = P - 1u;   // P is a power of two; P == 1: every b belongs to the pass
-            uint32_t my_e = 0;
+            uint32_t my_e = 0, s_e = 0;      // partner entries swept by this lane (split passes) / by this wave (whole passes)
             CF_STAMP(2);   // pop partition + clear table
             // ---- phase B: sweep again; pairs of this partition whose b is marked go to the wave's queue and are
             // inserted into the exact table 64 at a time by a full wave
             for_lists([&](uint32_t n_list) {
                 uint32_t qtail = 0, otail = 0;      // wave-uniform: queued inserts / parked inserts of this wave
-                const unsigned long long lt_ = (1ull << lane) - 1ull;
+                bool too_full = sh[0] > A.fill_limit;      // (another list of this pass may already have filled the table)
                 // pops the last N (<= 64) queued inserts, one per lane, and gives each ONE probe of its home bucket in
                 // straight-line code: match -> count it; empty slot -> claim it; bucket full or the slot lost to another key ->
                 // parked in the overflow list, which goes through the probe loop once it holds 32
@@ -1027,7 +1045,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     if (new_ && lane == 0) atomicAdd(&sh[0], new_);                                           \
                     const unsigned long long pm_ = __ballot(park_ != 0u);                                     \
                     if (pm_) {                                                                                \
-                        if (park_) ovq[otail + (uint32_t)__popcll(pm_ & lt_)] = it_;                          \
+                        if (park_) ovq[otail + cf_rank_in(pm_)] = it_;                                        \
                         otail += (uint32_t)__popcll(pm_);                                                     \
                     }                                                                                         \
                     __builtin_amdgcn_wave_barrier();                                                          \
@@ -1037,37 +1055,40 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     // a step pushes at most 4 x 64 inserts: the queue is brought below 64 first; after the wave's last step
                     // both lists are emptied (a pass whose table got too full is void and drops them)
                     const uint32_t lim = final ? 1u : 64u;
+                    if (qtail < lim && !(final && otail > 0u)) return;      // nothing to drain: no look at the fill level either
                     for (;;) {
-                        if (sh[0] > A.fill_limit) break;
+                        if (sh[0] > A.fill_limit) { too_full = true; break; }
                         if (qtail >= lim) { CF_DIST_DRAIN(min(qtail, 64u)) }
                         else if (!(final && otail > 0u)) break;
                         if (otail >= 32u || (final && qtail == 0u && otail > 0u)) { CF_DIST_OVERFLOW(min(otail, 64u)) }
                     }
-                }, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, bool partial) -> bool {
-                    if (sh[0] > A.fill_limit) return true;     // too full (or physically full): the pass will be split
-                    uint32_t w_[DIST_UNROLL], hbit_[DIST_UNROLL], live = 0, cand = 0;
+                }, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
+                    if (too_full) return true;     // (wave-uniform, set by the drains: the fill only changes there) the pass will be split
+                    // Entries equal to a itself are NOT told apart here (round 2 spent 13 vector instructions per step on it): they are
+                    // rare (a k-mer twice in one read), the filter never selects a slot whose b is a, and the emission count of the
+                    // launch has them subtracted on the host (cf_self_pairs_kernel counts them from the posting lists).
+                    uint32_t w_[DIST_UNROLL], hbit_[DIST_UNROLL], live = (1u << DIST_UNROLL) - 1u, cand = 0;
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
-                        live |= (uint32_t)(bb[u] != a) << u;
                         hbit_[u] = Tab::bm_bit(bb[u]);
                         w_[u] = bm[hbit_[u] >> 5];
                     }
-                    if (partial) live &= ok;      // (wave-uniform) only the last item of a posting has lanes past its end
+                    if (len < DIST_ITEM) live = ok;      // (wave-uniform) only the last item of a posting has lanes past its end
                     if (pmask) {       // (wave-uniform) only a first k-mer whose table was split tests the partition of b
 #pragma unroll
                         for (int u = 0; u < DIST_UNROLL; ++u) {
                             const uint32_t hb = Tab::hash(bb[u]);
                             if ((((hb ^ (hb >> 15)) >> 3) & pmask) != pidx) live &= ~(1u << u);
                         }
-                    }
-                    my_e += (uint32_t)__popcll((unsigned long long)live);
+                        my_e += (uint32_t)__popcll((unsigned long long)live);
+                    } else s_e += len;      // entries swept, counted on the scalar unit
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) cand |= (((live >> u) & (w_[u] >> (hbit_[u] & 31u))) & 1u) << u;
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         const unsigned long long cm = __ballot((cand >> u) & 1u);
                         if (cm) {
-                            if ((cand >> u) & 1u) wq[qtail + (uint32_t)__popcll(cm & lt_)] = T.q_of(bb[u], dd_[u], n_buckets);
+                            if ((cand >> u) & 1u) wq[qtail + cf_rank_in(cm)] = T.q_of(bb[u], dd_[u], n_buckets);
                             qtail += (uint32_t)__popcll(cm);
                         }
                     }
@@ -1089,7 +1110,7 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
             // ---- table of the pass complete: count emissions, filter in LDS (selected slots are marked and
             // staged), reserve the edge range with ONE global atomic, then write
             for (int d = 32; d >= 1; d >>= 1) my_e += __shfl_down(my_e, (unsigned)d);
-            if (lane == 0 && my_e) atomicAdd(&sh[7], my_e);
+            if (lane == 0 && (my_e + s_e)) atomicAdd(&sh[7], my_e + s_e);
             // Filter in two steps.  (1) A group of slots per thread and round: the slots whose count reaches min_cov (few: the
             // table is sparse and most pairs stay below) are compacted into a list that lies over the insert queues, dead
             // by now.  (2) The list is evaluated one slot per thread with all lanes busy: sum over d from the bucket's
@@ -1141,14 +1162,14 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
                     uint32_t s = 0;
                     if (i < n_hot) {
                         s = hot[i];
-                        T.eval_slot(s, n_buckets, A.min_cov, [&](uint32_t, uint32_t, uint32_t, uint32_t cnt, unsigned long long total) { sel = ((double)cnt / (double)total) >= A.thr; });
+                        T.eval_slot(s, n_buckets, A.min_cov, [&](uint32_t, uint32_t b, uint32_t, uint32_t cnt, unsigned long long total) { sel = b != a && ((double)cnt / (double)total) >= A.thr; });
                     }
                     keep(sel, s);
                 }
             } else {        // more than the list holds (never seen with the sketch): evaluate inside the bucket scan
                 for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt)
-                    T.for_counts_at_least(bk, n_buckets, A.min_cov, [&](uint32_t s, uint32_t, uint32_t, uint32_t cnt, unsigned long long total) {
-                        if (((double)cnt / (double)total) >= A.thr) {
+                    T.for_counts_at_least(bk, n_buckets, A.min_cov, [&](uint32_t s, uint32_t b, uint32_t, uint32_t cnt, unsigned long long total) {
+                        if (b != a && ((double)cnt / (double)total) >= A.thr) {
                             T.mark(s);
                             const uint32_t pos = atomicAdd(&sh[8], 1u);
                             if (pos < A.stage_cap) stage[pos] = (uint16_t)s;
@@ -1198,6 +1219,38 @@ __global__ void cf_dist_kernel(cf_dist_args A) {
         for (int i = 0; i < 8; ++i) atomicAdd(&A.counters[8 + i], stamp_acc[i]);
 #endif
     }
+}
+
+// Partner entries that are the first k-mer itself: for every first k-mer a of the launch, the pairs of its postings (u, v) in one
+// read with min_d <= v - u <= max_d (the reference skips a == b, distance_based_kmer_recruitment.py:118; the sweeps count such an
+// entry like any other and the host subtracts this sum).  One wave per first k-mer; postings in chunks of 64.
+__global__ void __launch_bounds__(256)
+cf_self_pairs_kernel(const int32_t* __restrict__ order, int64_t n_order, const int64_t* __restrict__ post_ptr, const int32_t* __restrict__ post,
+                     const int32_t* __restrict__ rbeg, int32_t min_d, int32_t max_d, unsigned long long* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long cnt = 0;
+    for (int64_t i = wave; i < n_order; i += n_waves) {
+        const int32_t a = order[i];
+        const int64_t p0 = post_ptr[a], p1 = post_ptr[a + 1];
+        if (p1 - p0 < 2) continue;
+        for (int64_t x0 = p0; x0 < p1; x0 += 64) {
+            const bool hx = x0 + lane < p1;
+            const int32_t ux = hx ? post[x0 + lane] : 0, rx = hx ? rbeg[ux] : -1;
+            for (int64_t y0 = p0; y0 < p1; y0 += 64) {
+                const int ny = (int)min((int64_t)64, p1 - y0);
+                const int32_t uy_l = y0 + lane < p1 ? post[y0 + lane] : 0, ry_l = y0 + lane < p1 ? rbeg[uy_l] : -2;
+                for (int j = 0; j < ny; ++j) {
+                    const int32_t uy = __shfl(uy_l, j), ry = __shfl(ry_l, j);
+                    const int32_t d = uy - ux;
+                    cnt += (unsigned long long)(hx && ry == rx && d >= min_d && d <= max_d);
+                }
+            }
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_down(cnt, (unsigned)d);
+    if (lane == 0 && cnt) atomicAdd(out, cnt);
 }
 
 // sum over all postings of their partner-range length = the number of pair emissions of the launch (before a != b)
@@ -1437,6 +1490,9 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                                    (const unsigned long long*)d_okeys, n_order, d_order);
         }
         A.order = d_order; A.n_order = n_order;
+        if (n_order && n_post && max_d >= min_d_eff)      // partner entries that are the first k-mer itself (subtracted from the emission count below)
+            hipLaunchKernelGGL(cf_self_pairs_kernel, dim3((unsigned)cf_grid_for(n_order * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                               (const int32_t*)d_order, n_order, (const int64_t*)d_post_ptr, (const int32_t*)d_post, (const int32_t*)d_rbeg, min_d_eff, max_d, d_cnt + 3);
         const int64_t n_a = n_order;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_a, (int64_t)std::max(1, ctx->n_cu) * per_cu));
         e = hipGetLastError();
@@ -1487,7 +1543,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     if (d_pcnt) cf_release_t(ctx, d_pcnt, (size_t)K + 1);
     if (rc) return rc;
     ctx->stats.n_edges = (int64_t)h_cnt[0];
-    ctx->stats.n_emissions = (int64_t)h_cnt[1];
+    ctx->stats.n_emissions = (int64_t)h_cnt[1] - (int64_t)h_cnt[3];      // partner entries swept, less those that are the first k-mer itself (a != b in the reference)
     ctx->stats.n_spilled = (int64_t)h_cnt[2];
     ctx->stats.n_dist_passes = (int64_t)h_cnt[5];
     ctx->n_edges_stored = std::min<int64_t>((int64_t)h_cnt[0], edge_cap);

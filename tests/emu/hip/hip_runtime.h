@@ -222,6 +222,9 @@ inline unsigned __builtin_amdgcn_ubfe(unsigned v, unsigned offset, unsigned widt
 
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+// v_mbcnt_lo / v_mbcnt_hi: bits of the mask below this lane, added to `add`
+inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned add) { const unsigned l = cfemu::lane_id(); return add + (unsigned)__builtin_popcount(l >= 32 ? mask : (mask & ((1u << l) - 1u))); }
+inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned add) { const unsigned l = cfemu::lane_id(); return add + (l <= 32 ? 0u : (unsigned)__builtin_popcount(mask & ((1u << (l - 32)) - 1u))); }
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
