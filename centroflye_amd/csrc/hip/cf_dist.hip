@@ -274,6 +274,7 @@ struct cf_tab_wide_t {
     }
     // filter, two steps: the slots of bucket bk whose count reaches min_cov as a bit mask ...
     static constexpr uint32_t kScanGroup = 4;      // slots per step of the scan (one bucket)
+    static __device__ __forceinline__ uint32_t slot_of_bit(uint32_t bit) { return bit; }      // hot_mask: bit i = slot i of the group
     __device__ __forceinline__ uint32_t hot_mask(uint32_t bk, uint32_t min_cov) const {
         const bucket k = read(bk);
         const unsigned long long v[4] = {k.lo.x, k.lo.y, k.hi.x, k.hi.y};
@@ -425,15 +426,17 @@ struct cf_tab_narrow_t {
     // filter, two steps: the slots of bucket bk whose count field reaches min_cov - 1 as a bit mask (an empty slot has the
     // field 0: with min_cov <= 1 it is in the mask and eval_slot drops it) ...
     static constexpr uint32_t kScanGroup = 8;      // slots per step of the scan: 16 bytes of count fields, whatever the bucket size
+    // two 16-bit fields per word compared at once: (field & 0x7FFF) + (0x8000 - need) has bit 15 set iff the field reaches need
+    // (no carry leaves a half: both terms are <= 0x8000).  Bit 2j of the result = slot 2j of the group, bit 16 + 2j = slot 2j + 1.
     __device__ __forceinline__ uint32_t hot_mask(uint32_t g, uint32_t min_cov) const {
         const cf_u32x4 v = *(const cf_u32x4*)&cnt32[4 * g];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        const uint32_t need = min_cov ? min_cov - 1u : 0u;
-        uint32_t m = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) m |= (uint32_t)(((w[j >> 1] >> ((j & 1) * 16)) & 0x7FFFu) >= need) << j;
-        return m;
+        const uint32_t need = min(min_cov ? min_cov - 1u : 0u, 0x8000u);
+        const uint32_t add = 0x80008000u - need * 0x00010001u;
+        const uint32_t y0 = ((v.x & 0x7FFF7FFFu) + add) & 0x80008000u, y1 = ((v.y & 0x7FFF7FFFu) + add) & 0x80008000u;
+        const uint32_t y2 = ((v.z & 0x7FFF7FFFu) + add) & 0x80008000u, y3 = ((v.w & 0x7FFF7FFFu) + add) & 0x80008000u;
+        return (y0 >> 15) | (y1 >> 13) | (y2 >> 11) | (y3 >> 9);
     }
+    static __device__ __forceinline__ uint32_t slot_of_bit(uint32_t bit) { return (bit & 15u) + (bit >> 4); }
     // ... and one such slot evaluated: f(slot, b, dd, cnt, sum over d of cnt(b, .)).  Usual case: b lives in its home bucket
     // and the bucket is not full, so all (b, .) keys are among the keys just read — no chain walk through LDS.
     template <class F>
@@ -603,15 +606,17 @@ struct cf_tab_region {
         }
     }
     static constexpr uint32_t kScanGroup = 8;
+    // two 16-bit fields per word compared at once: (field & 0x7FFF) + (0x8000 - need) has bit 15 set iff the field reaches need
+    // (no carry leaves a half: both terms are <= 0x8000).  Bit 2j of the result = slot 2j of the group, bit 16 + 2j = slot 2j + 1.
     __device__ __forceinline__ uint32_t hot_mask(uint32_t g, uint32_t min_cov) const {
         const cf_u32x4 v = *(const cf_u32x4*)&cnt32[4 * g];
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        const uint32_t need = min_cov ? min_cov - 1u : 0u;
-        uint32_t m = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) m |= (uint32_t)(((w[j >> 1] >> ((j & 1) * 16)) & 0x7FFFu) >= need) << j;
-        return m;
+        const uint32_t need = min(min_cov ? min_cov - 1u : 0u, 0x8000u);
+        const uint32_t add = 0x80008000u - need * 0x00010001u;
+        const uint32_t y0 = ((v.x & 0x7FFF7FFFu) + add) & 0x80008000u, y1 = ((v.y & 0x7FFF7FFFu) + add) & 0x80008000u;
+        const uint32_t y2 = ((v.z & 0x7FFF7FFFu) + add) & 0x80008000u, y3 = ((v.w & 0x7FFF7FFFu) + add) & 0x80008000u;
+        return (y0 >> 15) | (y1 >> 13) | (y2 >> 11) | (y3 >> 9);
     }
+    static __device__ __forceinline__ uint32_t slot_of_bit(uint32_t bit) { return (bit & 15u) + (bit >> 4); }
     template <class F>
     __device__ __forceinline__ void eval_slot(uint32_t s, uint32_t n_buckets, uint32_t min_cov, F&& f) const {
         const uint32_t bk = s / (uint32_t)PB, i = s % (uint32_t)PB;
@@ -791,7 +796,7 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
 }
 
 #ifndef CF_DIST_PF_A
-#define CF_DIST_PF_A 2      /* loads in flight per lane in the sketch sweep */
+#define CF_DIST_PF_A 1      /* loads in flight per lane in the sketch sweep */
 #endif
 #ifndef CF_DIST_PF_B
 #define CF_DIST_PF_B 1      /* ... and in the table sweep (its body holds the drain code: every copy costs 15 KB of instructions) */
@@ -862,6 +867,30 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         nx_idx = pop();
         if (nx_idx >= 0) { nx_a = (uint32_t)A.order[nx_idx]; nx_pp0 = A.post_ptr[nx_a]; nx_pp1 = A.post_ptr[nx_a + 1]; }
     }
+    // Wave 0 also fetches the NEXT first k-mer's partner ranges (post[] -> urange[]: two more dependent round trips, up to
+    // DIST_NP_CAP postings, DIST_NP_CAP / 64 per lane) while the workgroup filters and writes the current one: at the loop top
+    // they go from its registers to LDS.  pf_np = postings held (wave-0 uniform), -1 = none (no next first k-mer, or too many).
+    int32_t pf_u[DIST_NP_CAP / 64];
+    cf_dist_rec pf_rec[DIST_NP_CAP / 64];
+    int pf_np = -1;
+#pragma unroll
+    for (int k = 0; k < DIST_NP_CAP / 64; ++k) { pf_u[k] = -1; pf_rec[k] = cf_dist_rec{0, 0u, 0u}; }
+    auto pf_issue_post = [&]() {      // wave 0: thread 0 holds nx_idx / nx_pp0 / nx_pp1
+        pf_np = -1;
+        if (!__builtin_amdgcn_readfirstlane((int)(nx_idx >= 0))) return;
+        const int64_t p0 = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)((unsigned long long)nx_pp0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nx_pp0));
+        const int64_t npn = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)min(nx_pp1 - nx_pp0, (int64_t)0x7FFFFFFF));
+        if (npn > DIST_NP_CAP) return;
+        pf_np = (int)npn;
+#pragma unroll
+        for (int k = 0; k < DIST_NP_CAP / 64; ++k) pf_u[k] = lane + 64 * k < npn ? A.post[p0 + lane + 64 * k] : -1;
+    };
+    auto pf_issue_rec = [&]() {
+        if (pf_np < 0) return;
+#pragma unroll
+        for (int k = 0; k < DIST_NP_CAP / 64; ++k) pf_rec[k] = pf_u[k] >= 0 ? A.urange[pf_u[k]] : cf_dist_rec{0, 0u, 0u};
+    };
+    if (t < 64) { pf_issue_post(); pf_issue_rec(); }
 
     while (true) {
         __syncthreads();
@@ -869,6 +898,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             sh[5] = (uint32_t)(unsigned long long)nx_idx; sh[6] = (uint32_t)((unsigned long long)nx_idx >> 32);
             sh[1] = nx_a; sh[14] = (uint32_t)(unsigned long long)nx_pp0; sh[15] = (uint32_t)((unsigned long long)nx_pp0 >> 32);
             sh[12] = (uint32_t)(nx_pp1 - nx_pp0);
+            sh[7] = 0; sh[13] = 0;
         }
         __syncthreads();
         const int64_t ai = (int64_t)(((unsigned long long)sh[6] << 32) | sh[5]);
@@ -879,21 +909,54 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         CF_STAMP(0);   // queue pop
         if (pp1 == pp0) {                                            // (order[] holds only k-mers with postings)
             if (t == 0 && nx_idx >= 0) { nx_a = (uint32_t)A.order[nx_idx]; nx_pp0 = A.post_ptr[nx_a]; nx_pp1 = A.post_ptr[nx_a + 1]; }
+            if (t < 64) { pf_issue_post(); pf_issue_rec(); }
             continue;
         }
-        // Usual case: <= DIST_NP_CAP postings whose items fit the LDS list — records built ONCE, both sweeps run on them.
-        bool one_chunk = (pp1 - pp0) <= DIST_NP_CAP;
+        // Usual case: <= DIST_NP_CAP postings whose items fit the LDS list — records built ONCE, both sweeps run on them.  Wave 0
+        // builds them from the partner ranges it holds (no barrier inside: one wave, LDS operations of a wave execute in order)
+        // while the other waves clear the sketch and the bitmap; ONE barrier ends the prologue (round 2: five).
+        const int np_all = (int)min(pp1 - pp0, (int64_t)0x7FFFFFFF);
+        bool one_chunk = np_all <= DIST_NP_CAP;
+        bool cleared = false;
         uint32_t n_items_all = 0;
-        if (t == 0) { sh[7] = 0; sh[13] = 0; }
-        __syncthreads();
         if (one_chunk) {
-            cf_dist_setup(A, pp0, (int)(pp1 - pp0), rec, ipx, sh);
-            if (t == 0) sh[7] = sh[12];
-            n_items_all = ipx[4 + (int)(pp1 - pp0) - 1];
+            if (t < 64) {
+                const int np = np_all;
+                uint32_t c[DIST_NP_CAP / 64], run = 0;
+                unsigned long long lens = 0;
+#pragma unroll
+                for (int k = 0; k < DIST_NP_CAP / 64; ++k) {      // posting p = lane + 64 k: inclusive prefix of the item counts in that order
+                    rec[lane + 64 * k] = pf_rec[k];
+                    lens += pf_rec[k].len;
+                    uint32_t inc = (pf_rec[k].len + DIST_ITEM - 1u) / DIST_ITEM;
+                    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
+                    c[k] = run + inc;
+                    run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                    ipx[4 + lane + 64 * k] = lane + 64 * k < np ? c[k] : 0xFFFFFFFFu;
+                }
+                for (int d = 32; d >= 1; d >>= 1) lens += __shfl_down(lens, (unsigned)d);
+                if (lane == 0) { ipx[0] = 0; ipx[1] = 0; ipx[2] = 0; ipx[3] = 0; sh[12] = (uint32_t)min(lens, 0x3FFFFFFFull); sh[7] = (uint32_t)min(lens, 0x3FFFFFFFull); sh[9] = run; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (run <= A.it_cap) {      // (wave-uniform) the item records, 64 per round
+                    for (uint32_t j = (uint32_t)lane; j < run; j += 64u) {
+                        int lo = 0, hi = np - 1;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (ipx[4 + mid] > j) hi = mid; else lo = mid + 1; }
+                        const cf_dist_rec r = rec[lo];
+                        const uint32_t off = (j - ipx[3 + lo]) * DIST_ITEM;
+                        items[j] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | (r.ig & 0xFFFFu)};
+                    }
+                }
+            } else if (A.sketch) {
+                const cf_u32x4 z{0u, 0u, 0u, 0u};
+                for (uint32_t s_ = (uint32_t)t - 64u; s_ < (A.sk_counters >> 4); s_ += (uint32_t)nt - 64u) ((cf_u32x4*)sk)[s_] = z;
+                for (uint32_t s_ = (uint32_t)t - 64u; s_ < DIST_BM_BITS / 128; s_ += (uint32_t)nt - 64u) ((cf_u32x4*)bm)[s_] = z;
+            }
+            cleared = nt > 64;
+            __syncthreads();
+            n_items_all = sh[9];
             one_chunk = n_items_all <= A.it_cap;
-            if (one_chunk) cf_dist_build_items(rec, ipx, (int)(pp1 - pp0), 0u, n_items_all, items);
-        }
-        if (!one_chunk && (pp1 - pp0) > DIST_NP_CAP) {
+        } else {
             unsigned long long em = 0;
             for (int64_t p = pp0 + t; p < pp1; p += nt) {
                 em += (unsigned long long)A.urange[A.post[p]].len;
@@ -905,7 +968,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         // run(n) for every item list of the first k-mer: the one built above, or (many postings / more items than the list
         // holds) chunk after chunk of postings, list after list
         auto for_lists = [&](auto&& run) {
-            if (one_chunk) { run(n_items_all); __syncthreads(); return; }
+            if (one_chunk) { run(n_items_all); __syncthreads(); CF_STAMP(7); return; }      // (stamp 7: thread 0's wait for the other waves at the end of a sweep)
             for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
                 const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
                 cf_dist_setup(A, c0, np, rec, ipx, sh);
@@ -929,10 +992,12 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         bool mark_all = !A.sketch;
         const uint32_t min_cov_m1 = A.min_cov - 1u;      // (the sketch runs with min_cov >= 2)
         if (A.sketch) {
-            const cf_u32x4 z{0u, 0u, 0u, 0u};
-            for (uint32_t s = (uint32_t)t; s < (A.sk_counters >> 4); s += (uint32_t)nt) ((cf_u32x4*)sk)[s] = z;
-            for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = z;
-            __syncthreads();
+            if (!cleared) {      // (many postings, or a one-wave workgroup)
+                const cf_u32x4 z{0u, 0u, 0u, 0u};
+                for (uint32_t s = (uint32_t)t; s < (A.sk_counters >> 4); s += (uint32_t)nt) ((cf_u32x4*)sk)[s] = z;
+                for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = z;
+                __syncthreads();
+            }
             for_lists([&](uint32_t n_list) {
                 cf_dist_sweep<Tab, CF_DIST_PF_A>(A, items, n_list, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
                     // (entries equal to a are counted too: the sketch may only over-count, and the table sweep drops them)
@@ -968,9 +1033,9 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     }
                     return false;
                 });
+                CF_STAMP(6);   // sketch sweep (clear + wave 0's own items)
             });
             if (sh[13]) mark_all = true;
-            CF_STAMP(6);   // sketch sweep
         }
         if (t == 0 && nx_idx >= 0) nx_a = (uint32_t)A.order[nx_idx];      // next: its rank (used before phase B)
         if (mark_all) {
@@ -1081,7 +1146,9 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                             if ((((hb ^ (hb >> 15)) >> 3) & pmask) != pidx) live &= ~(1u << u);
                         }
                         my_e += (uint32_t)__popcll((unsigned long long)live);
-                    } else s_e += len;      // entries swept, counted on the scalar unit
+                    }
+                    s_e += pmask ? 0u : len;      // entries swept, counted on the scalar unit (an `else` here made the compiler keep both
+                                                  // counters in a scratch array picked by index: a scratch load + store per step)
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) cand |= (((live >> u) & (w_[u] >> (hbit_[u] & 31u))) & 1u) << u;
 #pragma unroll
@@ -1096,9 +1163,13 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 });
 #undef CF_DIST_DRAIN
 #undef CF_DIST_OVERFLOW
+                CF_STAMP(3);   // table sweep + inserts (wave 0's own items)
             });
-            CF_STAMP(3);   // stream + insert
+            // next first k-mer: its postings now, their partner ranges one phase later (before the edges are written, or right here when
+            // the pass is void) — on EVERY path through a pass, so that the registers are dead while the sweeps run
+            if (t < 64) pf_issue_post();
             if (sh[0] > A.fill_limit) {  // overflow: split this partition in two
+                if (t < 64) pf_issue_rec();
                 if (t == 0) {
                     uint32_t sp = sh[2];
                     if (P >= (1u << 20) || sp + 2 > DIST_STACK) { atomicOr(&A.counters[4], 1ull); }
@@ -1125,23 +1196,26 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)nt) {      // (uniform trip count: ballots inside)
                 const uint32_t bk = g0 + (uint32_t)t;                       // a group of kScanGroup consecutive slots
                 const uint32_t m = bk < n_groups ? T.hot_mask(bk, A.min_cov) : 0u;
-                if (__ballot(m != 0u)) {
-                    uint32_t before = 0, total = 0;      // hot slots of lower lanes (any slot index) / of the wave
-#pragma unroll
-                    for (int i = 0; i < (int)Tab::kScanGroup; ++i) {
-                        const unsigned long long mi = __ballot((m >> i) & 1u);
-                        before += (uint32_t)__popcll(mi & lt);
-                        total += (uint32_t)__popcll(mi);
-                    }
+                const uint32_t cnt = (uint32_t)__popc(m);
+                if (__ballot(cnt != 0u)) {
+                    // positions in the list: lanes hand in their k-th hot slot in round k (most lanes have none, few have
+                    // two: one or two rounds, against eight ballots — one per slot of the group — before)
+                    uint32_t total = 0;
+                    for (uint32_t k = 0; k < Tab::kScanGroup; ++k) { const unsigned long long bk_ = __ballot(cnt > k); if (!bk_) break; total += (uint32_t)__popcll(bk_); }
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&sh[11], total);
-                    uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + before;
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                     uint32_t mm = m;
-                    while (mm) {
-                        const uint32_t i = (uint32_t)__ffs((int)mm) - 1u;
-                        mm &= mm - 1u;
-                        if (pos < hot_cap) hot[pos] = (uint16_t)(Tab::kScanGroup * bk + i);
-                        ++pos;
+                    for (uint32_t k = 0; k < Tab::kScanGroup; ++k) {
+                        const unsigned long long bk_ = __ballot(cnt > k);
+                        if (!bk_) break;
+                        if (cnt > k) {
+                            const uint32_t bit = (uint32_t)__ffs((int)mm) - 1u;
+                            mm &= mm - 1u;
+                            const uint32_t pos = base + cf_rank_in(bk_);
+                            if (pos < hot_cap) hot[pos] = (uint16_t)(Tab::kScanGroup * bk + Tab::slot_of_bit(bit));
+                        }
+                        base += (uint32_t)__popcll(bk_);
                     }
                 }
             }
@@ -1178,6 +1252,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             }
             __syncthreads();
             CF_STAMP(4);   // filter
+            if (t < 64) pf_issue_rec();
             const uint32_t n_sel = sh[8];
             __syncthreads();  // everyone has read the count before thread 0 reuses the word as a cursor
             if (t == 0) {
@@ -1517,8 +1592,8 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         {
             unsigned long long st[8];
             if (hipMemcpy(st, d_cnt + 8, 64, hipMemcpyDeviceToHost) == hipSuccess)
-                std::fprintf(stderr, "[cf_dist stamps] pop=%llu prologue=%llu sketch=%llu clear=%llu stream=%llu filter=%llu write=%llu (shader cycles summed over %d workgroups; passes=%llu)\n",
-                             st[0], st[1], st[6], st[2], st[3], st[4], st[5], grid, h_cnt[5]);
+                std::fprintf(stderr, "[cf_dist stamps] pop=%llu prologue=%llu sketch=%llu clear=%llu stream=%llu filter=%llu write=%llu sweep_end_wait=%llu (shader cycles summed over %d workgroups; passes=%llu)\n",
+                             st[0], st[1], st[6], st[2], st[3], st[4], st[5], st[7], grid, h_cnt[5]);
         }
 #endif
         if (h_cnt[4]) { rc = cf_fail(ctx, -34, "cf_dist_edges: (b,d) table could not be partitioned far enough"); break; }
