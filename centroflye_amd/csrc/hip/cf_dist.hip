@@ -30,7 +30,7 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 #define DIST_ITEM (64u * DIST_UNROLL)    /* cloud entries one wave takes per step: DIST_UNROLL consecutive ones per lane */
 #define DIST_BM_BITS 65536u              /* bitmap over hash(b): k-mers that may have a selected edge */
 #define DIST_OVQ 96u                     /* per-wave list of inserts whose first probe did not finish (drained with the probe loop at >= 32) */
-#define DIST_LDS_HEAD (DIST_BM_BITS / 8 + 16 * DIST_NP_CAP + 4 * (4 + DIST_NP_CAP) + 64)   /* bitmap + posting ranges + item prefixes + sh: the fixed head of the kernel's LDS */
+#define DIST_LDS_HEAD (DIST_BM_BITS / 8 + 64)   /* bitmap + sh: the fixed head of the kernel's LDS */
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
 #define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
 
@@ -126,6 +126,15 @@ cf_order_extract_kernel(const unsigned long long* __restrict__ keys, int64_t n, 
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) order[i] = (int32_t)(keys[i] & 0xFFFFFFFFull);
 }
 
+// One item = up to DIST_ITEM consecutive partner entries of one posting: what one wave takes per step.
+//   e  index of its first entry in the cloud-entry arrays (32 bits: cf_dist_edges refuses more than 2^32 - DIST_ITEM entries)
+//   m  [entries of the item (1 .. DIST_ITEM) : 16 | unit index of the posting inside its read, mod 65536 : 16]
+struct alignas(8) cf_dist_item { uint32_t e, m; };
+// One first k-mer of the launch, in processing order: its rank, its number of items and where its item records start.
+// The records of a first k-mer are laid out per WAVE of the sweeping workgroup (W waves): item j belongs to wave j % W and is its
+// record number j / W; wave w's records are the contiguous run [ibase + w * per, ...), per = ceil(n_items / W).
+struct alignas(16) cf_dist_head { uint32_t a, n_items; unsigned long long ibase; uint32_t n_entries, pad0, pad1, pad2; };   // n_entries: partner entries (capped at 2^30 - 1)
+
 struct cf_dist_args {
     const int64_t* post_ptr;
     const int32_t* post;
@@ -148,7 +157,8 @@ struct cf_dist_args {
     uint32_t est_limit;            // emissions one partition is expected to hold (fill_limit / expected distinct share)
     int32_t sketch;                // 1: count first in 8-bit counters, build the exact table only for k-mers that can pass min_cov
     uint32_t sk_counters, sk_shift;   // counters (a power of two that fits the LDS that is dead during the sketch sweep) and 32 - log2 of it
-    uint32_t it_cap;               // item records the LDS list holds (a multiple of 64, >= 64)
+    const cf_dist_head* heads;     // the first k-mers of the launch in processing order (cf_items_fill_kernel) ...
+    const cf_dist_item* items;     // ... and the item records of their sweeps, laid out per wave of a workgroup of blockDim.x threads
     uint32_t stage_cap;            // <= DIST_STAGE_CAP
     uint32_t hot_cap;              // cap on the filter's list of hot slots (tests: a small one forces the in-scan evaluation)
     uint32_t* edges;
@@ -673,34 +683,6 @@ __device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buck
     return 0u;
 }
 
-// One posting of the first k-mer: its partner entries are ONE contiguous CSR range [e0, e0 + len); ig is the unit
-// index of the posting inside its read.  The range is swept in items of DIST_ITEM entries.
-// Partner ranges of the postings [c0, c0 + np) of one first k-mer -> LDS: rec[p], the inclusive prefix of their item
-// counts ipx[4 + p] (0xFFFFFFFF beyond np; ipx[0..3] = 0 so that ipx[3 + p] is the exclusive prefix) and the number
-// of partner entries in sh[12].  Called by all threads of the workgroup.
-__device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0, int np, cf_dist_rec* rec, uint32_t* ipx, uint32_t* sh) {
-    const int t = threadIdx.x, nt = blockDim.x;
-    for (int p = t; p < DIST_NP_CAP; p += nt) {
-        if (p < np) rec[p] = A.urange[A.post[c0 + p]];     // two dependent loads per posting (was four, three deep)
-        else rec[p] = cf_dist_rec{0, 0u, 0u};            // (written on both paths: a conditionally overwritten local ends up in scratch)
-    }
-    __syncthreads();
-    if (t < 64) {   // wave 0: inclusive scan of DIST_NP_CAP (= 4 x 64) item counts, 4 per lane
-        uint32_t v[DIST_NP_CAP / 64], sum = 0;
-        unsigned long long lens = 0;
-#pragma unroll
-        for (int i = 0; i < DIST_NP_CAP / 64; ++i) { const uint32_t len = rec[t * (DIST_NP_CAP / 64) + i].len; lens += len; sum += (len + DIST_ITEM - 1u) / DIST_ITEM; v[i] = sum; }
-        uint32_t inc = sum;
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, (unsigned)d); if (t >= d) inc += o; }
-        const uint32_t base = inc - sum;
-#pragma unroll
-        for (int i = 0; i < DIST_NP_CAP / 64; ++i) { const int p = t * (DIST_NP_CAP / 64) + i; ipx[4 + p] = p < np ? base + v[i] : 0xFFFFFFFFu; }
-        for (int d = 32; d >= 1; d >>= 1) lens += __shfl_down(lens, (unsigned)d);
-        if (t == 0) { ipx[0] = 0; ipx[1] = 0; ipx[2] = 0; ipx[3] = 0; sh[12] = (uint32_t)min(lens, 0x3FFFFFFFull); }
-    }
-    __syncthreads();
-}
-
 // Diagnostic build only (-DCF_DIST_STAMPS, tools/dist_stamps.py): per-phase shader-clock sums of thread 0 of every
 // workgroup into counters[8..15]; the shipped library compiles these to nothing.
 #if defined(CF_DIST_STAMPS)
@@ -709,46 +691,75 @@ __device__ __forceinline__ void cf_dist_setup(const cf_dist_args& A, int64_t c0,
 #define CF_STAMP(i) do { } while (0)
 #endif
 
-// One item = up to DIST_ITEM consecutive partner entries of one posting: what one wave takes per step.
-//   e  index of its first entry in the cloud-entry arrays (32 bits: cf_dist_edges refuses more than 2^32 - DIST_ITEM entries)
-//   m  [entries of the item (1 .. DIST_ITEM) : 16 | unit index of the posting inside its read, mod 65536 : 16]
-struct alignas(8) cf_dist_item { uint32_t e, m; };
-
-// Item records of the items [i0, i0 + n) of the current posting chunk (rec / ipx as cf_dist_setup left them) -> LDS, once per
-// first k-mer in the usual case; both sweeps then run on them.  Called by all threads; ends with a barrier.
-// Round 3: before, every wave found the posting of each item it took with 4 ballots + 4 popcounts + an LDS read of the
-// posting's record + 3 readfirstlanes + 64-bit address arithmetic, in both sweeps: about 25 vector and 40 scalar
-// instructions per step of 256 entries, on the dependency chain in front of the step's global load.
-__device__ __forceinline__ void cf_dist_build_items(const cf_dist_rec* rec, const uint32_t* ipx, int np, uint32_t i0, uint32_t n, cf_dist_item* items) {
-    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
-        const uint32_t item = i0 + j;
-        int lo = 0, hi = np - 1;                 // the posting of the item: the first p with inclusive prefix ipx[4 + p] > item
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (ipx[4 + mid] > item) hi = mid; else lo = mid + 1; }
-        const cf_dist_rec r = rec[lo];
-        const uint32_t off = (item - ipx[3 + lo]) * DIST_ITEM;
-        items[j] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | (r.ig & 0xFFFFu)};
+// Round 3: the work lists of the sweeps are built ONCE per launch, in HBM, by two small kernels (one wave per first k-mer),
+// instead of once per first k-mer inside cf_dist_kernel.  There every workgroup loaded its postings and their partner ranges
+// (two dependent round trips), scanned the item counts, searched the posting of every item and wrote the records to LDS behind
+// three barriers: 8 % of the kernel's time, 6.5 KB of its LDS, and every step of both sweeps first had to find its posting
+// (round 2: 25 vector + 40 scalar instructions per step).  Now a wave reads its 8-byte records with one coalesced load.
+__global__ void __launch_bounds__(256)
+cf_items_count_kernel(const int32_t* __restrict__ order, int64_t n_order, const int64_t* __restrict__ post_ptr, const int32_t* __restrict__ post,
+                      const cf_dist_rec* __restrict__ urange, uint32_t nw, uint32_t* __restrict__ n_items, uint32_t* __restrict__ n_alloc) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n_order; i += n_waves) {
+        const int32_t a = order[i];
+        const int64_t p0 = post_ptr[a], p1 = post_ptr[a + 1];
+        unsigned long long c = 0;
+        for (int64_t p = p0 + lane; p < p1; p += 64) c += (urange[post[p]].len + DIST_ITEM - 1u) / DIST_ITEM;
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, (unsigned)d);
+        if (lane == 0) {
+            const uint32_t n = (uint32_t)min(c, 0xFFFFFFFFull - 2048ull);      // (cf_dist_edges refuses a first k-mer with more items)
+            n_items[i] = n;
+            n_alloc[i] = ((n + nw - 1u) / nw) * nw;
+        }
     }
-    __syncthreads();
 }
 
-// Sweeps the items [0, n_items) in LDS: wave w takes the items w, w + W, w + 2W, ... (W waves per workgroup; round 2 found
-// this static deal faster than a shared cursor).  Every lane first loads ONE of its wave's item records (lane j: the j-th item of
-// the wave); a step then gets its record with two v_readlane into SGPRs — the base address of the step's global load is scalar,
-// the per-lane offset is the constant 16 * lane.  Software pipeline: the load of step j + 1 is issued before the body of step j.
+__global__ void __launch_bounds__(256)
+cf_items_fill_kernel(const int32_t* __restrict__ order, int64_t n_order, const int64_t* __restrict__ post_ptr, const int32_t* __restrict__ post,
+                     const cf_dist_rec* __restrict__ urange, uint32_t nw, const uint32_t* __restrict__ n_items, const int64_t* __restrict__ ibase,
+                     cf_dist_head* __restrict__ heads, cf_dist_item* __restrict__ items) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n_order; i += n_waves) {
+        const int32_t a = order[i];
+        const int64_t p0 = post_ptr[a], p1 = post_ptr[a + 1];
+        const uint32_t n = n_items[i], per = (n + nw - 1u) / nw;
+        cf_dist_item* out = items + ibase[i];
+        uint32_t j0 = 0;      // items of the postings before this one (wave-uniform)
+        unsigned long long ne = 0;
+        for (int64_t p = p0; p < p1; ++p) {      // postings one after the other, lanes over a posting's items
+            const cf_dist_rec r = urange[post[p]];
+            const uint32_t c = (r.len + DIST_ITEM - 1u) / DIST_ITEM;
+            ne += r.len;
+            for (uint32_t x = (uint32_t)lane; x < c; x += 64u) {
+                const uint32_t j = j0 + x, off = x * DIST_ITEM;
+                out[(size_t)(j % nw) * per + j / nw] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | (r.ig & 0xFFFFu)};
+            }
+            j0 += c;
+        }
+        if (lane == 0) heads[i] = cf_dist_head{(uint32_t)a, n, (unsigned long long)ibase[i], (uint32_t)min(ne, 0x3FFFFFFFull), 0u, 0u, 0u};
+    }
+}
+
+// Sweeps one wave's items: recs = the wave's records in HBM, mine = how many, my0 = the first 64 of them already in registers
+// (lane j: the j-th; loaded at the top of the first k-mer's iteration and used by both sweeps).  A step gets its record with
+// two v_readlane into SGPRs — the base address of the step's global load is scalar, the per-lane offset is the constant
+// 16 * lane.  Software pipeline: D loads in flight per lane.
+// pre(final) runs at ONE site before every step and once more (final = true) after the wave's last step: the table sweep drains
+// its insert queue there (one copy of that code in the loop instead of one per push site).
 // body(bb, dd, ok, len): the decoded entries of a step; ok = per-lane bit mask of the entries that exist (only the last item of
 // a posting has lanes past its end: len < DIST_ITEM, wave-uniform, says whether ok needs looking at); returns true to stop the wave.
-// pre(final) runs at ONE site before every step and once more (final = true) after the wave's last step: the table sweep drains
-// its insert queue there (one copy of that code in the loop instead of one per push site: 42 -> 27 KB of code).
 template <class Tab, int D, class Pre, class Body>
-__device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_dist_item* items, uint32_t n_items, Pre&& pre, Body&& body) {
+__device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_dist_item* recs, uint32_t mine, const cf_dist_item& my0, Pre&& pre, Body&& body) {
     const uint32_t lane = threadIdx.x & 63u, l4 = lane * DIST_UNROLL;
-    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
-    if (wv >= n_items) return;
-    const uint32_t mine = (n_items - wv + nw - 1u) / nw;
-    for (uint32_t j0 = 0; j0 < mine; j0 += 64u) {      // (one round whenever the item list fits 64 per wave)
+    if (mine == 0u) return;
+    for (uint32_t j0 = 0; j0 < mine; j0 += 64u) {      // (one round whenever the wave has at most 64 items)
         const uint32_t cnt = min(64u, mine - j0);
-        cf_dist_item my = cf_dist_item{0u, 0u};
-        if (lane < cnt) my = items[wv + (j0 + lane) * nw];
+        cf_dist_item my = my0;
+        if (j0) { my = cf_dist_item{0u, 0u}; if (lane < cnt) my = recs[j0 + lane]; }
         // D loads in flight per lane: a ring of D register sets, the loop unrolled D times so that every set has fixed registers
         typename Tab::raw ring[D][DIST_UNROLL];
         auto ok_of = [&](uint32_t m) -> uint32_t {      // per-lane mask of the entries of an item that exist
@@ -810,16 +821,12 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
 #endif
 template <class Tab>
 __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist_kernel(cf_dist_args A) {
-    // LDS: [bitmap | posting ranges | item prefixes | sh] at FIXED offsets (the bitmap at 0: its word address is the hash bits
-    // themselves, no base to add; the offsets of the rest fold into the instructions' offset fields), then
-    // [table | edge stage | partition stack | insert queues], then the item records.  The table group is dead while the sketch
-    // sweep runs, so its 8-bit counters (sk) lie over ALL of it: the 8-byte-slot layouts, whose table is smaller than 64 KiB
-    // next to their 8-byte queue items, keep 65 536 counters that way.
+    // LDS: [bitmap | sh] at FIXED offsets (the bitmap at 0: its word address is the hash bits themselves, no base to add), then
+    // [table | edge stage | partition stack | insert queues].  The table group is dead while the sketch sweep runs, so its
+    // 8-bit counters (sk) lie over ALL of it.  (The item records of the sweeps are in HBM: cf_items_fill_kernel.)
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
     uint32_t* bm = (uint32_t*)cf_lds;                          // DIST_BM_BITS bits: hash(b) of the k-mers b that may have a selected edge
-    cf_dist_rec* rec = (cf_dist_rec*)(cf_lds + DIST_BM_BITS / 8);      // partner range of each posting of the chunk
-    uint32_t* ipx = (uint32_t*)(rec + DIST_NP_CAP);            // 4 zeros, then the inclusive prefix of item counts
-    uint32_t* sh = ipx + 4 + DIST_NP_CAP;                      // [0] keys in table | DIST_FULL_BIT [1] first k-mer [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] hot-list cursor [12] entries of the chunk [13] a counter of the sketch wrapped [14,15] its first posting
+    uint32_t* sh = bm + DIST_BM_BITS / 32;                     // [0] keys in table | DIST_FULL_BIT [1] first k-mer [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] hot-list cursor [12] items of the first k-mer [13] a counter of the sketch wrapped [14,15] where its item records start
     unsigned char* lds_tab = cf_lds + DIST_LDS_HEAD;
     Tab T;
     T.init(lds_tab, (uint32_t)A.slots);
@@ -837,7 +844,6 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
     // through the probe loop 32 .. 64 at a time (round 2 ran that loop inside every drain: most drains went around twice for
     // one or two of their 64 lanes)
     typename Tab::qitem* ovq = wq0 + (size_t)(nt >> 6) * DIST_QCAP + (size_t)(t >> 6) * DIST_OVQ;
-    cf_dist_item* items = (cf_dist_item*)(wq0 + (size_t)(nt >> 6) * (DIST_QCAP + DIST_OVQ));   // A.it_cap item records: the work list of the sweeps
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
 #if defined(CF_DIST_STAMPS)
@@ -858,129 +864,40 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         }
         return idx;
     };
-    // Thread 0 fetches the NEXT first k-mer (ticket -> order[] -> post_ptr[]: three dependent HBM round trips) while the
-    // workgroup works on the current one; the values wait in its registers until the loop comes around.
+    // Thread 0 fetches the NEXT first k-mer's head (ticket -> heads[]: two dependent round trips) while the workgroup works on
+    // the current one; the values wait in its registers until the loop comes around.
     long long nx_idx = -1;
-    uint32_t nx_a = 0;
-    int64_t nx_pp0 = 0, nx_pp1 = 0;
+    cf_dist_head nx_head{0u, 0u, 0ull, 0u, 0u, 0u, 0u};
     if (t == 0) {
         nx_idx = pop();
-        if (nx_idx >= 0) { nx_a = (uint32_t)A.order[nx_idx]; nx_pp0 = A.post_ptr[nx_a]; nx_pp1 = A.post_ptr[nx_a + 1]; }
+        if (nx_idx >= 0) nx_head = A.heads[nx_idx];
     }
-    // Wave 0 also fetches the NEXT first k-mer's partner ranges (post[] -> urange[]: two more dependent round trips, up to
-    // DIST_NP_CAP postings, DIST_NP_CAP / 64 per lane) while the workgroup filters and writes the current one: at the loop top
-    // they go from its registers to LDS.  pf_np = postings held (wave-0 uniform), -1 = none (no next first k-mer, or too many).
-    int32_t pf_u[DIST_NP_CAP / 64];
-    cf_dist_rec pf_rec[DIST_NP_CAP / 64];
-    int pf_np = -1;
-#pragma unroll
-    for (int k = 0; k < DIST_NP_CAP / 64; ++k) { pf_u[k] = -1; pf_rec[k] = cf_dist_rec{0, 0u, 0u}; }
-    auto pf_issue_post = [&]() {      // wave 0: thread 0 holds nx_idx / nx_pp0 / nx_pp1
-        pf_np = -1;
-        if (!__builtin_amdgcn_readfirstlane((int)(nx_idx >= 0))) return;
-        const int64_t p0 = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)((unsigned long long)nx_pp0 >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nx_pp0));
-        const int64_t npn = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)min(nx_pp1 - nx_pp0, (int64_t)0x7FFFFFFF));
-        if (npn > DIST_NP_CAP) return;
-        pf_np = (int)npn;
-#pragma unroll
-        for (int k = 0; k < DIST_NP_CAP / 64; ++k) pf_u[k] = lane + 64 * k < npn ? A.post[p0 + lane + 64 * k] : -1;
-    };
-    auto pf_issue_rec = [&]() {
-        if (pf_np < 0) return;
-#pragma unroll
-        for (int k = 0; k < DIST_NP_CAP / 64; ++k) pf_rec[k] = pf_u[k] >= 0 ? A.urange[pf_u[k]] : cf_dist_rec{0, 0u, 0u};
-    };
-    if (t < 64) { pf_issue_post(); pf_issue_rec(); }
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), nw = (uint32_t)nt >> 6;
 
     while (true) {
         __syncthreads();
         if (t == 0) {
             sh[5] = (uint32_t)(unsigned long long)nx_idx; sh[6] = (uint32_t)((unsigned long long)nx_idx >> 32);
-            sh[1] = nx_a; sh[14] = (uint32_t)(unsigned long long)nx_pp0; sh[15] = (uint32_t)((unsigned long long)nx_pp0 >> 32);
-            sh[12] = (uint32_t)(nx_pp1 - nx_pp0);
-            sh[7] = 0; sh[13] = 0;
+            sh[1] = nx_head.a; sh[12] = nx_head.n_items; sh[14] = (uint32_t)nx_head.ibase; sh[15] = (uint32_t)(nx_head.ibase >> 32);
+            sh[7] = nx_head.n_entries;      // partner entries (sizes the passes when every b is marked)
+            sh[13] = 0;
         }
         __syncthreads();
         const int64_t ai = (int64_t)(((unsigned long long)sh[6] << 32) | sh[5]);
         if (ai < 0) break;
-        const uint32_t a = sh[1];
-        const int64_t pp0 = (int64_t)(((unsigned long long)sh[15] << 32) | sh[14]), pp1 = pp0 + (int64_t)sh[12];
+        const uint32_t a = sh[1], n_items = sh[12];
+        // this wave's item records: one coalesced load, in flight while the sketch is cleared; both sweeps run on them
+        const uint32_t per_w = (n_items + nw - 1u) / nw, mine = wv < n_items ? (n_items - wv + nw - 1u) / nw : 0u;
+        const cf_dist_item* recs = A.items + ((((unsigned long long)sh[15] << 32) | sh[14]) + (unsigned long long)wv * per_w);
+        cf_dist_item my0 = cf_dist_item{0u, 0u};
+        if ((uint32_t)lane < min(mine, 64u)) my0 = recs[lane];
         if (t == 0) nx_idx = pop();                                  // next: the ticket (used after phase A)
         CF_STAMP(0);   // queue pop
-        if (pp1 == pp0) {                                            // (order[] holds only k-mers with postings)
-            if (t == 0 && nx_idx >= 0) { nx_a = (uint32_t)A.order[nx_idx]; nx_pp0 = A.post_ptr[nx_a]; nx_pp1 = A.post_ptr[nx_a + 1]; }
-            if (t < 64) { pf_issue_post(); pf_issue_rec(); }
+        if (n_items == 0u) {
+            if (t == 0 && nx_idx >= 0) nx_head = A.heads[nx_idx];
             continue;
         }
-        // Usual case: <= DIST_NP_CAP postings whose items fit the LDS list — records built ONCE, both sweeps run on them.  Wave 0
-        // builds them from the partner ranges it holds (no barrier inside: one wave, LDS operations of a wave execute in order)
-        // while the other waves clear the sketch and the bitmap; ONE barrier ends the prologue (round 2: five).
-        const int np_all = (int)min(pp1 - pp0, (int64_t)0x7FFFFFFF);
-        bool one_chunk = np_all <= DIST_NP_CAP;
-        bool cleared = false;
-        uint32_t n_items_all = 0;
-        if (one_chunk) {
-            if (t < 64) {
-                const int np = np_all;
-                uint32_t c[DIST_NP_CAP / 64], run = 0;
-                unsigned long long lens = 0;
-#pragma unroll
-                for (int k = 0; k < DIST_NP_CAP / 64; ++k) {      // posting p = lane + 64 k: inclusive prefix of the item counts in that order
-                    rec[lane + 64 * k] = pf_rec[k];
-                    lens += pf_rec[k].len;
-                    uint32_t inc = (pf_rec[k].len + DIST_ITEM - 1u) / DIST_ITEM;
-                    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
-                    c[k] = run + inc;
-                    run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                    ipx[4 + lane + 64 * k] = lane + 64 * k < np ? c[k] : 0xFFFFFFFFu;
-                }
-                for (int d = 32; d >= 1; d >>= 1) lens += __shfl_down(lens, (unsigned)d);
-                if (lane == 0) { ipx[0] = 0; ipx[1] = 0; ipx[2] = 0; ipx[3] = 0; sh[12] = (uint32_t)min(lens, 0x3FFFFFFFull); sh[7] = (uint32_t)min(lens, 0x3FFFFFFFull); sh[9] = run; }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (run <= A.it_cap) {      // (wave-uniform) the item records, 64 per round
-                    for (uint32_t j = (uint32_t)lane; j < run; j += 64u) {
-                        int lo = 0, hi = np - 1;
-                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (ipx[4 + mid] > j) hi = mid; else lo = mid + 1; }
-                        const cf_dist_rec r = rec[lo];
-                        const uint32_t off = (j - ipx[3 + lo]) * DIST_ITEM;
-                        items[j] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | (r.ig & 0xFFFFu)};
-                    }
-                }
-            } else if (A.sketch) {
-                const cf_u32x4 z{0u, 0u, 0u, 0u};
-                for (uint32_t s_ = (uint32_t)t - 64u; s_ < (A.sk_counters >> 4); s_ += (uint32_t)nt - 64u) ((cf_u32x4*)sk)[s_] = z;
-                for (uint32_t s_ = (uint32_t)t - 64u; s_ < DIST_BM_BITS / 128; s_ += (uint32_t)nt - 64u) ((cf_u32x4*)bm)[s_] = z;
-            }
-            cleared = nt > 64;
-            __syncthreads();
-            n_items_all = sh[9];
-            one_chunk = n_items_all <= A.it_cap;
-        } else {
-            unsigned long long em = 0;
-            for (int64_t p = pp0 + t; p < pp1; p += nt) {
-                em += (unsigned long long)A.urange[A.post[p]].len;
-            }
-            for (int d = 32; d >= 1; d >>= 1) em += __shfl_down(em, (unsigned)d);
-            if (lane == 0 && em) atomicAdd(&sh[7], (uint32_t)min(em, 0x3FFFFFFFull));
-        }
-        CF_STAMP(1);   // prologue: posting ranges, item records, estimate
-        // run(n) for every item list of the first k-mer: the one built above, or (many postings / more items than the list
-        // holds) chunk after chunk of postings, list after list
-        auto for_lists = [&](auto&& run) {
-            if (one_chunk) { run(n_items_all); __syncthreads(); CF_STAMP(7); return; }      // (stamp 7: thread 0's wait for the other waves at the end of a sweep)
-            for (int64_t c0 = pp0; c0 < pp1; c0 += DIST_NP_CAP) {
-                const int np = (int)min((int64_t)DIST_NP_CAP, pp1 - c0);
-                cf_dist_setup(A, c0, np, rec, ipx, sh);
-                const uint32_t tot = ipx[4 + np - 1];
-                for (uint32_t i0 = 0; i0 < tot; i0 += A.it_cap) {
-                    const uint32_t n = min(A.it_cap, tot - i0);
-                    cf_dist_build_items(rec, ipx, np, i0, n, items);
-                    run(n);
-                    __syncthreads();      // every wave is done with the list before it is rebuilt
-                }
-            }
-        };
+        CF_STAMP(1);   // prologue
         // ---- phase A (min_cov >= 2): which k-mers b can have a selected edge at all?  Most (b, d) pairs of a are seen
         // once or twice and can never reach min_cov, but an exact table would have to hold them all.  So first every
         // pair is only COUNTED, in an array of 8-bit counters indexed by hash(b, d) that fills the table's LDS: a
@@ -992,14 +909,14 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         bool mark_all = !A.sketch;
         const uint32_t min_cov_m1 = A.min_cov - 1u;      // (the sketch runs with min_cov >= 2)
         if (A.sketch) {
-            if (!cleared) {      // (many postings, or a one-wave workgroup)
+            {
                 const cf_u32x4 z{0u, 0u, 0u, 0u};
                 for (uint32_t s = (uint32_t)t; s < (A.sk_counters >> 4); s += (uint32_t)nt) ((cf_u32x4*)sk)[s] = z;
                 for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = z;
                 __syncthreads();
             }
-            for_lists([&](uint32_t n_list) {
-                cf_dist_sweep<Tab, CF_DIST_PF_A>(A, items, n_list, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
+            {
+                cf_dist_sweep<Tab, CF_DIST_PF_A>(A, recs, mine, my0, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
                     // (entries equal to a are counted too: the sketch may only over-count, and the table sweep drops them)
                     uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL], inc_[DIST_UNROLL];
 #pragma unroll
@@ -1034,10 +951,12 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     return false;
                 });
                 CF_STAMP(6);   // sketch sweep (clear + wave 0's own items)
-            });
+            }
+            __syncthreads();
+            CF_STAMP(7);      // (stamp 7: thread 0's wait for the other waves at the end of a sweep)
             if (sh[13]) mark_all = true;
         }
-        if (t == 0 && nx_idx >= 0) nx_a = (uint32_t)A.order[nx_idx];      // next: its rank (used before phase B)
+        if (t == 0 && nx_idx >= 0) nx_head = A.heads[nx_idx];      // next: its head (used at the loop top)
         if (mark_all) {
             const cf_u32x4 ones{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = ones;
@@ -1051,7 +970,6 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             for (uint32_t i = 0; i < P0; ++i) { stack[2 * i] = P0; stack[2 * i + 1] = i; }
             sh[2] = P0;
         }
-        if (t == 0 && nx_idx >= 0) { nx_pp0 = A.post_ptr[nx_a]; nx_pp1 = A.post_ptr[nx_a + 1]; }   // next: its posting range (used at the loop top)
         bool spilled = false;
         while (true) {
             CF_STAMP(5);   // reserve + write edges of the previous pass
@@ -1067,7 +985,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             CF_STAMP(2);   // pop partition + clear table
             // ---- phase B: sweep again; pairs of this partition whose b is marked go to the wave's queue and are
             // inserted into the exact table 64 at a time by a full wave
-            for_lists([&](uint32_t n_list) {
+            {
                 uint32_t qtail = 0, otail = 0;      // wave-uniform: queued inserts / parked inserts of this wave
                 bool too_full = sh[0] > A.fill_limit;      // (another list of this pass may already have filled the table)
                 // pops the last N (<= 64) queued inserts, one per lane, and gives each ONE probe of its home bucket in
@@ -1116,7 +1034,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     __builtin_amdgcn_wave_barrier();                                                          \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                 }
-                cf_dist_sweep<Tab, CF_DIST_PF_B>(A, items, n_list, [&](bool final) {
+                cf_dist_sweep<Tab, CF_DIST_PF_B>(A, recs, mine, my0, [&](bool final) {
                     // a step pushes at most 4 x 64 inserts: the queue is brought below 64 first; after the wave's last step
                     // both lists are emptied (a pass whose table got too full is void and drops them)
                     const uint32_t lim = final ? 1u : 64u;
@@ -1164,12 +1082,10 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
 #undef CF_DIST_DRAIN
 #undef CF_DIST_OVERFLOW
                 CF_STAMP(3);   // table sweep + inserts (wave 0's own items)
-            });
-            // next first k-mer: its postings now, their partner ranges one phase later (before the edges are written, or right here when
-            // the pass is void) — on EVERY path through a pass, so that the registers are dead while the sweeps run
-            if (t < 64) pf_issue_post();
+            }
+            __syncthreads();
+            CF_STAMP(7);
             if (sh[0] > A.fill_limit) {  // overflow: split this partition in two
-                if (t < 64) pf_issue_rec();
                 if (t == 0) {
                     uint32_t sp = sh[2];
                     if (P >= (1u << 20) || sp + 2 > DIST_STACK) { atomicOr(&A.counters[4], 1ull); }
@@ -1252,7 +1168,6 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             }
             __syncthreads();
             CF_STAMP(4);   // filter
-            if (t < 64) pf_issue_rec();
             const uint32_t n_sel = sh[8];
             __syncthreads();  // everyone has read the count before thread 0 reuses the word as a cursor
             if (t == 0) {
@@ -1415,7 +1330,11 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     uint32_t *d_pcnt = nullptr, *d_cursor = nullptr, *d_first = nullptr;
     unsigned long long *d_okeys = nullptr, *d_otmp = nullptr;
     int32_t* d_order = nullptr;
-    int64_t n_order = 0, n_a_alloc = 0;
+    int64_t n_order = 0, n_a_alloc = 0, n_item_slots = 0;
+    uint32_t *d_icnt = nullptr, *d_ialloc = nullptr;
+    int64_t* d_ibase = nullptr;
+    cf_dist_head* d_heads = nullptr;
+    cf_dist_item* d_items = nullptr;
     int64_t* d_post_ptr = nullptr;
     int32_t *d_post = nullptr, *d_rend = nullptr, *d_rbeg = nullptr;
     uint16_t* d_entry_i = nullptr;
@@ -1508,7 +1427,6 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = v_cloud_ptr; A.entries = v_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.urange = d_urange; A.entry_i = d_entry_i; A.packed = d_packed; A.entry_i8 = d_entry_i8; A.reg_shift = (uint32_t)reg_shift;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
         A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
-        A.it_cap = 64;      // (set with the launch shape below)
         A.hot_cap = ctx->dist_hot_cap > 0 ? (uint32_t)ctx->dist_hot_cap : 0xFFFFFFFFu;
         const uint32_t slot_bytes = (narrow || region) ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
         // launch shape: two 512-thread workgroups per CU (80 KiB of LDS each) overlap each other's latency-bound phases
@@ -1528,14 +1446,10 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (block == 0) block = wgs == 1 ? 1024 : 512;
         // LDS: everything but the table is fixed; dist_slots (the table budget in 8-byte units) defaults to all the rest
         const size_t qitem_bytes = narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem);
-        // item records of a first k-mer's sweeps: 64 per wave (one v_readlane round); more with the whole LDS (long reads / high coverage)
-        const uint32_t it_cap = (uint32_t)(block / 64) * (wgs == 1 ? 128u : 64u);
-        const size_t lds_fixed = sizeof(cf_dist_rec) * DIST_NP_CAP + (size_t)(4 + DIST_NP_CAP + 2 * DIST_STACK + 16) * 4 + DIST_STAGE_CAP * 2 + 16
-                               + DIST_BM_BITS / 8 + (size_t)(block / 64) * (DIST_QCAP + DIST_OVQ) * qitem_bytes + (size_t)it_cap * sizeof(cf_dist_item);
+        const size_t lds_fixed = DIST_LDS_HEAD + (size_t)(2 * DIST_STACK) * 4 + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QCAP + DIST_OVQ) * qitem_bytes;
         const int64_t budget8 = ((int64_t)160 * 1024 / wgs - (int64_t)lds_fixed) / 8;
         if (budget8 < 256) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_wgs leaves no LDS for the table"); break; }
         if (ctx->dist_slots > budget8) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_slots does not fit the 160 KiB LDS next to the work lists"); break; }
-        A.it_cap = it_cap;
         const int64_t slots8 = ctx->dist_slots ? ctx->dist_slots : budget8;
         A.slots = (int32_t)((slots8 * 8 / slot_bytes) & ~(region ? (int64_t)(32 << reg_shift) - 1 : 7ll));      // (regions: equal parts of whole 8-slot groups)
         A.fill_limit = (uint32_t)((int64_t)A.slots * ctx->dist_fill_pct / 100);   // checked once per wave step: leave slack below the physical size
@@ -1568,6 +1482,22 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (n_order && n_post && max_d >= min_d_eff)      // partner entries that are the first k-mer itself (subtracted from the emission count below)
             hipLaunchKernelGGL(cf_self_pairs_kernel, dim3((unsigned)cf_grid_for(n_order * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
                                (const int32_t*)d_order, n_order, (const int64_t*)d_post_ptr, (const int32_t*)d_post, (const int32_t*)d_rbeg, min_d_eff, max_d, d_cnt + 3);
+        // the work lists of the sweeps (heads + item records, laid out for workgroups of `block` threads): count, scan, fill
+        if (n_order) {
+            const uint32_t nw = (uint32_t)block / 64u;
+            const int g_items = cf_grid_for(n_order * 64, 256, max_blocks);
+            if ((rc = cf_alloc_t(ctx, &d_icnt, (size_t)n_order + 1, "item counts"))) break;
+            if ((rc = cf_alloc_t(ctx, &d_ialloc, (size_t)n_order + 1, "item slots"))) break;
+            if ((rc = cf_alloc_t(ctx, &d_ibase, (size_t)n_order + 1, "item bases"))) break;
+            if ((rc = cf_alloc_t(ctx, &d_heads, (size_t)n_order, "first k-mer heads"))) break;
+            hipLaunchKernelGGL(cf_items_count_kernel, dim3((unsigned)g_items), dim3(256), 0, ctx->stream, (const int32_t*)d_order, n_order, (const int64_t*)d_post_ptr,
+                               (const int32_t*)d_post, (const cf_dist_rec*)d_urange, nw, d_icnt, d_ialloc);
+            if ((rc = cf_scan_exclusive_u32_to_i64(ctx, d_ialloc, d_ibase, n_order, &n_item_slots))) break;
+            if ((rc = cf_alloc_t(ctx, &d_items, (size_t)n_item_slots + 64, "item records"))) break;
+            hipLaunchKernelGGL(cf_items_fill_kernel, dim3((unsigned)g_items), dim3(256), 0, ctx->stream, (const int32_t*)d_order, n_order, (const int64_t*)d_post_ptr,
+                               (const int32_t*)d_post, (const cf_dist_rec*)d_urange, nw, (const uint32_t*)d_icnt, (const int64_t*)d_ibase, d_heads, d_items);
+        }
+        A.heads = d_heads; A.items = d_items;
         const int64_t n_a = n_order;
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_a, (int64_t)std::max(1, ctx->n_cu) * per_cu));
         e = hipGetLastError();
@@ -1601,6 +1531,11 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         (void)hipEventElapsedTime(&ctx->times.postings_ms, ctx->ev0, ctx->ev2);
         (void)hipEventElapsedTime(&ctx->times.dist_kernel_ms, ctx->ev2, ctx->ev3);
     } while (0);
+    if (d_items) cf_release_t(ctx, d_items, (size_t)n_item_slots + 64);
+    if (d_heads) cf_release_t(ctx, d_heads, (size_t)n_order);
+    if (d_ibase) cf_release_t(ctx, d_ibase, (size_t)n_order + 1);
+    if (d_ialloc) cf_release_t(ctx, d_ialloc, (size_t)n_order + 1);
+    if (d_icnt) cf_release_t(ctx, d_icnt, (size_t)n_order + 1);
     if (d_order) cf_release_t(ctx, d_order, (size_t)n_a_alloc);
     if (d_otmp) cf_release_t(ctx, d_otmp, (size_t)n_a_alloc);
     if (d_okeys) cf_release_t(ctx, d_okeys, (size_t)n_a_alloc);
