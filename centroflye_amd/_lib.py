@@ -17,7 +17,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_reads", "n_bases", "n_units", "n_windows", "n_read_kmers", "n_distinct", "n_kept",
         "n_kmers", "n_cloud_entries", "n_emissions", "n_edges", "n_unique", "table_capacity",
-        "n_spilled", "hbm_bytes_live", "n_dist_passes")]
+        "n_spilled", "hbm_bytes_live", "n_dist_passes", "n_edges_stored")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -382,6 +382,7 @@ int cf_get_stats(cf_ctx* ctx, cf_stats* out) {
     ctx->stats.hbm_bytes_live = (int64_t)ctx->live;
     ctx->stats.table_capacity = (int64_t)ctx->table_cap;
     ctx->stats.n_kmers = ctx->n_kmers;
+    ctx->stats.n_edges_stored = ctx->n_edges_stored;
     *out = ctx->stats;
     return 0;
 }
@@ -418,6 +419,11 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "dist_fill_pct") {
         if (value < 10 || value > 90) return cf_fail(ctx, -22, "dist_fill_pct out of range (10 .. 90)");
         ctx->dist_fill_pct = (int)value;
+    } else if (n == "dist_edge_chunk") {
+        if (value < 0 || value > (1 << 20)) return cf_fail(ctx, -22, "dist_edge_chunk out of range (0 = default, 1 .. 2^20)");
+        ctx->dist_edge_chunk = (int)value;
+    } else if (n == "dist_int_thr") {
+        ctx->dist_int_thr = value != 0;
     } else if (n == "dist_sketch") {
         ctx->dist_sketch = value != 0;
     } else if (n == "dist_est_pct") {

@@ -138,6 +138,8 @@ struct cf_ctx {
     int dist_regions = 0;    // 1, 2, 4, 8: force the region layout of the 6-byte slots with at least that many regions (tests), 0 = only when the ranks need it
     int dist_dbits = 0;      // 5 .. 8: upper limit of the distance-field bits of the 6-byte-slot layout (tests), 0 = as many as the k-mer ranks leave
     int dist_fill_pct = 70;  // a (b,d) table pass is split when more than this share of the slots is in use
+    int dist_edge_chunk = 0; // > 0: edge rows a workgroup reserves per global atomic (tests: small chunks cross often), 0 = 8192
+    int dist_int_thr = 1;    // 1: rel_threshold == 0.8 is tested as 5 cnt >= 4 total; 0: always the double division (tests)
     int dist_sketch = 1;     // 0: every (b,d) pair goes to the exact table (no counting sketch first)
     int dist_est_pct = 80;   // expected distinct (b,d) keys per 100 pair emissions: sizes the initial number of table partitions
     int dist_stage = 2048;   // selected edges staged in LDS per table pass (0 forces the table sweep)

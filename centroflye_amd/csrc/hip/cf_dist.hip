@@ -29,6 +29,7 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 #define DIST_UNROLL 4
 #define DIST_ITEM (64u * DIST_UNROLL)    /* cloud entries one wave takes per step: DIST_UNROLL consecutive ones per lane */
 #define DIST_BM_BITS 65536u              /* bitmap over hash(b): k-mers that may have a selected edge */
+#define DIST_EDGE_CHUNK 8192ull          /* edge rows a workgroup reserves per global atomic */
 #define DIST_OVQ 96u                     /* per-wave list of inserts whose first probe did not finish (drained with the probe loop at >= 32) */
 #define DIST_LDS_HEAD (DIST_BM_BITS / 8 + 64)   /* bitmap + sh: the fixed head of the kernel's LDS */
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
@@ -152,6 +153,7 @@ struct cf_dist_args {
     int32_t min_d, max_d;       // min_d already clamped to >= 1
     uint32_t min_cov;
     double thr;
+    uint32_t thr_num, thr_den;     // thr as an exact fraction when it is the literal 0.8 (4 / 5), else 0 / 0: the dominance test is then integer
     int32_t slots;
     uint32_t fill_limit;
     uint32_t est_limit;            // emissions one partition is expected to hold (fill_limit / expected distinct share)
@@ -165,7 +167,9 @@ struct cf_dist_args {
     unsigned long long edge_cap;
     const int32_t* order;          // first k-mers of this partition, sorted by their first posting (locality)
     int64_t n_order;
-    unsigned long long* counters;  // [0] edges [1] partner entries swept [2] spilled a [3] (host: self pairs) [4] error flags [5] passes; [16 + 16 x] queue head x
+    unsigned long long edge_chunk; // edge rows a workgroup reserves per global atomic (DIST_EDGE_CHUNK; tests: small)
+    unsigned long long* holes;     // (start, rows) of the unused rest of every workgroup's last chunk of the edge output
+    unsigned long long* counters;  // [0] edge rows reserved (chunks) [6] selected edges [7] holes [1] partner entries swept [2] spilled a [3] (host: self pairs) [4] error flags [5] passes; [16 + 16 x] queue head x
     uint32_t* unique_bits;
 };
 
@@ -728,17 +732,23 @@ cf_items_fill_kernel(const int32_t* __restrict__ order, int64_t n_order, const i
         const int64_t p0 = post_ptr[a], p1 = post_ptr[a + 1];
         const uint32_t n = n_items[i], per = (n + nw - 1u) / nw;
         cf_dist_item* out = items + ibase[i];
-        uint32_t j0 = 0;      // items of the postings before this one (wave-uniform)
+        uint32_t j0 = 0;      // items of the postings before this chunk (wave-uniform)
         unsigned long long ne = 0;
-        for (int64_t p = p0; p < p1; ++p) {      // postings one after the other, lanes over a posting's items
-            const cf_dist_rec r = urange[post[p]];
+        for (int64_t q0 = p0; q0 < p1; q0 += 64) {      // 64 postings at a time, one per lane: two dependent loads per chunk, not per posting
+            cf_dist_rec r{0, 0u, 0u};
+            if (q0 + lane < p1) r = urange[post[q0 + lane]];
             const uint32_t c = (r.len + DIST_ITEM - 1u) / DIST_ITEM;
-            ne += r.len;
-            for (uint32_t x = (uint32_t)lane; x < c; x += 64u) {
-                const uint32_t j = j0 + x, off = x * DIST_ITEM;
+            uint32_t inc = c;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
+            const uint32_t jb = j0 + inc - c;      // the lane's first item
+            for (uint32_t x = 0; x < c; ++x) {
+                const uint32_t j = jb + x, off = x * DIST_ITEM;
                 out[(size_t)(j % nw) * per + j / nw] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | (r.ig & 0xFFFFu)};
             }
-            j0 += c;
+            j0 += (uint32_t)__shfl((int)inc, 63);
+            unsigned long long l = r.len;
+            for (int d = 32; d >= 1; d >>= 1) l += __shfl_down(l, (unsigned)d);
+            ne += (unsigned long long)__shfl((long long)l, 0);
         }
         if (lane == 0) heads[i] = cf_dist_head{(uint32_t)a, n, (unsigned long long)ibase[i], (uint32_t)min(ne, 0x3FFFFFFFull), 0u, 0u, 0u};
     }
@@ -845,7 +855,8 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
     // one or two of their 64 lanes)
     typename Tab::qitem* ovq = wq0 + (size_t)(nt >> 6) * DIST_QCAP + (size_t)(t >> 6) * DIST_OVQ;
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
-    unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0;  // flushed once per workgroup (thread 0)
+    unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0, acc_edges = 0;  // flushed once per workgroup (thread 0)
+    unsigned long long e_cur = 0, e_end = 0;      // thread 0: the unused rows [e_cur, e_end) of the workgroup's chunk of the edge output
 #if defined(CF_DIST_STAMPS)
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -1137,6 +1148,14 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             }
             __syncthreads();
             const uint32_t n_hot = sh[11];
+            // cnt / total >= thr as Python evaluates it (distance_based_kmer_recruitment.py:143-144: true division of two ints, compared
+            // with a double).  For the default threshold — the literal 0.8, the double just above 4 / 5 — the test is exactly
+            // 5 cnt >= 4 total: a quotient below 4 / 5 lies at least 1 / (5 total) below it, far more than an ulp for any total < 2^40,
+            // and 4 / 5 itself rounds to the literal.  Other thresholds take the double division (about 40 instructions).
+            auto dominant = [&](uint32_t cnt, unsigned long long total) -> bool {
+                if (A.thr_den) return (unsigned long long)A.thr_den * cnt >= (unsigned long long)A.thr_num * total;
+                return ((double)cnt / (double)total) >= A.thr;
+            };
             auto keep = [&](bool sel, uint32_t s) {       // called by all lanes of a wave together
                 const unsigned long long m = __ballot(sel);
                 if (!m) return;
@@ -1152,14 +1171,14 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     uint32_t s = 0;
                     if (i < n_hot) {
                         s = hot[i];
-                        T.eval_slot(s, n_buckets, A.min_cov, [&](uint32_t, uint32_t b, uint32_t, uint32_t cnt, unsigned long long total) { sel = b != a && ((double)cnt / (double)total) >= A.thr; });
+                        T.eval_slot(s, n_buckets, A.min_cov, [&](uint32_t, uint32_t b, uint32_t, uint32_t cnt, unsigned long long total) { sel = b != a && dominant(cnt, total); });
                     }
                     keep(sel, s);
                 }
             } else {        // more than the list holds (never seen with the sketch): evaluate inside the bucket scan
                 for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt)
                     T.for_counts_at_least(bk, n_buckets, A.min_cov, [&](uint32_t s, uint32_t b, uint32_t, uint32_t cnt, unsigned long long total) {
-                        if (b != a && ((double)cnt / (double)total) >= A.thr) {
+                        if (b != a && dominant(cnt, total)) {
                             T.mark(s);
                             const uint32_t pos = atomicAdd(&sh[8], 1u);
                             if (pos < A.stage_cap) stage[pos] = (uint16_t)s;
@@ -1170,32 +1189,46 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             CF_STAMP(4);   // filter
             const uint32_t n_sel = sh[8];
             __syncthreads();  // everyone has read the count before thread 0 reuses the word as a cursor
+            // Edge rows come from a chunk of the output that the workgroup reserved earlier (DIST_EDGE_CHUNK rows per global atomic;
+            // round 2 reserved every pass's rows with its own returning atomic: a round trip to the memory side per first k-mer
+            // with the whole workgroup waiting at the barrier below).  A pass that does not fit the rest of the chunk fills it and
+            // continues in a new one, so only the LAST chunk of a workgroup keeps unused rows: those holes are listed at the end of
+            // the kernel and closed by cf_edge_compact_kernel.
             if (t == 0) {
                 acc_E += sh[7]; ++acc_pass;
                 if (n_sel) {
-                    const unsigned long long base = atomicAdd(&A.counters[0], (unsigned long long)n_sel);
-                    sh[9] = (uint32_t)base; sh[10] = (uint32_t)(base >> 32);
-                    const uint32_t bit = 1u << (a & 31);
-                    if (!(A.unique_bits[a >> 5] & bit)) atomicOr(&A.unique_bits[a >> 5], bit);
+                    const unsigned long long rem = e_end - e_cur;
+                    sh[9] = (uint32_t)e_cur; sh[10] = (uint32_t)(e_cur >> 32); sh[12] = (uint32_t)min(rem, (unsigned long long)n_sel);
+                    if ((unsigned long long)n_sel <= rem) e_cur += n_sel;
+                    else {
+                        const unsigned long long need = (unsigned long long)n_sel - rem, take = (need + A.edge_chunk - 1ull) / A.edge_chunk * A.edge_chunk;
+                        const unsigned long long nb = atomicAdd(&A.counters[0], take);
+                        sh[14] = (uint32_t)nb; sh[15] = (uint32_t)(nb >> 32);
+                        e_cur = nb + need; e_end = nb + take;
+                    }
+                    acc_edges += n_sel;
+                    atomicOr(&A.unique_bits[a >> 5], 1u << (a & 31));      // (fire and forget: a load to test the bit first would stall thread 0 in front of the barrier)
                 }
                 sh[8] = 0;
             }
             __syncthreads();
             if (n_sel) {
-                const unsigned long long base = ((unsigned long long)sh[10] << 32) | sh[9];
-                auto emit = [&](unsigned long long o, uint32_t b, uint32_t dd, uint32_t cnt) {
-                    if (o < A.edge_cap) { uint32_t* E = A.edges + 4 * o; E[0] = dd; E[1] = a; E[2] = b; E[3] = cnt; }
+                const unsigned long long base = ((unsigned long long)sh[10] << 32) | sh[9], nbase = ((unsigned long long)sh[15] << 32) | sh[14];
+                const uint32_t in_old = sh[12];      // rows that still fit the old chunk
+                auto emit = [&](uint32_t i, uint32_t b, uint32_t dd, uint32_t cnt) {
+                    const unsigned long long o = i < in_old ? base + i : nbase + (i - in_old);
+                    if (o < A.edge_cap) *(cf_u32x4*)(A.edges + 4 * o) = cf_u32x4{dd, a, b, cnt};
                     const uint32_t bit = 1u << (b & 31);
                     if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
                 };
                 if (n_sel <= A.stage_cap) {           // the staged slot list
                     for (uint32_t i = (uint32_t)t; i < n_sel; i += (uint32_t)nt) {
                         uint32_t b, dd, cnt;
-                        if (T.get(stage[i], b, dd, cnt)) emit(base + i, b, dd, cnt);
+                        if (T.get(stage[i], b, dd, cnt)) emit(i, b, dd, cnt);
                     }
                 } else {                               // more selected edges than the stage holds: sweep the marked slots, a bucket per thread
                     for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt)
-                        T.for_marked(bk, [&](uint32_t, uint32_t b, uint32_t dd, uint32_t cnt) { emit(base + atomicAdd(&sh[8], 1u), b, dd, cnt); });
+                        T.for_marked(bk, [&](uint32_t, uint32_t b, uint32_t dd, uint32_t cnt) { emit(atomicAdd(&sh[8], 1u), b, dd, cnt); });
                 }
             }
         }
@@ -1205,6 +1238,11 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         if (acc_E) atomicAdd(&A.counters[1], acc_E);
         if (acc_spill) atomicAdd(&A.counters[2], acc_spill);
         if (acc_pass) atomicAdd(&A.counters[5], acc_pass);
+        if (acc_edges) atomicAdd(&A.counters[6], acc_edges);
+        if (e_end > e_cur) {      // the unused rest of the last chunk: a hole for cf_edge_compact_kernel
+            const unsigned long long h = atomicAdd(&A.counters[7], 1ull);
+            A.holes[2 * h] = e_cur; A.holes[2 * h + 1] = e_end - e_cur;
+        }
 #if defined(CF_DIST_STAMPS)
         for (int i = 0; i < 8; ++i) atomicAdd(&A.counters[8 + i], stamp_acc[i]);
 #endif
@@ -1260,6 +1298,23 @@ cf_max_u32_kernel(const uint32_t* __restrict__ v, int64_t n, uint32_t* __restric
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) m = max(m, v[i]);
     for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_down(m, (unsigned)d));
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// Closes the holes of the chunked edge output: row k of the move list goes from the k-th valid row at or above n_valid to the k-th
+// hole row below it (segment lists with inclusive prefixes, built on the host from the <= grid holes of the kernel).
+__global__ void __launch_bounds__(256)
+cf_edge_compact_kernel(uint32_t* __restrict__ edges, const unsigned long long* __restrict__ src_start, const unsigned long long* __restrict__ src_pre, int n_src,
+                       const unsigned long long* __restrict__ dst_start, const unsigned long long* __restrict__ dst_pre, int n_dst, unsigned long long n_move) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_move; k += stride) {
+        int lo = 0, hi = n_src - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (src_pre[mid] > k) hi = mid; else lo = mid + 1; }
+        const unsigned long long from = src_start[lo] + (k - (lo ? src_pre[lo - 1] : 0ull));
+        lo = 0; hi = n_dst - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (dst_pre[mid] > k) hi = mid; else lo = mid + 1; }
+        const unsigned long long to = dst_start[lo] + (k - (lo ? dst_pre[lo - 1] : 0ull));
+        *(cf_u32x4*)(edges + 4 * to) = *(const cf_u32x4*)(edges + 4 * from);
+    }
 }
 
 // order-independent checksum of stored edges: sum over rows of mix(d, a, b, cnt) mod 2^64 (the oracle's edge checksum:
@@ -1335,6 +1390,9 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     int64_t* d_ibase = nullptr;
     cf_dist_head* d_heads = nullptr;
     cf_dist_item* d_items = nullptr;
+    unsigned long long* d_holes = nullptr;
+    size_t n_holes_alloc = 0;
+    int64_t n_stored = 0;
     int64_t* d_post_ptr = nullptr;
     int32_t *d_post = nullptr, *d_rend = nullptr, *d_rbeg = nullptr;
     uint16_t* d_entry_i = nullptr;
@@ -1350,9 +1408,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     const size_t n_cnt = 8 + 16 * 9;   // counters + 8 queue heads on their own cache lines
     const int max_blocks = std::max(1, ctx->n_cu) * 8;
     do {
-        cf_free_edges(ctx);
-        if ((rc = cf_alloc_t(ctx, &ctx->d_edges, (size_t)edge_cap * 4, "edges"))) break;
-        ctx->edge_cap = edge_cap;
+        cf_free_edges(ctx);      // (the buffer of this call is allocated below, once the launch shape is known)
         if ((rc = cf_alloc_t(ctx, &d_pcnt, (size_t)K + 1, "posting counts"))) break;
         if ((rc = cf_alloc_t(ctx, &d_cursor, (size_t)K + 1, "posting cursors"))) break;
         if ((rc = cf_alloc_t(ctx, &d_post_ptr, (size_t)K + 1, "posting offsets"))) break;
@@ -1426,6 +1482,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         cf_dist_args A;
         A.post_ptr = d_post_ptr; A.post = d_post; A.cloud_ptr = v_cloud_ptr; A.entries = v_entries; A.unit_rend = d_rend; A.unit_rbeg = d_rbeg; A.urange = d_urange; A.entry_i = d_entry_i; A.packed = d_packed; A.entry_i8 = d_entry_i8; A.reg_shift = (uint32_t)reg_shift;
         A.n_kmers = K; A.part = part; A.n_parts = n_parts; A.min_d = min_d_eff; A.max_d = max_d; A.min_cov = min_cov; A.thr = rel_threshold;
+        A.thr_num = (rel_threshold == 0.8 && ctx->dist_int_thr) ? 4u : 0u; A.thr_den = A.thr_num ? 5u : 0u;
         A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
         A.hot_cap = ctx->dist_hot_cap > 0 ? (uint32_t)ctx->dist_hot_cap : 0xFFFFFFFFu;
         const uint32_t slot_bytes = (narrow || region) ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
@@ -1454,7 +1511,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.slots = (int32_t)((slots8 * 8 / slot_bytes) & ~(region ? (int64_t)(32 << reg_shift) - 1 : 7ll));      // (regions: equal parts of whole 8-slot groups)
         A.fill_limit = (uint32_t)((int64_t)A.slots * ctx->dist_fill_pct / 100);   // checked once per wave step: leave slack below the physical size
         A.est_limit = (uint32_t)((int64_t)A.fill_limit * 100 / ctx->dist_est_pct);
-        A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)edge_cap; A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
+        A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
         const size_t lds = (size_t)A.slots * slot_bytes + lds_fixed;
         A.sketch = (ctx->dist_sketch && min_cov >= 2 && min_cov <= 200) ? 1 : 0;
         A.sk_shift = 32; A.sk_counters = 1;
@@ -1508,6 +1565,19 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                                    : narrow_db == 6 ? cf_dist_kernel<cf_tab_narrow_t<6>> : cf_dist_kernel<cf_tab_narrow_t<5>>;
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("dist LDS attribute: ") + hipGetErrorString(e)); break; }
+        // the edge output: edge_cap rows + the unused rest of one chunk per workgroup (the holes; closed below), so that every
+        // selected edge is in memory whenever edge_cap >= their number
+        {
+            A.edge_chunk = ctx->dist_edge_chunk > 0 ? (unsigned long long)ctx->dist_edge_chunk : DIST_EDGE_CHUNK;
+            const int64_t rows = edge_cap > 0 ? edge_cap + (int64_t)grid * (int64_t)A.edge_chunk : 0;
+            if ((rc = cf_alloc_t(ctx, &ctx->d_edges, (size_t)rows * 4, "edges"))) break;
+            ctx->edge_cap = rows;
+            A.edges = ctx->d_edges; A.edge_cap = (unsigned long long)rows;
+        }
+        n_holes_alloc = (size_t)grid + 1;
+        if ((rc = cf_alloc_t(ctx, &d_holes, 2 * n_holes_alloc, "edge holes"))) break;
+        A.holes = d_holes;
+        if (hipMemsetAsync(d_cnt + 6, 0, 16, ctx->stream) != hipSuccess) { rc = cf_fail(ctx, -5, "counter reset"); break; }      // [6] selected edges, [7] holes
         if (n_a > 0 && max_d >= min_d_eff && n_post > 0) {
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)block), lds, ctx->stream, A);
             e = hipGetLastError();
@@ -1527,10 +1597,57 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         }
 #endif
         if (h_cnt[4]) { rc = cf_fail(ctx, -34, "cf_dist_edges: (b,d) table could not be partitioned far enough"); break; }
+        // close the holes of the chunked edge output: the valid rows at or above n_valid move into the holes below it
+        {
+            const unsigned long long a_cap = std::min<unsigned long long>(h_cnt[0], A.edge_cap);      // rows that exist in memory
+            std::vector<unsigned long long> hh(2 * (size_t)h_cnt[7]);
+            if (!hh.empty() && hipMemcpy(hh.data(), d_holes, hh.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "edge holes copy"); break; }
+            std::vector<std::pair<unsigned long long, unsigned long long>> holes;      // [start, end) clipped to the rows in memory, sorted
+            for (size_t i = 0; i + 1 < hh.size(); i += 2) {
+                const unsigned long long s0 = std::min(hh[i], a_cap), s1 = std::min(hh[i] + hh[i + 1], a_cap);
+                if (s1 > s0) holes.emplace_back(s0, s1);
+            }
+            std::sort(holes.begin(), holes.end());
+            unsigned long long hole_rows = 0;
+            for (auto& h : holes) hole_rows += h.second - h.first;
+            const unsigned long long n_valid = a_cap - hole_rows;
+            n_stored = (int64_t)std::min<unsigned long long>(n_valid, (unsigned long long)edge_cap);
+            std::vector<unsigned long long> dst_start, dst_pre, src_start, src_pre;
+            unsigned long long dsum = 0, ssum = 0, at = n_valid;
+            for (auto& h : holes) {
+                if (h.first < n_valid) { const unsigned long long e1 = std::min(h.second, n_valid); dsum += e1 - h.first; dst_start.push_back(h.first); dst_pre.push_back(dsum); }
+                if (h.second > n_valid) {      // valid rows between `at` and this hole's part above n_valid
+                    const unsigned long long h0 = std::max(h.first, n_valid);
+                    if (h0 > at) { ssum += h0 - at; src_start.push_back(at); src_pre.push_back(ssum); }
+                    at = h.second;
+                }
+            }
+            if (a_cap > at) { ssum += a_cap - at; src_start.push_back(at); src_pre.push_back(ssum); }
+            if (dsum != ssum) { rc = cf_fail(ctx, -5, "cf_dist_edges: internal error, edge holes do not match the rows above them"); break; }
+            if (dsum) {
+                unsigned long long* d_seg = nullptr;
+                const size_t n_seg = src_start.size() * 2 + dst_start.size() * 2;
+                if ((rc = cf_alloc_t(ctx, &d_seg, n_seg, "edge move lists"))) break;
+                std::vector<unsigned long long> pack;
+                pack.insert(pack.end(), src_start.begin(), src_start.end()); pack.insert(pack.end(), src_pre.begin(), src_pre.end());
+                pack.insert(pack.end(), dst_start.begin(), dst_start.end()); pack.insert(pack.end(), dst_pre.begin(), dst_pre.end());
+                hipError_t e2 = hipMemcpyAsync(d_seg, pack.data(), n_seg * 8, hipMemcpyHostToDevice, ctx->stream);
+                if (e2 == hipSuccess) {
+                    hipLaunchKernelGGL(cf_edge_compact_kernel, dim3((unsigned)cf_grid_for((int64_t)dsum, 256, max_blocks)), dim3(256), 0, ctx->stream, ctx->d_edges,
+                                       (const unsigned long long*)d_seg, (const unsigned long long*)(d_seg + src_start.size()), (int)src_start.size(),
+                                       (const unsigned long long*)(d_seg + 2 * src_start.size()), (const unsigned long long*)(d_seg + 2 * src_start.size() + dst_start.size()), (int)dst_start.size(), dsum);
+                    e2 = hipGetLastError();
+                }
+                if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+                cf_release_t(ctx, d_seg, n_seg);
+                if (e2 != hipSuccess) { rc = cf_fail(ctx, -5, std::string("edge compaction: ") + hipGetErrorString(e2)); break; }
+            }
+        }
         (void)hipEventElapsedTime(&ctx->times.dist_ms, ctx->ev0, ctx->ev1);
         (void)hipEventElapsedTime(&ctx->times.postings_ms, ctx->ev0, ctx->ev2);
         (void)hipEventElapsedTime(&ctx->times.dist_kernel_ms, ctx->ev2, ctx->ev3);
     } while (0);
+    if (d_holes) cf_release_t(ctx, d_holes, 2 * n_holes_alloc);
     if (d_items) cf_release_t(ctx, d_items, (size_t)n_item_slots + 64);
     if (d_heads) cf_release_t(ctx, d_heads, (size_t)n_order);
     if (d_ibase) cf_release_t(ctx, d_ibase, (size_t)n_order + 1);
@@ -1552,13 +1669,13 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     if (d_cursor) cf_release_t(ctx, d_cursor, (size_t)K + 1);
     if (d_pcnt) cf_release_t(ctx, d_pcnt, (size_t)K + 1);
     if (rc) return rc;
-    ctx->stats.n_edges = (int64_t)h_cnt[0];
+    ctx->stats.n_edges = (int64_t)h_cnt[6];
     ctx->stats.n_emissions = (int64_t)h_cnt[1] - (int64_t)h_cnt[3];      // partner entries swept, less those that are the first k-mer itself (a != b in the reference)
     ctx->stats.n_spilled = (int64_t)h_cnt[2];
     ctx->stats.n_dist_passes = (int64_t)h_cnt[5];
-    ctx->n_edges_stored = std::min<int64_t>((int64_t)h_cnt[0], edge_cap);
+    ctx->n_edges_stored = n_stored;      // every selected edge when edge_cap allowed it, else the valid rows below the cap
     CF_TRY(cf_refresh_unique_count(ctx));
-    if (n_edges) *n_edges = (int64_t)h_cnt[0];
+    if (n_edges) *n_edges = (int64_t)h_cnt[6];
     return 0;
 }
 

@@ -536,7 +536,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
         int64_t dbg_it = -1, dbg_r[2] = {-1, -1};
         if (const char* dv = std::getenv("CF_PLACE_DEBUG")) { long long a_ = -1, b_ = -1, c_ = -1; if (std::sscanf(dv, "%lld,%lld,%lld", &a_, &b_, &c_) == 3 && stage_cls == 1) { dbg_it = a_; dbg_r[0] = b_; dbg_r[1] = c_; } }
         for (int64_t it = 0; it < n_iter; ++it) {
-            if (it == dbg_it || it == dbg_it + 1) {
+            if (dbg_it >= 0 && (it == dbg_it || it == dbg_it + 1)) {
                 CF_HIP(hipStreamSynchronize(st));
                 std::vector<unsigned long long> hk((size_t)score_cap), hv((size_t)score_cap);
                 std::vector<uint8_t> hf((size_t)score_cap);

@@ -36,7 +36,9 @@ extern "C" {
 
 typedef struct cf_ctx cf_ctx;
 
-/* Work counters; identical for the oracle and the HIP path on one input. */
+/* Work counters; the counters of the reference's algorithm (n_bases ... n_unique) are identical for the oracle and
+ * the HIP path on one input; table_capacity, n_spilled, hbm_bytes_live, n_dist_passes and n_edges_stored describe the device run
+ * (n_dist_passes and n_spilled depend on how workgroups interleave and may differ by a few between two runs). */
 typedef struct cf_stats {
     int64_t n_reads, n_bases, n_units;
     int64_t n_windows;      /* N_w  = sum max(0, len - k + 1)                       */
@@ -52,6 +54,7 @@ typedef struct cf_stats {
     int64_t n_spilled;      /* first k-mers whose (b,d) table had to be partitioned  */
     int64_t hbm_bytes_live; /* device memory currently owned by the context          */
     int64_t n_dist_passes;  /* (first k-mer, partition) table passes of the last cf_dist_edges */
+    int64_t n_edges_stored; /* edge rows of the last cf_dist_edges held on the device: n_edges when edge_cap allowed it, else at most edge_cap */
 } cf_stats;
 
 /* Device time (HIP events on the context's stream) of the last call of each stage. */
@@ -175,7 +178,7 @@ int cf_allreduce_unique(cf_ctx* ctx, int64_t* n_unique);
 
 /* Tuning knobs (defaults are chosen for gfx950): name in {"dist_block" (threads per workgroup, 0 = auto), "dist_wgs"
  * (workgroups per CU the LDS is split between, 0 = auto: by the pair emissions per first k-mer), "dist_slots" (LDS budget of the (b,d) table in 8-byte units, 0 = all that
- * is left), "dist_sketch" (0: every pair goes to the exact table), "dist_fill_pct", "dist_est_pct", "dist_stage",
+ * is left), "dist_sketch" (0: every pair goes to the exact table), "dist_fill_pct", "dist_est_pct", "dist_stage", "dist_edge_chunk" (edge rows a workgroup reserves in the output per global atomic, 0 = 8192; tests use small chunks), "dist_int_thr" (0: the dominance test always divides in doubles; 1, the default: the literal 0.8 is tested as 5 cnt >= 4 total, which is the same predicate),
  * "dist_wide", "dist_hot_cap" (tests: a small cap on the filter's hot-slot list forces the evaluation inside the bucket scan), "dist_regions" (1, 2, 4, 8: force the region layout of the 6-byte slots, which k-mer sets of 2^24 .. 2^27 ranks with long reads take by themselves), "dist_dbits" (5 .. 8: cap on the distance-field bits of the 6-byte table slots [d | b]; 0 = 32 minus the bits the k-mer ranks need), "place_chunk", "place_grid" (cloud entries per wave step and workgroups of the fused placement kernel), "place_fused" (1: score updates applied by the waves that lay a read onto the contig, 0: through an event list and a third kernel per greedy iteration), "count_mode" (1: A1 by sort and reduce, 0: the atomic table), "count_bits" (bucket bits of the former, 0 = auto), "count_slots", "count_tile", "comm_round_bytes" (bytes per pair of ranks and round of the multi-GPU exchanges, default 2^28; tests force many rounds), "comm_self_p2p" (1: the message a rank sends to itself goes through ncclSend / ncclRecv like every other one, so that a one-GPU box runs the whole p2p path)}.  Results never depend on them (tests/test_gpu_parity.py). */
 int cf_set_param(cf_ctx* ctx, const char* name, int64_t value);
 

@@ -45,6 +45,18 @@ def test_stage2_small(engine, report, oracle_stage2):
     assert engine.stats()["n_spilled"] == 0
 
 
+@pytest.mark.parametrize("chunk", [1, 7, 64])
+def test_edge_output_chunks_and_holes(engine, report, oracle_stage2, chunk):
+    """Workgroups reserve the edge output in chunks; a pass that does not fit the rest of a chunk continues in the next one, the
+    unused rest of every workgroup's last chunk is a hole that is closed after the kernel: tiny chunks make both happen often."""
+    tup = oracle_stage2("lowcov", max_distance=2)
+    engine.set_param("dist_edge_chunk", chunk)
+    try:
+        pathcheck.check_stage2(engine, report("lowcov"), tup, n_parts=2, check_table=False)
+    finally:
+        engine.set_param("dist_edge_chunk", 0)
+
+
 def test_stage2_wide_table_layout(engine, report, oracle_stage2):
     # 8-byte slots (any k-mer set size); the default above is the 6-byte layout (ranks < 2^24, counts < 2^15)
     tup = oracle_stage2("lowcov", max_distance=2)

@@ -215,8 +215,15 @@ def test_full_size_properties(engine):
     finally:
         engine.set_param("dist_block", 0); engine.set_param("dist_wgs", 0)
     engine.reset_unique()
-    ne = engine.dist_edges(0, 2 ** 62, 1, 150, 4, 0.8, 0, 1, edge_cap=1000)   # count-only beyond the cap
-    assert ne == ref[0] and engine.edges(1000).shape == (1000, 4) and engine.unique_mask().tobytes() == ref[3]
+    ne = engine.dist_edges(0, 2 ** 62, 1, 150, 4, 0.8, 0, 1, edge_cap=60_000_000)
+    full = {tuple(r) for r in engine.edges(ne).tolist()}
+    for cap in (1000, 20000, ne - 1):      # count-only beyond the cap; the rows kept are whole, distinct edges of the full set (the chunks of
+        engine.reset_unique()              # the output that workgroups reserve leave holes that are closed after the kernel)
+        ne2 = engine.dist_edges(0, 2 ** 62, 1, 150, 4, 0.8, 0, 1, edge_cap=cap)
+        stored = engine.stats()["n_edges_stored"]
+        rows = [tuple(r) for r in engine.edges(stored).tolist()]
+        assert ne2 == ref[0] and 0 < stored <= cap and len(set(rows)) == stored and set(rows) <= full, cap
+        assert engine.unique_mask().tobytes() == ref[3]
 
 
 def test_errors_and_degenerate_inputs(engine):
