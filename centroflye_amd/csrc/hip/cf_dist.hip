@@ -700,57 +700,91 @@ __device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buck
 // (two dependent round trips), scanned the item counts, searched the posting of every item and wrote the records to LDS behind
 // three barriers: 8 % of the kernel's time, 6.5 KB of its LDS, and every step of both sweeps first had to find its posting
 // (round 2: 25 vector + 40 scalar instructions per step).  Now a wave reads its 8-byte records with one coalesced load.
+// Both kernels give every first k-mer a GROUP of 16 lanes (most have fewer than 16 postings): four first k-mers per wave are in
+// flight at once — the work per first k-mer is a chain of dependent loads (order -> post_ptr -> post -> urange), so the kernels are
+// bound by how many chains run side by side.
+// cf_items_count_kernel also counts the partner entries that are the first k-mer itself: the pairs of its postings (u, v) in one
+// read with min_d <= v - u <= max_d (the reference skips a == b, distance_based_kmer_recruitment.py:118; the sweeps count such an
+// entry like any other and the host subtracts this sum).
 __global__ void __launch_bounds__(256)
 cf_items_count_kernel(const int32_t* __restrict__ order, int64_t n_order, const int64_t* __restrict__ post_ptr, const int32_t* __restrict__ post,
-                      const cf_dist_rec* __restrict__ urange, uint32_t nw, uint32_t* __restrict__ n_items, uint32_t* __restrict__ n_alloc) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t i = wave; i < n_order; i += n_waves) {
-        const int32_t a = order[i];
-        const int64_t p0 = post_ptr[a], p1 = post_ptr[a + 1];
+                      const cf_dist_rec* __restrict__ urange, const int32_t* __restrict__ rbeg, int32_t min_d, int32_t max_d, uint32_t nw,
+                      uint32_t* __restrict__ n_items, uint32_t* __restrict__ n_alloc, unsigned long long* __restrict__ self_pairs) {
+    const int gl = threadIdx.x & 15;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t n_grp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    unsigned long long self = 0;
+    for (int64_t i0 = 0; i0 < n_order; i0 += n_grp) {      // (uniform trip count: shuffles inside)
+        const int64_t i = i0 + grp;
+        const bool on = i < n_order;
+        const int32_t a = on ? order[i] : 0;
+        const int64_t p0 = on ? post_ptr[a] : 0, p1 = on ? post_ptr[a + 1] : 0;
         unsigned long long c = 0;
-        for (int64_t p = p0 + lane; p < p1; p += 64) c += (urange[post[p]].len + DIST_ITEM - 1u) / DIST_ITEM;
-        for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, (unsigned)d);
-        if (lane == 0) {
-            const uint32_t n = (uint32_t)min(c, 0xFFFFFFFFull - 2048ull);      // (cf_dist_edges refuses a first k-mer with more items)
+        int64_t np_max = p1 - p0;      // the longest posting list among the wave's four groups bounds the loops
+        for (int d = 16; d <= 32; d <<= 1) np_max = max(np_max, __shfl_xor(np_max, d));
+        for (int64_t x0 = 0; x0 < np_max; x0 += 16) {
+            const bool hx = p0 + x0 + gl < p1;
+            const int32_t ux = hx ? post[p0 + x0 + gl] : 0;
+            const int32_t rx = hx ? rbeg[ux] : -1;
+            if (hx) c += (urange[ux].len + DIST_ITEM - 1u) / DIST_ITEM;
+            if (np_max < 2) continue;
+            for (int64_t y0 = 0; y0 < np_max; y0 += 16) {
+                const bool hy = p0 + y0 + gl < p1;
+                const int32_t uy_l = hy ? post[p0 + y0 + gl] : 0, ry_l = hy ? rbeg[uy_l] : -2;
+                for (int j = 0; j < 16; ++j) {
+                    const int32_t uy = __shfl(uy_l, j, 16), ry = __shfl(ry_l, j, 16);
+                    const int32_t d = uy - ux;
+                    self += (unsigned long long)(hx && ry == rx && d >= min_d && d <= max_d);
+                }
+            }
+        }
+        for (int d = 8; d >= 1; d >>= 1) c += __shfl_down(c, (unsigned)d, 16);
+        if (on && gl == 0) {
+            const uint32_t n = (uint32_t)min(c, 0xFFFFFFFFull - 2048ull);
             n_items[i] = n;
             n_alloc[i] = ((n + nw - 1u) / nw) * nw;
         }
     }
+    for (int d = 32; d >= 1; d >>= 1) self += __shfl_down(self, (unsigned)d);
+    if ((threadIdx.x & 63) == 0 && self) atomicAdd(self_pairs, self);
 }
 
 __global__ void __launch_bounds__(256)
 cf_items_fill_kernel(const int32_t* __restrict__ order, int64_t n_order, const int64_t* __restrict__ post_ptr, const int32_t* __restrict__ post,
                      const cf_dist_rec* __restrict__ urange, uint32_t nw, const uint32_t* __restrict__ n_items, const int64_t* __restrict__ ibase,
                      cf_dist_head* __restrict__ heads, cf_dist_item* __restrict__ items) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t i = wave; i < n_order; i += n_waves) {
-        const int32_t a = order[i];
-        const int64_t p0 = post_ptr[a], p1 = post_ptr[a + 1];
-        const uint32_t n = n_items[i], per = (n + nw - 1u) / nw;
-        cf_dist_item* out = items + ibase[i];
-        uint32_t j0 = 0;      // items of the postings before this chunk (wave-uniform)
+    const int gl = threadIdx.x & 15;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t n_grp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (int64_t i0 = 0; i0 < n_order; i0 += n_grp) {      // (uniform trip count: shuffles inside)
+        const int64_t i = i0 + grp;
+        const bool on = i < n_order;
+        const int32_t a = on ? order[i] : 0;
+        const int64_t p0 = on ? post_ptr[a] : 0, p1 = on ? post_ptr[a + 1] : 0;
+        const uint32_t n = on ? n_items[i] : 0u, per = (n + nw - 1u) / nw;
+        const int64_t ib = on ? ibase[i] : 0;
+        cf_dist_item* out = items + ib;
+        int64_t np_max = p1 - p0;
+        for (int d = 16; d <= 32; d <<= 1) np_max = max(np_max, __shfl_xor(np_max, d));
+        uint32_t j0 = 0;      // items of the postings before this chunk (group-uniform)
         unsigned long long ne = 0;
-        for (int64_t q0 = p0; q0 < p1; q0 += 64) {      // 64 postings at a time, one per lane: two dependent loads per chunk, not per posting
+        for (int64_t q0 = 0; q0 < np_max; q0 += 16) {      // 16 postings at a time, one per lane of the group
             cf_dist_rec r{0, 0u, 0u};
-            if (q0 + lane < p1) r = urange[post[q0 + lane]];
+            if (p0 + q0 + gl < p1) r = urange[post[p0 + q0 + gl]];
             const uint32_t c = (r.len + DIST_ITEM - 1u) / DIST_ITEM;
             uint32_t inc = c;
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, (unsigned)d); if (lane >= d) inc += o; }
+            for (int d = 1; d < 16; d <<= 1) { const uint32_t o = __shfl_up(inc, (unsigned)d, 16); if (gl >= d) inc += o; }
             const uint32_t jb = j0 + inc - c;      // the lane's first item
             for (uint32_t x = 0; x < c; ++x) {
                 const uint32_t j = jb + x, off = x * DIST_ITEM;
                 out[(size_t)(j % nw) * per + j / nw] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | (r.ig & 0xFFFFu)};
             }
-            j0 += (uint32_t)__shfl((int)inc, 63);
+            j0 += (uint32_t)__shfl((int)inc, 15, 16);
             unsigned long long l = r.len;
-            for (int d = 32; d >= 1; d >>= 1) l += __shfl_down(l, (unsigned)d);
-            ne += (unsigned long long)__shfl((long long)l, 0);
+            for (int d = 8; d >= 1; d >>= 1) l += __shfl_down(l, (unsigned)d, 16);
+            ne += (unsigned long long)__shfl((long long)l, 0, 16);
         }
-        if (lane == 0) heads[i] = cf_dist_head{(uint32_t)a, n, (unsigned long long)ibase[i], (uint32_t)min(ne, 0x3FFFFFFFull), 0u, 0u, 0u};
+        if (on && gl == 0) heads[i] = cf_dist_head{(uint32_t)a, n, (unsigned long long)ib, (uint32_t)min(ne, 0x3FFFFFFFull), 0u, 0u, 0u};
     }
 }
 
@@ -863,24 +897,32 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
 
     // 8 ticket queues over 8 contiguous ranges of the locality-sorted first k-mers: workgroups with equal blockIdx % 8
     // (observed to share an XCD, i.e. an L2) drain one range; idle ones steal
-    auto pop = [&]() -> long long {
-        long long idx = -1;
-        const int64_t per = (A.n_order + 7) / 8;
-        for (int s8 = 0; s8 < 8 && idx < 0; ++s8) {
+    // The ticket of the next first k-mer is taken in two halves: pop_issue() sends the atomic on this workgroup's own queue and
+    // returns at once, pop_finish() — a phase later — looks at what came back and, only when that queue is exhausted, tries the
+    // others.  (Round 2 waited for the returning atomic right where it was issued, at the top of every iteration: a round trip
+    // to the memory side with the whole workgroup behind thread 0 at the next barrier, 9 % of the kernel.)
+    const int64_t q_per = (A.n_order + 7) / 8;
+    auto pop_issue = [&]() -> unsigned long long { return atomicAdd(&A.counters[16 + 16 * (blockIdx.x & 7)], 1ull); };
+    auto pop_finish = [&](unsigned long long q) -> long long {
+        const int x0 = (int)(blockIdx.x & 7);
+        const int64_t lo0 = x0 * q_per, hi0 = min((int64_t)(x0 + 1) * q_per, A.n_order);
+        if (lo0 + (int64_t)q < hi0) return lo0 + (int64_t)q;
+        for (int s8 = 1; s8 < 8; ++s8) {
             const int x = (int)((blockIdx.x + s8) & 7);
-            const int64_t lo = x * per, hi = min((int64_t)(x + 1) * per, A.n_order);
+            const int64_t lo = x * q_per, hi = min((int64_t)(x + 1) * q_per, A.n_order);
             if (lo >= hi) continue;
-            const unsigned long long q = atomicAdd(&A.counters[16 + 16 * x], 1ull);
-            if (lo + (int64_t)q < hi) idx = lo + (int64_t)q;
+            const unsigned long long q2 = atomicAdd(&A.counters[16 + 16 * x], 1ull);
+            if (lo + (int64_t)q2 < hi) return lo + (int64_t)q2;
         }
-        return idx;
+        return -1;
     };
     // Thread 0 fetches the NEXT first k-mer's head (ticket -> heads[]: two dependent round trips) while the workgroup works on
     // the current one; the values wait in its registers until the loop comes around.
     long long nx_idx = -1;
     cf_dist_head nx_head{0u, 0u, 0ull, 0u, 0u, 0u, 0u};
+    unsigned long long nx_q = 0;
     if (t == 0) {
-        nx_idx = pop();
+        nx_idx = pop_finish(pop_issue());
         if (nx_idx >= 0) nx_head = A.heads[nx_idx];
     }
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), nw = (uint32_t)nt >> 6;
@@ -902,10 +944,10 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         const cf_dist_item* recs = A.items + ((((unsigned long long)sh[15] << 32) | sh[14]) + (unsigned long long)wv * per_w);
         cf_dist_item my0 = cf_dist_item{0u, 0u};
         if ((uint32_t)lane < min(mine, 64u)) my0 = recs[lane];
-        if (t == 0) nx_idx = pop();                                  // next: the ticket (used after phase A)
+        if (t == 0) nx_q = pop_issue();                               // next: the ticket (looked at after phase A)
         CF_STAMP(0);   // queue pop
         if (n_items == 0u) {
-            if (t == 0 && nx_idx >= 0) nx_head = A.heads[nx_idx];
+            if (t == 0) { nx_idx = pop_finish(nx_q); if (nx_idx >= 0) nx_head = A.heads[nx_idx]; }
             continue;
         }
         CF_STAMP(1);   // prologue
@@ -967,7 +1009,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             CF_STAMP(7);      // (stamp 7: thread 0's wait for the other waves at the end of a sweep)
             if (sh[13]) mark_all = true;
         }
-        if (t == 0 && nx_idx >= 0) nx_head = A.heads[nx_idx];      // next: its head (used at the loop top)
+        if (t == 0) { nx_idx = pop_finish(nx_q); if (nx_idx >= 0) nx_head = A.heads[nx_idx]; }      // next: its head (used at the loop top)
         if (mark_all) {
             const cf_u32x4 ones{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = ones;
@@ -1249,38 +1291,6 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
     }
 }
 
-// Partner entries that are the first k-mer itself: for every first k-mer a of the launch, the pairs of its postings (u, v) in one
-// read with min_d <= v - u <= max_d (the reference skips a == b, distance_based_kmer_recruitment.py:118; the sweeps count such an
-// entry like any other and the host subtracts this sum).  One wave per first k-mer; postings in chunks of 64.
-__global__ void __launch_bounds__(256)
-cf_self_pairs_kernel(const int32_t* __restrict__ order, int64_t n_order, const int64_t* __restrict__ post_ptr, const int32_t* __restrict__ post,
-                     const int32_t* __restrict__ rbeg, int32_t min_d, int32_t max_d, unsigned long long* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    unsigned long long cnt = 0;
-    for (int64_t i = wave; i < n_order; i += n_waves) {
-        const int32_t a = order[i];
-        const int64_t p0 = post_ptr[a], p1 = post_ptr[a + 1];
-        if (p1 - p0 < 2) continue;
-        for (int64_t x0 = p0; x0 < p1; x0 += 64) {
-            const bool hx = x0 + lane < p1;
-            const int32_t ux = hx ? post[x0 + lane] : 0, rx = hx ? rbeg[ux] : -1;
-            for (int64_t y0 = p0; y0 < p1; y0 += 64) {
-                const int ny = (int)min((int64_t)64, p1 - y0);
-                const int32_t uy_l = y0 + lane < p1 ? post[y0 + lane] : 0, ry_l = y0 + lane < p1 ? rbeg[uy_l] : -2;
-                for (int j = 0; j < ny; ++j) {
-                    const int32_t uy = __shfl(uy_l, j), ry = __shfl(ry_l, j);
-                    const int32_t d = uy - ux;
-                    cnt += (unsigned long long)(hx && ry == rx && d >= min_d && d <= max_d);
-                }
-            }
-        }
-    }
-    for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_down(cnt, (unsigned)d);
-    if (lane == 0 && cnt) atomicAdd(out, cnt);
-}
-
 // sum over all postings of their partner-range length = the number of pair emissions of the launch (before a != b)
 __global__ void __launch_bounds__(256)
 cf_sum_partner_kernel(const int32_t* __restrict__ post, int64_t n_post, const cf_dist_rec* __restrict__ urange, unsigned long long* __restrict__ out) {
@@ -1536,19 +1546,16 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                                    (const unsigned long long*)d_okeys, n_order, d_order);
         }
         A.order = d_order; A.n_order = n_order;
-        if (n_order && n_post && max_d >= min_d_eff)      // partner entries that are the first k-mer itself (subtracted from the emission count below)
-            hipLaunchKernelGGL(cf_self_pairs_kernel, dim3((unsigned)cf_grid_for(n_order * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const int32_t*)d_order, n_order, (const int64_t*)d_post_ptr, (const int32_t*)d_post, (const int32_t*)d_rbeg, min_d_eff, max_d, d_cnt + 3);
         // the work lists of the sweeps (heads + item records, laid out for workgroups of `block` threads): count, scan, fill
         if (n_order) {
             const uint32_t nw = (uint32_t)block / 64u;
-            const int g_items = cf_grid_for(n_order * 64, 256, max_blocks);
+            const int g_items = cf_grid_for(n_order * 16, 256, max_blocks);
             if ((rc = cf_alloc_t(ctx, &d_icnt, (size_t)n_order + 1, "item counts"))) break;
             if ((rc = cf_alloc_t(ctx, &d_ialloc, (size_t)n_order + 1, "item slots"))) break;
             if ((rc = cf_alloc_t(ctx, &d_ibase, (size_t)n_order + 1, "item bases"))) break;
             if ((rc = cf_alloc_t(ctx, &d_heads, (size_t)n_order, "first k-mer heads"))) break;
             hipLaunchKernelGGL(cf_items_count_kernel, dim3((unsigned)g_items), dim3(256), 0, ctx->stream, (const int32_t*)d_order, n_order, (const int64_t*)d_post_ptr,
-                               (const int32_t*)d_post, (const cf_dist_rec*)d_urange, nw, d_icnt, d_ialloc);
+                               (const int32_t*)d_post, (const cf_dist_rec*)d_urange, (const int32_t*)d_rbeg, min_d_eff, max_d, nw, d_icnt, d_ialloc, d_cnt + 3);
             if ((rc = cf_scan_exclusive_u32_to_i64(ctx, d_ialloc, d_ibase, n_order, &n_item_slots))) break;
             if ((rc = cf_alloc_t(ctx, &d_items, (size_t)n_item_slots + 64, "item records"))) break;
             hipLaunchKernelGGL(cf_items_fill_kernel, dim3((unsigned)g_items), dim3(256), 0, ctx->stream, (const int32_t*)d_order, n_order, (const int64_t*)d_post_ptr,
