@@ -29,6 +29,7 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 #define DIST_UNROLL 4
 #define DIST_ITEM (64u * DIST_UNROLL)    /* cloud entries one wave takes per step: DIST_UNROLL consecutive ones per lane */
 #define DIST_BM_BITS 65536u              /* bitmap over hash(b): k-mers that may have a selected edge */
+#define DIST_HOT_CAP 2048u               /* slots the insert path can hand to the filter per pass (more: the filter scans the table) */
 #define DIST_EDGE_CHUNK 8192ull          /* edge rows a workgroup reserves per global atomic */
 #define DIST_OVQ 96u                     /* per-wave list of inserts whose first probe did not finish (drained with the probe loop at >= 32) */
 #define DIST_LDS_HEAD (DIST_BM_BITS / 8 + 64)   /* bitmap + sh: the fixed head of the kernel's LDS */
@@ -245,14 +246,17 @@ struct cf_tab_wide_t {
         const uint32_t m = (uint32_t)(k.lo.x == 0ull) | ((uint32_t)(k.lo.y == 0ull) << 1) | ((uint32_t)(k.hi.x == 0ull) << 2) | ((uint32_t)(k.hi.y == 0ull) << 3);
         return __ffs((int)m) - 1;
     }
-    __device__ __forceinline__ void add(uint32_t bk, int i) const { atomicAdd(&tab[4 * bk + i], 1ull); }
+    // counts one more occurrence of the key in slot i of bucket bk; returns its count after the add
+    __device__ __forceinline__ uint32_t add(uint32_t bk, int i) const { return ((uint32_t)atomicAdd(&tab[4 * bk + i], 1ull) & kCntMask) + 1u; }
+    static constexpr uint32_t kSlotsPerBucket = 4;
     // claim slot i of bucket bk for (b, dd): 0 = claimed (count 1), 1 = the same key got there first (counted), 2 = another key
     __device__ __forceinline__ unsigned long long claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const {
         return atomicCAS(&tab[4 * bk + i], 0ull, ((unsigned long long)b << 32) | ((unsigned long long)dd << kDShift) | 1ull);
     }
-    __device__ __forceinline__ int claim_finish(unsigned long long old, uint32_t bk, int i, uint32_t b, uint32_t dd) const {
+    __device__ __forceinline__ int claim_finish(unsigned long long old, uint32_t bk, int i, uint32_t b, uint32_t dd, uint32_t& cnt) const {
+        cnt = 1u;
         if (old == 0ull) return 0;
-        if (is(old, b, dd)) { add(bk, i); return 1; }
+        if (is(old, b, dd)) { cnt = add(bk, i); return 1; }
         return 2;
     }
     // filter side: slot s -> (b, dd, cnt) or false when empty
@@ -384,11 +388,17 @@ struct cf_tab_narrow_t {
     }
     static __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) { return first_equal(k, key_of(b, dd)); }
     static __device__ __forceinline__ int empty(const bucket& k) { return first_equal(k, kEmpty); }
-    __device__ __forceinline__ void add(uint32_t bk, int i) const { const uint32_t s = PB * bk + (uint32_t)i; atomicAdd(&cnt32[s >> 1], 1u << ((s & 1u) * 16u)); }
+    // counts one more occurrence of the key in slot i of bucket bk; returns its count after the add (the field holds count - 1)
+    __device__ __forceinline__ uint32_t add(uint32_t bk, int i) const {
+        const uint32_t s = PB * bk + (uint32_t)i, sh_ = (s & 1u) * 16u;
+        return ((atomicAdd(&cnt32[s >> 1], 1u << sh_) >> sh_) & 0x7FFFu) + 2u;
+    }
+    static constexpr uint32_t kSlotsPerBucket = PB;
     __device__ __forceinline__ uint32_t claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const { return atomicCAS(&keys[PB * bk + i], kEmpty, key_of(b, dd)); }
-    __device__ __forceinline__ int claim_finish(uint32_t old, uint32_t bk, int i, uint32_t b, uint32_t dd) const {
+    __device__ __forceinline__ int claim_finish(uint32_t old, uint32_t bk, int i, uint32_t b, uint32_t dd, uint32_t& cnt) const {
+        cnt = 1u;
         if (old == kEmpty) return 0;                        // claimed: the zero count field already means "seen once"
-        if (old == key_of(b, dd)) { add(bk, i); return 1; }  // the same key was claimed by someone else: count it
+        if (old == key_of(b, dd)) { cnt = add(bk, i); return 1; }  // the same key was claimed by someone else: count it
         return 2;
     }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
@@ -568,11 +578,17 @@ struct cf_tab_region {
     }
     __device__ __forceinline__ int match(const bucket& k, uint32_t b, uint32_t dd) const { return first_equal(k, key_of(b, dd)); }
     static __device__ __forceinline__ int empty(const bucket& k) { return first_equal(k, kEmpty); }
-    __device__ __forceinline__ void add(uint32_t bk, int i) const { const uint32_t s = PB * bk + (uint32_t)i; atomicAdd(&cnt32[s >> 1], 1u << ((s & 1u) * 16u)); }
+    // counts one more occurrence of the key in slot i of bucket bk; returns its count after the add (the field holds count - 1)
+    __device__ __forceinline__ uint32_t add(uint32_t bk, int i) const {
+        const uint32_t s = PB * bk + (uint32_t)i, sh_ = (s & 1u) * 16u;
+        return ((atomicAdd(&cnt32[s >> 1], 1u << sh_) >> sh_) & 0x7FFFu) + 2u;
+    }
+    static constexpr uint32_t kSlotsPerBucket = PB;
     __device__ __forceinline__ uint32_t claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const { return atomicCAS(&keys[PB * bk + i], kEmpty, key_of(b, dd)); }
-    __device__ __forceinline__ int claim_finish(uint32_t old, uint32_t bk, int i, uint32_t b, uint32_t dd) const {
+    __device__ __forceinline__ int claim_finish(uint32_t old, uint32_t bk, int i, uint32_t b, uint32_t dd, uint32_t& cnt) const {
+        cnt = 1u;
         if (old == kEmpty) return 0;
-        if (old == key_of(b, dd)) { add(bk, i); return 1; }
+        if (old == key_of(b, dd)) { cnt = add(bk, i); return 1; }
         return 2;
     }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
@@ -667,16 +683,18 @@ __device__ __forceinline__ uint32_t cf_rank_in(unsigned long long m) { return __
 #define DIST_FULL_BIT 0x80000000u        /* sh[0]: the table is physically full (the pass is void and will be split) */
 
 // general insert: walk buckets from bk; claims the first empty slot with a CAS when the key is absent.
-// Returns 1 when a new key was created.
+// Returns 1 when a new key was created; hot := the slot when this occurrence brought its count to exactly min_cov.
 template <class Tab>
-__device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buckets, uint32_t bk, uint32_t b, uint32_t dd, uint32_t* sh) {
+__device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buckets, uint32_t bk, uint32_t b, uint32_t dd, uint32_t* sh, uint32_t min_cov, uint32_t& hot) {
     for (uint32_t tries = 0; tries < 9 * n_buckets; ++tries) {
         const typename Tab::bucket k = T.read(bk);
         const int m = T.match(k, b, dd);
-        if (m >= 0) { T.add(bk, m); return 0u; }
+        if (m >= 0) { if (T.add(bk, m) == min_cov) hot = Tab::kSlotsPerBucket * bk + (uint32_t)m; return 0u; }
         const int e = Tab::empty(k);
         if (e >= 0) {
-            const int st = T.claim_finish(T.claim_issue(bk, e, b, dd), bk, e, b, dd);
+            uint32_t cnt;
+            const int st = T.claim_finish(T.claim_issue(bk, e, b, dd), bk, e, b, dd, cnt);
+            if (st != 2 && cnt == min_cov) hot = Tab::kSlotsPerBucket * bk + (uint32_t)e;
             if (st == 0) return 1u;
             if (st == 1) return 0u;
             continue;   // another key took the slot: look at the same bucket again
@@ -888,6 +906,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
     // through the probe loop 32 .. 64 at a time (round 2 ran that loop inside every drain: most drains went around twice for
     // one or two of their 64 lanes)
     typename Tab::qitem* ovq = wq0 + (size_t)(nt >> 6) * DIST_QCAP + (size_t)(t >> 6) * DIST_OVQ;
+    uint16_t* hotl = (uint16_t*)(wq0 + (size_t)(nt >> 6) * (DIST_QCAP + DIST_OVQ));      // DIST_HOT_CAP slots whose count reached min_cov during the inserts of the pass
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0, acc_edges = 0;  // flushed once per workgroup (thread 0)
     unsigned long long e_cur = 0, e_end = 0;      // thread 0: the unused rows [e_cur, e_end) of the workgroup's chunk of the edge output
@@ -1044,22 +1063,35 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 // pops the last N (<= 64) queued inserts, one per lane, and gives each ONE probe of its home bucket in
                 // straight-line code: match -> count it; empty slot -> claim it; bucket full or the slot lost to another key ->
                 // parked in the overflow list, which goes through the probe loop once it holds 32
+                // slots whose count just reached min_cov go to the filter's list (one LDS atomic per wave and drain): the filter then
+                // evaluates that list instead of scanning every slot of the table for counts >= min_cov (round 2: 3 scan rounds per
+                // first k-mer, 7 % of the kernel)
+#define CF_DIST_HOT(SLOT) {                                                                                   \
+                    const unsigned long long hm_ = __ballot((SLOT) != 0xFFFFFFFFu);                           \
+                    if (hm_) {                                                                                \
+                        uint32_t hb_ = 0;                                                                     \
+                        if (lane == 0) hb_ = atomicAdd(&sh[11], (uint32_t)__popcll(hm_));                     \
+                        hb_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb_) + cf_rank_in(hm_);          \
+                        if ((SLOT) != 0xFFFFFFFFu && hb_ < DIST_HOT_CAP) hotl[hb_] = (uint16_t)(SLOT);        \
+                    }                                                                                         \
+                }
 #define CF_DIST_OVERFLOW(N) {                                                                                 \
                     const uint32_t m_ = (N); otail -= m_;                                                     \
-                    uint32_t omade_ = 0;                                                                      \
+                    uint32_t omade_ = 0, ohot_ = 0xFFFFFFFFu;                                                 \
                     if ((uint32_t)lane < m_) {                                                                \
                         uint32_t xb, xd, xk;                                                                  \
                         T.q_take(ovq[otail + (uint32_t)lane], n_buckets, xb, xd, xk);                        \
-                        omade_ = cf_dist_insert(T, n_buckets, xk, xb, xd, sh);                                \
+                        omade_ = cf_dist_insert(T, n_buckets, xk, xb, xd, sh, A.min_cov, ohot_);              \
                     }                                                                                         \
                     const uint32_t onew_ = (uint32_t)__popcll(__ballot(omade_ != 0u));                        \
                     if (onew_ && lane == 0) atomicAdd(&sh[0], onew_);                                         \
+                    CF_DIST_HOT(ohot_)                                                                        \
                 }
 #define CF_DIST_DRAIN(N) {                                                                                    \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                     __builtin_amdgcn_wave_barrier();                                                          \
                     const uint32_t n_ = (N); qtail -= n_;                                                     \
-                    uint32_t made_ = 0, park_ = 0;                                                            \
+                    uint32_t made_ = 0, park_ = 0, hot_ = 0xFFFFFFFFu;                                        \
                     typename Tab::qitem it_ = 0;                                                              \
                     if ((uint32_t)lane < n_) {                                                                \
                         uint32_t xb, xd, xk;                                                                  \
@@ -1067,13 +1099,15 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                         T.q_take(it_, n_buckets, xb, xd, xk);                                                 \
                         const typename Tab::bucket k_ = T.read(xk);                                           \
                         const int mt_ = T.match(k_, xb, xd);                                                  \
-                        if (mt_ >= 0) T.add(xk, mt_);                                                         \
+                        if (mt_ >= 0) { if (T.add(xk, mt_) == A.min_cov) hot_ = Tab::kSlotsPerBucket * xk + (uint32_t)mt_; } \
                         else {                                                                                \
                             const int em_ = Tab::empty(k_);                                                   \
                             park_ = 1u;                                                                       \
                             if (em_ >= 0) {                                                                   \
-                                const int st_ = T.claim_finish(T.claim_issue(xk, em_, xb, xd), xk, em_, xb, xd); \
+                                uint32_t cn_;                                                                 \
+                                const int st_ = T.claim_finish(T.claim_issue(xk, em_, xb, xd), xk, em_, xb, xd, cn_); \
                                 made_ = (uint32_t)(st_ == 0); park_ = (uint32_t)(st_ == 2);                  \
+                                if (st_ != 2 && cn_ == A.min_cov) hot_ = Tab::kSlotsPerBucket * xk + (uint32_t)em_; \
                             }                                                                                 \
                         }                                                                                     \
                     }                                                                                         \
@@ -1084,6 +1118,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                         if (park_) ovq[otail + cf_rank_in(pm_)] = it_;                                        \
                         otail += (uint32_t)__popcll(pm_);                                                     \
                     }                                                                                         \
+                    CF_DIST_HOT(hot_)                                                                         \
                     __builtin_amdgcn_wave_barrier();                                                          \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                 }
@@ -1134,6 +1169,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 });
 #undef CF_DIST_DRAIN
 #undef CF_DIST_OVERFLOW
+#undef CF_DIST_HOT
                 CF_STAMP(3);   // table sweep + inserts (wave 0's own items)
             }
             __syncthreads();
@@ -1156,11 +1192,18 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             // by now.  (2) The list is evaluated one slot per thread with all lanes busy: sum over d from the bucket's
             // registers or a chain walk, the double division, mark + stage.  (Evaluating inside the bucket scan ran the
             // division code at 8 unrolled sites per round with 4 % of the lanes active: 9 100 cycles per first k-mer.)
-            uint16_t* hot = (uint16_t*)wq0;
-            const uint32_t hot_cap = min(A.hot_cap, (uint32_t)((size_t)(nt >> 6) * DIST_QCAP * sizeof(typename Tab::qitem) / 2));
-            // (every position comes from ONE LDS atomic per wave: 64 returning adds on one address serialise — 570 of them
-            // per first k-mer were the cost of this phase, not the arithmetic)
+            // The slots to evaluate: the list the insert path made (slots whose count reached min_cov) — or, when that list
+            // overflowed / min_cov < 2 / a test asks for it, a scan of the whole table into a list over the insert queues.
+            uint16_t* hot = hotl;
+            uint32_t hot_cap = min(A.hot_cap, DIST_HOT_CAP);
+            const bool from_inserts = A.min_cov >= 2u && sh[11] <= hot_cap;      // (uniform: nothing changes sh[11] after the sweep's barrier)
             const unsigned long long lt = (1ull << lane) - 1ull;
+            if (!from_inserts) {
+            __syncthreads();
+            if (t == 0) sh[11] = 0;
+            __syncthreads();
+            hot = (uint16_t*)wq0;
+            hot_cap = min(A.hot_cap, (uint32_t)((size_t)(nt >> 6) * DIST_QCAP * sizeof(typename Tab::qitem) / 2));
             const uint32_t n_groups = slots / Tab::kScanGroup;
             for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)nt) {      // (uniform trip count: ballots inside)
                 const uint32_t bk = g0 + (uint32_t)t;                       // a group of kScanGroup consecutive slots
@@ -1189,6 +1232,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 }
             }
             __syncthreads();
+            }
             const uint32_t n_hot = sh[11];
             // cnt / total >= thr as Python evaluates it (distance_based_kmer_recruitment.py:143-144: true division of two ints, compared
             // with a double).  For the default threshold — the literal 0.8, the double just above 4 / 5 — the test is exactly
@@ -1513,7 +1557,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (block == 0) block = wgs == 1 ? 1024 : 512;
         // LDS: everything but the table is fixed; dist_slots (the table budget in 8-byte units) defaults to all the rest
         const size_t qitem_bytes = narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem);
-        const size_t lds_fixed = DIST_LDS_HEAD + (size_t)(2 * DIST_STACK) * 4 + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QCAP + DIST_OVQ) * qitem_bytes;
+        const size_t lds_fixed = DIST_LDS_HEAD + (size_t)(2 * DIST_STACK) * 4 + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QCAP + DIST_OVQ) * qitem_bytes + DIST_HOT_CAP * 2;
         const int64_t budget8 = ((int64_t)160 * 1024 / wgs - (int64_t)lds_fixed) / 8;
         if (budget8 < 256) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_wgs leaves no LDS for the table"); break; }
         if (ctx->dist_slots > budget8) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_slots does not fit the 160 KiB LDS next to the work lists"); break; }
