@@ -2,6 +2,7 @@
 #include "cf_common.h"
 
 #include <atomic>
+#include <cstdlib>
 #include <thread>
 
 int cf_fail(cf_ctx* ctx, int code, const std::string& msg) {
@@ -97,9 +98,18 @@ static bool cf_is_host_pointer(const void* p) {
     if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return true; }      // unknown to the runtime: ordinary host memory
     return at.type != hipMemoryTypeDevice;
 }
-static int cf_copy_staged(cf_ctx* ctx, void* dst, const void* src, size_t bytes, bool to_device) {
+// true when some byte is not an upper-case A, C, G or T
+static bool cf_any_exotic(const unsigned char* p, size_t n) {
+    unsigned char bad = 0;
+    for (size_t i = 0; i < n; ++i) { const unsigned char c = p[i]; bad |= (unsigned char)!(c == 'A' || c == 'C' || c == 'G' || c == 'T'); }
+    return bad != 0;
+}
+// exotic (H2D of the read bases only): set when a byte outside upper-case ACGT goes by — the copy threads look at every chunk
+// while it sits in their pinned slot, so the alphabet check costs no pass of its own
+static int cf_copy_staged(cf_ctx* ctx, void* dst, const void* src, size_t bytes, bool to_device, std::atomic<int>* exotic = nullptr) {
     const void* host = to_device ? src : dst;
     if (bytes < CF_PIN_MIN || !cf_is_host_pointer(host) || !cf_pin_ready(ctx)) {
+        if (exotic && cf_is_host_pointer(host) && cf_any_exotic((const unsigned char*)src, bytes)) *exotic = 1;
         CF_HIP(hipStreamSynchronize(ctx->stream));
         CF_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
         return 0;
@@ -117,6 +127,7 @@ static int cf_copy_staged(cf_ctx* ctx, void* dst, const void* src, size_t bytes,
             const size_t off = c * CF_PIN_SLOT, n = std::min(CF_PIN_SLOT, bytes - off);
             if (to_device) {
                 std::memcpy(slot, (const char*)src + off, n);
+                if (exotic && cf_any_exotic((const unsigned char*)slot, n)) *exotic = 1;
                 if (hipMemcpyAsync((char*)dst + off, slot, n, hipMemcpyHostToDevice, ctx->pin_stream[t]) != hipSuccess ||
                     hipStreamSynchronize(ctx->pin_stream[t]) != hipSuccess) { bad = 1; return; }
             } else {
@@ -126,7 +137,9 @@ static int cf_copy_staged(cf_ctx* ctx, void* dst, const void* src, size_t bytes,
             }
         }
     };
-    const int nt = (int)std::min<size_t>(cf_ctx::kCopyThreads, n_chunks);
+    int want_t = 8;
+    if (const char* ev = std::getenv("CF_COPY_THREADS")) want_t = std::max(1, std::min((int)cf_ctx::kCopyThreads, std::atoi(ev)));
+    const int nt = (int)std::min<size_t>((size_t)want_t, n_chunks);
     std::vector<std::thread> th;
     try {
         for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
@@ -137,6 +150,12 @@ static int cf_copy_staged(cf_ctx* ctx, void* dst, const void* src, size_t bytes,
     return 0;
 }
 int cf_copy_h2d(cf_ctx* ctx, void* dev, const void* host, size_t bytes) { return bytes ? cf_copy_staged(ctx, dev, host, bytes, true) : 0; }
+static int cf_copy_bases(cf_ctx* ctx, void* dev, const void* host, size_t bytes, bool* exotic) {
+    std::atomic<int> ex{0};
+    const int rc = bytes ? cf_copy_staged(ctx, dev, host, bytes, true, &ex) : 0;
+    *exotic = ex.load() != 0;
+    return rc;
+}
 int cf_copy_d2h(cf_ctx* ctx, void* host, const void* dev, size_t bytes) { return bytes ? cf_copy_staged(ctx, host, dev, bytes, false) : 0; }
 
 static void free_reads(cf_ctx* c) {
@@ -279,15 +298,7 @@ int cf_load_reads(cf_ctx* ctx, const uint8_t* bases, const int64_t* read_off, in
     // alphabet (never silently 2-bit-encode other symbols): windows that hold anything but
     // upper-case A, C, G, T are skipped by cf_count_kmers (they have no code; the reference counts them as strings of their
     // own — the host keeps that side: cfh_exotic_summary), and cf_build_clouds upper-cases a, c, g, t as the reference does
-    bool exotic = false;
-    {
-        unsigned char bad = 0;
-        for (int64_t i = 0; i < nb; ++i) {
-            const unsigned char c = bases[i];
-            bad |= (unsigned char)!(c == 'A' || c == 'C' || c == 'G' || c == 'T');
-        }
-        exotic = bad != 0;
-    }
+    bool exotic = false;      // (found out by the copy threads below)
     CF_HIP(hipSetDevice(ctx->device));
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     cf_free_edges(ctx);
@@ -297,13 +308,13 @@ int cf_load_reads(cf_ctx* ctx, const uint8_t* bases, const int64_t* read_off, in
     free_reads(ctx);
     ctx->n_reads = n_reads;
     ctx->n_bases = nb;
-    ctx->has_exotic = exotic;
     ctx->h_read_off.assign(read_off, read_off + n_reads + 1);
     CF_TRY(cf_alloc_t(ctx, &ctx->d_bases, (size_t)nb + 64, "bases"));
     CF_TRY(cf_alloc_t(ctx, &ctx->d_read_off, (size_t)n_reads + 1, "read_off"));
     // note: d_bases was allocated with +64 slack; account it under n_bases for release
     ctx->live -= 64;
-    CF_TRY(cf_copy_h2d(ctx, ctx->d_bases, bases, (size_t)nb));
+    CF_TRY(cf_copy_bases(ctx, ctx->d_bases, bases, (size_t)nb, &exotic));
+    ctx->has_exotic = exotic;
     CF_HIP(hipMemcpyAsync(ctx->d_read_off, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     CF_HIP(hipStreamSynchronize(ctx->stream));
     ctx->stats = cf_stats{};

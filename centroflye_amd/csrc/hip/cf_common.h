@@ -121,7 +121,7 @@ struct cf_ctx {
 
     // host <-> device copies of the caller's (pageable) buffers go through pinned staging slots, one per copy thread
     // (cf_api.hip: cf_copy_h2d / cf_copy_d2h)
-    static constexpr int kCopyThreads = 8;
+    static constexpr int kCopyThreads = 16;      // slots; CF_COPY_THREADS (1 .. 16, default 8) picks how many are used
     void* pin_slot[kCopyThreads] = {nullptr};
     hipStream_t pin_stream[kCopyThreads] = {nullptr};
     size_t pin_bytes = 0;
@@ -208,4 +208,5 @@ int cf_scan_exclusive_i64(cf_ctx* ctx, const int64_t* d_in, int64_t* d_out, int6
 int cf_scan_exclusive_u32_to_i64(cf_ctx* ctx, const uint32_t* d_in, int64_t* d_out, int64_t n, int64_t* total);
 // LSD radix sort of 64-bit keys on `bits` low bits; result lands in d_keys (d_tmp is scratch)
 int cf_radix_sort_u64(cf_ctx* ctx, unsigned long long* d_keys, unsigned long long* d_tmp, int64_t n, int bits);
+int cf_radix_sort_u64_any(cf_ctx* ctx, unsigned long long* d_keys, unsigned long long* d_tmp, int64_t n, int bits, unsigned long long** result);
 int cf_radix_sort_rec16(cf_ctx* ctx, void* d_recs, void* d_tmp, int64_t n, const int* words, const int* bits, int n_fields);

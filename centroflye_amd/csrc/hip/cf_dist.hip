@@ -69,6 +69,41 @@ cf_post_fill_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __rest
     }
 }
 
+// Postings by SORT (one GPU, every first k-mer: n_parts == 1).  The postings are the transpose of the cloud CSR; round 2 built them
+// with one device-scope returning atomic per cloud entry (a histogram pass and a fill pass: 12 ms, 40 GB of traffic for 0.45 GB of
+// output).  Here every cloud entry becomes one record [unit : high | rank : low kb bits], the records are radix-sorted on the
+// rank bits (stable: the units of a k-mer stay in ascending order), and the run boundaries give the counts and the first unit.
+__global__ void __launch_bounds__(256)
+cf_post_recs_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ entries, int64_t u0, int64_t u1, int64_t e0, int kb,
+                    unsigned long long* __restrict__ recs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = u0 + wave; u < u1; u += n_waves) {
+        const int64_t a = cloud_ptr[u], b = cloud_ptr[u + 1];
+        for (int64_t e = a + lane; e < b; e += 64) recs[e - e0] = ((unsigned long long)u << kb) | (unsigned long long)(uint32_t)entries[e];
+    }
+}
+// sorted records -> post[] (the units), run starts (rs[x]) / ends (re[x]) of every rank x that occurs, and its first unit
+__global__ void __launch_bounds__(256)
+cf_post_bounds_kernel(const unsigned long long* __restrict__ recs, int64_t n, int kb, int32_t* __restrict__ post, uint32_t* __restrict__ rs,
+                      uint32_t* __restrict__ re, uint32_t* __restrict__ first_unit) {
+    const unsigned long long mask = (1ull << kb) - 1ull;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const unsigned long long r = recs[i];
+        const uint32_t x = (uint32_t)(r & mask), u = (uint32_t)(r >> kb);
+        post[i] = (int32_t)u;
+        if (i == 0 || (uint32_t)(recs[i - 1] & mask) != x) { rs[x] = (uint32_t)i; first_unit[x] = u; }
+        if (i == n - 1 || (uint32_t)(recs[i + 1] & mask) != x) re[x] = (uint32_t)(i + 1);
+    }
+}
+__global__ void __launch_bounds__(256)
+cf_post_counts_kernel(const uint32_t* __restrict__ rs, uint32_t* __restrict__ re_to_cnt, int64_t n_kmers) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n_kmers; x += stride) re_to_cnt[x] = re_to_cnt[x] - rs[x];      // (both 0 for a rank that does not occur)
+}
+
 __global__ void __launch_bounds__(256)
 cf_unit_rend_kernel(const int64_t* __restrict__ unit_ptr, const int64_t* __restrict__ cloud_ptr, int64_t n_reads, int32_t min_d, int32_t max_d,
                     int32_t* __restrict__ rend, int32_t* __restrict__ rbeg, cf_dist_rec* __restrict__ urange) {
@@ -1483,6 +1518,32 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                 hipMemcpy(&tmp[1], v_cloud_ptr + u1, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "cloud_ptr read"); break; }
             e0 = tmp[0]; e1 = tmp[1];
         }
+        const bool by_sort = n_parts == 1 && e1 > e0 && (e1 - e0) < ((int64_t)1 << 32) && U < ((int64_t)1 << 31);
+        if (by_sort) {
+            const int64_t n = e1 - e0;
+            int kb = 1; while (kb < 32 && ((int64_t)1 << kb) < std::max<int64_t>(K, 2)) ++kb;
+            kb = (kb + 7) & ~7;      // whole 8-bit digits: the last radix pass must not reach into the unit bits
+            unsigned long long *d_recs = nullptr, *d_rtmp = nullptr, *d_sorted = nullptr;
+            if ((rc = cf_alloc_t(ctx, &d_recs, (size_t)n + 1, "posting records"))) break;
+            if ((rc = cf_alloc_t(ctx, &d_rtmp, (size_t)n + 1, "posting records (sort)"))) { cf_release_t(ctx, d_recs, (size_t)n + 1); break; }
+            hipLaunchKernelGGL(cf_post_recs_kernel, dim3((unsigned)cf_grid_for((u1 - u0) * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                               v_cloud_ptr, v_entries, u0, u1, e0, kb, d_recs);
+            rc = cf_radix_sort_u64_any(ctx, d_recs, d_rtmp, n, kb, &d_sorted);
+            if (!rc) rc = cf_alloc_t(ctx, &d_post, (size_t)n, "postings");
+            if (!rc) {
+                n_post = n;
+                hipLaunchKernelGGL(cf_post_bounds_kernel, dim3((unsigned)cf_grid_for(n, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                                   (const unsigned long long*)d_sorted, n, kb, d_post, d_cursor, d_pcnt, d_first);      // (d_cursor = run starts, d_pcnt = run ends)
+                hipLaunchKernelGGL(cf_post_counts_kernel, dim3((unsigned)cf_grid_for(K, 256, max_blocks)), dim3(256), 0, ctx->stream, (const uint32_t*)d_cursor, d_pcnt, K);
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = cf_fail(ctx, -5, "postings by sort");
+            }
+            cf_release_t(ctx, d_rtmp, (size_t)n + 1);
+            cf_release_t(ctx, d_recs, (size_t)n + 1);
+            if (rc) break;
+            int64_t n_chk = 0;
+            if ((rc = cf_scan_exclusive_u32_to_i64(ctx, d_pcnt, d_post_ptr, K + 1, &n_chk))) break;
+            if (n_chk != n_post) { rc = cf_fail(ctx, -5, "cf_dist_edges: internal error, posting counts do not add up"); break; }
+        } else {
         if (e1 > e0)
             hipLaunchKernelGGL(cf_post_hist_kernel, dim3((unsigned)cf_grid_for(e1 - e0, 256, max_blocks)), dim3(256), 0, ctx->stream,
                                v_entries, e0, e1, (uint32_t)part, (uint32_t)n_parts, d_pcnt);
@@ -1491,6 +1552,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (u1 > u0 && n_post)
             hipLaunchKernelGGL(cf_post_fill_kernel, dim3((unsigned)cf_grid_for((u1 - u0) * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
                                v_cloud_ptr, v_entries, u0, u1, (uint32_t)part, (uint32_t)n_parts, (const int64_t*)d_post_ptr, d_cursor, d_post, d_first);
+        }
         if (R)
             hipLaunchKernelGGL(cf_unit_rend_kernel, dim3((unsigned)cf_grid_for(R, 256, max_blocks)), dim3(256), 0, ctx->stream,
                                v_unit_ptr, v_cloud_ptr, R, min_d_eff, max_d, d_rend, d_rbeg, d_urange);

@@ -161,6 +161,13 @@ cf_radix_scatter(const unsigned long long* __restrict__ in, unsigned long long* 
 }
 
 int cf_radix_sort_u64(cf_ctx* ctx, unsigned long long* d_keys, unsigned long long* d_tmp, int64_t n, int bits) {
+    return cf_radix_sort_u64_any(ctx, d_keys, d_tmp, n, bits, nullptr);
+}
+
+// the same; with `result` the sorted keys stay in whichever of the two buffers the last pass wrote (no copy back) and
+// *result tells which
+int cf_radix_sort_u64_any(cf_ctx* ctx, unsigned long long* d_keys, unsigned long long* d_tmp, int64_t n, int bits, unsigned long long** result) {
+    if (result) *result = d_keys;
     if (n <= 1) return 0;
     const int ntiles = (int)((n + RS_TILE - 1) / RS_TILE);
     const int64_t nh = (int64_t)ntiles * 256;
@@ -179,7 +186,8 @@ int cf_radix_sort_u64(cf_ctx* ctx, unsigned long long* d_keys, unsigned long lon
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("radix launch: ") + hipGetErrorString(e)); break; }
         std::swap(src, dst);
     }
-    if (rc == 0 && src != d_keys) {
+    if (rc == 0 && result) *result = src;
+    if (rc == 0 && src != d_keys && !result) {
         hipError_t e = hipMemcpyAsync(d_keys, src, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream);
         if (e != hipSuccess) rc = cf_fail(ctx, -5, std::string("radix copy back: ") + hipGetErrorString(e));
     }
