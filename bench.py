@@ -99,6 +99,15 @@ def cpu_baseline(a, pk, engine):
     return out
 
 
+def pmc_traffic(a, world, stored, out):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes — only for the configuration they were taken on."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_dist_kernel.json")
+    if world != 1 or a.reads != 50000 or a.seed != 2 or stored != out["local_edges"] or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("traffic_bytes_per_launch")
+
+
 def committed_parity(out, engine, a, world):
     """The result of this run against profiles/r03_full_parity.json: the 64 / 64 CPU run of the oracle on the same reads
     (tools/full_parity.py), i.e. every pair emission and every selected edge of BASELINE configs[2]."""
@@ -314,8 +323,9 @@ def main():
                        "parallelism": f"reads sharded x{world}, first k-mers partitioned x{world}"},
             "value_incl_transfers": incl,
             "roofline": {"bound": "hbm", "kernel": "cf_dist_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_note": "not measured inside this run; the rocprofv3 --pmc passes of the same command are under profiles/",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a, world, stored, out),
+                         "traffic_note": "HBM-side bytes of ONE launch from the committed rocprofv3 --pmc passes of this configuration (profiles/r03_pmc_dist_kernel.json: "
+                                         "(2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate passes, tools/profile_round.sh); counters cannot be read inside a timed run; null when the workload differs",
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": mean_k_ms,
                          "pair_emissions_per_s": out["local_emissions"] / (mean_k_ms * 1e-3) if mean_k_ms else 0.0,
                          "whole_step_algorithmic_bytes": b_alg,

@@ -3,6 +3,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <thread>
 
 int cf_fail(cf_ctx* ctx, int code, const std::string& msg) {
@@ -14,16 +15,29 @@ int cf_fail(cf_ctx* ctx, int code, const std::string& msg) {
 // record arrays of A1 alone are 128 GB, and giving them back to the driver after every step cost 1.5 s per step).  A
 // hipMalloc that fails flushes the pool and tries again, so a large pool never causes an out-of-memory error by itself.
 
-static void cf_pool_flush(cf_ctx* ctx) {
+// Several contexts may live on one device (session.engine() next to a ShardedRecruiter, tools that open more than one Engine):
+// each keeps freed blocks for reuse, so a hipMalloc that fails flushes the pools of ALL contexts of that device before it gives
+// up (round 2 flushed only the caller's: memory idle in a sibling's pool made the allocation fail).  One process-wide lock
+// guards the registry and every pool operation (calls on ONE context are serialised by the caller; different contexts may be
+// driven from different threads).
+static std::mutex g_pool_lock;
+static std::vector<cf_ctx*> g_contexts;
+
+static void cf_pool_flush_locked(cf_ctx* ctx) {
     for (auto& kv : ctx->pool) { ctx->block_bytes.erase(kv.second); (void)hipFree(kv.second); }
     ctx->pool.clear();
     ctx->pooled = 0;
+}
+static void cf_pool_flush(cf_ctx* ctx) {
+    std::lock_guard<std::mutex> g(g_pool_lock);
+    cf_pool_flush_locked(ctx);
 }
 
 int cf_alloc(cf_ctx* ctx, void** p, size_t bytes, const char* what) {
     *p = nullptr;
     if (bytes == 0) bytes = 16;
     const size_t want = (bytes + 255) & ~(size_t)255;
+    std::lock_guard<std::mutex> g(g_pool_lock);
     // smallest pooled block that fits without wasting more than a quarter
     auto it = ctx->pool.lower_bound(want);
     if (it != ctx->pool.end() && it->first <= want + want / 4 + 4096) {
@@ -34,9 +48,10 @@ int cf_alloc(cf_ctx* ctx, void** p, size_t bytes, const char* what) {
         return 0;
     }
     hipError_t e = hipMalloc(p, want);
-    if (e != hipSuccess || !*p) {          // give the pooled memory back and try once more
+    if (e != hipSuccess || !*p) {          // give the pooled memory of every context of this device back and try once more
         (void)hipGetLastError();
-        cf_pool_flush(ctx);
+        for (cf_ctx* c : g_contexts) if (c->device == ctx->device) cf_pool_flush_locked(c);
+        cf_pool_flush_locked(ctx);
         e = hipMalloc(p, want);
     }
     if (e != hipSuccess || !*p) {
@@ -51,6 +66,7 @@ int cf_alloc(cf_ctx* ctx, void** p, size_t bytes, const char* what) {
 void cf_release(cf_ctx* ctx, void* p, size_t bytes) {
     if (!p) return;
     if (bytes == 0) bytes = 16;
+    std::lock_guard<std::mutex> g(g_pool_lock);
     ctx->live -= bytes < ctx->live ? bytes : ctx->live;
     auto it = ctx->block_bytes.find(p);
     if (it == ctx->block_bytes.end() || ctx->pooled + it->second > ctx->pool_max) {
@@ -217,11 +233,13 @@ int cf_create(int device, cf_ctx** out) {
     CF_HIP(hipEventCreate(&ctx->ev1));
     CF_HIP(hipEventCreate(&ctx->ev2));
     CF_HIP(hipEventCreate(&ctx->ev3));
+    { std::lock_guard<std::mutex> g(g_pool_lock); g_contexts.push_back(ctx); }
     return 0;
 }
 
 void cf_destroy(cf_ctx* ctx) {
     if (!ctx) return;
+    { std::lock_guard<std::mutex> g(g_pool_lock); g_contexts.erase(std::remove(g_contexts.begin(), g_contexts.end(), ctx), g_contexts.end()); }
     (void)hipSetDevice(ctx->device);
     (void)cf_comm_free(ctx);
     cf_free_edges(ctx);

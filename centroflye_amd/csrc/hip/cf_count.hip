@@ -116,9 +116,14 @@ cf_count_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ r
             const int64_t my_n = min((int64_t)tile_w, n_win - w0 - my0);
             if (my_n > 0) {
                 unsigned long long code = 0;
-                for (int j = 0; j < k - 1; ++j) code = (code << 2) | cf_base2(stage[my0 + j]);
+                int run = 0;      // upper-case A, C, G, T in a row, ending at the current base: a window holding anything else has no
+                                  // 2-bit code and is skipped (the reference counts it as a k-mer of its own: cfh_exotic_summary)
+                for (int j = 0; j < k - 1; ++j) { const uint32_t c = stage[my0 + j]; code = (code << 2) | cf_base2(c); run = cf_is_acgt(c) ? run + 1 : 0; }
                 for (int64_t i = 0; i < my_n; ++i) {
-                    code = ((code << 2) | cf_base2(stage[my0 + i + k - 1])) & kmask;
+                    const uint32_t c = stage[my0 + i + k - 1];
+                    code = ((code << 2) | cf_base2(c)) & kmask;
+                    run = cf_is_acgt(c) ? run + 1 : 0;
+                    if (run < k) continue;
                     const uint32_t hh = cf_window_hash(code);
                     if ((int)(((hh >> 16) * ((uint32_t)item.n_cls & 0xFFFFu)) >> 16) != item.cls) continue;   // class of the k-mer (n_cls < 65536)
                     const unsigned long long want = code | CF_OCC;
@@ -193,9 +198,14 @@ cf_occ_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ rea
             const int64_t my_n = min((int64_t)tile_w, n_win - w0 - my0);
             if (my_n > 0) {
                 unsigned long long code = 0;
-                for (int j = 0; j < k - 1; ++j) code = (code << 2) | cf_base2(stage[my0 + j]);
+                int run = 0;      // upper-case A, C, G, T in a row, ending at the current base: a window holding anything else has no
+                                  // 2-bit code and is skipped (the reference counts it as a k-mer of its own: cfh_exotic_summary)
+                for (int j = 0; j < k - 1; ++j) { const uint32_t c = stage[my0 + j]; code = (code << 2) | cf_base2(c); run = cf_is_acgt(c) ? run + 1 : 0; }
                 for (int64_t i = 0; i < my_n; ++i) {
-                    code = ((code << 2) | cf_base2(stage[my0 + i + k - 1])) & kmask;
+                    const uint32_t c = stage[my0 + i + k - 1];
+                    code = ((code << 2) | cf_base2(c)) & kmask;
+                    run = cf_is_acgt(c) ? run + 1 : 0;
+                    if (run < k) continue;
                     const uint32_t hh = cf_window_hash(code);
                     if ((int)(((hh >> 16) * ((uint32_t)item.n_cls & 0xFFFFu)) >> 16) != item.cls) continue;   // class of the k-mer (n_cls < 65536)
                     const unsigned long long want = code | CF_OCC;
@@ -375,9 +385,7 @@ static int count_impl(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, 
         const int rc2 = cf_count_sorted(ctx, k, read_lo, read_hi, n_w, mode);
         if (rc2 <= 0) return rc2;
     }
-    if (ctx->has_exotic)
-        return cf_fail(ctx, -22, mode == 1 ? "cf_count_occurrences: reads with symbols other than upper-case A, C, G, T are not supported"
-                                           : "cf_count_kmers: reads with symbols other than upper-case A, C, G, T need the sort-and-reduce path (2k + bits(reads) <= 62, count_mode 1)");
+    // (the atomic-table path below skips windows with symbols other than upper-case A, C, G, T as well: round 3, ADVICE)
     const int slots = ctx->count_slots;
     int shrink = 0;
     for (int attempt = 0; attempt < 8; ++attempt) {

@@ -1138,7 +1138,18 @@ int32_t cfh_non_acgt(const cfh_pack* p) { return p->non_acgt ? 1 : 0; }
 // The windows the device path skips (reference scripts/distance_based_kmer_recruitment.py:39-63 counts EVERY window of the raw,
 // not upper-cased row as a string): those holding a symbol other than upper-case A, C, G, T.  They are rare (N calls,
 // soft-masked stretches), so a dictionary keyed by the window's text is enough.
+static int exotic_summary_impl(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, int64_t read_lo, int64_t read_hi, int64_t out[5]);
+// (nothing may cross the C ABI: the maps below can throw bad_alloc on a read set full of N)
 int cfh_exotic_summary(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, int64_t read_lo, int64_t read_hi, int64_t out[5]) {
+    try {
+        return exotic_summary_impl(p, k, max_nonuniq, lo, hi, read_lo, read_hi, out);
+    } catch (const std::bad_alloc&) {
+        return -12;
+    } catch (...) {
+        return -5;
+    }
+}
+static int exotic_summary_impl(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, int64_t read_lo, int64_t read_hi, int64_t out[5]) {
     if (!p || !out || k < 1) return -22;
     const int64_t R = (int64_t)p->read_off.size() - 1;
     if (read_lo < 0) read_lo = 0;

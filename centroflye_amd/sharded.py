@@ -72,6 +72,7 @@ class ShardedRecruiter:
         self.engine.close()
 
     def load(self, packed, n_motif=1):
+        self.packed = packed
         self.engine.load(packed, n_motif)
 
     def barrier(self):
@@ -98,6 +99,20 @@ class ShardedRecruiter:
         if self.exchange:
             self.exchange_bytes = E.exchange_table()
             lap("table_exchange")
+        # windows with symbols other than upper-case A, C, G, T are skipped on the device; the reference counts them as k-mers of
+        # their own: if one of them is rare over ALL shards and could reach an output, refuse (as the single-GPU entry point does).
+        # Presence counts of a raw window add up over shards only when its reads sit on one rank, so the test here is the
+        # conservative one: any rank sees a window of that kind that is not already too frequent on its own shard.
+        packed = getattr(self, "packed", None)
+        if packed is not None:
+            blocking = 0
+            if packed.non_acgt:
+                blocking = packed.exotic_summary(k, max_nonuniq, 1, hi)["n_blocking"]
+            if self.exchange:
+                blocking = int(self.allreduce([blocking], "sum")[0])
+            if blocking:
+                raise ValueError(f"{blocking} k-mer window(s) with a symbol other than A, C, G, T (and no lower-case letter) may be rare: "
+                                 "the device path has no code for them; mask or drop those reads")
         E.select_rare(max_nonuniq, lo, hi)
         st_owner = E.stats()
         n_rare = E.allgather_kmers() if self.exchange else st_owner["n_kmers"]
