@@ -18,6 +18,17 @@ extern __shared__ __attribute__((aligned(16))) unsigned char cf_lds[];
 
 #define CF_WAVE 64
 
+// The dynamic LDS window begins at address 0 of the workgroup's LDS (no kernel of this library has static LDS).  A pointer
+// made from that NUMBER lets the compiler fold an array's offset into the offset field of the ds_ instruction; through the
+// symbol cf_lds it puts a `v_add_u32 v, 0, v` in front of every access (the symbol's address is assigned after instruction
+// selection): four of the 48 vector instructions of cf_dist_kernel's sketch step.  cf_lds_base_ok() is the kernel's check
+// of the premise.  (The host emulator of tests/emu defines both itself.)
+#ifndef cf_lds_at
+typedef __attribute__((address_space(3))) unsigned char cf_lds_u8;
+__device__ __forceinline__ unsigned char* cf_lds_at(uint32_t off) { return (unsigned char*)((cf_lds_u8*)(uintptr_t)(off + 16u) - 16); }
+__device__ __forceinline__ bool cf_lds_base_ok() { return (uint32_t)(uintptr_t)(cf_lds_u8*)cf_lds == 0u; }
+#endif
+
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ uint64_t cf_mix64(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdull;

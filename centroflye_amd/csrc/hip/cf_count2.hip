@@ -9,9 +9,9 @@
 //   1. every window becomes ONE 8-byte record [k-mer : 2k | read : RB]                       (no per-read work yet)
 //   2. the records are partitioned by a hash of the k-mer with stable LSD radix passes (<= 9 bits each; the first pass
 //      makes its records straight from the bases), so all records of a k-mer end up in one bucket, in read order
-//   3. one streaming pass reduces every bucket in LDS: a tile of records goes through a (k-mer, read) set, which tells
-//      first and repeated occurrences inside the tile; a per-bucket table keyed by k-mer carries pres, multi and the last
-//      read seen (records of one k-mer arrive in read order), so a read that spans tiles is not counted twice
+//   3. one streaming pass reduces every bucket in LDS: a record looks back along its read's run of the bucket (the sort is
+//      stable, so the records of one read stand together) and is the first, the second or a later occurrence of its k-mer in
+//      that read; first ones add to pres, second ones to multi in a per-bucket table keyed by k-mer
 //   4. the result is a DENSE array of table slots {key | OCC, pres | multi << 32}: every consumer that scans the table
 //      (A2 select, cf_get_table, the multi-GPU bucketing) reads it like a table without holes.
 // All traffic is streamed: N_b x 2 + 8 N_w x 5 + 16 K_dist bytes (~45 GB per Gbase).  Needs 2k + bits(reads) <= 64 and
@@ -30,9 +30,6 @@ void cf_free_table(cf_ctx* c);
 #endif
 #ifndef C2_RTILE
 #define C2_RTILE 2048                       /* records per reduce tile */
-#endif
-#ifndef C2_SET
-#define C2_SET 4096                         /* (k-mer, read) set slots: twice the tile */
 #endif
 #ifndef C2_TAB
 #define C2_TAB 2048                         /* k-mers per bucket table */
@@ -63,32 +60,57 @@ __device__ __forceinline__ cf_c2_rank cf_c2_wave_rank(uint32_t digit, bool valid
     return cf_c2_rank{(uint32_t)__popcll(peers & ((1ull << lane) - 1ull)), (uint32_t)__popcll(peers)};
 }
 
-// windows of a pass-1 tile -> records, 16 consecutive windows per thread (rolled); calls f(j, record, valid) for j < 16
+// windows of a pass-1 tile -> records, 16 consecutive windows per thread (rolled); calls f(j, record, valid) for j < 16.
+// The tile's bases come in as aligned 32-bit words (`a` = the tile's first base's offset in its word, uniform) and are
+// handled four to a word: 2-bit codes ((w >> 1) ^ (w >> 2)) & 0x03030303, folded to one byte per word; the alphabet test
+// is a byte lookup of the code (v_perm_b32 into "ACGT") compared with the word itself.  Round 2 walked the thread's 46 bases
+// one at a time (~50 instructions per window of ~80).
 template <class F>
-__device__ __forceinline__ void cf_c2_tile_records(const uint8_t* __restrict__ bases, const int64_t* __restrict__ read_off, cf_c2_tile tl, int k, int rb,
+__device__ __forceinline__ void cf_c2_tile_records(const uint8_t* __restrict__ bases, int64_t n_bases, const int64_t* __restrict__ read_off, cf_c2_tile tl, int k, int rb,
                                                    uint8_t* stage, F&& f) {
     const int t = threadIdx.x;
     const int64_t r0 = read_off[tl.read], r1 = read_off[tl.read + 1];
     const int64_t n_win = r1 - r0 - k + 1, w0 = (int64_t)tl.chunk * C2_TILE;
     const int64_t nb = min((int64_t)C2_TILE + k - 1, r1 - r0 - w0);
-    for (int64_t i = t; i < nb; i += C2_THREADS) stage[i] = bases[r0 + w0 + i];
+    const int64_t g0 = r0 + w0;
+    const uint32_t a = (uint32_t)(g0 & 3);
+    const int64_t gw = g0 - a;                                 // (the array begins on a word boundary)
+    const int n_dw = (int)((a + nb + 3) >> 2);
+    uint32_t* st32 = (uint32_t*)stage;
+    for (int d = t; d < n_dw; d += C2_THREADS) {
+        uint32_t v = 0;
+        if (gw + 4 * (int64_t)d + 4 <= n_bases) v = *(const uint32_t*)(bases + gw + 4 * (int64_t)d);
+        else for (int q = 0; q < 4; ++q) { const int64_t p = gw + 4 * (int64_t)d + q; if (p < n_bases) v |= (uint32_t)bases[p] << (8 * q); }
+        st32[d] = v;
+    }
     __syncthreads();
     const unsigned long long kmask = (1ull << (2 * k)) - 1ull;
     const int64_t my0 = (int64_t)t * C2_ITEMS;
     const int64_t my_n = min((int64_t)C2_ITEMS, n_win - w0 - my0);
-    // the thread's 16 + k - 1 <= 46 bases: three 16-byte LDS reads (lane stride 16 bytes: conflict free; byte reads at that
-    // stride are 8-way bank conflicts), 2-bit codes packed into 92 bits (first base highest), a window = a 128-bit shift
+    // the thread's 16 + k - 1 <= 46 bases start `a` bytes into the 13 words at my0: three 16-byte LDS reads + one word (lane
+    // stride 16 bytes: conflict free), shifted into place two words at a time
     struct alignas(16) q4 { uint32_t x, y, z, w; };
     const q4 qa = *(const q4*)(stage + my0), qb = *(const q4*)(stage + my0 + 16), qc = *(const q4*)(stage + my0 + 32);
-    const uint32_t w32[12] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w};
-    unsigned long long hi = 0, lo = 0;      // codes of bases 0 .. 13 in hi (28 bits), 14 .. 45 in lo (64 bits)
-    unsigned long long bad = 0;             // bit i: base i is not upper-case A, C, G, T (A1 does not upper-case: reference :47-53)
+    const uint32_t raw[13] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y, qc.z, qc.w, st32[(my0 >> 2) + 12]};
+    uint32_t w32[12], c8[12], diff = 0;
 #pragma unroll
-    for (int i = 0; i < 46; ++i) {
-        const uint32_t ch = (w32[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-        const unsigned long long c = cf_base2(ch);
-        if (i < 14) hi |= c << (2 * (13 - i)); else lo |= c << (2 * (45 - i));
-        bad |= (unsigned long long)!cf_is_acgt(ch) << i;
+    for (int i = 0; i < 12; ++i) {
+        w32[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], a);
+        const uint32_t c = ((w32[i] >> 1) ^ (w32[i] >> 2)) & 0x03030303u;                // codes of the word's four bases, one per byte
+        const uint32_t back = __builtin_amdgcn_perm(0u, 0x54474341u, c);                  // code -> 'A', 'C', 'G', 'T'
+        diff |= (back ^ w32[i]) & (i == 11 ? 0x0000FFFFu : 0xFFFFFFFFu);                  // (bases 46, 47 belong to no window of this thread)
+        c8[i] = ((c << 6) | (c >> 4) | (c >> 14) | (c >> 24)) & 0xFFu;                   // first base highest
+    }
+    const uint32_t W0 = (c8[0] << 24) | (c8[1] << 16) | (c8[2] << 8) | c8[3], W1 = (c8[4] << 24) | (c8[5] << 16) | (c8[6] << 8) | c8[7],
+                   W2 = (c8[8] << 24) | (c8[9] << 16) | (c8[10] << 8) | c8[11];
+    // codes of bases 0 .. 13 in hi (28 bits), 14 .. 45 in lo (64 bits); a window = a 128-bit shift
+    const unsigned long long hi = W0 >> 4, lo = ((((unsigned long long)W1 << 32) | W2) >> 4) | ((unsigned long long)W0 << 60);
+    unsigned long long bad = 0;             // bit i: base i is not upper-case A, C, G, T (A1 does not upper-case: reference :47-53)
+    if (diff) {
+        for (int i = 0; i < 46; ++i) {
+            const uint32_t ch = (w32[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            bad |= (unsigned long long)!cf_is_acgt(ch) << i;
+        }
     }
     const unsigned long long wmask = (1ull << k) - 1ull;
 #pragma unroll
@@ -103,7 +125,7 @@ __device__ __forceinline__ void cf_c2_tile_records(const uint8_t* __restrict__ b
 
 // pass 1, histogram: digit counts of every tile -> hist[digit * n_tiles + tile]
 __global__ void __launch_bounds__(C2_THREADS)
-cf_c2_hist1_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ read_off, const cf_c2_tile* __restrict__ tiles, int n_tiles,
+cf_c2_hist1_kernel(const uint8_t* __restrict__ bases, int64_t n_bases, const int64_t* __restrict__ read_off, const cf_c2_tile* __restrict__ tiles, int n_tiles,
                    int k, int rb, int bits, int shift, int nb, uint32_t* __restrict__ hist) {
     uint32_t* h = (uint32_t*)cf_lds;                          // 1 << nb counters
     uint8_t* stage = cf_lds + ((((size_t)4 << nb) + 15) & ~(size_t)15);
@@ -111,7 +133,7 @@ cf_c2_hist1_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict_
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         for (int d = threadIdx.x; d < (1 << nb); d += C2_THREADS) h[d] = 0;
         __syncthreads();
-        cf_c2_tile_records(bases, read_off, tiles[tile], k, rb, stage, [&](int, unsigned long long rec, bool valid) {
+        cf_c2_tile_records(bases, n_bases, read_off, tiles[tile], k, rb, stage, [&](int, unsigned long long rec, bool valid) {
             if (valid) atomicAdd(&h[(cf_c2_bucket(rec >> rb, bits) >> shift) & mask], 1u);
         });
         __syncthreads();
@@ -140,7 +162,7 @@ __device__ __forceinline__ uint32_t cf_c2_rank_round(uint32_t digit, bool valid,
 }
 // after all rounds: wcount rows -> exclusive prefix over the waves (in place), dstart[d] = first position of digit d in
 // the tile sorted by digit (exclusive scan of the tile's digit counts; 1 << NB <= 2 * C2_THREADS)
-template <int NB>
+template <int NB, int ROWS = C2_THREADS / 64>
 __device__ __forceinline__ void cf_c2_tile_bases(uint32_t* dstart, uint32_t* wcount, uint32_t* scan_tmp) {
     __syncthreads();
     const int t = threadIdx.x;
@@ -150,7 +172,7 @@ __device__ __forceinline__ void cf_c2_tile_bases(uint32_t* dstart, uint32_t* wco
         const int d = 2 * t + h;
         if (d < (1 << NB)) {
             uint32_t s = 0;
-            for (int w = 0; w < C2_THREADS / 64; ++w) { const uint32_t c = wcount[w * (1 << NB) + d]; wcount[w * (1 << NB) + d] = s; s += c; }
+            for (int w = 0; w < ROWS; ++w) { const uint32_t c = wcount[w * (1 << NB) + d]; wcount[w * (1 << NB) + d] = s; s += c; }
             tot[h] = s;
         }
     }
@@ -180,43 +202,46 @@ __device__ __forceinline__ void cf_c2_copy_out(const unsigned long long* stage_r
     }
 }
 
-// pass 1, scatter: offs = exclusive scan of hist
-// LDS of a scatter workgroup: gbase int64[D] | wcount u32[waves][D] | dstart u32[D] | scan_tmp u32[8] | staged records u64[C2_TILE] | (pass 1) bases
+// pass 1, scatter: offs = exclusive scan of hist.  The windows of a tile belong to ONE read, so their order inside the tile
+// is free: a record's rank among the tile's records with its digit is what a returning LDS add hands out (the ballot
+// ranking of the later passes, which keeps the order, costs ~45 instructions per record); the digit is kept next to the
+// staged record for the copy-out.
+// LDS: gbase int64[D] | cnt u32[D] | dstart u32[D] | scan_tmp u32[8] | staged records u64[C2_TILE] | their digits u16[C2_TILE] | bases
 template <int NB>
 __global__ void __launch_bounds__(C2_THREADS)
-cf_c2_scatter1_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ read_off, const cf_c2_tile* __restrict__ tiles, int n_tiles,
+cf_c2_scatter1_kernel(const uint8_t* __restrict__ bases, int64_t n_bases, const int64_t* __restrict__ read_off, const cf_c2_tile* __restrict__ tiles, int n_tiles,
                       int k, int rb, int bits, int shift, const int64_t* __restrict__ offs, unsigned long long* __restrict__ out) {
     constexpr int D = 1 << NB;
     int64_t* gbase = (int64_t*)cf_lds;
-    uint32_t* wcount = (uint32_t*)(gbase + D);
-    uint32_t* dstart = wcount + (C2_THREADS / 64) * D;
+    uint32_t* cnt = (uint32_t*)(gbase + D);
+    uint32_t* dstart = cnt + D;
     uint32_t* scan_tmp = dstart + D;
     unsigned long long* srec = (unsigned long long*)(((uintptr_t)(scan_tmp + 8) + 15) & ~(uintptr_t)15);
-    uint8_t* stage = (uint8_t*)(srec + C2_TILE);
+    uint16_t* sdig = (uint16_t*)(srec + C2_TILE);
+    uint8_t* stage = (uint8_t*)(sdig + C2_TILE);
     const uint32_t mask = D - 1u;
-    const int wave = threadIdx.x >> 6;
-    for (int d = threadIdx.x; d < (C2_THREADS / 64) * D; d += C2_THREADS) wcount[d] = 0;
+    for (int d = threadIdx.x; d < D; d += C2_THREADS) cnt[d] = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         for (int d = threadIdx.x; d < D; d += C2_THREADS) gbase[d] = offs[(int64_t)d * n_tiles + tile];
         unsigned long long rec_[C2_ITEMS];
-        uint32_t rank_[C2_ITEMS];
+        uint32_t rd_[C2_ITEMS];       // rank | digit << 16
         uint32_t ok = 0;
-        // (the windows of a tile belong to ONE read: their order inside the tile is free; thread t takes 16 consecutive ones)
-        cf_c2_tile_records(bases, read_off, tiles[tile], k, rb, stage, [&](int j, unsigned long long rec, bool valid) {
+        cf_c2_tile_records(bases, n_bases, read_off, tiles[tile], k, rb, stage, [&](int j, unsigned long long rec, bool valid) {      // (its barrier orders the zeroed counters)
+            const uint32_t d = (cf_c2_bucket(rec >> rb, bits) >> shift) & mask;
             rec_[j] = rec; ok |= (uint32_t)valid << j;
-            rank_[j] = cf_c2_rank_round<NB>((cf_c2_bucket(rec >> rb, bits) >> shift) & mask, valid, wcount + wave * D);
+            rd_[j] = (valid ? atomicAdd(&cnt[d], 1u) : 0u) | (d << 16);
         });
-        cf_c2_tile_bases<NB>(dstart, wcount, scan_tmp);
-        uint32_t mine = 0;
+        cf_c2_tile_bases<NB, 1>(dstart, cnt, scan_tmp);       // (leaves the counters at 0 for the next tile)
 #pragma unroll
         for (int j = 0; j < C2_ITEMS; ++j)
-            if ((ok >> j) & 1u) { const uint32_t d = (cf_c2_bucket(rec_[j] >> rb, bits) >> shift) & mask; srec[dstart[d] + wcount[wave * D + d] + rank_[j]] = rec_[j]; ++mine; }
+            if ((ok >> j) & 1u) { const uint32_t d = rd_[j] >> 16, at = dstart[d] + (rd_[j] & 0xFFFFu); srec[at] = rec_[j]; sdig[at] = (uint16_t)d; }
         const uint32_t n_tile = scan_tmp[7];      // records of the tile: its windows of plain A, C, G, T
-        (void)mine;
         __syncthreads();
-        cf_c2_copy_out<NB>(srec, n_tile, dstart, gbase, rb, bits, shift, out);
+        for (uint32_t i = threadIdx.x; i < n_tile; i += C2_THREADS) {      // consecutive threads write consecutive addresses inside a digit's run
+            const uint32_t d = sdig[i];
+            out[gbase[d] + (int64_t)(i - dstart[d])] = srec[i];
+        }
         __syncthreads();
-        for (int d = threadIdx.x; d < (C2_THREADS / 64) * D; d += C2_THREADS) wcount[d] = 0;
     }
 }
 
@@ -304,21 +329,29 @@ cf_c2_chunk_starts_kernel(const unsigned long long* __restrict__ recs, int64_t n
 // The dense table is written in chunks a workgroup reserves with one global atomic each (one reservation per bucket
 // cost a round trip of ~2 us per ~4000 records); the part of a chunk it does not fill is zeroed: empty slots, which every
 // consumer of the table skips.
+//
+// What a record adds is decided by LOOKING BACK: the sort is stable, so inside a bucket the records of one read are a
+// contiguous run (a handful of records: a read has 2e4 windows for 2.6e5 buckets), and a record is the first / the second /
+// a later occurrence of its k-mer in its read according to how many equal records stand before it in that run:
+//   first  -> pres of the k-mer + 1;   second -> multi + 1;   later -> nothing.
+// The tile is staged in LDS for that; a run that began in an earlier tile is followed into the record array itself (down to
+// the bucket's first record).  Rounds 1-2 kept a (k-mer, read) hash set per tile and a "last read" word per k-mer instead:
+// a CAS chain, a flag, a clean-up store and an atomicMax per record more than this.  bstart[b] = first record of bucket b
+// (cf_c2_chunk_starts_kernel with one bucket per chunk), so a tile knows its length without hashing its records.
 __global__ void __launch_bounds__(C2_RTHREADS)
 cf_c2_reduce_kernel(const unsigned long long* __restrict__ recs, int64_t n, int rb, int bits, cf_slot* __restrict__ out, unsigned long long out_cap,
-                    unsigned long long chunk, int64_t per, int64_t n_chunks, const int64_t* __restrict__ starts, unsigned long long* __restrict__ counters) {
-    unsigned long long* set = (unsigned long long*)cf_lds;                     // C2_SET x [DUP | k-mer | read]
-    unsigned long long* tkey = set + C2_SET;                                    // C2_TAB x (k-mer + 1); 0 = empty
+                    unsigned long long chunk, int64_t per, int64_t n_chunks, const int64_t* __restrict__ bstart, unsigned long long* __restrict__ counters) {
+    unsigned long long* srec = (unsigned long long*)cf_lds;                    // the tile's records
+    unsigned long long* tkey = srec + C2_RTILE;                                 // C2_TAB x (k-mer + 1); 0 = empty
     uint32_t* tpres = (uint32_t*)(tkey + C2_TAB);
     uint32_t* tmulti = tpres + C2_TAB;
-    uint32_t* tlast = tmulti + C2_TAB;                                          // (read + 1) << 1 | "that read already counted in multi"
-    unsigned long long* sh64 = (unsigned long long*)(tlast + C2_TAB);           // [0] current position [1] next free slot of the chunk [2] end of the chunk
-    uint32_t* sh = (uint32_t*)(sh64 + 3);                                       // [0] records of the tile in the bucket [1] k-mers in the table [2] sum of pres
+    unsigned long long* sh64 = (unsigned long long*)(tmulti + C2_TAB);          // [0] ticket / flush base [1] next free slot of the chunk [2] end of the chunk
+    uint32_t* sh = (uint32_t*)(sh64 + 3);                                       // [1] k-mers in the table
     const int t = threadIdx.x, lane = t & 63;
     const unsigned long long read_mask = (1ull << rb) - 1ull;
     const int64_t n_buckets = (int64_t)1 << bits;
+    constexpr int RJ = C2_RTILE / C2_RTHREADS;
     if (t == 0) { sh64[1] = 0; sh64[2] = 0; }
-    for (int s = t; s < C2_SET; s += C2_RTHREADS) set[s] = 0ull;
     unsigned long long n_dist = 0;      // thread 0: k-mers written by this workgroup
     unsigned long long psum_all = 0;    // sum of pres of the k-mers this thread flushed
 #if defined(CF_C2_STAMPS)
@@ -332,80 +365,72 @@ cf_c2_reduce_kernel(const unsigned long long* __restrict__ recs, int64_t n, int 
     C2_STAMP(0);   // ticket
     if (ck >= n_chunks) break;
     const int64_t b0 = ck * per, b1 = min(n_buckets, b0 + per);
-    int64_t pos = starts[ck];
-    // ld[] holds the records [ld_pos, ld_pos + C2_RTILE): the loads of the NEXT tile are issued as soon as this tile knows
-    // where it ends (right behind its first barrier) and land while its table phase and the bucket's flush run
-    unsigned long long ld[C2_RTILE / C2_RTHREADS];
+    // ld[] holds the records [ld_pos, ld_pos + C2_RTILE): the loads of the NEXT tile (the buckets of a chunk follow one another
+    // in the array) are issued as soon as this tile is staged and land while its table phase and the bucket's flush run
+    unsigned long long ld[RJ];
     int64_t ld_pos = -1;
     for (int64_t b = b0; b < b1; ++b) {
-        for (int s = t; s < C2_TAB; s += C2_RTHREADS) { tkey[s] = 0ull; tpres[s] = 0; tmulti[s] = 0; tlast[s] = 0; }
-        if (t == 0) { sh[1] = 0; sh[2] = 0; }
-        __syncthreads();
+        const int64_t bpos = bstart[b], bend = bstart[b + 1];
+        if (bpos >= bend) continue;      // (uniform) an empty bucket
+        for (int s = t; s < C2_TAB; s += C2_RTHREADS) { tkey[s] = 0ull; tpres[s] = 0; tmulti[s] = 0; }
+        if (t == 0) sh[1] = 0;
         C2_STAMP(1);   // table clear
-        bool more = true;
-        while (more) {
-            // ---- a tile: the next C2_RTILE records, as far as they belong to bucket b (a prefix: the array is sorted by bucket)
-            if (t == 0) sh[0] = 0;
-            __syncthreads();
-            unsigned long long rec[C2_RTILE / C2_RTHREADS];
-            uint32_t own = 0;                 // bit j: this thread created the set slot of its j-th record
-            uint32_t slot[C2_RTILE / C2_RTHREADS];
-            uint32_t mine = 0;
+        for (int64_t pos = bpos; pos < bend; pos += C2_RTILE) {
+            const uint32_t got = (uint32_t)min((int64_t)C2_RTILE, bend - pos);
             if (ld_pos != pos) {
 #pragma unroll
-                for (int j = 0; j < C2_RTILE / C2_RTHREADS; ++j) {      // all loads of the tile in flight before the first is used
+                for (int j = 0; j < RJ; ++j) {      // all loads of the tile in flight before the first is used
                     const int64_t i = pos + (int64_t)j * C2_RTHREADS + t;
                     ld[j] = i < n ? recs[i] : ~0ull;
                 }
-                ld_pos = pos;
             }
-            // (k-mer, read) set: the first record of a pair creates the slot, later ones flag it.  The thread's records probe in
-            // lockstep — every round issues the LDS reads of all unfinished ones, then their CAS — so the dependent LDS round
-            // trips of the probe chains overlap instead of adding up (a wave runs as long as its slowest lane's chain)
-            constexpr int RJ = C2_RTILE / C2_RTHREADS;
-            uint32_t hh[RJ];
-            uint32_t act = 0;
+            unsigned long long rec[RJ];
 #pragma unroll
-            for (int j = 0; j < RJ; ++j) {
-                const int64_t i = pos + (int64_t)j * C2_RTHREADS + t;
-                rec[j] = 0ull; slot[j] = 0; hh[j] = 0;
-                if (i < n && (int64_t)cf_c2_bucket(ld[j] >> rb, bits) == b) { rec[j] = ld[j]; ++mine; act |= 1u << j; hh[j] = cf_c2_hash_set(ld[j]) & (C2_SET - 1); }
-            }
-            while (__any(act != 0u)) {
-                unsigned long long cur[RJ];
-#pragma unroll
-                for (int j = 0; j < RJ; ++j) cur[j] = ((act >> j) & 1u) ? set[hh[j]] : 1ull;
-#pragma unroll
-                for (int j = 0; j < RJ; ++j)          // + 1: record 0 (k-mer AAA.., read 0) is not "empty"; bit 63 stays free (2k + rb <= 62)
-                    if (((act >> j) & 1u) && cur[j] == 0ull) cur[j] = atomicCAS(&set[hh[j]], 0ull, rec[j] + 1ull);     // 0: created; else who was faster
+            for (int j = 0; j < RJ; ++j) { rec[j] = ld[j]; if ((uint32_t)(j * C2_RTHREADS + t) < got) srec[j * C2_RTHREADS + t] = rec[j]; }
+            __syncthreads();            // the tile is staged (and the table clear of a bucket's first tile is done)
+            {
 #pragma unroll
                 for (int j = 0; j < RJ; ++j) {
-                    if (!((act >> j) & 1u)) continue;
-                    if (cur[j] == 0ull) { own |= 1u << j; slot[j] = hh[j]; act &= ~(1u << j); }
-                    else if ((cur[j] & ~C2_DUP) == rec[j] + 1ull) { if (!(cur[j] & C2_DUP)) atomicOr(&set[hh[j]], C2_DUP); act &= ~(1u << j); }
-                    else hh[j] = (hh[j] + 1) & (C2_SET - 1);
-                }
-            }
-            for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, (unsigned)d);
-            if (lane == 0 && mine) atomicAdd(&sh[0], mine);
-            C2_STAMP(2);   // loads + set phase (thread 0's own)
-            __syncthreads();
-            C2_STAMP(3);   // wait for the others
-            const uint32_t got = sh[0];
-            if (got) {          // the next tile (of this bucket or of the next one) starts at pos + got: fetch it now
-#pragma unroll
-                for (int j = 0; j < C2_RTILE / C2_RTHREADS; ++j) {
                     const int64_t i = pos + (int64_t)got + (int64_t)j * C2_RTHREADS + t;
                     ld[j] = i < n ? recs[i] : ~0ull;
                 }
                 ld_pos = pos + (int64_t)got;
             }
-            // ---- the distinct (k-mer, read) pairs of the tile, by their creators: table entry, old "last read", increments
-            uint32_t ent[RJ], packed[RJ], th[RJ];
-            uint32_t tact = own, made = 0;
+            C2_STAMP(2);   // loads + staging
+            // ---- occurrences of the record's k-mer earlier in its read's run: 0, 1 or "2 or more"
+            uint32_t seen[RJ], act = 0;
+            unsigned long long prev[RJ];
 #pragma unroll
-            for (int j = 0; j < RJ; ++j) { ent[j] = 0; packed[j] = 0; th[j] = cf_c2_hash_tab(rec[j] >> rb) & (C2_TAB - 1); }
-            for (int probe = 0; probe < C2_TAB && __any(tact != 0u); ++probe) {      // the k-mer's table entry, probe chains in lockstep as above
+            for (int j = 0; j < RJ; ++j) {          // the step that settles almost every record — the record before it is of another read — for all four at once
+                const uint32_t x = (uint32_t)(j * C2_RTHREADS + t);
+                seen[j] = 0; prev[j] = ~0ull;
+                if (x < got) { act |= 1u << j; if (x > 0u) prev[j] = srec[x - 1u]; else if (pos > bpos) prev[j] = recs[pos - 1]; }
+            }
+            uint32_t deep = 0;
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) {
+                if (!((act >> j) & 1u)) continue;
+                if (prev[j] != ~0ull && ((prev[j] ^ rec[j]) & read_mask) == 0ull) { seen[j] = prev[j] == rec[j] ? 1u : 0u; deep |= 1u << j; }
+            }
+            if (deep) {
+#pragma unroll
+                for (int j = 0; j < RJ; ++j) {
+                    if (!((deep >> j) & 1u)) continue;
+                    for (int64_t y = (int64_t)(j * C2_RTHREADS + t) - 2; pos + y >= bpos && seen[j] < 2u; --y) {
+                        const unsigned long long p = y >= 0 ? srec[y] : recs[pos + y];
+                        if (((p ^ rec[j]) & read_mask) != 0ull) break;      // the run of the read begins here
+                        if (p == rec[j]) ++seen[j];
+                    }
+                }
+            }
+            C2_STAMP(3);   // look back
+            // ---- first and second occurrences: the k-mer's table entry (probe chains of the thread's records in lockstep: their
+            // dependent LDS round trips overlap instead of adding up), then the add
+            uint32_t th[RJ], tact = 0, made = 0;
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) { th[j] = cf_c2_hash_tab(rec[j] >> rb) & (C2_TAB - 1); if (((act >> j) & 1u) && seen[j] < 2u) tact |= 1u << j; }
+            const uint32_t want = tact;
+            for (int probe = 0; probe < C2_TAB && __any(tact != 0u); ++probe) {
                 unsigned long long cur[RJ];
 #pragma unroll
                 for (int j = 0; j < RJ; ++j) cur[j] = ((tact >> j) & 1u) ? tkey[th[j]] : 1ull;
@@ -415,40 +440,19 @@ cf_c2_reduce_kernel(const unsigned long long* __restrict__ recs, int64_t n, int 
 #pragma unroll
                 for (int j = 0; j < RJ; ++j) {
                     if (!((tact >> j) & 1u)) continue;
-                    if (cur[j] == (rec[j] >> rb) + 1ull) { ent[j] = th[j] + 1u; tact &= ~(1u << j); }
+                    if (cur[j] == (rec[j] >> rb) + 1ull) tact &= ~(1u << j);
                     else th[j] = (th[j] + 1) & (C2_TAB - 1);
                 }
             }
             if (tact) atomicOr(&counters[2], 1ull);       // the bucket holds more k-mers than the table: the caller falls back
+#pragma unroll
+            for (int j = 0; j < RJ; ++j)
+                if (((want & ~tact) >> j) & 1u) atomicAdd(seen[j] ? &tmulti[th[j]] : &tpres[th[j]], 1u);
             for (int d = 32; d >= 1; d >>= 1) made += __shfl_down(made, (unsigned)d);
             if (lane == 0 && made) atomicAdd(&sh[1], made);
-#pragma unroll
-            for (int j = 0; j < RJ; ++j) {
-                if (!ent[j]) continue;
-                const uint32_t h = ent[j] - 1u;
-                const bool dup = (set[slot[j]] & C2_DUP) != 0ull;
-                const uint32_t rd1 = (uint32_t)(rec[j] & read_mask) + 1u;
-                const uint32_t last = tlast[h];                 // written only behind the next barrier
-                if ((last >> 1) == rd1) {                       // the read continues from an earlier tile: already in pres
-                    if (!(last & 1u)) atomicAdd(&tmulti[h], 1u);    // ... and now it has its second occurrence
-                    packed[j] = (rd1 << 1) | 1u;
-                } else {
-                    atomicAdd(&tpres[h], 1u);
-                    if (dup) atomicAdd(&tmulti[h], 1u);
-                    packed[j] = (rd1 << 1) | (dup ? 1u : 0u);
-                }
-            }
             C2_STAMP(4);   // table phase
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < C2_RTILE / C2_RTHREADS; ++j) {
-                if (ent[j]) atomicMax(&tlast[ent[j] - 1u], packed[j]);
-                if ((own >> j) & 1u) set[slot[j]] = 0ull;       // leave the set empty for the next tile
-            }
-            pos += got;
-            more = got == C2_RTILE && pos < n;                  // a full tile: the bucket may go on
-            __syncthreads();
-            C2_STAMP(5);   // last-read update, set clean-up
+            __syncthreads();            // the staged tile may be overwritten; (last tile) the table is complete
+            C2_STAMP(5);   // wait for the others
         }
         // ---- bucket done: its k-mers go to the table, into the workgroup's current chunk or a fresh one
         const uint32_t n_k = sh[1];
@@ -460,7 +464,7 @@ cf_c2_reduce_kernel(const unsigned long long* __restrict__ recs, int64_t n, int 
             unsigned long long at = c_free;
             if (fresh) { at = atomicAdd(&counters[0], chunk); sh64[2] = at + chunk; }
             sh64[1] = at + n_k;
-            sh64[0] = at;            // (the position word is free during the flush: base of this bucket)
+            sh64[0] = at;            // (the ticket word is free during the flush: base of this bucket)
             sh[1] = 0;
             n_dist += n_k;
         }
@@ -651,10 +655,12 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
     if (2 * k + rb > 62 || rb > 26) return 1;
     // tiles of pass 1
     std::vector<cf_c2_tile> tiles;
+    int64_t max_win = 0;      // windows of the longest read
     for (int64_t r = read_lo; r < read_hi; ++r) {
         const int64_t len = ctx->h_read_off[(size_t)r + 1] - ctx->h_read_off[(size_t)r];
         if (len < k) continue;
         const int64_t nw = len - k + 1;
+        max_win = std::max(max_win, nw);
         for (int64_t c = 0; c * C2_TILE < nw; ++c) tiles.push_back(cf_c2_tile{(int32_t)r, (int32_t)c});
     }
     if (tiles.size() >= (size_t)1 << 31) return 1;
@@ -668,6 +674,9 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
     if ((bits + C2_MAXBITS - 1) / C2_MAXBITS > passes_min) bits = passes_min * C2_MAXBITS;
     if (ctx->count_bits) bits = ctx->count_bits;
     const int n_pass = (bits + C2_MAXBITS - 1) / C2_MAXBITS;
+    // the reduce looks back along a read's run of records inside a bucket (~ the read's windows >> bits of them): a few very
+    // long sequences in a large input would make those runs thousands long — not reads; the table path takes such input
+    if (!occ && !ctx->count_bits && n_w > ((int64_t)1 << 24) && (max_win >> bits) > 256) return 1;
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     cf_free_table(ctx);
     Bufs2 tmp(ctx);
@@ -696,9 +705,10 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
         CF_TRY(pass.get(&d_offs, (size_t)nh + 1, "count offsets"));
         const int grid = std::min(n_tiles, max_grid);
         const size_t lds_h = ((((size_t)4 << nb) + 15) & ~(size_t)15) + (p == 0 ? C2_TILE + 64 : 0);
-        const size_t lds_s = ((size_t)8 << nb) + (size_t)(C2_THREADS / 64 + 1) * ((size_t)4 << nb) + 32 + 16 + (size_t)C2_TILE * 8 + (p == 0 ? C2_TILE + 64 : 0);
+        const size_t lds_s = p == 0 ? ((size_t)8 << nb) + 2 * ((size_t)4 << nb) + 32 + 16 + (size_t)C2_TILE * (8 + 2) + C2_TILE + 64
+                                    : ((size_t)8 << nb) + (size_t)(C2_THREADS / 64 + 1) * ((size_t)4 << nb) + 32 + 16 + (size_t)C2_TILE * 8;
         if (p == 0)
-            hipLaunchKernelGGL(cf_c2_hist1_kernel, dim3((unsigned)grid), dim3(C2_THREADS), lds_h, ctx->stream, (const uint8_t*)ctx->d_bases,
+            hipLaunchKernelGGL(cf_c2_hist1_kernel, dim3((unsigned)grid), dim3(C2_THREADS), lds_h, ctx->stream, (const uint8_t*)ctx->d_bases, ctx->n_bases,
                                (const int64_t*)ctx->d_read_off, (const cf_c2_tile*)d_tiles, n_tiles, (int)k, rb, bits, shift, nb, d_hist);
         else
             hipLaunchKernelGGL(cf_c2_hist_kernel, dim3((unsigned)grid), dim3(C2_THREADS), lds_h, ctx->stream, (const unsigned long long*)src, n_rec, n_tiles, rb, bits,
@@ -709,7 +719,7 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
         if (p == 0) n_rec = n_made;         // windows holding other symbols than A, C, G, T make no record
         const int rc = launch_nb(nb, [&](auto NB) {
             if (p == 0)
-                hipLaunchKernelGGL((cf_c2_scatter1_kernel<decltype(NB)::value>), dim3((unsigned)grid), dim3(C2_THREADS), lds_s, ctx->stream, (const uint8_t*)ctx->d_bases,
+                hipLaunchKernelGGL((cf_c2_scatter1_kernel<decltype(NB)::value>), dim3((unsigned)grid), dim3(C2_THREADS), lds_s, ctx->stream, (const uint8_t*)ctx->d_bases, ctx->n_bases,
                                    (const int64_t*)ctx->d_read_off, (const cf_c2_tile*)d_tiles, n_tiles, (int)k, rb, bits, shift, (const int64_t*)d_offs, dst);
             else
                 hipLaunchKernelGGL((cf_c2_scatter_kernel<decltype(NB)::value>), dim3((unsigned)grid), dim3(C2_THREADS), lds_s, ctx->stream, (const unsigned long long*)src,
@@ -726,16 +736,18 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
     cf_slot* d_out = (cf_slot*)dst;
     unsigned long long out_cap = (unsigned long long)std::max<int64_t>(n_w, 2) / 2;
     size_t out_bytes = (size_t)std::max<int64_t>(n_w, 2) * 8;
-    const size_t lds_r = (size_t)C2_SET * 8 + (size_t)C2_TAB * (8 + 4 + 4 + 4) + 24 + 16;
+    const size_t lds_r = (size_t)C2_RTILE * 8 + (size_t)C2_TAB * (8 + 4 + 4) + 24 + 16;
     cf_slot* d_exact = nullptr;
     const int64_t n_buckets = (int64_t)1 << bits;
     const int64_t per = std::max<int64_t>(1, n_buckets / ((int64_t)std::max(1, ctx->n_cu) * 64));     // ~16 k chunks
     const int64_t n_chunks = (n_buckets + per - 1) / per;
+    // first record of every chunk (occurrence counts) / of every bucket (presence table: its tiles take their lengths from it)
+    const int64_t per_s = occ ? per : 1, n_starts = occ ? n_chunks : n_buckets;
     int64_t* d_starts = nullptr;
-    CF_TRY(tmp.get(&d_starts, (size_t)n_chunks + 2, "count chunk starts"));
+    CF_TRY(tmp.get(&d_starts, (size_t)n_starts + 2, "count bucket starts"));
     if (n_w > 0) {
-        hipLaunchKernelGGL(cf_c2_chunk_starts_kernel, dim3((unsigned)((n_chunks + 256) / 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)src, n_rec, rb, bits,
-                           per, n_chunks, d_starts);
+        hipLaunchKernelGGL(cf_c2_chunk_starts_kernel, dim3((unsigned)((n_starts + 256) / 256)), dim3(256), 0, ctx->stream, (const unsigned long long*)src, n_rec, rb, bits,
+                           per_s, n_starts, d_starts);
         CF_KERNEL_CHECK("cf_c2_chunk_starts_kernel");
     }
     for (int attempt = 0; attempt < 2 && n_w > 0; ++attempt) {
@@ -752,7 +764,7 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
         CF_HIP(hipMemcpy(h_cnt, d_cnt, 32, hipMemcpyDeviceToHost));
 #if defined(CF_C2_STAMPS)
         { unsigned long long st[8]; if (hipMemcpy(st, d_cnt + 8, 64, hipMemcpyDeviceToHost) == hipSuccess)
-            std::fprintf(stderr, "[cf_c2 stamps] ticket=%llu clear=%llu set=%llu wait=%llu table=%llu last=%llu flush=%llu (shader cycles over %d workgroups)\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], grid); }
+            std::fprintf(stderr, "[cf_c2 stamps] ticket=%llu clear=%llu stage=%llu lookback=%llu table=%llu wait=%llu flush=%llu (shader cycles over %d workgroups)\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], grid); }
 #endif
         if (h_cnt[2] & 1ull) { if (d_exact) cf_release(ctx, d_exact, out_bytes); return 1; }     // a bucket with too many k-mers for the LDS table: table path
         if (h_cnt[0] <= out_cap) break;

@@ -922,9 +922,9 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
     // [table | edge stage | partition stack | insert queues].  The table group is dead while the sketch sweep runs, so its
     // 8-bit counters (sk) lie over ALL of it.  (The item records of the sweeps are in HBM: cf_items_fill_kernel.)
     const int t = threadIdx.x, lane = t & 63, nt = blockDim.x;
-    uint32_t* bm = (uint32_t*)cf_lds;                          // DIST_BM_BITS bits: hash(b) of the k-mers b that may have a selected edge
+    uint32_t* bm = (uint32_t*)cf_lds_at(0u);                          // DIST_BM_BITS bits: hash(b) of the k-mers b that may have a selected edge
     uint32_t* sh = bm + DIST_BM_BITS / 32;                     // [0] keys in table | DIST_FULL_BIT [1] first k-mer [2] sp [3] P [4] idx [5,6] queue ticket [7] E of pass [8] selected [9,10] edge base [11] hot-list cursor [12] items of the first k-mer [13] a counter of the sketch wrapped [14,15] where its item records start
-    unsigned char* lds_tab = cf_lds + DIST_LDS_HEAD;
+    unsigned char* lds_tab = cf_lds_at(DIST_LDS_HEAD);
     Tab T;
     T.init(lds_tab, (uint32_t)A.slots);
     T.configure(A, (uint32_t)A.slots / Tab::kPerBucket);
@@ -980,6 +980,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         if (nx_idx >= 0) nx_head = A.heads[nx_idx];
     }
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), nw = (uint32_t)nt >> 6;
+    if (!cf_lds_base_ok()) { if (t == 0) atomicOr(&A.counters[4], 2ull); return; }      // (cf_common.h: cf_lds_at)
 
     while (true) {
         __syncthreads();
@@ -1709,6 +1710,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                              st[0], st[1], st[6], st[2], st[3], st[4], st[5], st[7], grid, h_cnt[5]);
         }
 #endif
+        if (h_cnt[4] & 2ull) { rc = cf_fail(ctx, -5, "cf_dist_edges: the kernel's dynamic LDS does not begin at address 0"); break; }
         if (h_cnt[4]) { rc = cf_fail(ctx, -34, "cf_dist_edges: (b,d) table could not be partitioned far enough"); break; }
         // close the holes of the chunked edge output: the valid rows at or above n_valid move into the holes below it
         {

@@ -148,6 +148,9 @@ inline unsigned long long __ballot(int pred) {
     return r;
 }
 inline int __any(int pred) { return __ballot(pred) != 0; }
+// (cf_common.h: on the device the LDS window is addressed from the number 0)
+#define cf_lds_at(off) (cf_lds + (off))
+#define cf_lds_base_ok() true
 #define __builtin_amdgcn_fence(order, scope) ((void)0)   /* lanes are fibers on one thread: program order is memory order */
 inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(1); }   // lanes of a wave run in lock step on the GPU: rendezvous here
 inline int __all(int pred) {
@@ -225,6 +228,19 @@ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 // v_mbcnt_lo / v_mbcnt_hi: bits of the mask below this lane, added to `add`
 inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned add) { const unsigned l = cfemu::lane_id(); return add + (unsigned)__builtin_popcount(l >= 32 ? mask : (mask & ((1u << l) - 1u))); }
 inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned add) { const unsigned l = cfemu::lane_id(); return add + (l <= 32 ? 0u : (unsigned)__builtin_popcount(mask & ((1u << (l - 32)) - 1u))); }
+// v_alignbyte_b32: ({hi, lo} >> 8 * (s & 3)), low word;  v_perm_b32: byte i of the result = byte sel.byte[i] of {s0 (bytes 7..4), s1 (bytes 3..0)}
+// (selector values 0 .. 7 only; 12 = 0x00 and 13 .. 15 = 0xFF as the hardware defines them)
+inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned s) { return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (s & 3u))); }
+inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
+    const unsigned long long pool = (((unsigned long long)s0) << 32) | s1;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const unsigned c = (sel >> (8 * i)) & 0xFFu;
+        const unsigned b = c < 8u ? (unsigned)((pool >> (8 * c)) & 0xFFu) : (c == 12u ? 0u : (c >= 13u ? 0xFFu : 0u));
+        r |= b << (8 * i);
+    }
+    return r;
+}
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
