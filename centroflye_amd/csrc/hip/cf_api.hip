@@ -189,8 +189,7 @@ void cf_free_table(cf_ctx* c) {
 }
 void cf_free_kmers(cf_ctx* c) {
     cf_release_t(c, c->d_kmers, (size_t)c->n_kmers);
-    cf_release_t(c, c->d_lut_keys, (size_t)c->lut_cap);
-    cf_release_t(c, c->d_lut_vals, (size_t)c->lut_cap);
+    cf_release_t(c, c->d_lut, (size_t)c->lut_cap);
     cf_release_t(c, c->d_lut_pre, (size_t)c->lut_pre_words);
     cf_release_t(c, c->d_unique_bits, (size_t)c->unique_words);
     c->n_kmers = 0; c->lut_cap = 0; c->lut_pre_words = 0; c->unique_words = 0;

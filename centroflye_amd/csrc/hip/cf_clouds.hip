@@ -18,21 +18,41 @@ void cf_free_gview(cf_ctx* c);
 #define CL_THREADS 256
 #define CL_TILE_W 8
 #define CL_EMPTY 0xFFFFFFFFu
+struct alignas(16) cf_u32x4_cl { uint32_t x, y, z, w; };
 
+// Hashes of the lookup: one 32-bit multiply for the fold and one for each of the two words (cf_mix64 — two 64 x 64
+// multiplies, sixteen quarter-rate 32-bit ones — was a quarter of the cloud kernel's instructions).  h1 picks the slot,
+// h2 the prefilter word (its high bits) and the two bits tested in it (its low 10 bits).
+struct cf_lut_hash { uint32_t h1, h2; };
+__device__ __forceinline__ cf_lut_hash cf_lut_hash_of(unsigned long long code) {
+    const uint32_t lo = (uint32_t)code, hi = (uint32_t)(code >> 32);
+    uint32_t f = lo ^ (hi * 0x85EBCA6Bu) ^ (hi >> 7);
+    f ^= f >> 15;
+    uint32_t h1 = f * 0x9E3779B1u, h2 = (f ^ 0x5BD1E995u) * 0xC2B2AE35u;
+    h1 ^= h1 >> 16; h2 ^= h2 >> 13;
+    return cf_lut_hash{h1, h2};
+}
+// The set holds a small share of all k-mers (1 window in 9 of a HOR read is a rare k-mer): a Bloom word — 8 bits per
+// lookup slot (16 MB for 7.5 M k-mers: Infinity-Cache resident), two bits per k-mer inside ONE 32-bit word, 1.5 % false
+// positives (round 2, one bit: 6 %) — answers most windows without touching the lookup table.
+__device__ __forceinline__ uint64_t cf_lut_pre_word(cf_lut_hash h, uint64_t pre_words_mask) { return ((uint64_t)(h.h2 >> 10) | ((uint64_t)(h.h1 >> 20) << 22)) & pre_words_mask; }
+__device__ __forceinline__ uint32_t cf_lut_pre_bits(uint32_t h2) { return (1u << (h2 & 31u)) | (1u << ((h2 >> 5) & 31u)); }
+
+// One 16-byte slot {k-mer | CF_OCC, rank} per entry: key and rank arrive with ONE random HBM access (round 2 kept the ranks in
+// an array of their own: a second, dependent round trip and as many 64-byte sectors again for every window that is in the set)
 __global__ void __launch_bounds__(256)
-cf_lut_build_kernel(const unsigned long long* __restrict__ kmers, int64_t n, unsigned long long* __restrict__ keys,
-                    uint32_t* __restrict__ vals, uint64_t mask, uint32_t* __restrict__ pre, uint64_t pre_mask, unsigned int* __restrict__ flags) {
+cf_lut_build_kernel(const unsigned long long* __restrict__ kmers, int64_t n, cf_slot* __restrict__ lut, uint64_t mask, uint32_t* __restrict__ pre,
+                    uint64_t pre_words_mask, unsigned int* __restrict__ flags) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const unsigned long long want = kmers[i] | CF_OCC;
-        const uint64_t hm = cf_mix64(kmers[i]);
-        uint64_t h = hm & mask;
-        const uint64_t bit = (hm >> 24) & pre_mask;
-        atomicOr(&pre[bit >> 5], 1u << (bit & 31u));
+        const cf_lut_hash hh = cf_lut_hash_of(kmers[i]);
+        uint64_t h = hh.h1 & mask;
+        atomicOr(&pre[cf_lut_pre_word(hh, pre_words_mask)], cf_lut_pre_bits(hh.h2));
         bool done = false;
         for (uint64_t probe = 0; probe <= mask; ++probe) {
-            const unsigned long long cur = atomicCAS(&keys[h], 0ull, want);
-            if (cur == 0ull) { vals[h] = (uint32_t)i; done = true; break; }
+            const unsigned long long cur = atomicCAS(&lut[h].key, 0ull, want);
+            if (cur == 0ull) { lut[h].val = (unsigned long long)i; done = true; break; }
             if (cur == want) { atomicOr(flags, 2u); done = true; break; }  // duplicate in the set
             h = (h + 1) & mask;
         }
@@ -41,31 +61,12 @@ cf_lut_build_kernel(const unsigned long long* __restrict__ kmers, int64_t n, uns
     }
 }
 
-// The set holds a small share of all k-mers (1 window in 9 of a HOR read is a rare k-mer): a hash bitmap of 8 bits per
-// lookup slot (16 MB for 7.5 M k-mers: L2 / Infinity-Cache resident, 6 % false positives) answers most windows without
-// touching the 200 MB lookup table.
-__device__ __forceinline__ uint32_t cf_lut_find(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                uint64_t mask, const uint32_t* __restrict__ pre, uint64_t pre_mask, unsigned long long code) {
-    const unsigned long long want = code | CF_OCC;
-    const uint64_t hm = cf_mix64(code);
-    const uint64_t bit = (hm >> 24) & pre_mask;
-    if (!((pre[bit >> 5] >> (bit & 31u)) & 1u)) return CL_EMPTY;
-    uint64_t h = hm & mask;
-    for (uint64_t probe = 0; probe <= mask; ++probe) {
-        const unsigned long long cur = keys[h];
-        if (cur == want) return vals[h];
-        if (cur == 0ull) return CL_EMPTY;
-        h = (h + 1) & mask;
-    }
-    return CL_EMPTY;
-}
-
 // mode 0: sizes[u] = |cloud(u)|; mode 1: entries[cloud_ptr[u] ...] = sorted cloud; mode 2 (one pass over the reads instead
 // of two): sizes[u] AND the sorted cloud at entries[u * row_stride ...] of a scratch buffer, compacted afterwards
 __global__ void __launch_bounds__(CL_THREADS)
 cf_cloud_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ unit_start, const int64_t* __restrict__ unit_end,
-                int64_t n_units, int k, int CL_SET /* LDS set slots, power of two */, const unsigned long long* __restrict__ lut_keys, const uint32_t* __restrict__ lut_vals,
-                uint64_t lut_mask, const uint32_t* __restrict__ lut_pre, uint64_t lut_pre_mask, int mode, int64_t row_stride, uint32_t* __restrict__ sizes, const int64_t* __restrict__ cloud_ptr,
+                int64_t n_units, int k, int CL_SET /* LDS set slots, power of two */, const cf_slot* __restrict__ lut,
+                uint64_t lut_mask, const uint32_t* __restrict__ lut_pre, uint64_t lut_pre_mask /* words - 1 */, int mode, int64_t row_stride, uint32_t* __restrict__ sizes, const int64_t* __restrict__ cloud_ptr,
                 int32_t* __restrict__ entries, unsigned int* __restrict__ flags) {
     uint32_t* set = (uint32_t*)cf_lds;                         // CL_SET
     uint32_t* list = set + CL_SET;                             // CL_SET
@@ -112,32 +113,31 @@ cf_cloud_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ u
                         }
                     }
                 }
-                uint64_t hm[CL_TILE_W];
+                cf_lut_hash hh[CL_TILE_W];
                 uint32_t pw[CL_TILE_W];
 #pragma unroll
                 for (int i = 0; i < CL_TILE_W; ++i) {
-                    hm[i] = cf_mix64(codes[i]);
-                    const uint64_t bit = (hm[i] >> 24) & lut_pre_mask;
-                    pw[i] = ((live >> i) & 1u) ? lut_pre[bit >> 5] : 0u;
+                    hh[i] = cf_lut_hash_of(codes[i]);
+                    pw[i] = ((live >> i) & 1u) ? lut_pre[cf_lut_pre_word(hh[i], lut_pre_mask)] : 0u;
                 }
                 uint32_t act = 0;            // windows still walking their probe chain
                 uint64_t hs[CL_TILE_W];
 #pragma unroll
                 for (int i = 0; i < CL_TILE_W; ++i) {
-                    const uint64_t bit = (hm[i] >> 24) & lut_pre_mask;
-                    if ((pw[i] >> (bit & 31u)) & 1u) act |= 1u << i;
-                    hs[i] = hm[i] & lut_mask;
+                    const uint32_t need = cf_lut_pre_bits(hh[i].h2);
+                    if ((pw[i] & need) == need) act |= 1u << i;      // (a window that is not live has pw = 0)
+                    hs[i] = hh[i].h1 & lut_mask;
                 }
                 uint32_t found = 0, idx[CL_TILE_W];
                 for (uint64_t probe = 0; act && probe <= lut_mask; ++probe) {
-                    unsigned long long cur[CL_TILE_W];
+                    cf_slot cur[CL_TILE_W];
 #pragma unroll
-                    for (int i = 0; i < CL_TILE_W; ++i) cur[i] = ((act >> i) & 1u) ? lut_keys[hs[i]] : 0ull;
+                    for (int i = 0; i < CL_TILE_W; ++i) { cur[i].key = 0ull; cur[i].val = 0ull; if ((act >> i) & 1u) cur[i] = lut[hs[i]]; }
 #pragma unroll
                     for (int i = 0; i < CL_TILE_W; ++i) {
                         if (!((act >> i) & 1u)) continue;
-                        if (cur[i] == (codes[i] | CF_OCC)) { idx[i] = lut_vals[hs[i]]; found |= 1u << i; act &= ~(1u << i); }
-                        else if (cur[i] == 0ull) act &= ~(1u << i);
+                        if (cur[i].key == (codes[i] | CF_OCC)) { idx[i] = (uint32_t)cur[i].val; found |= 1u << i; act &= ~(1u << i); }
+                        else if (cur[i].key == 0ull) act &= ~(1u << i);
                         else hs[i] = (hs[i] + 1) & lut_mask;
                     }
                 }
@@ -183,7 +183,25 @@ cf_cloud_kernel(const uint8_t* __restrict__ bases, const int64_t* __restrict__ u
             uint32_t n2 = 1;
             while (n2 < cnt) n2 <<= 1;
             __syncthreads();
-            for (uint32_t s = cnt + t; s < n2; s += CL_THREADS) list[s] = CL_EMPTY;
+            if (cnt <= 2 * CL_THREADS) {
+                // a cloud of a few hundred ranks, all different: an entry's place is the number of smaller ones — the whole list read
+                // once per thread (every lane the same address: a broadcast), two barriers; the bitonic network below takes 36 rounds
+                // with a barrier each for 256 entries (18.0 -> 17.2 ms; walking the list in registers with v_readlane instead: 21.6 ms)
+                for (uint32_t s = cnt + t; s < ((cnt + 3u) & ~3u); s += CL_THREADS) list[s] = CL_EMPTY;
+                __syncthreads();
+                const uint32_t m0 = (uint32_t)t < cnt ? list[t] : CL_EMPTY, m1 = (uint32_t)t + CL_THREADS < cnt ? list[t + CL_THREADS] : CL_EMPTY;
+                uint32_t r0 = 0, r1 = 0;
+                for (uint32_t s = 0; s < cnt; s += 4) {
+                    const cf_u32x4_cl q = *(const cf_u32x4_cl*)(list + s);
+                    r0 += (uint32_t)(q.x < m0) + (uint32_t)(q.y < m0) + (uint32_t)(q.z < m0) + (uint32_t)(q.w < m0);
+                    if (cnt > CL_THREADS) r1 += (uint32_t)(q.x < m1) + (uint32_t)(q.y < m1) + (uint32_t)(q.z < m1) + (uint32_t)(q.w < m1);
+                }
+                __syncthreads();
+                if ((uint32_t)t < cnt) list[r0] = m0;
+                if ((uint32_t)t + CL_THREADS < cnt) list[r1] = m1;
+                n2 = 0;      // (no network)
+            } else
+                for (uint32_t s = cnt + t; s < n2; s += CL_THREADS) list[s] = CL_EMPTY;
             for (uint32_t size = 2; size <= n2; size <<= 1) {
                 for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
                     __syncthreads();
@@ -264,14 +282,14 @@ int cf_install_kmers(cf_ctx* ctx, int32_t k) {
     const int64_t n = ctx->n_kmers;
     ctx->set_k = k;
     ctx->lut_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(2 * n, 1024));
-    CF_TRY(cf_alloc_t(ctx, &ctx->d_lut_keys, (size_t)ctx->lut_cap, "k-mer lookup keys"));
-    CF_TRY(cf_alloc_t(ctx, &ctx->d_lut_vals, (size_t)ctx->lut_cap, "k-mer lookup values"));
+    if (ctx->lut_cap > (1ull << 32)) return cf_fail(ctx, -34, "k-mer set too large for the lookup table's 32-bit hash");
+    CF_TRY(cf_alloc_t(ctx, &ctx->d_lut, (size_t)ctx->lut_cap, "k-mer lookup table"));
     ctx->lut_pre_words = ctx->lut_cap * 8 / 32;
     CF_TRY(cf_alloc_t(ctx, &ctx->d_lut_pre, (size_t)ctx->lut_pre_words, "k-mer lookup prefilter"));
     CF_HIP(hipMemsetAsync(ctx->d_lut_pre, 0, (size_t)ctx->lut_pre_words * 4, ctx->stream));
     ctx->unique_words = (n + 31) / 32 + 1;
     CF_TRY(cf_alloc_t(ctx, &ctx->d_unique_bits, (size_t)ctx->unique_words, "unique bitmap"));
-    CF_HIP(hipMemsetAsync(ctx->d_lut_keys, 0, (size_t)ctx->lut_cap * 8, ctx->stream));
+    CF_HIP(hipMemsetAsync(ctx->d_lut, 0, (size_t)ctx->lut_cap * sizeof(cf_slot), ctx->stream));
     CF_HIP(hipMemsetAsync(ctx->d_unique_bits, 0, (size_t)ctx->unique_words * 4, ctx->stream));
     ctx->stats.n_unique = 0;
     unsigned int* d_flags = nullptr;
@@ -282,7 +300,7 @@ int cf_install_kmers(cf_ctx* ctx, int32_t k) {
     if (e == hipSuccess && n) {
         const int grid = cf_grid_for(n, 256, std::max(1, ctx->n_cu) * 8);
         hipLaunchKernelGGL(cf_lut_build_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const unsigned long long*)ctx->d_kmers,
-                           n, ctx->d_lut_keys, ctx->d_lut_vals, (uint64_t)(ctx->lut_cap - 1), ctx->d_lut_pre, (uint64_t)(ctx->lut_cap * 8 - 1), d_flags);
+                           n, ctx->d_lut, (uint64_t)(ctx->lut_cap - 1), ctx->d_lut_pre, (uint64_t)(ctx->lut_pre_words - 1), d_flags);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&flags, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -372,7 +390,7 @@ static int build_clouds_attempt(cf_ctx* ctx, int set_slots, int64_t* n_entries) 
         if (U) {
             hipLaunchKernelGGL(cf_cloud_kernel, dim3((unsigned)grid), dim3(CL_THREADS), lds, ctx->stream, (const uint8_t*)ctx->d_bases,
                                (const int64_t*)ctx->d_unit_start, (const int64_t*)ctx->d_unit_end, U, ctx->set_k, set_slots,
-                               (const unsigned long long*)ctx->d_lut_keys, (const uint32_t*)ctx->d_lut_vals, (uint64_t)(ctx->lut_cap - 1), (const uint32_t*)ctx->d_lut_pre, (uint64_t)(ctx->lut_cap * 8 - 1),
+                               (const cf_slot*)ctx->d_lut, (uint64_t)(ctx->lut_cap - 1), (const uint32_t*)ctx->d_lut_pre, (uint64_t)(ctx->lut_pre_words - 1),
                                2, row_stride, d_sizes, (const int64_t*)nullptr, d_rows, d_flags);
             e = hipGetLastError();
             if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_cloud_kernel: ") + hipGetErrorString(e)); break; }
@@ -406,7 +424,7 @@ static int build_clouds_attempt(cf_ctx* ctx, int set_slots, int64_t* n_entries) 
 int cf_build_clouds(cf_ctx* ctx, int64_t* n_entries) {
     if (!ctx) return -22;
     if (!ctx->d_unit_ptr) return cf_fail(ctx, -22, "cf_build_clouds: no reads loaded");
-    if (!ctx->d_lut_keys) return cf_fail(ctx, -22, "cf_build_clouds: no k-mer set installed");
+    if (!ctx->d_lut) return cf_fail(ctx, -22, "cf_build_clouds: no k-mer set installed");
     CF_HIP(hipSetDevice(ctx->device));
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     // small LDS set first (16 KiB: many workgroups per CU); clouds of > 1536 k-mers get the 64 KiB set

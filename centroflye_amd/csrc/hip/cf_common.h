@@ -53,7 +53,7 @@ __device__ __forceinline__ bool cf_is_acgt_nocase(uint32_t c) { return cf_is_acg
 #define CF_OCC (1ull << 63)
 
 // 16-byte slot of the HBM k-mer table: key | CF_OCC, then pres (low 32) | multi (high 32)
-struct cf_slot {
+struct alignas(16) cf_slot {
     unsigned long long key;
     unsigned long long val;
 };
@@ -101,10 +101,9 @@ struct cf_ctx {
     unsigned long long* d_kmers = nullptr;
     int64_t n_kmers = 0;
     int set_k = 0;
-    unsigned long long* d_lut_keys = nullptr;
-    uint32_t* d_lut_vals = nullptr;
+    cf_slot* d_lut = nullptr;        // lookup table k-mer -> rank: lut_cap slots {k-mer | CF_OCC, rank}
     uint64_t lut_cap = 0;
-    uint32_t* d_lut_pre = nullptr;   // 8 bits per lookup slot: hash bitmap tested before the lookup table (most windows are not in the set)
+    uint32_t* d_lut_pre = nullptr;   // 8 bits per lookup slot: Bloom words tested before the lookup table (most windows are not in the set)
     uint64_t lut_pre_words = 0;
 
     // clouds

@@ -303,7 +303,7 @@ int cf_exchange_table(cf_ctx* ctx, int64_t* bytes_sent) {
 int cf_allgather_kmers(cf_ctx* ctx, int64_t* n_out) {
     if (!ctx) return -22;
     if (!ctx->comm) return cf_fail(ctx, -22, "cf_allgather_kmers: no communicator (cf_comm_init)");
-    if (!ctx->d_lut_keys) return cf_fail(ctx, -22, "cf_allgather_kmers: no k-mer set selected");
+    if (!ctx->d_lut) return cf_fail(ctx, -22, "cf_allgather_kmers: no k-mer set selected");
     CF_HIP(hipSetDevice(ctx->device));
     Bufs tmp(ctx);
     char* d_all = nullptr;
