@@ -32,7 +32,7 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 #define DIST_HOT_CAP 2048u               /* slots the insert path can hand to the filter per pass (more: the filter scans the table) */
 #define DIST_EDGE_CHUNK 8192ull          /* edge rows a workgroup reserves per global atomic */
 #define DIST_OVQ 96u                     /* per-wave list of inserts whose first probe did not finish (drained with the probe loop at >= 32) */
-#define DIST_LDS_HEAD (DIST_BM_BITS / 8 + 64)   /* bitmap + sh: the fixed head of the kernel's LDS */
+#define DIST_LDS_HEAD (DIST_BM_BITS / 8 + 128)  /* bitmap + sh (32 words): the fixed head of the kernel's LDS */
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
 #define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
 
@@ -975,34 +975,46 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
     long long nx_idx = -1;
     cf_dist_head nx_head{0u, 0u, 0ull, 0u, 0u, 0u, 0u};
     unsigned long long nx_q = 0;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), nw = (uint32_t)nt >> 6;
+    if (!cf_lds_base_ok()) { if (t == 0) atomicOr(&A.counters[4], 2ull); return; }      // (cf_common.h: cf_lds_at)
+    // Barriers.  A first k-mer whose table needs one pass — nearly all — meets the workgroup SEVEN times: [top] the previous
+    // one's edge rows are written, [sketch cleared], [sketch swept], [table cleared], [table swept], [filtered], [rows reserved].
+    // Round 2 and the first half of round 3 had fifteen (the head of the next first k-mer published between two barriers of
+    // its own, the partition stack read between two more at the top of every pass and again to find it empty, a barrier
+    // between reading the number of selected edges and reusing its word): with ~10 steps per wave and sweep the waves arrive
+    // skewed at every one of them, and thread 0's stamps put a third of the kernel into those waits.  Now the next first
+    // k-mer's head goes into words of its own (sh[16..22]) in front of an existing barrier — the last pass's reservation —
+    // and the default pass (one partition) is set up in front of the sketch's barrier.
+    auto publish_next = [&]() {      // thread 0
+        sh[16] = (uint32_t)(unsigned long long)nx_idx; sh[17] = (uint32_t)((unsigned long long)nx_idx >> 32);
+        sh[18] = nx_head.a; sh[19] = nx_head.n_items; sh[20] = (uint32_t)nx_head.ibase; sh[21] = (uint32_t)(nx_head.ibase >> 32);
+        sh[22] = nx_head.n_entries;      // partner entries (sizes the passes when every b is marked)
+    };
+    auto pop_pass = [&]() {          // thread 0: the next partition of the stack becomes the pass
+        const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[7] = 0; sh[8] = 0; sh[11] = 0;
+    };
     if (t == 0) {
         nx_idx = pop_finish(pop_issue());
         if (nx_idx >= 0) nx_head = A.heads[nx_idx];
+        publish_next();
     }
-    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), nw = (uint32_t)nt >> 6;
-    if (!cf_lds_base_ok()) { if (t == 0) atomicOr(&A.counters[4], 2ull); return; }      // (cf_common.h: cf_lds_at)
+    __syncthreads();
 
     while (true) {
-        __syncthreads();
-        if (t == 0) {
-            sh[5] = (uint32_t)(unsigned long long)nx_idx; sh[6] = (uint32_t)((unsigned long long)nx_idx >> 32);
-            sh[1] = nx_head.a; sh[12] = nx_head.n_items; sh[14] = (uint32_t)nx_head.ibase; sh[15] = (uint32_t)(nx_head.ibase >> 32);
-            sh[7] = nx_head.n_entries;      // partner entries (sizes the passes when every b is marked)
-            sh[13] = 0;
-        }
-        __syncthreads();
-        const int64_t ai = (int64_t)(((unsigned long long)sh[6] << 32) | sh[5]);
+        const int64_t ai = (int64_t)(((unsigned long long)sh[17] << 32) | sh[16]);
         if (ai < 0) break;
-        const uint32_t a = sh[1], n_items = sh[12];
+        const uint32_t a = sh[18], n_items = sh[19], n_ent_a = sh[22];
         // this wave's item records: one coalesced load, in flight while the sketch is cleared; both sweeps run on them
         const uint32_t per_w = (n_items + nw - 1u) / nw, mine = wv < n_items ? (n_items - wv + nw - 1u) / nw : 0u;
-        const cf_dist_item* recs = A.items + ((((unsigned long long)sh[15] << 32) | sh[14]) + (unsigned long long)wv * per_w);
+        const cf_dist_item* recs = A.items + ((((unsigned long long)sh[21] << 32) | sh[20]) + (unsigned long long)wv * per_w);
         cf_dist_item my0 = cf_dist_item{0u, 0u};
         if ((uint32_t)lane < min(mine, 64u)) my0 = recs[lane];
         if (t == 0) nx_q = pop_issue();                               // next: the ticket (looked at after phase A)
+        __syncthreads();      // [top] the rows of the previous first k-mer are out of the table, and everyone has this one's head
         CF_STAMP(0);   // queue pop
         if (n_items == 0u) {
-            if (t == 0) { nx_idx = pop_finish(nx_q); if (nx_idx >= 0) nx_head = A.heads[nx_idx]; }
+            if (t == 0) { nx_idx = pop_finish(nx_q); if (nx_idx >= 0) nx_head = A.heads[nx_idx]; publish_next(); }
+            __syncthreads();
             continue;
         }
         CF_STAMP(1);   // prologue
@@ -1016,12 +1028,15 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         // to wrap (255 -> 0) is seen by the add that wraps it: the first k-mer then falls back to "every b marked".
         bool mark_all = !A.sketch;
         const uint32_t min_cov_m1 = A.min_cov - 1u;      // (the sketch runs with min_cov >= 2)
+        // the pass that nearly every first k-mer gets by with: one partition, every marked b in it (set up here, in front of a
+        // barrier that is there anyway; "every b marked" below replaces it)
+        if (t == 0) { sh[13] = 0; sh[2] = 0; sh[3] = 1; sh[4] = 0; sh[0] = 0; sh[7] = 0; sh[8] = 0; sh[11] = 0; }
         if (A.sketch) {
             {
                 const cf_u32x4 z{0u, 0u, 0u, 0u};
                 for (uint32_t s = (uint32_t)t; s < (A.sk_counters >> 4); s += (uint32_t)nt) ((cf_u32x4*)sk)[s] = z;
                 for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = z;
-                __syncthreads();
+                __syncthreads();      // [sketch cleared]
             }
             {
                 cf_dist_sweep<Tab, CF_DIST_PF_A>(A, recs, mine, my0, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
@@ -1060,34 +1075,28 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 });
                 CF_STAMP(6);   // sketch sweep (clear + wave 0's own items)
             }
-            __syncthreads();
+            __syncthreads();      // [sketch swept]
             CF_STAMP(7);      // (stamp 7: thread 0's wait for the other waves at the end of a sweep)
             if (sh[13]) mark_all = true;
         }
-        if (t == 0) { nx_idx = pop_finish(nx_q); if (nx_idx >= 0) nx_head = A.heads[nx_idx]; }      // next: its head (used at the loop top)
+        if (t == 0) { nx_idx = pop_finish(nx_q); if (nx_idx >= 0) nx_head = A.heads[nx_idx]; }      // next: its head (published with the last pass's reservation)
         if (mark_all) {
             const cf_u32x4 ones{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = ones;
-        }
-        __syncthreads();
-        if (t == 0) {
-            // number of partitions of the exact (b, d) table: every pair may need a slot when all b are marked
-            // (upper bound from the emission count); with the bitmap only a fraction does — start with one
-            uint32_t P0 = 1;
-            if (mark_all) while (P0 < 64u && (unsigned long long)sh[7] > (unsigned long long)A.est_limit * P0) P0 <<= 1;
-            for (uint32_t i = 0; i < P0; ++i) { stack[2 * i] = P0; stack[2 * i + 1] = i; }
-            sh[2] = P0;
+            if (t == 0) {
+                // number of partitions of the exact (b, d) table: every pair may need a slot when all b are marked
+                // (upper bound from the emission count); with the bitmap only a fraction does — one, set up above
+                uint32_t P0 = 1;
+                while (P0 < 64u && (unsigned long long)n_ent_a > (unsigned long long)A.est_limit * P0) P0 <<= 1;
+                for (uint32_t i = 0; i < P0; ++i) { stack[2 * i] = P0; stack[2 * i + 1] = i; }
+                sh[2] = P0;
+                pop_pass();
+            }
         }
         bool spilled = false;
+        T.clear(slots, (uint32_t)t, (uint32_t)nt);      // (the sketch is dead: its counters lay over the table)
+        __syncthreads();      // [table cleared] (and, when every b is marked, the bitmap filled and the passes set up)
         while (true) {
-            CF_STAMP(5);   // reserve + write edges of the previous pass
-            __syncthreads();
-            const uint32_t sp_now = sh[2];
-            __syncthreads();  // everyone has read the stack pointer before thread 0 pops
-            if (sp_now == 0) break;
-            if (t == 0) { const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[7] = 0; sh[8] = 0; sh[11] = 0; }
-            T.clear(slots, (uint32_t)t, (uint32_t)nt);
-            __syncthreads();
             const uint32_t P = sh[3], pidx = sh[4], pmask = P - 1u;   // P is a power of two; P == 1: every b belongs to the pass
             uint32_t my_e = 0, s_e = 0;      // partner entries swept by this lane (split passes) / by this wave (whole passes)
             CF_STAMP(2);   // pop partition + clear table
@@ -1208,15 +1217,20 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
 #undef CF_DIST_HOT
                 CF_STAMP(3);   // table sweep + inserts (wave 0's own items)
             }
-            __syncthreads();
+            __syncthreads();      // [table swept]
             CF_STAMP(7);
-            if (sh[0] > A.fill_limit) {  // overflow: split this partition in two
+            if (sh[0] > A.fill_limit) {  // overflow: split this partition in two, go on with one of the halves
+                __syncthreads();      // (everyone has seen the fill level before thread 0 resets it)
                 if (t == 0) {
                     uint32_t sp = sh[2];
-                    if (P >= (1u << 20) || sp + 2 > DIST_STACK) { atomicOr(&A.counters[4], 1ull); }
+                    if (P >= (1u << 20) || sp + 2 > DIST_STACK) { atomicOr(&A.counters[4], 1ull); }      // (the launch fails: -34)
                     else { stack[2 * sp] = 2 * P; stack[2 * sp + 1] = pidx; stack[2 * sp + 2] = 2 * P; stack[2 * sp + 3] = pidx + P; sh[2] = sp + 2; }
+                    if (sh[2]) pop_pass(); else { publish_next(); sh[3] = 0; }      // (nothing left only after that error: on to the next first k-mer)
                 }
                 spilled = true;
+                T.clear(slots, (uint32_t)t, (uint32_t)nt);
+                __syncthreads();
+                if (sh[3] == 0u) break;
                 continue;
             }
             // ---- table of the pass complete: count emissions, filter in LDS (selected slots are marked and
@@ -1307,10 +1321,10 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                         }
                     });
             }
-            __syncthreads();
+            __syncthreads();      // [filtered]
             CF_STAMP(4);   // filter
             const uint32_t n_sel = sh[8];
-            __syncthreads();  // everyone has read the count before thread 0 reuses the word as a cursor
+            const uint32_t sp_left = sh[2];      // partitions still on the stack (thread 0 changes the word only behind the next barrier)
             // Edge rows come from a chunk of the output that the workgroup reserved earlier (DIST_EDGE_CHUNK rows per global atomic;
             // round 2 reserved every pass's rows with its own returning atomic: a round trip to the memory side per first k-mer
             // with the whole workgroup waiting at the barrier below).  A pass that does not fit the rest of the chunk fills it and
@@ -1331,9 +1345,10 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     acc_edges += n_sel;
                     atomicOr(&A.unique_bits[a >> 5], 1u << (a & 31));      // (fire and forget: a load to test the bit first would stall thread 0 in front of the barrier)
                 }
-                sh[8] = 0;
+                sh[13] = 0;                          // cursor of the marked-slot sweep below (the sketch's flag is long read)
+                if (sp_left == 0u) publish_next();   // the last pass: the next first k-mer's head rides on this barrier
             }
-            __syncthreads();
+            __syncthreads();      // [rows reserved]
             if (n_sel) {
                 const unsigned long long base = ((unsigned long long)sh[10] << 32) | sh[9], nbase = ((unsigned long long)sh[15] << 32) | sh[14];
                 const uint32_t in_old = sh[12];      // rows that still fit the old chunk
@@ -1350,9 +1365,15 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     }
                 } else {                               // more selected edges than the stage holds: sweep the marked slots, a bucket per thread
                     for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt)
-                        T.for_marked(bk, [&](uint32_t, uint32_t b, uint32_t dd, uint32_t cnt) { emit(atomicAdd(&sh[8], 1u), b, dd, cnt); });
+                        T.for_marked(bk, [&](uint32_t, uint32_t b, uint32_t dd, uint32_t cnt) { emit(atomicAdd(&sh[13], 1u), b, dd, cnt); });
                 }
             }
+            CF_STAMP(5);   // reserve + write edges
+            if (sp_left == 0u) break;
+            __syncthreads();      // (more partitions) the rows are out of the table before it is cleared for the next one
+            if (t == 0) pop_pass();
+            T.clear(slots, (uint32_t)t, (uint32_t)nt);
+            __syncthreads();
         }
         if (spilled && t == 0) ++acc_spill;
     }
