@@ -46,6 +46,7 @@ struct cf_place_state {
     const int64_t* cloud_ptr;
     const int32_t* entries;
     const int32_t* unit2read;
+    const int32_t* entry_unit;      // unit of every cloud entry (the fused iteration kernel walks a read's entries, not its units)
     // contig map
     unsigned long long* ckeys; uint32_t* ccnt; uint64_t cmask;
     uint8_t* freq_flag;
@@ -75,8 +76,7 @@ __device__ __forceinline__ void cf_contig_add(const cf_place_state& S, uint32_t 
     const unsigned long long want = (((unsigned long long)q << 32) | x) | CF_OCC;
     uint64_t h = cf_mix64(want) & S.cmask;
     for (uint64_t probe = 0; probe <= S.cmask; ++probe) {
-        unsigned long long cur = S.ckeys[h];
-        if (cur == 0ull) cur = atomicCAS(&S.ckeys[h], 0ull, want);
+        const unsigned long long cur = atomicCAS(&S.ckeys[h], 0ull, want);      // (the claim IS the look: one round trip, not load + claim)
         if (cur == 0ull || cur == want) {
             const uint32_t c = atomicAdd(&S.ccnt[h], 1u) + 1u;
             if (c == S.thr) {
@@ -96,8 +96,7 @@ __device__ __forceinline__ bool cf_contig_add_hit(const cf_place_state& S, uint3
     const unsigned long long want = (((unsigned long long)q << 32) | x) | CF_OCC;
     uint64_t h = cf_mix64(want) & S.cmask;
     for (uint64_t probe = 0; probe <= S.cmask; ++probe) {
-        unsigned long long cur = S.ckeys[h];
-        if (cur == 0ull) cur = atomicCAS(&S.ckeys[h], 0ull, want);
+        const unsigned long long cur = atomicCAS(&S.ckeys[h], 0ull, want);
         if (cur == 0ull || cur == want) {
             const uint32_t c = atomicAdd(&S.ccnt[h], 1u) + 1u;
             if (c == S.thr) { S.freq_flag[x] = 1; return true; }
@@ -148,11 +147,8 @@ __device__ __forceinline__ void cf_score_hit(const cf_place_state& S, uint32_t r
     uint64_t h = cf_mix64(want) & S.smask;
     bool ok = false;
     for (uint64_t probe = 0; probe <= S.smask && probe < 4096; ++probe) {   // a long probe = table too full: grow and restart
-        unsigned long long cur = S.skeys[h];
-        if (cur == 0ull) {
-            cur = atomicCAS(&S.skeys[h], 0ull, want);
-            if (cur == 0ull && atomicAdd(&S.ctl[4], 1u) > (unsigned int)(S.smask >> 1)) atomicOr(&S.ctl[2], 2u);   // load > 0.5
-        }
+        const unsigned long long cur = atomicCAS(&S.skeys[h], 0ull, want);
+        if (cur == 0ull && atomicAdd(&S.ctl[4], 1u) > (unsigned int)(S.smask >> 1)) atomicOr(&S.ctl[2], 2u);   // load > 0.5
         if (cur == 0ull || cur == want) { ok = true; break; }
         h = (h + 1) & S.smask;
     }
@@ -162,8 +158,8 @@ __device__ __forceinline__ void cf_score_hit(const cf_place_state& S, uint32_t r
     uint64_t hs = cf_mix64(sk) & S.seen_mask;
     bool fresh = false, placed = false;
     for (uint64_t probe = 0; probe <= S.seen_mask && probe < 4096; ++probe) {
-        unsigned long long cur = S.seen[hs];
-        if (cur == 0ull) { cur = atomicCAS(&S.seen[hs], 0ull, sk); if (cur == 0ull) { fresh = true; placed = true; break; } }
+        const unsigned long long cur = atomicCAS(&S.seen[hs], 0ull, sk);
+        if (cur == 0ull) { fresh = true; placed = true; break; }
         if (cur == sk) { placed = true; break; }
         hs = (hs + 1) & S.seen_mask;
     }
@@ -260,9 +256,8 @@ cf_place_argmax_kernel(cf_place_state S) {
     if (S.ctl[0]) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) S.n_events[0] = 0ull;   // consumed by the update kernel before this one; refilled by the next
     uint32_t* rescan = (uint32_t*)(cf_lds + 16 * sizeof(cf_cand));
-    if (threadIdx.x == 0) {
-        const cf_cand c = S.block_best[blockIdx.x];
-        const bool r = S.dirty[blockIdx.x] || (c.valid && S.used[c.read]);
+    if (threadIdx.x == 0) {      // (a slice whose cached candidate is the read just placed was marked by the kernel that placed it)
+        const bool r = S.dirty[blockIdx.x] != 0;
         if (r) S.dirty[blockIdx.x] = 0;
         *rescan = r ? 1u : 0u;
     }
@@ -318,6 +313,8 @@ cf_place_pick_add_kernel(cf_place_state S, int n_cand) {
         }
     }
     if (!b.valid) return;
+    if (blockIdx.x == gridDim.x - 1)      // (see cf_place_pick_add_update_kernel)
+        for (int i = threadIdx.x; i < n_cand; i += blockDim.x) { const cf_cand c = S.block_best[i]; if (c.valid && c.read == b.read) S.dirty[i] = 1; }
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -350,6 +347,10 @@ cf_place_pick_add_update_kernel(cf_place_state S, int n_cand, int PL_CHUNK) {
         }
     }
     if (!b.valid) return;
+    // the slices whose cached candidate names the read placed now have to be scanned again (the arg-max kernel used to find
+    // that out itself: its cached candidate, then used[] of that read — two dependent loads at the head of every block)
+    if (blockIdx.x == gridDim.x - 1)
+        for (int i = threadIdx.x; i < n_cand; i += blockDim.x) { const cf_cand c = S.block_best[i]; if (c.valid && c.read == b.read) S.dirty[i] = 1; }
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -362,10 +363,8 @@ cf_place_pick_add_update_kernel(cf_place_state S, int n_cand, int PL_CHUNK) {
         uint32_t x = 0, q = 0;
         bool hit = false;
         if (act) {
-            int64_t lo = u0, hi = u1 - 1;          // the unit of entry e: the last u with cloud_ptr[u] <= e (a ballot over the unit starts held by the lanes instead of this search changed nothing)
-            while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (S.cloud_ptr[mid] <= e) lo = mid; else hi = mid - 1; }
             x = (uint32_t)S.entries[e];
-            q = b.off + (uint32_t)(lo - u0);
+            q = b.off + (uint32_t)((int64_t)S.entry_unit[e] - u0);      // (a table instead of a binary search over cloud_ptr: four dependent loads less in every wave's chain)
             hit = cf_contig_add_hit(S, x, q);
         }
         unsigned long long m = __ballot(hit);
@@ -391,6 +390,14 @@ cf_place_pick_add_update_kernel(cf_place_state S, int n_cand, int PL_CHUNK) {
 // kernels below at 50 000 reads (two agent-scope barriers under load cost more than three dependent launches whose
 // grids fit their work), and entries updated by other XCDs' atomics were read stale through this XCD's L2 by the plain
 // loads of the scan.  Removed; the kernel boundary is the cheapest correct grid-wide barrier this loop has.)
+
+__global__ void __launch_bounds__(256)
+cf_entry2unit_kernel(const int64_t* __restrict__ cloud_ptr, int64_t n_units, int32_t* __restrict__ e2u) {      // one wave per unit
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = wave; u < n_units; u += n_waves)
+        for (int64_t e = cloud_ptr[u] + lane; e < cloud_ptr[u + 1]; e += 64) e2u[e] = (int32_t)u;
+}
 
 __global__ void __launch_bounds__(256)
 cf_unit2read_kernel(const int64_t* __restrict__ unit_ptr, int64_t n_reads, int32_t* __restrict__ u2r) {
@@ -445,13 +452,14 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     S.unit_ptr = ctx->d_unit_ptr; S.cloud_ptr = ctx->d_cloud_ptr; S.entries = ctx->d_entries;
     S.thr = (uint32_t)std::max(1, min_freq); S.min_unit = (uint32_t)std::max(0, min_unit);
     S.min_inters = (uint32_t)std::max(0, min_inters); S.min_prop = (uint32_t)std::max(0, min_prop);
-    int32_t *d_u2r = nullptr, *d_rank = nullptr;
+    int32_t *d_u2r = nullptr, *d_rank = nullptr, *d_e2u = nullptr;
     unsigned long long* d_post = nullptr;
     uint8_t *d_cls = nullptr, *d_used = nullptr;
     uint32_t* d_pcnt = nullptr;
     int64_t* d_post_ptr = nullptr;
     const uint64_t ccap = cf_pow2_ceil((uint64_t)std::max<int64_t>(2 * N, 1024));
     CF_TRY(B.get(&d_u2r, (size_t)U + 1, "unit2read"));
+    CF_TRY(B.get(&d_e2u, (size_t)N + 1, "entry2unit"));
     CF_TRY(B.get(&d_cls, (size_t)R + 1, "classes"));
     CF_TRY(B.get(&d_used, (size_t)R + 1, "used flags"));
     CF_TRY(B.get(&d_rank, (size_t)R + 1, "id ranks"));
@@ -481,7 +489,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     CF_TRY(B.get(&S.out_pos, (size_t)R + 1, "out_pos"));
     CF_TRY(B.get(&S.out_s0, (size_t)R + 1, "out_s0"));
     CF_TRY(B.get(&S.out_s1, (size_t)R + 1, "out_s1"));
-    S.unit2read = d_u2r; S.cmask = ccap - 1; S.smask = score_cap - 1; S.seen_mask = seen_cap - 1;
+    S.unit2read = d_u2r; S.entry_unit = d_e2u; S.cmask = ccap - 1; S.smask = score_cap - 1; S.seen_mask = seen_cap - 1;
     S.used = d_used; S.id_rank = d_rank; S.post_ptr = d_post_ptr; S.post_ri = d_post;
     hipStream_t st = ctx->stream;
     CF_HIP(hipMemcpyAsync(d_cls, cls, (size_t)R, hipMemcpyHostToDevice, st));
@@ -493,6 +501,7 @@ static int place_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank
     CF_HIP(hipMemsetAsync(S.n_events, 0, 16, st));
     CF_HIP(hipMemsetAsync(S.ctl, 0, 32, st));
     const int g_units = cf_grid_for(std::max<int64_t>(U, 1) * 64, 256, n_blocks);
+    if (U) hipLaunchKernelGGL(cf_entry2unit_kernel, dim3((unsigned)g_units), dim3(256), 0, st, (const int64_t*)ctx->d_cloud_ptr, U, d_e2u);
     if (R) hipLaunchKernelGGL(cf_unit2read_kernel, dim3((unsigned)cf_grid_for(R, 256, n_blocks)), dim3(256), 0, st, (const int64_t*)ctx->d_unit_ptr, R, d_u2r);
     // prefix reads at position 0, in record order (reference read_placer.py:35-40)
     o_read.clear(); o_pos.clear(); o_s0.clear(); o_s1.clear();
