@@ -123,7 +123,9 @@ __device__ __forceinline__ void cf_c2_tile_records(const uint8_t* __restrict__ b
     }
 }
 
-// pass 1, histogram: digit counts of every tile -> hist[digit * n_tiles + tile]
+// pass 1, histogram: digit counts of every tile -> hist[tile * D + digit] (tile-major: a tile writes and reads ONE run of D
+// counters; digit-major — round 2 — made every counter its own 64-byte sector on the way out and on the way back in: 20 GB of
+// the stage's 91 GB of HBM traffic)
 __global__ void __launch_bounds__(C2_THREADS)
 cf_c2_hist1_kernel(const uint8_t* __restrict__ bases, int64_t n_bases, const int64_t* __restrict__ read_off, const cf_c2_tile* __restrict__ tiles, int n_tiles,
                    int k, int rb, int bits, int shift, int nb, uint32_t* __restrict__ hist) {
@@ -137,7 +139,7 @@ cf_c2_hist1_kernel(const uint8_t* __restrict__ bases, int64_t n_bases, const int
             if (valid) atomicAdd(&h[(cf_c2_bucket(rec >> rb, bits) >> shift) & mask], 1u);
         });
         __syncthreads();
-        for (int d = threadIdx.x; d < (1 << nb); d += C2_THREADS) hist[(int64_t)d * n_tiles + tile] = h[d];
+        for (int d = threadIdx.x; d < (1 << nb); d += C2_THREADS) hist[((int64_t)tile << nb) + d] = h[d];
         __syncthreads();
     }
 }
@@ -202,7 +204,7 @@ __device__ __forceinline__ void cf_c2_copy_out(const unsigned long long* stage_r
     }
 }
 
-// pass 1, scatter: offs = exclusive scan of hist.  The windows of a tile belong to ONE read, so their order inside the tile
+// pass 1, scatter: offs = exclusive scan of hist in (digit, tile) order (cf_c2_col* below).  The windows of a tile belong to ONE read, so their order inside the tile
 // is free: a record's rank among the tile's records with its digit is what a returning LDS add hands out (the ballot
 // ranking of the later passes, which keeps the order, costs ~45 instructions per record); the digit is kept next to the
 // staged record for the copy-out.
@@ -222,7 +224,7 @@ cf_c2_scatter1_kernel(const uint8_t* __restrict__ bases, int64_t n_bases, const 
     const uint32_t mask = D - 1u;
     for (int d = threadIdx.x; d < D; d += C2_THREADS) cnt[d] = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        for (int d = threadIdx.x; d < D; d += C2_THREADS) gbase[d] = offs[(int64_t)d * n_tiles + tile];
+        for (int d = threadIdx.x; d < D; d += C2_THREADS) gbase[d] = offs[(int64_t)tile * D + d];
         unsigned long long rec_[C2_ITEMS];
         uint32_t rd_[C2_ITEMS];       // rank | digit << 16
         uint32_t ok = 0;
@@ -260,7 +262,7 @@ cf_c2_hist_kernel(const unsigned long long* __restrict__ in, int64_t n, int n_ti
             if (i < n) atomicAdd(&h[(cf_c2_bucket(in[i] >> rb, bits) >> shift) & mask], 1u);
         }
         __syncthreads();
-        for (int d = threadIdx.x; d < (1 << nb); d += C2_THREADS) hist[(int64_t)d * n_tiles + tile] = h[d];
+        for (int d = threadIdx.x; d < (1 << nb); d += C2_THREADS) hist[((int64_t)tile << nb) + d] = h[d];
         __syncthreads();
     }
 }
@@ -280,7 +282,7 @@ cf_c2_scatter_kernel(const unsigned long long* __restrict__ in, int64_t n, int n
     for (int d = threadIdx.x; d < (C2_THREADS / 64) * D; d += C2_THREADS) wcount[d] = 0;
     __syncthreads();
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        for (int d = threadIdx.x; d < D; d += C2_THREADS) gbase[d] = offs[(int64_t)d * n_tiles + tile];
+        for (int d = threadIdx.x; d < D; d += C2_THREADS) gbase[d] = offs[(int64_t)tile * D + d];
         // wave w takes the records [w * 64 * C2_ITEMS, ...) of the tile in rounds of 64: array order = (wave, round, lane)
         const int64_t base = (int64_t)tile * C2_TILE + (int64_t)wave * 64 * C2_ITEMS + lane;
         unsigned long long rec_[C2_ITEMS];
@@ -299,6 +301,72 @@ cf_c2_scatter_kernel(const unsigned long long* __restrict__ in, int64_t n, int n
         cf_c2_copy_out<NB>(srec, n_tile, dstart, gbase, rb, bits, shift, out);
         __syncthreads();
         for (int d = threadIdx.x; d < (C2_THREADS / 64) * D; d += C2_THREADS) wcount[d] = 0;
+    }
+}
+
+// ---- offsets of a pass: offs[tile][d] = records with a smaller digit + records of digit d in earlier tiles = the exclusive scan
+// of hist in (digit, tile) order, computed on the tile-major arrays by columns: (1) column sums of chunks of C2_SCAN_CHUNK
+// tiles, (2) one workgroup turns them into the chunks' bases (column totals, scan over the digits, running sums down the
+// chunks), (3) every chunk walks its tiles again.  All accesses are runs of D counters; the loads of a walk do not depend on
+// its running sum and are issued eight at a time.
+#define C2_SCAN_CHUNK 512
+#define C2_SCAN_THREADS 512                 /* >= 1 << C2_MAXBITS: a thread per digit */
+__global__ void __launch_bounds__(C2_SCAN_THREADS)
+cf_c2_colsum_kernel(const uint32_t* __restrict__ hist, int n_tiles, int D, uint32_t* __restrict__ part) {
+    const int d = threadIdx.x;
+    if (d >= D) return;
+    const int t0 = blockIdx.x * C2_SCAN_CHUNK, t1 = min(n_tiles, t0 + C2_SCAN_CHUNK);
+    uint32_t acc = 0;
+    for (int t = t0; t < t1; t += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = t + u < t1 ? hist[(int64_t)(t + u) * D + d] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    part[(int64_t)blockIdx.x * D + d] = acc;
+}
+__global__ void __launch_bounds__(C2_SCAN_THREADS)
+cf_c2_colbase_kernel(const uint32_t* __restrict__ part, int n_chunks, int D, int64_t* __restrict__ base, int64_t* __restrict__ total_out) {
+    long long* sh = (long long*)cf_lds;                       // C2_SCAN_THREADS / 64 wave totals
+    const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
+    long long tot = 0;
+    if (d < D)
+        for (int c = 0; c < n_chunks; c += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = c + u < n_chunks ? part[(int64_t)(c + u) * D + d] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tot += v[u];
+        }
+    long long inc = tot;                                       // inclusive scan over the digits
+    for (int s = 1; s < 64; s <<= 1) { const long long o = __shfl_up(inc, (unsigned)s); if (lane >= s) inc += o; }
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    long long run = inc - tot;
+    for (int w = 0; w < wave; ++w) run += sh[w];
+    if (d == D - 1) *total_out = run + tot;
+    if (d < D)
+        for (int c = 0; c < n_chunks; c += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = c + u < n_chunks ? part[(int64_t)(c + u) * D + d] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (c + u < n_chunks) { base[(int64_t)(c + u) * D + d] = run; run += v[u]; }
+        }
+}
+__global__ void __launch_bounds__(C2_SCAN_THREADS)
+cf_c2_coloffs_kernel(const uint32_t* __restrict__ hist, int n_tiles, int D, const int64_t* __restrict__ base, int64_t* __restrict__ offs) {
+    const int d = threadIdx.x;
+    if (d >= D) return;
+    const int t0 = blockIdx.x * C2_SCAN_CHUNK, t1 = min(n_tiles, t0 + C2_SCAN_CHUNK);
+    long long run = base[(int64_t)blockIdx.x * D + d];
+    for (int t = t0; t < t1; t += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = t + u < t1 ? hist[(int64_t)(t + u) * D + d] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (t + u < t1) { offs[(int64_t)(t + u) * D + d] = run; run += v[u]; }
     }
 }
 
@@ -715,7 +783,20 @@ int cf_count_sorted(cf_ctx* ctx, int32_t k, int64_t read_lo, int64_t read_hi, in
                                shift, nb, d_hist);
         CF_KERNEL_CHECK("cf_c2_hist");
         int64_t n_made = 0;
-        CF_TRY(cf_scan_exclusive_u32_to_i64(ctx, d_hist, d_offs, nh, &n_made));
+        {
+            const int D = 1 << nb, n_chunks = (n_tiles + C2_SCAN_CHUNK - 1) / C2_SCAN_CHUNK;
+            uint32_t* d_part = nullptr;
+            int64_t* d_base = nullptr;
+            CF_TRY(pass.get(&d_part, (size_t)n_chunks * D + 1, "count column sums"));
+            CF_TRY(pass.get(&d_base, (size_t)n_chunks * D + 2, "count column bases"));
+            int64_t* d_total = d_base + (size_t)n_chunks * D;
+            hipLaunchKernelGGL(cf_c2_colsum_kernel, dim3((unsigned)n_chunks), dim3(C2_SCAN_THREADS), 0, ctx->stream, (const uint32_t*)d_hist, n_tiles, D, d_part);
+            hipLaunchKernelGGL(cf_c2_colbase_kernel, dim3(1), dim3(C2_SCAN_THREADS), 64, ctx->stream, (const uint32_t*)d_part, n_chunks, D, d_base, d_total);
+            hipLaunchKernelGGL(cf_c2_coloffs_kernel, dim3((unsigned)n_chunks), dim3(C2_SCAN_THREADS), 0, ctx->stream, (const uint32_t*)d_hist, n_tiles, D, (const int64_t*)d_base, d_offs);
+            CF_KERNEL_CHECK("cf_c2_col*");
+            CF_HIP(hipMemcpyAsync(&n_made, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+            CF_HIP(hipStreamSynchronize(ctx->stream));
+        }
         if (p == 0) n_rec = n_made;         // windows holding other symbols than A, C, G, T make no record
         const int rc = launch_nb(nb, [&](auto NB) {
             if (p == 0)
