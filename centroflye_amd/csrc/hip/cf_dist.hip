@@ -1355,6 +1355,9 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 auto emit = [&](uint32_t i, uint32_t b, uint32_t dd, uint32_t cnt) {
                     const unsigned long long o = i < in_old ? base + i : nbase + (i - in_old);
                     if (o < A.edge_cap) *(cf_u32x4*)(A.edges + 4 * o) = cf_u32x4{dd, a, b, cnt};
+                    // (the load in front of the atomic is a round trip at the end of every first k-mer, 2.2 % of the kernel; a 1024-entry LDS
+                    // cache of the b whose bit this workgroup has set, with fire-and-forget atomics on a miss, gave it back in LDS
+                    // room for the table and in atomics: 331.7 vs 330.8 ms)
                     const uint32_t bit = 1u << (b & 31);
                     if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
                 };
@@ -1653,7 +1656,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         const size_t lds = (size_t)A.slots * slot_bytes + lds_fixed;
         A.sketch = (ctx->dist_sketch && min_cov >= 2 && min_cov <= 200) ? 1 : 0;
         A.sk_shift = 32; A.sk_counters = 1;
-        const size_t sk_room = (size_t)A.slots * slot_bytes + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QCAP + DIST_OVQ) * qitem_bytes + 2 * DIST_STACK * 4;   // table + stage + queues + stack
+        const size_t sk_room = (size_t)A.slots * slot_bytes + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QCAP + DIST_OVQ) * qitem_bytes + 2 * DIST_STACK * 4 + DIST_HOT_CAP * 2;   // table + stage + stack + queues + hot list: all dead while the sketch runs
         while (A.sk_shift > 8 && (size_t)A.sk_counters * 2 <= sk_room) { A.sk_counters *= 2; --A.sk_shift; }
         if (A.sk_counters < 16) A.sketch = 0;
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / block));
