@@ -2,8 +2,8 @@
 # Larger single-GPU workloads (same generator, coverage 32): 200 000 and 400 000 reads per GPU.
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-for n in 400000; do
-  timeout 900 python bench.py --reads $n --steps 2 --warmup 1 --no-cpu-baseline --transfer-steps 0 --edge-cap 67108864 > gpurun_out/big_$n.json 2> gpurun_out/big_$n.err
+for n in 200000 400000; do
+  timeout 900 python bench.py --reads $n --steps 2 --warmup 1 --no-cpu-baseline --transfer-steps 0 --no-place --edge-cap 67108864 > gpurun_out/big_$n.json 2> gpurun_out/big_$n.err
   echo "rc=$? reads=$n"
   python - <<PY
 import json
