@@ -944,7 +944,6 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
     uint16_t* hotl = (uint16_t*)(wq0 + (size_t)(nt >> 6) * (DIST_QCAP + DIST_OVQ));      // DIST_HOT_CAP slots whose count reached min_cov during the inserts of the pass
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0, acc_edges = 0;  // flushed once per workgroup (thread 0)
-    unsigned long long e_cur = 0, e_end = 0;      // thread 0: the unused rows [e_cur, e_end) of the workgroup's chunk of the edge output
 #if defined(CF_DIST_STAMPS)
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -991,12 +990,13 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         sh[22] = nx_head.n_entries;      // partner entries (sizes the passes when every b is marked)
     };
     auto pop_pass = [&]() {          // thread 0: the next partition of the stack becomes the pass
-        const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[7] = 0; sh[8] = 0; sh[11] = 0;
+        const uint32_t sp = sh[2] - 1; sh[2] = sp; sh[3] = stack[2 * sp]; sh[4] = stack[2 * sp + 1]; sh[0] = 0; sh[7] = 0; sh[8] = 0; sh[11] = 0; sh[30] = 0;
     };
     if (t == 0) {
         nx_idx = pop_finish(pop_issue());
         if (nx_idx >= 0) nx_head = A.heads[nx_idx];
         publish_next();
+        sh[26] = 0; sh[27] = 0; sh[28] = 0; sh[29] = 0;      // no chunk of the edge output yet
     }
     __syncthreads();
 
@@ -1030,7 +1030,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         const uint32_t min_cov_m1 = A.min_cov - 1u;      // (the sketch runs with min_cov >= 2)
         // the pass that nearly every first k-mer gets by with: one partition, every marked b in it (set up here, in front of a
         // barrier that is there anyway; "every b marked" below replaces it)
-        if (t == 0) { sh[13] = 0; sh[2] = 0; sh[3] = 1; sh[4] = 0; sh[0] = 0; sh[7] = 0; sh[8] = 0; sh[11] = 0; }
+        if (t == 0) { sh[13] = 0; sh[2] = 0; sh[3] = 1; sh[4] = 0; sh[0] = 0; sh[7] = 0; sh[8] = 0; sh[11] = 0; sh[30] = 0; }
         if (A.sketch) {
             {
                 const cf_u32x4 z{0u, 0u, 0u, 0u};
@@ -1237,6 +1237,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             // staged), reserve the edge range with ONE global atomic, then write
             for (int d = 32; d >= 1; d >>= 1) my_e += __shfl_down(my_e, (unsigned)d);
             if (lane == 0 && (my_e + s_e)) atomicAdd(&sh[7], my_e + s_e);
+            if (t == 0 && sh[2] == 0u) publish_next();      // the last pass: the next first k-mer's head rides on the filter's barrier
             // Filter in two steps.  (1) A group of slots per thread and round: the slots whose count reaches min_cov (few: the
             // table is sparse and most pairs stay below) are compacted into a list that lies over the insert queues, dead
             // by now.  (2) The list is evaluated one slot per thread with all lanes busy: sum over d from the bucket's
@@ -1292,83 +1293,87 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 if (A.thr_den) return (unsigned long long)A.thr_den * cnt >= (unsigned long long)A.thr_num * total;
                 return ((double)cnt / (double)total) >= A.thr;
             };
-            auto keep = [&](bool sel, uint32_t s) {       // called by all lanes of a wave together
+            // A selected edge takes its row of the output right here: the workgroup's chunk (DIST_EDGE_CHUNK rows reserved with
+            // one global atomic; base in sh[28,29], rows in sh[27], cursor sh[26]) hands out rows through an LDS atomic per wave
+            // and round, and the lane that evaluated the slot writes the row from its registers.  Only an edge whose row does not
+            // fit the rest of the chunk is marked and staged (count sh[30]); those are written behind a barrier, after thread 0 has
+            // reserved the next chunk.  (The first half of round 3 staged EVERY selected slot, met at a barrier for thread 0 to
+            // hand out the rows and read the slots again: the write phase was 9 % of the kernel.)
+            const unsigned long long ch_base = ((unsigned long long)sh[29] << 32) | sh[28];
+            const uint32_t ch_rows = sh[27];
+            auto put_row = [&](unsigned long long o, uint32_t b, uint32_t dd, uint32_t cnt) {
+                if (o < A.edge_cap) *(cf_u32x4*)(A.edges + 4 * o) = cf_u32x4{dd, a, b, cnt};
+                const uint32_t bit = 1u << (b & 31);
+                if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
+            };
+            auto keep = [&](bool sel, uint32_t s, uint32_t b, uint32_t dd, uint32_t cnt) {       // called by all lanes of a wave together
                 const unsigned long long m = __ballot(sel);
                 if (!m) return;
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&sh[8], (uint32_t)__popcll(m));
-                const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + (uint32_t)__popcll(m & lt);
-                if (sel) { T.mark(s); if (pos < A.stage_cap) stage[pos] = (uint16_t)s; }
+                uint32_t row0 = 0;
+                if (lane == 0) { const uint32_t n = (uint32_t)__popcll(m); atomicAdd(&sh[8], n); row0 = atomicAdd(&sh[26], n); }
+                const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0) + (uint32_t)__popcll(m & lt);
+                const bool late = sel && row >= ch_rows;
+                if (sel && !late) put_row(ch_base + row, b, dd, cnt);
+                const unsigned long long ml = __ballot(late);
+                if (ml) {
+                    uint32_t p0 = 0;
+                    if (lane == 0) p0 = atomicAdd(&sh[30], (uint32_t)__popcll(ml));
+                    const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0) + (uint32_t)__popcll(ml & lt);
+                    if (late) { T.mark(s); if (pos < A.stage_cap) stage[pos] = (uint16_t)s; }
+                }
             };
             if (n_hot <= hot_cap) {
                 for (uint32_t i0 = 0; i0 < n_hot; i0 += (uint32_t)nt) {
                     const uint32_t i = i0 + (uint32_t)t;
                     bool sel = false;
-                    uint32_t s = 0;
+                    uint32_t s = 0, eb = 0, ed = 0, ec = 0;
                     if (i < n_hot) {
                         s = hot[i];
-                        T.eval_slot(s, n_buckets, A.min_cov, [&](uint32_t, uint32_t b, uint32_t, uint32_t cnt, unsigned long long total) { sel = b != a && dominant(cnt, total); });
+                        T.eval_slot(s, n_buckets, A.min_cov, [&](uint32_t, uint32_t b, uint32_t dd, uint32_t cnt, unsigned long long total) { sel = b != a && dominant(cnt, total); eb = b; ed = dd; ec = cnt; });
                     }
-                    keep(sel, s);
+                    keep(sel, s, eb, ed, ec);
                 }
-            } else {        // more than the list holds (never seen with the sketch): evaluate inside the bucket scan
+            } else {        // more than the list holds (never seen with the sketch): evaluate inside the bucket scan, a row per atomic
                 for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt)
-                    T.for_counts_at_least(bk, n_buckets, A.min_cov, [&](uint32_t s, uint32_t b, uint32_t, uint32_t cnt, unsigned long long total) {
+                    T.for_counts_at_least(bk, n_buckets, A.min_cov, [&](uint32_t s, uint32_t b, uint32_t dd, uint32_t cnt, unsigned long long total) {
                         if (b != a && dominant(cnt, total)) {
-                            T.mark(s);
-                            const uint32_t pos = atomicAdd(&sh[8], 1u);
-                            if (pos < A.stage_cap) stage[pos] = (uint16_t)s;
+                            atomicAdd(&sh[8], 1u);
+                            const uint32_t row = atomicAdd(&sh[26], 1u);
+                            if (row < ch_rows) put_row(ch_base + row, b, dd, cnt);
+                            else {
+                                T.mark(s);
+                                const uint32_t pos = atomicAdd(&sh[30], 1u);
+                                if (pos < A.stage_cap) stage[pos] = (uint16_t)s;
+                            }
                         }
                     });
             }
             __syncthreads();      // [filtered]
             CF_STAMP(4);   // filter
-            const uint32_t n_sel = sh[8];
+            const uint32_t n_sel = sh[8], n_late = sh[30];
             const uint32_t sp_left = sh[2];      // partitions still on the stack (thread 0 changes the word only behind the next barrier)
-            // Edge rows come from a chunk of the output that the workgroup reserved earlier (DIST_EDGE_CHUNK rows per global atomic;
-            // round 2 reserved every pass's rows with its own returning atomic: a round trip to the memory side per first k-mer
-            // with the whole workgroup waiting at the barrier below).  A pass that does not fit the rest of the chunk fills it and
-            // continues in a new one, so only the LAST chunk of a workgroup keeps unused rows: those holes are listed at the end of
-            // the kernel and closed by cf_edge_compact_kernel.
             if (t == 0) {
                 acc_E += sh[7]; ++acc_pass;
-                if (n_sel) {
-                    const unsigned long long rem = e_end - e_cur;
-                    sh[9] = (uint32_t)e_cur; sh[10] = (uint32_t)(e_cur >> 32); sh[12] = (uint32_t)min(rem, (unsigned long long)n_sel);
-                    if ((unsigned long long)n_sel <= rem) e_cur += n_sel;
-                    else {
-                        const unsigned long long need = (unsigned long long)n_sel - rem, take = (need + A.edge_chunk - 1ull) / A.edge_chunk * A.edge_chunk;
-                        const unsigned long long nb = atomicAdd(&A.counters[0], take);
-                        sh[14] = (uint32_t)nb; sh[15] = (uint32_t)(nb >> 32);
-                        e_cur = nb + need; e_end = nb + take;
-                    }
-                    acc_edges += n_sel;
-                    atomicOr(&A.unique_bits[a >> 5], 1u << (a & 31));      // (fire and forget: a load to test the bit first would stall thread 0 in front of the barrier)
-                }
-                sh[13] = 0;                          // cursor of the marked-slot sweep below (the sketch's flag is long read)
-                if (sp_left == 0u) publish_next();   // the last pass: the next first k-mer's head rides on this barrier
+                if (n_sel) { acc_edges += n_sel; atomicOr(&A.unique_bits[a >> 5], 1u << (a & 31)); }      // (fire and forget: a load to test the bit first would stall thread 0)
             }
-            __syncthreads();      // [rows reserved]
-            if (n_sel) {
-                const unsigned long long base = ((unsigned long long)sh[10] << 32) | sh[9], nbase = ((unsigned long long)sh[15] << 32) | sh[14];
-                const uint32_t in_old = sh[12];      // rows that still fit the old chunk
-                auto emit = [&](uint32_t i, uint32_t b, uint32_t dd, uint32_t cnt) {
-                    const unsigned long long o = i < in_old ? base + i : nbase + (i - in_old);
-                    if (o < A.edge_cap) *(cf_u32x4*)(A.edges + 4 * o) = cf_u32x4{dd, a, b, cnt};
-                    // (the load in front of the atomic is a round trip at the end of every first k-mer, 2.2 % of the kernel; a 1024-entry LDS
-                    // cache of the b whose bit this workgroup has set, with fire-and-forget atomics on a miss, gave it back in LDS
-                    // room for the table and in atomics: 331.7 vs 330.8 ms)
-                    const uint32_t bit = 1u << (b & 31);
-                    if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
-                };
-                if (n_sel <= A.stage_cap) {           // the staged slot list
-                    for (uint32_t i = (uint32_t)t; i < n_sel; i += (uint32_t)nt) {
+            if (n_late) {      // (uniform; once per DIST_EDGE_CHUNK rows) the chunk is full: the late rows open the next one
+                __syncthreads();      // everyone has read the chunk and the counts
+                if (t == 0) {
+                    const unsigned long long take = ((unsigned long long)n_late + A.edge_chunk - 1ull) / A.edge_chunk * A.edge_chunk;
+                    const unsigned long long nb = atomicAdd(&A.counters[0], take);
+                    sh[28] = (uint32_t)nb; sh[29] = (uint32_t)(nb >> 32); sh[27] = (uint32_t)take; sh[26] = n_late;
+                    sh[30] = 0; sh[13] = 0;      // ([13]: cursor of the marked-slot sweep below; the sketch's flag is long read)
+                }
+                __syncthreads();      // [rows reserved]
+                const unsigned long long nbase = ((unsigned long long)sh[29] << 32) | sh[28];
+                if (n_late <= A.stage_cap) {           // the staged slot list
+                    for (uint32_t i = (uint32_t)t; i < n_late; i += (uint32_t)nt) {
                         uint32_t b, dd, cnt;
-                        if (T.get(stage[i], b, dd, cnt)) emit(i, b, dd, cnt);
+                        if (T.get(stage[i], b, dd, cnt)) put_row(nbase + i, b, dd, cnt);
                     }
-                } else {                               // more selected edges than the stage holds: sweep the marked slots, a bucket per thread
+                } else {                               // more late edges than the stage holds: sweep the marked slots, a bucket per thread
                     for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt)
-                        T.for_marked(bk, [&](uint32_t, uint32_t b, uint32_t dd, uint32_t cnt) { emit(atomicAdd(&sh[13], 1u), b, dd, cnt); });
+                        T.for_marked(bk, [&](uint32_t, uint32_t b, uint32_t dd, uint32_t cnt) { put_row(nbase + atomicAdd(&sh[13], 1u), b, dd, cnt); });
                 }
             }
             CF_STAMP(5);   // reserve + write edges
@@ -1385,9 +1390,9 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         if (acc_spill) atomicAdd(&A.counters[2], acc_spill);
         if (acc_pass) atomicAdd(&A.counters[5], acc_pass);
         if (acc_edges) atomicAdd(&A.counters[6], acc_edges);
-        if (e_end > e_cur) {      // the unused rest of the last chunk: a hole for cf_edge_compact_kernel
-            const unsigned long long h = atomicAdd(&A.counters[7], 1ull);
-            A.holes[2 * h] = e_cur; A.holes[2 * h + 1] = e_end - e_cur;
+        if (sh[27] > sh[26]) {      // the unused rest of the last chunk: a hole for cf_edge_compact_kernel
+            const unsigned long long h = atomicAdd(&A.counters[7], 1ull), cb = ((unsigned long long)sh[29] << 32) | sh[28];
+            A.holes[2 * h] = cb + sh[26]; A.holes[2 * h + 1] = (unsigned long long)(sh[27] - sh[26]);
         }
 #if defined(CF_DIST_STAMPS)
         for (int i = 0; i < 8; ++i) atomicAdd(&A.counters[8 + i], stamp_acc[i]);
