@@ -152,7 +152,7 @@ struct cf_ctx {
     int dist_int_thr = 1;    // 1: rel_threshold == 0.8 is tested as 5 cnt >= 4 total; 0: always the double division (tests)
     int dist_sketch = 1;     // 0: every (b,d) pair goes to the exact table (no counting sketch first)
     int dist_est_pct = 80;   // expected distinct (b,d) keys per 100 pair emissions: sizes the initial number of table partitions
-    int dist_stage = 2048;   // selected edges staged in LDS per table pass (0 forces the table sweep)
+    int dist_stage = 2048;   // edges of a pass whose rows do not fit the rest of the workgroup's output chunk, staged in LDS (more: a sweep of the marked slots)
     int place_chunk = 2, place_grid = 0;     // cloud entries per wave step of that kernel (1 .. 64), its workgroups (0 = one per CU)
     int place_fused = 1;         // 1: the greedy iteration is arg-max + (pick, add, score updates) = 2 kernels; 0: 3 kernels with an event list
     int count_mode = 1;          // 1: sort and reduce (cf_count2.hip) when it applies; 0: the atomic table of round 1 (cf_count.hip)

@@ -95,7 +95,8 @@ def test_stage2_spill_and_partition(engine, report, oracle_stage2):
     tup = oracle_stage2("lowcov", max_distance=2)
     engine.set_param("dist_slots", 256)   # forces the (b, d) table to be split by a second hash of b
     engine.set_param("dist_block", 64)
-    engine.set_param("dist_stage", 3)     # forces the marked-slot sweep instead of the staged edge list
+    engine.set_param("dist_stage", 3)     # with the small chunks of the edge output below: rows that do not fit the rest of a chunk are
+    engine.set_param("dist_edge_chunk", 16)   # often more than the staged list holds -> the marked-slot sweep writes them
     engine.set_param("dist_sketch", 0)    # every (b, d) pair goes to the exact table
     try:
         pathcheck.check_stage2(engine, report("lowcov"), tup, n_parts=3, check_table=False)
@@ -103,6 +104,7 @@ def test_stage2_spill_and_partition(engine, report, oracle_stage2):
     finally:
         engine.set_param("dist_sketch", 1)
         engine.set_param("dist_stage", 2048)
+        engine.set_param("dist_edge_chunk", 0)
 
 
 def test_long_posting_lists_take_the_multi_chunk_path(engine):

@@ -80,7 +80,8 @@ def test_wide_table_layout(engine, report, oracle_stage2):
 def test_partitions_spill_and_slices(engine, report, oracle_stage2):
     # first k-mers split 3 ways (the multi-GPU partition), tiny LDS table (forces the spill path)
     engine.set_param("dist_slots", 1024)
-    engine.set_param("dist_stage", 5)
+    engine.set_param("dist_stage", 5)           # with chunks of 32 rows of the edge output: late rows beyond the staged list -> marked-slot sweep
+    engine.set_param("dist_edge_chunk", 32)
     try:
         engine.set_param("dist_sketch", 0)      # every (b, d) pair in the exact table
         pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov"), n_parts=3, check_table=False)
@@ -92,6 +93,7 @@ def test_partitions_spill_and_slices(engine, report, oracle_stage2):
     finally:
         engine.set_param("dist_slots", 0)
         engine.set_param("dist_stage", 2048)
+        engine.set_param("dist_edge_chunk", 0)
         engine.set_param("dist_sketch", 1)
     # --min-nreads / --max-nreads slice and --min-distance 0 (kmer_clouds[:-0] is empty) and a narrow d window
     for ov in (dict(min_nreads=3, max_nreads=11), dict(min_distance=0, max_distance=4), dict(min_distance=2, max_distance=3)):
