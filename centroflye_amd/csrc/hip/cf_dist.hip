@@ -767,23 +767,29 @@ cf_items_count_kernel(const int32_t* __restrict__ order, int64_t n_order, const 
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t n_grp = ((int64_t)gridDim.x * blockDim.x) >> 4;
     unsigned long long self = 0;
+    // (the first two links of an iteration's chain — order -> post_ptr — are fetched one iteration ahead)
+    int64_t p0_n = 0, p1_n = 0;
+    { const int32_t a0 = grp < n_order ? order[grp] : 0; if (grp < n_order) { p0_n = post_ptr[a0]; p1_n = post_ptr[a0 + 1]; } }
     for (int64_t i0 = 0; i0 < n_order; i0 += n_grp) {      // (uniform trip count: shuffles inside)
         const int64_t i = i0 + grp;
         const bool on = i < n_order;
-        const int32_t a = on ? order[i] : 0;
-        const int64_t p0 = on ? post_ptr[a] : 0, p1 = on ? post_ptr[a + 1] : 0;
+        const int64_t p0 = p0_n, p1 = p1_n;
+        { const int64_t in = i + n_grp; p0_n = 0; p1_n = 0; if (in < n_order) { const int32_t an = order[in]; p0_n = post_ptr[an]; p1_n = post_ptr[an + 1]; } }
         unsigned long long c = 0;
         int64_t np_max = p1 - p0;      // the longest posting list among the wave's four groups bounds the loops
         for (int d = 16; d <= 32; d <<= 1) np_max = max(np_max, __shfl_xor(np_max, d));
         for (int64_t x0 = 0; x0 < np_max; x0 += 16) {
             const bool hx = p0 + x0 + gl < p1;
             const int32_t ux = hx ? post[p0 + x0 + gl] : 0;
-            const int32_t rx = hx ? rbeg[ux] : -1;
-            if (hx) c += (urange[ux].len + DIST_ITEM - 1u) / DIST_ITEM;
+            cf_dist_rec rx_{0, 0u, 0u};
+            if (hx) rx_ = urange[ux];
+            const int32_t rx = hx ? ux - (int32_t)rx_.ig : -1;      // first unit of the posting's read (ig = the unit's index in its read): ONE gather per posting
+            if (hx) c += (rx_.len + DIST_ITEM - 1u) / DIST_ITEM;
             if (np_max < 2) continue;
             for (int64_t y0 = 0; y0 < np_max; y0 += 16) {
                 const bool hy = p0 + y0 + gl < p1;
-                const int32_t uy_l = hy ? post[p0 + y0 + gl] : 0, ry_l = hy ? rbeg[uy_l] : -2;
+                int32_t uy_l = ux, ry_l = hx ? rx : -2;      // (the same 16 postings: nearly every first k-mer has at most 16)
+                if (y0 != x0) { uy_l = hy ? post[p0 + y0 + gl] : 0; ry_l = hy ? uy_l - (int32_t)urange[uy_l].ig : -2; }
                 for (int j = 0; j < 16; ++j) {
                     const int32_t uy = __shfl(uy_l, j, 16), ry = __shfl(ry_l, j, 16);
                     const int32_t d = uy - ux;
@@ -809,13 +815,17 @@ cf_items_fill_kernel(const int32_t* __restrict__ order, int64_t n_order, const i
     const int gl = threadIdx.x & 15;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t n_grp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    int32_t a_n = 0; int64_t p0_n = 0, p1_n = 0, ib_n = 0; uint32_t n_n = 0;      // (fetched one iteration ahead, as in cf_items_count_kernel)
+    if (grp < n_order) { a_n = order[grp]; p0_n = post_ptr[a_n]; p1_n = post_ptr[a_n + 1]; n_n = n_items[grp]; ib_n = ibase[grp]; }
     for (int64_t i0 = 0; i0 < n_order; i0 += n_grp) {      // (uniform trip count: shuffles inside)
         const int64_t i = i0 + grp;
         const bool on = i < n_order;
-        const int32_t a = on ? order[i] : 0;
-        const int64_t p0 = on ? post_ptr[a] : 0, p1 = on ? post_ptr[a + 1] : 0;
-        const uint32_t n = on ? n_items[i] : 0u, per = (n + nw - 1u) / nw;
-        const int64_t ib = on ? ibase[i] : 0;
+        const int32_t a = a_n;
+        const int64_t p0 = p0_n, p1 = p1_n;
+        const uint32_t n = n_n, per = (n + nw - 1u) / nw;
+        const int64_t ib = ib_n;
+        { const int64_t in = i + n_grp; a_n = 0; p0_n = 0; p1_n = 0; n_n = 0; ib_n = 0;
+          if (in < n_order) { a_n = order[in]; p0_n = post_ptr[a_n]; p1_n = post_ptr[a_n + 1]; n_n = n_items[in]; ib_n = ibase[in]; } }
         cf_dist_item* out = items + ib;
         int64_t np_max = p1 - p0;
         for (int d = 16; d <= 32; d <<= 1) np_max = max(np_max, __shfl_xor(np_max, d));
