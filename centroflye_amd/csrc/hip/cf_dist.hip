@@ -5,16 +5,19 @@
 // b in C_{i+d}, a != b), cnt[d][a][b] += 1; :131-149 keeps (d, a, b, cnt) with cnt >= min_cov
 // and cnt / sum_d' cnt[d'][a][b] >= 0.8 (true division), and marks a and b as selected.
 //
-// Device design (the dominant kernel of the path; HBM/L2 streaming + LDS atomics, no MFMA):
-//   * dist_cnt[d][a] is owned by the first k-mer a in the reference; so is it here: one
-//     workgroup owns one a at a time (dynamic queue), walks a's posting list
-//     (the (read, unit) clouds that contain a), streams the later unit clouds of those reads
-//     (contiguous int32 CSR ranges, coalesced, 4 B per pair emission) and counts (b, d) in an
-//     LDS open-addressed table of 64-bit slots [b:32 | d:8 | cnt:24] with one LDS atomic per
-//     emission.  The slot hash depends on b only, so all d of one b share a probe chain and
-//     sum_d cnt is a chain walk — both filters run in LDS and only selected edges reach HBM.
-//   * a table that would overflow is split by a second hash of b into 2, 4, ... partitions,
-//     each processed (re-streamed) on its own: exact, no HBM spill.
+// Device design (the dominant kernel of the path; HBM/L2 streaming + LDS atomics, no MFMA; DESIGN.md 3.4):
+//   * dist_cnt[d][a] is owned by the first k-mer a in the reference; so is it here: one workgroup owns one a at a time
+//     (ticket queues in the locality order of the first k-mers).  Before the launch two builder kernels cut a's partner
+//     entries — for every posting (a unit holding a) the clouds of the later units of that read, ONE contiguous CSR range —
+//     into item records of <= 256 entries in HBM; a wave reads its records with one load and both sweeps run on them.
+//   * sweep 1 only COUNTS every (b, d) pair in 8-bit counters laid over the table's LDS (most pairs never reach min_cov) and
+//     marks hash(b) of the pairs that can; sweep 2 queues the pairs of marked b and inserts them, 64 at a time, into an exact
+//     open-addressed LDS table (6-byte slots [d | b] + 15-bit count in 4-key buckets; 8-byte slots / region layouts for
+//     large k-mer sets).  The slot hash depends on b only, so all d of one b share a probe chain and sum_d cnt is a chain walk:
+//     both filters run in LDS, and the lane that evaluates a selected slot writes the edge row itself, into a chunk of the
+//     output the workgroup reserved earlier.
+//   * a table that would overflow is split by a second hash of b into 2, 4, ... partitions, each processed (re-streamed)
+//     on its own: exact, no HBM spill.
 //   * first k-mers partition across GPUs (a % n_parts == part) with no reduction.
 #include "cf_common.h"
 
@@ -23,8 +26,7 @@
 void cf_free_edges(cf_ctx* c);
 int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 
-#define DIST_NP_CAP 128
-#define DIST_STAGE_CAP 1024              /* selected slots staged per table pass (u16 slot indices) */
+#define DIST_STAGE_CAP 1024              /* selected slots whose rows do not fit the workgroup's output chunk, staged per table pass (u16 slot indices) */
 #define DIST_STACK 112
 #define DIST_UNROLL 4
 #define DIST_ITEM (64u * DIST_UNROLL)    /* cloud entries one wave takes per step: DIST_UNROLL consecutive ones per lane */
