@@ -249,6 +249,30 @@ def test_errors_and_degenerate_inputs(engine):
         engine.select_rare(3, 1, 1); engine.build_clouds(); engine.dist_edges(0, 10, 1, 70000, 1, 0.8)
 
 
+def test_a_few_very_long_sequences_take_the_table_path(engine):
+    """The reduce of the sort-and-reduce A1 looks back along a read's run of records inside a bucket; four 5-Mb sequences would
+    make those runs hundreds of records long, so the host hands such input to the atomic table (cf_count2.hip:
+    cf_count_sorted returns 1).  Same table either way: presence / multi against numpy, a repeated stretch included."""
+    rng = np.random.default_rng(11)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    seqs = [alpha[rng.integers(0, 4, 5_200_000)] for _ in range(4)]
+    seqs[1][1000:3000] = seqs[0][5000:7000]          # shared between two reads
+    seqs[2][100_000:102_000] = seqs[2][500:2500]     # twice in one read
+    bases = np.concatenate(seqs)
+    off = np.concatenate([[0], np.cumsum([s.size for s in seqs])])
+    engine.load_arrays(bases, off, np.zeros(len(seqs) + 1, np.int64), [], [])
+    engine.count_kmers(19)
+    keys, pres, multi = engine.table()
+    per = [np.unique(recruit.encode_windows(s.tobytes(), 19), return_counts=True) for s in seqs]
+    allk = np.concatenate([u for u, _ in per]); allm = np.concatenate([(c > 1) for _, c in per])
+    o = np.argsort(allk, kind="stable")
+    wk, start, wp = np.unique(allk[o], return_index=True, return_counts=True)
+    wm = np.add.reduceat(allm[o].astype(np.int64), start)
+    assert np.array_equal(keys, wk) and np.array_equal(pres, wp.astype(np.uint32)) and np.array_equal(multi, wm.astype(np.uint32))
+    assert int((pres == 2).sum()) >= 1900 and int(multi.sum()) >= 1900
+    assert engine.stats()["n_read_kmers"] == int(sum(u.size for u, _ in per))
+
+
 def test_exchange_path_on_one_rank_rccl():
     """The multi-GPU path (device-side owner bucketing, all-to-all of table records, all-gathers of rare lists and
     clouds, gathered cloud view for the distance stage, mask all-reduce) executed for real with RCCL on a single
