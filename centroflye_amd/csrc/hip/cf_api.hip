@@ -462,6 +462,20 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
         ctx->dist_stage = (int)value;
     } else if (n == "place_fused") {
         ctx->place_fused = value != 0;
+    } else if (n == "place_mode") {
+        if (value < 1 || value > 2) return cf_fail(ctx, -22, "place_mode out of range (1 = hash map, 2 = per-read regions)");
+        ctx->place_mode = (int)value;
+    } else if (n == "place_spec") {
+        ctx->place_spec = value != 0;
+    } else if (n == "place_block") {
+        if (value != 0 && (value < 128 || value > 1024 || value % 128)) return cf_fail(ctx, -22, "place_block must be 0 or a multiple of 128 in 128 .. 1024");
+        ctx->place_block = (int)value;
+    } else if (n == "place_row_words") {
+        if (value != 0 && value != 32 && value != 64) return cf_fail(ctx, -22, "place_row_words must be 0 (auto), 32 or 64");
+        ctx->place_row_words = (int)value;
+    } else if (n == "place_slots_per_unit") {
+        if (value < 0 || value > 65536) return cf_fail(ctx, -22, "place_slots_per_unit out of range (0 = default, 1 .. 65536)");
+        ctx->place_slots_per_unit = (int)value;
     } else if (n == "place_chunk") {
         if (value < 1 || value > 64) return cf_fail(ctx, -22, "place_chunk out of range (1 .. 64)");
         ctx->place_chunk = (int)value;

@@ -149,8 +149,12 @@ inline unsigned long long __ballot(int pred) {
 }
 inline int __any(int pred) { return __ballot(pred) != 0; }
 // (cf_common.h: on the device the LDS window is addressed from the number 0)
+struct uint2 { unsigned x, y; };
+inline uint2 make_uint2(unsigned x, unsigned y) { uint2 v; v.x = x; v.y = y; return v; }
 #define cf_lds_at(off) (cf_lds + (off))
 #define cf_lds_base_ok() true
+#define cf_ld_agent(p) (*(p))          /* cf_place2.hip: device-scope loads / the wave's drain of its memory operations */
+#define cf_drain_vm() ((void)0)
 #define __builtin_amdgcn_fence(order, scope) ((void)0)   /* lanes are fibers on one thread: program order is memory order */
 inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(1); }   // lanes of a wave run in lock step on the GPU: rendezvous here
 inline int __all(int pred) {
