@@ -156,7 +156,6 @@ struct cf_ctx {
     int place_chunk = 2, place_grid = 0;     // cloud entries per wave step of that kernel (1 .. 64), its workgroups (0 = one per CU)
     int place_fused = 1;         // 1: the greedy iteration is arg-max + (pick, add, score updates) = 2 kernels; 0: 3 kernels with an event list
     int place_mode = 2;          // 2: per-read score regions, one kernel per greedy iteration (cf_place2.hip); 1: the hash-map path of rounds 1-3 (cf_place.hip)
-    int place_spec = 0;          // cf_place2: 1 = the region records of a posting row's reads are loaded before the contig count is back
     int place_block = 0;         // cf_place2: threads per workgroup of the iteration kernel (128 .. 1024, a multiple of 128; 0 = 1024)
     int place_row_words = 0;     // cf_place2: 32-bit words of a posting row (32 or 64); 0 = the smaller one that holds the longest posting list
     int place_slots_per_unit = 0; // cf_place2: score-region slots per unit of a read (0 = 48); doubled-up automatically when a region fills

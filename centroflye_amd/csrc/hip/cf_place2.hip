@@ -1,6 +1,6 @@
 // cf_place2.hip — A8 + A9 (cloud contig + greedy read placement), round 4: ONE kernel per greedy iteration.
 //
-// Reference (same semantics as cf_place.hip, which keeps the round 1-3 path as `place_mode` 0 / 1):
+// Reference (same semantics as cf_place.hip, which keeps the round 1-3 path as `place_mode` 1):
 //   scripts/cloud_contig.py:26-41   add_read: count[(pos, k-mer)] += 1; the pair is reported when the count EQUALS the threshold
 //   scripts/cloud_contig.py:87-95   update_mapping_scores: a reported (k-mer, q) adds 1 to scores[read][q - i][i] for every
 //                                   posting (read, i) of the k-mer with q >= i
@@ -10,38 +10,44 @@
 // What rounds 1-3 measured: 24.6 us per greedy iteration, 25.0 of them INSIDE two kernels whose waves walk
 // a chain of ten dependent HBM round trips (candidates, unit_ptr, cloud_ptr, entries, contig claim, contig count, posting
 // range, postings, score-map claim, seen-set claim, score add) and then scan flag bytes of a 16 M-slot hash map.
-// tools/ubench/chain.hip: a dependent round trip costs 0.4 - 0.45 us, a dependent launch 1.6 (graph) - 3.3 us (eager,
-// host bound), "last workgroup done" 0.7 us at 16 - 32 workgroups.  So the iteration is priced in round trips:
+// Round 4 prices the iteration in dependent steps (tools/ubench/chain.hip; the in-kernel per-wave timelines of
+// -DCF_PL2_STAMPS2): a load 0.45 - 0.65 us, a device-scope atomic 1.1 - 1.2 us whether it returns or not, a dependent
+// launch 1.6 - 3.3 us, "last workgroup done" 0.8 us; a wave's memory operations complete IN ORDER (one counter), so a
+// load issued behind an atomic waits with it; and everything waits for the slowest lane.
 //
-//   iteration kernel (G workgroups x 1024 threads, 16 lanes per cloud entry of the read being laid down):
+//   iteration kernel (G workgroups; PW = 32 or 64 lanes per cloud entry of the read being laid down, one posting per lane):
 //     1 the winner record {read, offset, first entry, entries}          (written by the previous launch's tail)
 //     2 the entry {k-mer, unit index}                                    (one 8-byte array built per run)
-//     3 contig claim (CAS)            ||  the k-mer's POSTING ROW: 31 packed postings + count, one aligned 128-byte line
-//     4 contig count (returning add)  ||  (optionally, `place_spec`) the posting reads' region records
-//     5 region record of the posting's read {slot base, cell base, slots, units, anchor}
-//     6 the score update: header add || cell add || dirty bit            (no dependence between them)
-//   tail, by the workgroup that arrives last at a counter:
-//     7 dirty-read bitmap (exchange with 0)  8 hot lists  9 headers + cells of the hot rows  10 the rescanned reads' blocks
-//     11 block candidates -> winner record for the next launch.
+//     3 the k-mer's CONTIG RECORD (its positions and counts, 32 bytes)  ||  its POSTING ROW (packed postings + count)
+//       -> the event is decided from the record as loaded (no other lane touches the pair in this launch); the add is owed
+//     4 the region record of the posting's read                          (only lanes of entries that raised an event)
+//     5 the row's home bucket of 4 headers
+//     6 ONE round of independent atomics: cell, count, claim (new rows), hot / dirty bits, the owed contig add;  drain
+//   tail, by the workgroup that arrives last at a counter (one lane per dirty read, packed densely):
+//     7 dirty-read bitmap  8 region records  9 hot bits + the anchor row  10 other hot rows, in lockstep over the wave
+//     11 the RB records of the touched blocks of 64 reads || the L2 records of the others -> winner record for the next launch.
+//   50 000 reads: 15.8 us per iteration (6.3 lay-down + 0.8 arrive + 7 tail + launch gap), 0.79 s in all (round 3: 1.25 - 1.35 s).
 //
 // Scores.  scores[read][offset][unit] is kept as the reference keeps it — one counter per (read, offset, unit) — in a
-// REGION PER READ: H_r slots (a power of two >= place_slots_per_unit x units, open addressing by offset inside the
-// region), slot = one 64-bit header [offset + 1 : 32 | s1 : 32] + U_r 32-bit cells.  s1 is the header's low half, s0 the
-// number of non-zero cells: nothing else is stored, so a hit is header += 1 and cell += 1, two independent atomics.  A
-// read's rows are enumerable (the round 1-3 hash map was not: it needed flag bytes and slice scans for the arg-max).
+// REGION PER READ: H_r slots (a power of two >= place_slots_per_unit x units) in buckets of 4, slot = one 64-bit header
+// [offset + 1 : 32 | hits taken through the bucket path : 32] + a row of 16-bit cells, one per unit.  s1 is the sum of
+// the cells, s0 the number of non-zero ones: nothing else is stored.  A read's rows are enumerable (the round 1-3 hash map
+// was not: it needed flag bytes and slice scans for the arg-max).
 // tools/place_stats.py on the bench's 50 000 reads: 87 % of all hits land on the ONE row per read that finally wins, the
 // rest is ~125 rows per read with 1.3 hits each, scattered over all offsets.  So:
 //   * the row that the last rescan of a read found strongest is its ANCHOR {offset, slot}: a hit on the anchor offset
-//     goes to the known slot without looking (two fire-and-forget adds);
-//   * any other hit claims / finds its row by CAS on the header and adds the cell optimistically in the same round trip
-//     (undone if the slot turns out to be another row's: counters are only READ after every workgroup has arrived, so a
-//     transient +1 is invisible);
-//   * a row becomes "hot" when its s1 reaches max(1, min_inters) — the header adds of the CAS path return exact values,
-//     so exactly one lane sees that — and is appended to the read's hot list; only hot rows can qualify, so the rescan of a
-//     read looks at its hot rows only (1 - 2 of ~125), and only hits on hot rows mark the read dirty.
-// Arg-max.  RB[read] = best qualifying row of the read, BB[block of 64 reads] = best of the block; the tail rescans
-// the dirty reads, re-reduces their blocks, reduces all blocks.  (s0 * min_prop <= s1 is not monotone; nothing here
-// assumes it is: every dirty read is recomputed from its counters.)
+//     goes to the known slot without looking (a fire-and-forget cell add);
+//   * any other hit looks at the offset's home bucket, then claims / finds its row and adds count and cell in one round
+//     (taken back if the claim loses: counters are only READ after every workgroup has arrived, so a transient +1 is
+//     invisible);
+//   * a row is "hot" from max(1, min_inters) hits on: its bit in a per-slot bitmap is set by the adder that sees the count
+//     there (a transient excess can only set it early); only hot rows can qualify, so the rescan of a read looks at its hot
+//     rows only (1 - 2 of ~125), and only hits on hot rows mark the read dirty.
+// Contig.  clouds[pos][k-mer] BY K-MER: four [position + 1 | count] words per k-mer (a genomic k-mer sits at one or two
+// positions; a fifth position continues in the (position, k-mer) hash map of rounds 1-3).
+// Arg-max.  RB[read] = best qualifying row of the read, L2[block of 64 reads] = best of the block; the tail rescans the
+// dirty reads, re-reduces their blocks, reduces all blocks.  (s0 * min_prop <= s1 is not monotone; nothing here assumes
+// it is: every dirty read is recomputed from its counters.)
 #include "cf_place.h"
 
 #include <cstdlib>
@@ -73,12 +79,12 @@ struct cf_pl2 {
     unsigned long long* hdr; uint32_t* cells;      // per slot: header [offset + 1 : 32 | hits taken before the row became an anchor : 32], cell row
     uint32_t* hotbits;               // one bit per slot: the row has reached hot_thr hits (it may qualify: rescans look at it)
     uint32_t* dirty; uint32_t n_dirty_words;
-    cf_pl2_rec* RB; cf_pl2_rec* L1; cf_pl2_rec* L2;      // best candidate per read, per 8 reads, per 64 reads
-    uint32_t n_reads, n1, n2;
+    cf_pl2_rec* RB; cf_pl2_rec* L2;      // best candidate per read, per 64 reads
+    uint32_t n_reads, n2;
     cf_pl2_rec* win;                 // the read the next launch lays down (hi == 0: none, the stage is over)
     uint32_t hot_thr;
     unsigned long long* stamps;      // -DCF_PL2_STAMPS: time per phase, summed by the last workgroup's thread 0
-    unsigned long long* trace; uint32_t trace_iter;      // -DCF_PL2_STAMPS2: every wave's clock at 8 points of ONE iteration
+    unsigned long long* trace; unsigned long long* ttrace; uint32_t trace_iter;      // -DCF_PL2_STAMPS2: every wave's clock at 8 points of ONE iteration
 };
 
 // what crosses workgroups inside ONE launch is written by device-scope atomics and read with these (sc1: past the
@@ -86,6 +92,8 @@ struct cf_pl2 {
 #ifndef cf_ld_agent
 __device__ __forceinline__ uint32_t cf_ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long cf_ld_agent(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a workgroup barrier that waits for this wave's LDS traffic only (__syncthreads also waits for its global stores to be acknowledged)
+__device__ __forceinline__ void cf_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // every memory operation of this wave has been performed (device-scope atomics: at the memory side)
 __device__ __forceinline__ void cf_drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
@@ -257,52 +265,58 @@ __device__ __forceinline__ void pl2_row(const cf_pl2& S, const cf_pl2_rinfo& ri,
     }
 }
 
-// ---- one dirty block of 8 reads by 8 lanes, one LANE per read: a dirty read is recomputed from its hot rows (RB, anchor),
-// the others bring their RB record; the 8 are reduced in registers to L1[block]; the block of 64 is marked (LDS).
-// entry = block << 8 | dirty bits of its reads, or ~0 for a group without work (its lanes still take part in the shuffles)
-__device__ __forceinline__ void pl2_rescan_block(const cf_pl2& S, uint32_t entry, uint32_t* bb2, uint32_t* list2, uint32_t* n_list2) {
-    const int sub = threadIdx.x & 7;
-    const bool have = entry != 0xFFFFFFFFu;
-    const uint32_t b8 = entry >> 8, r = b8 * 8u + (uint32_t)sub;
-    cf_pl2_rec rec{0ull, 0ull, 0ull, r, 0u};
-    if (have && r < S.n_reads) {
-        if (!((entry >> sub) & 1u)) rec = pl2_load(&S.RB[r]);
-        else {
-            const cf_pl2_rinfo ri = S.rinfo[r];
-            const bool used = S.C.used[r] != 0;
-            const uint32_t rank = (uint32_t)S.C.id_rank[r];
-            const int64_t e0 = S.read_e[r], e1 = S.read_e[r + 1];
-            rec.ext = ((unsigned long long)e0 << 24) | (unsigned long long)(e1 - e0);
-            unsigned long long anchor = 0ull;      // (s1 << 32 | slot) + 1 of the strongest hot row
-            uint32_t anchor_off1 = 0u;
-            if (!used) {
-                const unsigned long long* hb = (const unsigned long long*)S.hotbits + (ri.slot_base >> 6);      // (regions begin at multiples of 64 slots)
-                const uint32_t n_w = (ri.hmask + 1u) >> 6;
-                const uint32_t a_slot = ri.anchor_off1 ? ri.anchor_slot : 0xFFFFFFFFu;
-                for (uint32_t w0 = 0; w0 < n_w; w0 += 8) {
-                    unsigned long long bits[8];
+// ---- one dirty read by one LANE: recomputed from its hot rows (RB, anchor); its block of 64 is marked (LDS)
+__device__ __forceinline__ void pl2_rescan_read(const cf_pl2& S, uint32_t r, uint32_t* bb2, uint32_t* list2, uint32_t* n_list2) {
+    const cf_pl2_rinfo ri = S.rinfo[r];
+    const bool used = S.C.used[r] != 0;
+    const uint32_t rank = (uint32_t)S.C.id_rank[r];
+    const int64_t e0 = S.read_e[r], e1 = S.read_e[r + 1];
+    cf_pl2_rec rec{0ull, 0ull, ((unsigned long long)e0 << 24) | (unsigned long long)(e1 - e0), r, 0u};
+    unsigned long long anchor = 0ull;      // (s1 << 32 | slot) + 1 of the strongest hot row
+    uint32_t anchor_off1 = 0u;
+    if (!used) {
+        // Lanes of a wave rescan different reads: whatever ONE lane does costs the wave a round trip.  So a lane first gathers its
+        // hot slots from the bitmap words (registers only), then the wave looks at everybody's first hot row, then everybody's
+        // second, ...: as many round trips as the read with most hot rows has — not one per bitmap word that holds a bit of
+        // some lane, which made one pass of a busy tail take 11 us.
+        const unsigned long long* hb = (const unsigned long long*)S.hotbits + (ri.slot_base >> 6);      // (regions begin at multiples of 64 slots)
+        const uint32_t n_w = (ri.hmask + 1u) >> 6;
+        const uint32_t a_slot = ri.anchor_off1 ? ri.anchor_slot : 0xFFFFFFFFu;
+        uint32_t p0 = 0xFFFFFFFFu, p1 = 0xFFFFFFFFu, p2 = 0xFFFFFFFFu, p3 = 0xFFFFFFFFu;
+        uint32_t np = 0;      // hot rows besides the anchor (the first four are kept)
+        for (uint32_t w0 = 0; w0 < n_w; w0 += 16) {
+            unsigned long long bits[16];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) bits[j] = w0 + (uint32_t)j < n_w ? cf_ld_agent(hb + w0 + j) : 0ull;
-                    // the anchor is hot and, mostly, the read's only hot row: its header and cells are asked for with the bits
-                    if (w0 == 0 && a_slot != 0xFFFFFFFFu) pl2_row(S, ri, a_slot, rank, r, rec, anchor, anchor_off1);
+            for (int j = 0; j < 16; ++j) bits[j] = w0 + (uint32_t)j < n_w ? cf_ld_agent(hb + w0 + j) : 0ull;
+            // the anchor is hot and, mostly, the read's only hot row: its header and cells are asked for with the bits
+            if (w0 == 0 && a_slot != 0xFFFFFFFFu) pl2_row(S, ri, a_slot, rank, r, rec, anchor, anchor_off1);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        for (unsigned long long b = bits[j]; b; b &= b - 1ull) {
-                            const uint32_t slot = (w0 + (uint32_t)j) * 64u + (uint32_t)(__ffsll((long long)b) - 1);
-                            if (slot != a_slot) pl2_row(S, ri, slot, rank, r, rec, anchor, anchor_off1);
-                        }
+            for (int j = 0; j < 16; ++j)
+                for (unsigned long long b = bits[j]; b; b &= b - 1ull) {
+                    const uint32_t slot = (w0 + (uint32_t)j) * 64u + (uint32_t)(__ffsll((long long)b) - 1);
+                    if (slot == a_slot) continue;
+                    p0 = np == 0 ? slot : p0; p1 = np == 1 ? slot : p1; p2 = np == 2 ? slot : p2; p3 = np == 3 ? slot : p3;
+                    ++np;
                 }
-            }
-            pl2_store(&S.RB[r], rec);
-            if (anchor) { S.rinfo[r].anchor_slot = (uint32_t)(anchor - 1ull); S.rinfo[r].anchor_off1 = anchor_off1; }
+        }
+        if (np > 0) pl2_row(S, ri, p0, rank, r, rec, anchor, anchor_off1);
+        if (np > 1) pl2_row(S, ri, p1, rank, r, rec, anchor, anchor_off1);
+        if (np > 2) pl2_row(S, ri, p2, rank, r, rec, anchor, anchor_off1);
+        if (np > 3) pl2_row(S, ri, p3, rank, r, rec, anchor, anchor_off1);
+        if (np > 4) {      // more than four: the rest, word by word (never seen at the default thresholds)
+            uint32_t seen = 0;
+            for (uint32_t w = 0; w < n_w; ++w)
+                for (unsigned long long b = cf_ld_agent(hb + w); b; b &= b - 1ull) {
+                    const uint32_t slot = w * 64u + (uint32_t)(__ffsll((long long)b) - 1);
+                    if (slot == a_slot) continue;
+                    if (seen++ >= 4) pl2_row(S, ri, slot, rank, r, rec, anchor, anchor_off1);
+                }
         }
     }
-    pl2_take(rec, pl2_shfl_xor(rec, 1)); pl2_take(rec, pl2_shfl_xor(rec, 2)); pl2_take(rec, pl2_shfl_xor(rec, 4));
-    if (have && sub == 0) {
-        pl2_store(&S.L1[b8], rec);
-        const uint32_t i2 = b8 >> 3, bit = 1u << (i2 & 31);
-        if (!(atomicOr(&bb2[i2 >> 5], bit) & bit)) list2[atomicAdd(n_list2, 1u)] = i2;
-    }
+    pl2_store(&S.RB[r], rec);
+    if (anchor) { S.rinfo[r].anchor_slot = (uint32_t)(anchor - 1ull); S.rinfo[r].anchor_off1 = anchor_off1; }
+    const uint32_t i2 = r >> 6, bit = 1u << (i2 & 31);
+    if (!(atomicOr(&bb2[i2 >> 5], bit) & bit)) list2[atomicAdd(n_list2, 1u)] = i2;
 }
 
 #ifdef CF_PL2_STAMPS
@@ -311,10 +325,20 @@ __device__ __forceinline__ void pl2_rescan_block(const cf_pl2& S, uint32_t entry
 #define PL2_STAMP(i) do { } while (0)
 #endif
 
-// ---- the tail: recompute the dirty reads and their blocks of 8, then the dirty blocks of 64, reduce those, publish the next
-// winner.  One workgroup.
+// ---- the tail: recompute the dirty reads, then the blocks of 64 reads that hold one, reduce the blocks, publish the next
+// winner.  One workgroup.  A busy iteration dirties a thousand reads scattered over the read numbers: they are packed into
+// a dense list so that every lane of the workgroup has one (rescans by blocks of 8 left most lanes of a pass without work
+// and needed eight passes).
 __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
     (void)t_last;
+#ifdef CF_PL2_STAMPS2
+    const bool ttr = S.C.ctl[1] == S.trace_iter && (threadIdx.x & 63) == 0;
+    unsigned long long* ttw = S.ttrace + (threadIdx.x >> 6) * 8;
+#define PL2_TTRACE(i) do { if (ttr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ttw[i] = wall_clock64(); } } while (0)
+#else
+#define PL2_TTRACE(i) do { } while (0)
+#endif
+    PL2_TTRACE(0);
     uint32_t* lds32 = (uint32_t*)cf_lds;
     uint32_t* n_list = lds32; uint32_t* more = lds32 + 1; uint32_t* n_list2 = lds32 + 2;
     uint32_t* list = lds32 + 4;
@@ -334,32 +358,37 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
             const uint32_t w1 = w0 + nthr;
             const uint32_t b0 = cf_ld_agent(&S.dirty[w0]), b1 = w1 < S.n_dirty_words ? cf_ld_agent(&S.dirty[w1]) : 0u;
             for (int t = 0; t < 2; ++t) {
-                const uint32_t bits = t ? b1 : b0, wi = t ? w1 : w0;
+                uint32_t bits = t ? b1 : b0;
+                const uint32_t wi = t ? w1 : w0;
                 if (!bits) continue;
-                uint32_t keep = 0u;
-                for (uint32_t q = 0; q < 4; ++q) {
-                    const uint32_t byte = (bits >> (8 * q)) & 0xFFu;
-                    if (!byte) continue;
-                    const uint32_t k = atomicAdd(n_list, 1u);
-                    if (k < PL2_LIST) list[k] = ((wi * 4u + q) << 8) | byte; else keep |= byte << (8 * q);
+                const uint32_t cnt = (uint32_t)__popc(bits);
+                const uint32_t k0 = atomicAdd(n_list, cnt);
+                if (k0 + cnt <= PL2_LIST) {
+                    for (uint32_t k = k0; bits; bits &= bits - 1u) list[k++] = wi * 32u + (uint32_t)(__ffs((int)bits) - 1);
+                    S.dirty[wi] = 0u;
+                } else {      // (what does not fit the list stays in the bitmap for the next round)
+                    for (uint32_t k = k0; k < k0 + cnt && k < PL2_LIST; ++k) list[k] = 0xFFFFFFFFu;
+                    *more = 1u;
                 }
-                S.dirty[wi] = keep;      // (what did not fit the list waits for the next round)
-                if (keep) *more = 1u;
             }
         }
-        __syncthreads();
+        PL2_TTRACE(1);
+        cf_barrier_lds();      // (the rescans read the list, which is in LDS: the stores that cleared the bitmap need not have landed)
+        PL2_TTRACE(2);
         PL2_STAMP(3);
         const uint32_t n = min(*n_list, (uint32_t)PL2_LIST);
         again = *more != 0u;
-        for (uint32_t k = (uint32_t)wave * 8u; k < n; k += (uint32_t)nw * 8u) {
-            const uint32_t kk = k + ((uint32_t)lane >> 3);
-            pl2_rescan_block(S, kk < n ? list[kk] : 0xFFFFFFFFu, bb2, list2, n_list2);
+        for (uint32_t k = tid; k < n; k += nthr) {
+            const uint32_t r = list[k];
+            if (r < S.n_reads && r != 0xFFFFFFFFu) pl2_rescan_read(S, r, bb2, list2, n_list2);
         }
+        PL2_TTRACE(3);
         __syncthreads();
+        PL2_TTRACE(4);
         PL2_STAMP(4);
-        // Blocks of 64 reads: 8 L1 records each, 8 lanes per block.  In the last round (almost always the only one) the blocks
-        // that were NOT touched are reduced at the same time by the first waves — they skip the touched ones, whose new
-        // records come through LDS — so the two levels cost one round trip and one barrier, not two of each.
+        // Blocks of 64 reads with a rescanned read: 8 lanes per block, 8 RB records per lane.  In the last round (almost always the
+        // only one) the blocks that were NOT touched are reduced at the same time by the first waves — they skip the touched
+        // ones, whose new records come through LDS — so the two levels cost one round trip and one barrier, not two of each.
         const uint32_t m = *n_list2;
         const bool fused = !again && m <= PL2_CRES;
         const int nfw = (int)min((uint32_t)(nw / 2), (S.n2 + 255u) >> 8);      // waves of the sweep over all blocks
@@ -368,9 +397,15 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
             for (uint32_t k = (uint32_t)(wave - w_first) * 8u; k < m; k += (uint32_t)w_n * 8u) {
                 const uint32_t kk = k + ((uint32_t)lane >> 3);
                 const bool have = kk < m;
-                const uint32_t i2 = have ? list2[kk] : 0u, i1 = i2 * 8u + ((uint32_t)lane & 7u);
+                const uint32_t i2 = have ? list2[kk] : 0u, r0 = i2 * 64u + ((uint32_t)lane & 7u) * 8u;
                 cf_pl2_rec rec{0ull, 0ull, 0ull, 0u, 0u};
-                if (have && i1 < S.n1) rec = pl2_load(&S.L1[i1]);
+                if (have) {
+                    cf_pl2_rec o[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) o[t] = r0 + (uint32_t)t < S.n_reads ? pl2_load(&S.RB[r0 + (uint32_t)t]) : cf_pl2_rec{0ull, 0ull, 0ull, 0u, 0u};
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) pl2_take(rec, o[t]);
+                }
                 pl2_take(rec, pl2_shfl_xor(rec, 1)); pl2_take(rec, pl2_shfl_xor(rec, 2)); pl2_take(rec, pl2_shfl_xor(rec, 4));
                 if (have && (lane & 7) == 0) {
                     pl2_store(&S.L2[i2], rec);
@@ -400,7 +435,9 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
                 for (int d = 1; d <= 32; d <<= 1) pl2_take(mine, pl2_shfl_xor(mine, d));
                 if (lane == 0) { red[4 * wave] = mine.hi; red[4 * wave + 1] = mine.lo; red[4 * wave + 2] = mine.ext; red[4 * wave + 3] = mine.read; }
             }
+            PL2_TTRACE(5);
             __syncthreads();
+            PL2_TTRACE(6);
             PL2_STAMP(6);
             if (wave == 0) {      // the sweep's wave results and the touched blocks' new records
                 cf_pl2_rec w{0ull, 0ull, 0ull, 0u, 0u};
@@ -423,6 +460,7 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
             }
         }
     }
+    PL2_TTRACE(7);
     PL2_STAMP(7);
 }
 
@@ -476,7 +514,7 @@ cf_pl2_iter_kernel(cf_pl2 S) {
             const cf_pl2_crec seen = pl2_crec_load(S, x);
             int word;
             hit = pl2_contig_decide(S, q, seen, word) ? 1 : 0;
-            if (word >= 0) { owed = S.crec[x].s + word; if (hit) S.C.freq_flag[x] = 1; }
+            if (word >= 0) owed = S.crec[x].s + word;
             else hit = pl2_contig_commit(S, x, q, seen, word) ? 1 : 0;      // a new pair: claimed at once (frequent at once only with a threshold of 1)
         }
         const uint32_t n_post = (uint32_t)__shfl((int)pw, PW - 1, PW);
@@ -493,6 +531,7 @@ cf_pl2_iter_kernel(cf_pl2 S) {
                 if (q >= i2) pl2_hit(S, true, r2, i2, q - i2, nullptr);
             }
         }
+        if (sub == 0) S.C.freq_flag[x] = 1;      // (a store: behind the loads, like the atomics)
     }
     // arrive; the last workgroup runs the tail.  Everything the tail reads from this phase was written by device-scope
     // atomics: once a wave's counter of outstanding memory operations is zero they have been performed.
@@ -622,7 +661,7 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
     S.C.thr = (uint32_t)std::max(1, min_freq); S.C.min_unit = (uint32_t)std::max(0, min_unit);
     S.C.min_inters = (uint32_t)std::max(0, min_inters); S.C.min_prop = (uint32_t)std::max(0, min_prop);
     S.hot_thr = std::max(1u, S.C.min_inters);
-    S.n_reads = (uint32_t)R; S.n1 = (uint32_t)((R + 7) / 8); S.n2 = (uint32_t)((R + 63) / 64); S.n_dirty_words = (uint32_t)((R + 31) / 32);
+    S.n_reads = (uint32_t)R; S.n2 = (uint32_t)((R + 63) / 64); S.n_dirty_words = (uint32_t)((R + 31) / 32);
     int64_t max_u = 1;
     for (int64_t r = 0; r < R; ++r) max_u = std::max(max_u, up[(size_t)r + 1] - up[(size_t)r]);
     S.ib = 1; while ((1ll << S.ib) < max_u) ++S.ib;
@@ -646,12 +685,12 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
     CF_TRY(B.get(&S.rinfo, (size_t)R + 1, "read regions"));
     CF_TRY(B.get(&S.dirty, (size_t)S.n_dirty_words + 1, "dirty bits"));
     CF_TRY(B.get(&S.RB, (size_t)S.n2 * 64 + 64, "read candidates"));
-    CF_TRY(B.get(&S.L1, (size_t)S.n2 * 8 + 8, "candidates per 8 reads"));
     CF_TRY(B.get(&S.L2, (size_t)S.n2 + 1, "candidates per 64 reads"));
     CF_TRY(B.get(&S.win, 1, "winner"));
     CF_TRY(B.get(&S.C.ctl, 8, "control"));
     CF_TRY(B.get(&S.stamps, 16, "phase stamps"));
     CF_TRY(B.get(&S.trace, 4096 * 16 * 8, "wave trace"));
+    CF_TRY(B.get(&S.ttrace, 16 * 8, "tail trace"));
     S.trace_iter = std::getenv("CF_PL2_TRACE") ? (uint32_t)std::atoll(std::getenv("CF_PL2_TRACE")) : 0xFFFFFFFFu;
     CF_TRY(B.get(&S.C.out_read, (size_t)R + 1, "out_read"));
     CF_TRY(B.get(&S.C.out_pos, (size_t)R + 1, "out_pos"));
@@ -671,6 +710,7 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
     CF_HIP(hipMemsetAsync(S.C.ctl, 0, 32, st));
     CF_HIP(hipMemsetAsync(S.stamps, 0, 128, st));
     CF_HIP(hipMemsetAsync(S.trace, 0, (size_t)4096 * 16 * 8 * 8, st));
+    CF_HIP(hipMemsetAsync(S.ttrace, 0, 16 * 8 * 8, st));
     hipLaunchKernelGGL(cf_pl2_ent_kernel, dim3((unsigned)cf_grid_for((R + 1) * 64, 256, n_blocks)), dim3(256), 0, st, (const int64_t*)ctx->d_unit_ptr,
                        (const int64_t*)ctx->d_cloud_ptr, (const int32_t*)ctx->d_entries, R, d_ent, d_read_e);
     CF_KERNEL_CHECK("cf_pl2_ent_kernel");
@@ -682,7 +722,8 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
     }
     CF_KERNEL_CHECK("cf_pl2_add_kernel");
     const size_t lds = pl2_lds_bytes(S.n2);
-    const int grid = ctx->place_grid > 0 ? ctx->place_grid : 32;
+    // (one posting per lane: a read of 1 500 entries with 64-word rows is 1 500 waves = 94 workgroups; 96 / 128 / 192 measured 16.5 / 15.8 / 15.8 us per iteration)
+    const int grid = ctx->place_grid > 0 ? ctx->place_grid : 128;
     const int block = ctx->place_block > 0 ? ctx->place_block : PL2_B;
     std::vector<cf_pl2_rinfo> h_ri((size_t)R + 1);
     for (int stage_cls = 1; stage_cls <= 2; ++stage_cls) {
@@ -742,7 +783,6 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
             CF_HIP(hipMemsetAsync(S.hotbits, 0, ((size_t)n_slots / 32 + 16) * 4, st));
             CF_HIP(hipMemsetAsync(S.dirty, 0, (size_t)S.n_dirty_words * 4, st));
             CF_HIP(hipMemsetAsync(S.RB, 0, (size_t)S.n2 * 64 * sizeof(cf_pl2_rec), st));
-            CF_HIP(hipMemsetAsync(S.L1, 0, (size_t)S.n2 * 8 * sizeof(cf_pl2_rec), st));
             CF_HIP(hipMemsetAsync(S.L2, 0, (size_t)S.n2 * sizeof(cf_pl2_rec), st));
             CF_HIP(hipMemsetAsync(S.win, 0, sizeof(cf_pl2_rec), st));
             CF_HIP(hipMemsetAsync(S.C.ctl, 0, 8, st));         // done = 0, n_out = 0 (error flags kept)
@@ -816,6 +856,15 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
                     for (int k = 0; k < 7; ++k) std::fprintf(stderr, " %6.2f", t[k] ? (double)(t[k] - t0) / 100.0 : -1.0);
                     std::fprintf(stderr, "\n");
                 }
+            unsigned long long tt[16 * 8];
+            CF_HIP(hipMemcpy(tt, S.ttrace, sizeof tt, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "[cf_place2 tail trace] per wave, us since the first wave's entry of the launch: tail entry, dirty list done, barrier, rescans done, barrier, blocks + sweep done, barrier, end\n");
+            for (int wv = 0; wv < 16; ++wv) {
+                if (!tt[wv * 8]) continue;
+                std::fprintf(stderr, "  tail wave %2d:", wv);
+                for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %6.2f", tt[wv * 8 + k] ? (double)(tt[wv * 8 + k] - t0) / 100.0 : -1.0);
+                std::fprintf(stderr, "\n");
+            }
         }
 #endif
         if (h_st[14]) std::fprintf(stderr, "   one round trip at a time (first wave of every workgroup, %llu samples): entry record %.2f us, posting row + contig record %.2f, contig claim / add %.2f\n",

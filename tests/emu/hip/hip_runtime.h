@@ -155,6 +155,7 @@ inline uint2 make_uint2(unsigned x, unsigned y) { uint2 v; v.x = x; v.y = y; ret
 #define cf_lds_base_ok() true
 #define cf_ld_agent(p) (*(p))          /* cf_place2.hip: device-scope loads / the wave's drain of its memory operations */
 #define cf_drain_vm() ((void)0)
+#define cf_barrier_lds() __syncthreads()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)   /* lanes are fibers on one thread: program order is memory order */
 inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(1); }   // lanes of a wave run in lock step on the GPU: rendezvous here
 inline int __all(int pred) {

@@ -178,6 +178,30 @@ def test_stage3_against_reference_golden(engine, report, golden):
     assert any(ln.endswith(" None") for ln in lines)
 
 
+@pytest.mark.parametrize("knobs", [{"place_grid": 3, "place_block": 256}, {"place_row_words": 64, "place_grid": 1}, {"place_slots_per_unit": 1},
+                                   {"place_mode": 1}, {"place_mode": 1, "place_fused": 0}])
+def test_stage3_launch_shapes_and_region_restart(engine, report, golden, knobs):
+    """The greedy placement in other shapes of the round-4 path (cf_place2.hip: odd grids, 4-wave tails, wide posting rows,
+    score regions that start too small: the seed of a stage, then the whole run, start over with larger ones) and on the round
+    1-3 path (cf_place.hip): the reference's read_positions.csv every time."""
+    from centroflye_amd import _host
+    from oracle import ncrf
+    name = "lowcov"
+    g = golden(name)
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.unique_kmers.txt")) as f:
+        gk = np.array(sorted(recruit.encode_kmer(x.strip()) for x in f if x.strip()), dtype=np.uint64)
+    records, alns, lens = ncrf.parse_report(report(name))
+    pk = _host.parse_report(report(name))
+    defaults = {"place_mode": 2, "place_grid": 0, "place_block": 0, "place_row_words": 0, "place_slots_per_unit": 0, "place_fused": 1}
+    try:
+        for k, v in knobs.items():
+            engine.set_param(k, v)
+        pathcheck.check_stage3(engine, pk, records, alns, lens, gk, g["stage3"], expect_lines=g["read_positions"])
+    finally:
+        for k, v in defaults.items():
+            engine.set_param(k, v)
+
+
 def test_unit_kmer_occurrences_and_top_n(engine, report):
     import json
     with open(os.path.join(ROOT, "tests", "golden", "lowcov.unit_kmers.json")) as f:

@@ -10,6 +10,10 @@
     against a full GPU launch here and by bench.py every run;
   * placement (A4 + A8/A9) of 3 000 reads vs the C restatement of the greedy loop: identical lines; and of the 50 000
     reads of configs[2] vs the same C placer (the arg-max scan threaded).
+  * BASELINE configs[3]'s single-GPU-feasible share — 200 000 reads (~4 Gb): A1 (three bucket passes, 18 read-id bits), A2, A3 and
+    one first-k-mer partition of A5/A6 (2.2e7 rare k-mers: the 6-byte table slots with a 7-bit distance field) vs the CPU
+    path (tests/bigparity.py; the same check at 400 000 reads — the region layout — is tools/rank_emulation.py --check,
+    record in profiles/r04_rank_emulation.json).
 The oracle side is pinned on CPU (tests/test_oracle_golden.py).  Reference: distance_based_kmer_recruitment.py:39-149,
 read_placer.py:42-94."""
 import os
@@ -34,6 +38,24 @@ def engine():
     e = Engine(0)
     yield e
     e.close()
+
+
+@pytest.mark.timeout(1500)
+def test_config3_share_200k_reads_count_clouds_and_one_distance_partition_vs_cpu():
+    import json
+    import bigparity
+    pk = synth(200000, 2)
+    assert pk.n_bases > 3.5e9
+    e = Engine(0)
+    try:
+        rec = bigparity.check(e, pk, 21, 64)
+    finally:
+        e.close()
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_200k.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    assert rec["identical"], rec["checks"]
+    assert rec["n_rare"] > (1 << 24) and rec["n_emissions_partition"] > 3e9      # (ranks beyond 24 bits: not the bench's table layout)
 
 
 @pytest.mark.timeout(900)
@@ -194,13 +216,19 @@ def test_placement_3k_reads_vs_c_placer(engine):
     gl = lines_from_placement(pk.ids, *[x.tolist() for x in got])
     assert sum(1 for x in gl if not x.endswith("None")) > 2500
     assert gl == wl
-    # the greedy iteration as three kernels with an event list (round 1) and with other chunk / grid shapes of the fused
-    # kernel: the same placement
-    for knobs in ({"place_fused": 0}, {"place_chunk": 7, "place_grid": 13}, {"place_chunk": 64, "place_grid": 512}):
+    # the default is the round-4 path (per-read score regions, one kernel per greedy iteration).  Other shapes of it — odd grids,
+    # 256-thread workgroups (a 4-wave tail), 32-word posting rows (longer posting lists continue in the CSR arrays), regions that
+    # start too small (the seed of a stage and then the whole run start over with larger ones) — and the round 1-3 path (hash
+    # map + seen set: two kernels per iteration, three with an event list, other chunk / grid shapes): the same placement
+    defaults = {"place_mode": 2, "place_grid": 0, "place_block": 0, "place_row_words": 0, "place_slots_per_unit": 0, "place_fused": 1, "place_chunk": 2}
+    for knobs in ({"place_grid": 13, "place_block": 256}, {"place_row_words": 32, "place_grid": 7}, {"place_row_words": 64}, {"place_slots_per_unit": 2},
+                  {"place_mode": 1}, {"place_mode": 1, "place_fused": 0}, {"place_mode": 1, "place_chunk": 7, "place_grid": 13},
+                  {"place_mode": 1, "place_chunk": 64, "place_grid": 512}):
         try:
             for k, v in knobs.items():
                 engine.set_param(k, v)
             again = engine.place_reads(cls, rank, 2, 2, 10, 3)
         finally:
-            engine.set_param("place_fused", 1); engine.set_param("place_chunk", 2); engine.set_param("place_grid", 0)
+            for k, v in defaults.items():
+                engine.set_param(k, v)
         assert all(np.array_equal(a, b) for a, b in zip(again, got)), knobs
