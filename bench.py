@@ -86,17 +86,33 @@ def cpu_baseline(a, pk, engine):
                            f"({w['n_emissions']} pair emissions, {w['secs']:.1f} s) x {n_parts}; oracle/c/cf_oracle_mt.c OpenMP, {ncpu} threads",
                     emissions_per_s=w["n_emissions"] / w["secs"], secs=dict(count_select=st.secs_count_select, clouds=st.secs_clouds,
                                                                            postings=w["secs_postings"], dist_part=w["secs"]),
-                    sample_matches_gpu=bool(match))
+                    sample_matches_gpu=bool(match),
+                    #  the A5/A6 share of `value` is ONE partition's time x n_parts, not a measured whole run
+                    extrapolated=True, scale_factor=n_parts, measured_whole_run=measured_cpu_whole_run(pk, a))
         n1 = a.cpu_parts_1t
         w1 = st.dist_part(n1 // 3, n1, 0, 2 ** 62, PARAMS["min_d"], PARAMS["max_d"], PARAMS["min_cov"], PARAMS["rel_threshold"], threads=1)
         one = dict(value=pk.n_bases / (n1 * w1["secs"]), unit="bases/s", cores=1, kind="port",
                    sample=f"the same reads, distance stage only (A5/A6; A1-A3 of 1 Gb on one thread do not fit a bounded sample): first k-mers a % {n1} == {n1 // 3} "
                           f"({w1['n_emissions']} pair emissions, {w1['secs']:.1f} s) x {n1}; oracle/c/cf_oracle_mt.c, 1 thread",
-                   emissions_per_s=w1["n_emissions"] / w1["secs"])
+                   emissions_per_s=w1["n_emissions"] / w1["secs"], extrapolated=True, scale_factor=n1)
     out = dict(allc)                 # the headline leg: every core of the host
     out["host_cpus"] = os.cpu_count()
     out["legs"] = [one, allc]
     return out
+
+
+def measured_cpu_whole_run(pk, a):
+    """The committed 64 / 64-partition CPU run of the same reads (profiles/r03_full_parity.json, tools/full_parity.py): total seconds
+    of every partition, when this workload is the one it was taken on — the measured counterpart of the extrapolated leg."""
+    path = os.path.join(ROOT, "profiles", "r03_full_parity.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        fp = json.load(f)
+    wl = fp.get("workload", {})
+    if (wl.get("reads"), wl.get("seed")) != (a.reads, a.seed) or fp.get("n_bases") != pk.n_bases or "cpu_total_secs" not in fp:
+        return None
+    return dict(secs=fp["cpu_total_secs"], bases_per_s=pk.n_bases / fp["cpu_total_secs"], threads=fp.get("host_cpus"), source="profiles/r03_full_parity.json")
 
 
 def pmc_traffic(a, world, stored, out):

@@ -57,6 +57,8 @@ def lib():
     L.cfh_non_acgt.argtypes = [P]
     L.cfh_non_acgt.restype = i32
     L.cfh_exotic_summary.argtypes = [P, i32, i32, C.c_uint32, C.c_uint32, i64, i64, pi64]
+    L.cfh_exotic_list.restype = i64
+    L.cfh_exotic_list.argtypes = [P, i32, i64, i64, C.c_void_p, i64]
     for name in ("cfh_bases", "cfh_read_off", "cfh_ids", "cfh_id_off", "cfh_meta"):
         getattr(L, name).argtypes = [P]
         getattr(L, name).restype = C.c_void_p
@@ -162,6 +164,18 @@ class PackedReads:
         if rc:
             raise HostError(f"cfh_exotic_summary failed ({rc})")
         return dict(n_distinct=out[0], n_read_kmers=out[1], n_kept=out[2], n_rare=out[3], n_blocking=out[4])
+
+    def exotic_list(self, k, read_lo=0, read_hi=None):
+        """int64[n, 5]: per distinct window with a symbol other than upper-case A, C, G, T: two hashes of its text, pres, multi,
+        1 if it holds no lower-case letter — counts that ADD over disjoint read sets (one row per window and shard)."""
+        hi = self.n_reads if read_hi is None else read_hi
+        n = lib().cfh_exotic_list(self._h, int(k), int(read_lo), int(hi), None, 0)
+        if n < 0:
+            raise HostError(f"cfh_exotic_list failed ({n})")
+        rows = np.zeros((n, 5), np.int64)
+        if n and lib().cfh_exotic_list(self._h, int(k), int(read_lo), int(hi), rows.ctypes.data, n) != n:
+            raise HostError("cfh_exotic_list: the window set changed between two calls")
+        return rows
 
     def export_read_units(self, rec, pos, outdir, min_pos=0, max_pos=None, n_threads=0):
         """Per-position read-unit FASTA files (reference eltr_polisher.py:53-97).  rec / pos: record indices and

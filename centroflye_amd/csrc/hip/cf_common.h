@@ -135,6 +135,7 @@ struct cf_ctx {
     void* pin_slot[kCopyThreads] = {nullptr};
     hipStream_t pin_stream[kCopyThreads] = {nullptr};
     size_t pin_bytes = 0;
+    int copy_threads = 8;        // CF_COPY_THREADS (1 .. 16), read once by cf_create
 
     cf_stats stats{};
     cf_times times{};

@@ -1758,7 +1758,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         {
             const unsigned long long a_cap = std::min<unsigned long long>(h_cnt[0], A.edge_cap);      // rows that exist in memory
             std::vector<unsigned long long> hh(2 * (size_t)h_cnt[7]);
-            if (!hh.empty() && hipMemcpy(hh.data(), d_holes, hh.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "edge holes copy"); break; }
+            if (!hh.empty() && (hipMemcpyAsync(hh.data(), d_holes, hh.size() * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) { rc = cf_fail(ctx, -5, "edge holes copy"); break; }
             std::vector<std::pair<unsigned long long, unsigned long long>> holes;      // [start, end) clipped to the rows in memory, sorted
             for (size_t i = 0; i + 1 < hh.size(); i += 2) {
                 const unsigned long long s0 = std::min(hh[i], a_cap), s1 = std::min(hh[i] + hh[i + 1], a_cap);
@@ -1800,6 +1800,8 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                 if (e2 != hipSuccess) { rc = cf_fail(ctx, -5, std::string("edge compaction: ") + hipGetErrorString(e2)); break; }
             }
         }
+        // (the stage ends behind the compaction of the chunked edge output, not behind the kernel)
+        if (hipEventRecord(ctx->ev1, ctx->stream) != hipSuccess || hipEventSynchronize(ctx->ev1) != hipSuccess) { rc = cf_fail(ctx, -5, "cf_dist_edges: final event"); break; }
         (void)hipEventElapsedTime(&ctx->times.dist_ms, ctx->ev0, ctx->ev1);
         (void)hipEventElapsedTime(&ctx->times.postings_ms, ctx->ev0, ctx->ev2);
         (void)hipEventElapsedTime(&ctx->times.dist_kernel_ms, ctx->ev2, ctx->ev3);

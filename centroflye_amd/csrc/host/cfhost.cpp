@@ -1149,13 +1149,12 @@ int cfh_exotic_summary(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32
         return -5;
     }
 }
-static int exotic_summary_impl(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, int64_t read_lo, int64_t read_hi, int64_t out[5]) {
-    if (!p || !out || k < 1) return -22;
+// k-mer (raw window text) -> (reads holding it, reads holding it twice) over reads [read_lo, read_hi)
+static void exotic_windows(const cfh_pack* p, int32_t k, int64_t read_lo, int64_t read_hi, std::unordered_map<std::string, std::pair<uint32_t, uint32_t>>& all, int64_t& n_pairs) {
     const int64_t R = (int64_t)p->read_off.size() - 1;
     if (read_lo < 0) read_lo = 0;
     if (read_hi > R) read_hi = R;
-    std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> all;      // k-mer -> (reads holding it, reads holding it twice)
-    int64_t n_pairs = 0, n_windows = 0;
+    n_pairs = 0;
     std::unordered_map<std::string, uint32_t> mine;
     for (int64_t r = read_lo; r < read_hi; ++r) {
         const int64_t b0 = p->read_off[(size_t)r], len = p->read_off[(size_t)r + 1] - b0;
@@ -1166,7 +1165,7 @@ static int exotic_summary_impl(const cfh_pack* p, int32_t k, int32_t max_nonuniq
             const char c = p->bases[(size_t)(b0 + i)];
             if (c == 'A' || c == 'C' || c == 'G' || c == 'T') continue;
             const int64_t w_lo = std::max<int64_t>(next_w, i - k + 1), w_hi = std::min<int64_t>(i, len - k);
-            for (int64_t w = w_lo; w <= w_hi; ++w) { ++mine[std::string(p->bases.data() + (b0 + w), (size_t)k)]; ++n_windows; }
+            for (int64_t w = w_lo; w <= w_hi; ++w) ++mine[std::string(p->bases.data() + (b0 + w), (size_t)k)];
             if (w_hi + 1 > next_w) next_w = w_hi + 1;
         }
         for (const auto& kv : mine) {
@@ -1176,6 +1175,12 @@ static int exotic_summary_impl(const cfh_pack* p, int32_t k, int32_t max_nonuniq
             ++n_pairs;
         }
     }
+}
+static int exotic_summary_impl(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, int64_t read_lo, int64_t read_hi, int64_t out[5]) {
+    if (!p || !out || k < 1) return -22;
+    std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> all;
+    int64_t n_pairs = 0;
+    exotic_windows(p, k, read_lo, read_hi, all, n_pairs);
     int64_t n_kept = 0, n_rare = 0, n_block = 0;
     for (const auto& kv : all) {
         if (max_nonuniq < 0 || kv.second.second > (uint32_t)max_nonuniq) continue;
@@ -1187,8 +1192,34 @@ static int exotic_summary_impl(const cfh_pack* p, int32_t k, int32_t max_nonuniq
         if (!lower) ++n_block;               // equals its own upper-case form: could match a window of an upper-cased unit (read_kmer_cloud.py:25)
     }
     out[0] = (int64_t)all.size(); out[1] = n_pairs; out[2] = n_kept; out[3] = n_rare; out[4] = n_block;
-    (void)n_windows;
     return 0;
+}
+// The same windows one by one, for a caller that has to ADD the counts of several read shards before it can tell which are rare
+// (centroflye_amd/sharded.py): rows of 5 int64 {h1, h2 (two independent 63-bit hashes of the window's text), pres, multi,
+// 1 if the window holds no lower-case letter}.  Returns the number of distinct windows; fills at most `cap` rows.
+int64_t cfh_exotic_list(const cfh_pack* p, int32_t k, int64_t read_lo, int64_t read_hi, int64_t* rows, int64_t cap) {
+    try {
+        if (!p || k < 1 || (cap > 0 && !rows)) return -22;
+        std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> all;
+        int64_t n_pairs = 0;
+        exotic_windows(p, k, read_lo, read_hi, all, n_pairs);
+        int64_t n = 0;
+        for (const auto& kv : all) {
+            if (n < cap) {
+                uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x9E3779B97F4A7C15ull;
+                bool lower = false;
+                for (unsigned char c : kv.first) { h1 = (h1 ^ c) * 0x100000001b3ull; h2 = (h2 + c) * 0xff51afd7ed558ccdull; h2 ^= h2 >> 29; lower |= (c >= 'a' && c <= 'z'); }
+                int64_t* o = rows + 5 * n;
+                o[0] = (int64_t)(h1 >> 1); o[1] = (int64_t)(h2 >> 1); o[2] = kv.second.first; o[3] = kv.second.second; o[4] = lower ? 0 : 1;
+            }
+            ++n;
+        }
+        return n;
+    } catch (const std::bad_alloc&) {
+        return -12;
+    } catch (...) {
+        return -5;
+    }
 }
 const uint8_t* cfh_bases(const cfh_pack* p) { return (const uint8_t*)p->bases.data(); }
 const int64_t* cfh_read_off(const cfh_pack* p) { return p->read_off.data(); }

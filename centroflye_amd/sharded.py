@@ -96,23 +96,40 @@ class ShardedRecruiter:
         E.count_kmers(k)
         st_local = E.stats()
         lap("count")
+        # Windows with symbols other than upper-case A, C, G, T are skipped on the device; the reference counts them as k-mers of
+        # their own (distance_based_kmer_recruitment.py:47-53).  One of them changes an output only if it is rare over ALL
+        # shards and could match a window of an upper-cased unit: decided on GLOBAL counts, exactly as the single-GPU entry
+        # point decides (check_exotic_windows) — presence and multiplicity of a window add over disjoint read shards — and
+        # before the table exchange is paid for.
+        packed = getattr(self, "packed", None)
+        if packed is not None:
+            rows = packed.exotic_list(k) if packed.non_acgt else np.zeros((0, 5), np.int64)
+            if self.exchange and self.world > 1:
+                n_max = int(self.allreduce([rows.shape[0]], "max")[0])
+                if n_max:
+                    slab = np.zeros((self.world, n_max, 5), np.int64)
+                    slab[self.rank, :rows.shape[0]] = rows
+                    slab[self.rank, :rows.shape[0], 2] += 1      # (pres + 1 marks a used row: a window's pres is never 0)
+                    slab = np.asarray(self.allreduce(slab.reshape(-1), "sum"), np.int64).reshape(self.world * n_max, 5)
+                    rows = slab[slab[:, 2] > 0]
+                    rows[:, 2] -= 1
+                else:
+                    rows = np.zeros((0, 5), np.int64)
+            blocking = 0
+            if rows.shape[0]:
+                _, inv = np.unique(np.stack([rows[:, 0], rows[:, 1]], 1), axis=0, return_inverse=True)
+                inv = np.asarray(inv).reshape(-1)
+                pres = np.bincount(inv, weights=rows[:, 2]).astype(np.int64)
+                multi = np.bincount(inv, weights=rows[:, 3]).astype(np.int64)
+                upper = np.bincount(inv, weights=rows[:, 4]) > 0
+                blocking = int(((multi <= max_nonuniq) & (pres >= lo) & (pres <= hi) & upper).sum())
+            if blocking:
+                raise ValueError(f"{blocking} rare k-mer(s) hold a symbol other than A, C, G, T and no lower-case letter (e.g. N): "
+                                 "the device path has no code for them; mask or drop those reads")
+        lap("exotic_windows")
         if self.exchange:
             self.exchange_bytes = E.exchange_table()
             lap("table_exchange")
-        # windows with symbols other than upper-case A, C, G, T are skipped on the device; the reference counts them as k-mers of
-        # their own: if one of them is rare over ALL shards and could reach an output, refuse (as the single-GPU entry point does).
-        # Presence counts of a raw window add up over shards only when its reads sit on one rank, so the test here is the
-        # conservative one: any rank sees a window of that kind that is not already too frequent on its own shard.
-        packed = getattr(self, "packed", None)
-        if packed is not None:
-            blocking = 0
-            if packed.non_acgt:
-                blocking = packed.exotic_summary(k, max_nonuniq, 1, hi)["n_blocking"]
-            if self.exchange:
-                blocking = int(self.allreduce([blocking], "sum")[0])
-            if blocking:
-                raise ValueError(f"{blocking} k-mer window(s) with a symbol other than A, C, G, T (and no lower-case letter) may be rare: "
-                                 "the device path has no code for them; mask or drop those reads")
         E.select_rare(max_nonuniq, lo, hi)
         st_owner = E.stats()
         n_rare = E.allgather_kmers() if self.exchange else st_owner["n_kmers"]

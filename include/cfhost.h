@@ -83,6 +83,10 @@ int32_t cfh_non_acgt(const cfh_pack* p);     /* 1 if any kept base is outside {A
  * reference), out[4] of those holding no lower-case letter: only these could match a window of an upper-cased unit
  * (read_kmer_cloud.py:25) and reach the outputs; the others cannot.  The caller refuses the input when out[4] > 0. */
 int cfh_exotic_summary(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, int64_t read_lo, int64_t read_hi, int64_t out[5]);
+/* The same windows one by one — rows of 5 int64 {h1, h2: two independent 63-bit hashes of the window's text, pres, multi, 1 if it
+ * holds no lower-case letter} — for a caller that must add the counts of several read shards before it can tell which
+ * windows are rare (centroflye_amd/sharded.py).  Returns the number of distinct windows (or < 0); fills at most cap rows. */
+int64_t cfh_exotic_list(const cfh_pack* p, int32_t k, int64_t read_lo, int64_t read_hi, int64_t* rows, int64_t cap);
 
 /* Flat arrays. */
 const uint8_t* cfh_bases(const cfh_pack* p);     /* ASCII, de-gapped oriented r_al, length N_b */

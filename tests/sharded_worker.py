@@ -35,6 +35,31 @@ def main():
     if len(sys.argv) > 5:
         sr.engine.set_param("comm_self_p2p", int(sys.argv[5]))
     sr.load(pk, 1)
+    if len(sys.argv) > 6:       # exotic windows (symbols other than upper-case ACGT): the decision is made on counts ADDED over the shards
+        mode = sys.argv[6]
+
+        class WithExotic:       # the rank's pack + crafted rows of cfh_exotic_list: {h1, h2, pres, multi, no lower-case letter}
+            def __init__(self, inner, rows):
+                self._inner, self._rows, self.non_acgt = inner, np.array(rows, np.int64).reshape(-1, 5), bool(len(rows))
+
+            def exotic_list(self, k):
+                return self._rows
+
+            def __getattr__(self, name):
+                return getattr(self._inner, name)
+        W, X = [11, 22], [33, 44]
+        rows = {"exotic_block": {0: [W + [2, 0, 1], X + [1, 0, 1]], 1: [W + [3, 1, 1]]},        # W: pres 2 + 3 = 5 in [4, 14], multi 1 <= 3, upper case: rare
+                "exotic_pass": {0: [W + [1, 0, 1]], 1: [X + [2, 0, 1], W + [9, 4, 1]]},          # W: pres 10 but multi 4 > 3; X: pres 2 < 4: nothing rare
+                "exotic_lower": {0: [W + [3, 0, 0]], 1: [W + [3, 0, 0]]}}[mode].get(rank, [])  # rare, but holds a lower-case letter: cannot match an upper-cased unit
+        sr.packed = WithExotic(pk, rows)
+        try:
+            sr.run(edge_cap=200000, **PARAMS)
+            refused = False
+        except ValueError as e:
+            refused = "rare k-mer" in str(e)
+        print("EXOTIC_RESULT " + json.dumps(dict(rank=rank, mode=mode, refused=refused)), flush=True)
+        sr.close()
+        return
     outs = [sr.run(edge_cap=200000, **PARAMS) for _ in range(2)]       # two steps: the local table is rebuilt from the shard
     out = outs[-1]
     edges = sr.engine.edges(out["local_edges"])

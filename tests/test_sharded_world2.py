@@ -37,3 +37,28 @@ def test_sharded_equals_single_process_oracle(emu_lib, tmp_path, world, extra):
     res = json.loads(line[0].split(" ", 1)[1])
     assert res["world"] == world and res["n_rare"] > 100 and res["n_edges"] > 100 and res["exchange_bytes"] > 0
     assert res["rare"] and res["unique"] and res["counters"] and res["edge_checksum"] and res["steps_identical"], res
+
+
+@pytest.mark.parametrize("mode,refused", [("exotic_block", True), ("exotic_pass", False), ("exotic_lower", False)])
+def test_exotic_windows_are_judged_on_counts_added_over_the_shards(emu_lib, tmp_path, mode, refused):
+    """Windows with a symbol other than upper-case A, C, G, T have no 2-bit code; the reference counts them as k-mers of their own
+    (distance_based_kmer_recruitment.py:47-53).  A shard alone cannot tell whether one is rare: presence and multiplicity add over
+    the shards, and every rank takes the same decision as the single-GPU entry point would on the whole read set (round-3
+    advice: a lone N on one shard used to stop the multi-GPU run)."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    rdv = tmp_path / "rdv"
+    rdv.mkdir()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"), str(r), "2", str(rdv), str(1 << 28), "0", mode],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=900))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-3000:] + se[-3000:]
+        res = json.loads([ln for ln in so.splitlines() if ln.startswith("EXOTIC_RESULT ")][0].split(" ", 1)[1])
+        assert res["refused"] == refused, res
