@@ -717,6 +717,10 @@ struct cf_tab_region {
 __device__ __forceinline__ uint32_t cf_rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
 #define DIST_QCAP 320                    /* deferred inserts per wave: fewer than 64 left by the drains before a step + at most 4 x 64 pushed by it */
+#ifndef CF_DIST_PUSH_DUMP
+#define CF_DIST_PUSH_DUMP 1
+#endif
+#define DIST_QSTRIDE (DIST_QCAP + (CF_DIST_PUSH_DUMP ? 64 : 0))      /* + one dump word per lane (see the table sweep's pushes) */
 #define DIST_FULL_BIT 0x80000000u        /* sh[0]: the table is physically full (the pass is void and will be split) */
 
 // general insert: walk buckets from bk; claims the first empty slot with a CAS when the key is absent.
@@ -949,12 +953,12 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
     // every push into a FLAT store followed by a full vmcnt wait (it did: 4 per step in the first version).
     uint32_t* stack = (uint32_t*)(stage + DIST_STAGE_CAP + 8);                   // (P, idx) pairs
     typename Tab::qitem* wq0 = (typename Tab::qitem*)(stack + 2 * DIST_STACK);
-    typename Tab::qitem* wq = wq0 + (size_t)(t >> 6) * DIST_QCAP;
+    typename Tab::qitem* wq = wq0 + (size_t)(t >> 6) * DIST_QSTRIDE;
     // inserts whose FIRST probe did not finish (bucket full, or another key took the slot it wanted): parked here and run
     // through the probe loop 32 .. 64 at a time (round 2 ran that loop inside every drain: most drains went around twice for
     // one or two of their 64 lanes)
-    typename Tab::qitem* ovq = wq0 + (size_t)(nt >> 6) * DIST_QCAP + (size_t)(t >> 6) * DIST_OVQ;
-    uint16_t* hotl = (uint16_t*)(wq0 + (size_t)(nt >> 6) * (DIST_QCAP + DIST_OVQ));      // DIST_HOT_CAP slots whose count reached min_cov during the inserts of the pass
+    typename Tab::qitem* ovq = wq0 + (size_t)(nt >> 6) * DIST_QSTRIDE + (size_t)(t >> 6) * DIST_OVQ;
+    uint16_t* hotl = (uint16_t*)(wq0 + (size_t)(nt >> 6) * (DIST_QSTRIDE + DIST_OVQ));      // DIST_HOT_CAP slots whose count reached min_cov during the inserts of the pass
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0, acc_edges = 0;  // flushed once per workgroup (thread 0)
 #if defined(CF_DIST_STAMPS)
@@ -1215,6 +1219,17 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                                                   // counters in a scratch array picked by index: a scratch load + store per step)
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) cand |= (((live >> u) & (w_[u] >> (hbit_[u] & 31u))) & 1u) << u;
+#if CF_DIST_PUSH_DUMP
+                    // every lane stores: a candidate at its rank in the queue, the others into a dump word of their own behind the
+                    // queue — a select instead of four scalar instructions per entry (skip branch, exec save, skip branch, exec restore)
+#pragma unroll
+                    for (int u = 0; u < DIST_UNROLL; ++u) {
+                        const bool c = ((cand >> u) & 1u) != 0u;
+                        const unsigned long long cm = __ballot(c);
+                        wq[c ? qtail + cf_rank_in(cm) : (uint32_t)DIST_QCAP + (uint32_t)lane] = T.q_of(bb[u], dd_[u], n_buckets);
+                        qtail += (uint32_t)__popcll(cm);
+                    }
+#else
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         const unsigned long long cm = __ballot((cand >> u) & 1u);
@@ -1223,6 +1238,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                             qtail += (uint32_t)__popcll(cm);
                         }
                     }
+#endif
                     return false;
                 });
 #undef CF_DIST_DRAIN
@@ -1662,7 +1678,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (block == 0) block = wgs == 1 ? 1024 : 512;
         // LDS: everything but the table is fixed; dist_slots (the table budget in 8-byte units) defaults to all the rest
         const size_t qitem_bytes = narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem);
-        const size_t lds_fixed = DIST_LDS_HEAD + (size_t)(2 * DIST_STACK) * 4 + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QCAP + DIST_OVQ) * qitem_bytes + DIST_HOT_CAP * 2;
+        const size_t lds_fixed = DIST_LDS_HEAD + (size_t)(2 * DIST_STACK) * 4 + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QSTRIDE + DIST_OVQ) * qitem_bytes + DIST_HOT_CAP * 2;
         const int64_t budget8 = ((int64_t)160 * 1024 / wgs - (int64_t)lds_fixed) / 8;
         if (budget8 < 256) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_wgs leaves no LDS for the table"); break; }
         if (ctx->dist_slots > budget8) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_slots does not fit the 160 KiB LDS next to the work lists"); break; }
@@ -1674,7 +1690,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         const size_t lds = (size_t)A.slots * slot_bytes + lds_fixed;
         A.sketch = (ctx->dist_sketch && min_cov >= 2 && min_cov <= 200) ? 1 : 0;
         A.sk_shift = 32; A.sk_counters = 1;
-        const size_t sk_room = (size_t)A.slots * slot_bytes + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QCAP + DIST_OVQ) * qitem_bytes + 2 * DIST_STACK * 4 + DIST_HOT_CAP * 2;   // table + stage + stack + queues + hot list: all dead while the sketch runs
+        const size_t sk_room = (size_t)A.slots * slot_bytes + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QSTRIDE + DIST_OVQ) * qitem_bytes + 2 * DIST_STACK * 4 + DIST_HOT_CAP * 2;   // table + stage + stack + queues + hot list: all dead while the sketch runs
         while (A.sk_shift > 8 && (size_t)A.sk_counters * 2 <= sk_room) { A.sk_counters *= 2; --A.sk_shift; }
         if (A.sk_counters < 16) A.sketch = 0;
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / block));
