@@ -717,10 +717,13 @@ struct cf_tab_region {
 __device__ __forceinline__ uint32_t cf_rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
 #define DIST_QCAP 320                    /* deferred inserts per wave: fewer than 64 left by the drains before a step + at most 4 x 64 pushed by it */
-#ifndef CF_DIST_PUSH_DUMP
-#define CF_DIST_PUSH_DUMP 1
+#define DIST_QSTRIDE DIST_QCAP
+// Diagnostic builds only (tools/dist_ablation.sh): -DCF_DIST_ABL=n removes the kernel's phases from the END — 1 no filter / rows, 2 also no
+// inserts (the drains drop their queue), 3 no pushes, 4 no table sweep, 5 no sketch arithmetic, 6 no sketch sweep, 7 no clears — so that
+// the instruction counters of successive builds differ by ONE phase (results are wrong, what runs before the cut is unchanged)
+#ifndef CF_DIST_ABL
+#define CF_DIST_ABL 0
 #endif
-#define DIST_QSTRIDE (DIST_QCAP + (CF_DIST_PUSH_DUMP ? 64 : 0))      /* + one dump word per lane (see the table sweep's pushes) */
 #define DIST_FULL_BIT 0x80000000u        /* sh[0]: the table is physically full (the pass is void and will be split) */
 
 // general insert: walk buckets from bk; claims the first empty slot with a CAS when the key is absent.
@@ -1051,12 +1054,15 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         if (A.sketch) {
             {
                 const cf_u32x4 z{0u, 0u, 0u, 0u};
+                if (CF_DIST_ABL < 7) {
                 for (uint32_t s = (uint32_t)t; s < (A.sk_counters >> 4); s += (uint32_t)nt) ((cf_u32x4*)sk)[s] = z;
                 for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = z;
+                }
                 __syncthreads();      // [sketch cleared]
             }
             {
-                cf_dist_sweep<Tab, CF_DIST_PF_A>(A, recs, mine, my0, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
+                if (CF_DIST_ABL < 6) cf_dist_sweep<Tab, CF_DIST_PF_A>(A, recs, mine, my0, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
+                    if (CF_DIST_ABL >= 5) { if (bb[0] == 0xFFFFFFF1u && dd_[0] == 77u) sh[13] = 1u; return false; }      // (the loads stay: their data is looked at)
                     // (entries equal to a are counted too: the sketch may only over-count, and the table sweep drops them)
                     uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL], inc_[DIST_UNROLL];
 #pragma unroll
@@ -1111,7 +1117,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             }
         }
         bool spilled = false;
-        T.clear(slots, (uint32_t)t, (uint32_t)nt);      // (the sketch is dead: its counters lay over the table)
+        if (CF_DIST_ABL < 7) T.clear(slots, (uint32_t)t, (uint32_t)nt);      // (the sketch is dead: its counters lay over the table)
         __syncthreads();      // [table cleared] (and, when every b is marked, the bitmap filled and the passes set up)
         while (true) {
             const uint32_t P = sh[3], pidx = sh[4], pmask = P - 1u;   // P is a power of two; P == 1: every b belongs to the pass
@@ -1184,7 +1190,8 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     __builtin_amdgcn_wave_barrier();                                                          \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                 }
-                cf_dist_sweep<Tab, CF_DIST_PF_B>(A, recs, mine, my0, [&](bool final) {
+                if (CF_DIST_ABL < 4) cf_dist_sweep<Tab, CF_DIST_PF_B>(A, recs, mine, my0, [&](bool final) {
+                    if (CF_DIST_ABL >= 2) { qtail = 0; return; }
                     // a step pushes at most 4 x 64 inserts: the queue is brought below 64 first; after the wave's last step
                     // both lists are emptied (a pass whose table got too full is void and drops them)
                     const uint32_t lim = final ? 1u : 64u;
@@ -1219,17 +1226,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                                                   // counters in a scratch array picked by index: a scratch load + store per step)
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) cand |= (((live >> u) & (w_[u] >> (hbit_[u] & 31u))) & 1u) << u;
-#if CF_DIST_PUSH_DUMP
-                    // every lane stores: a candidate at its rank in the queue, the others into a dump word of their own behind the
-                    // queue — a select instead of four scalar instructions per entry (skip branch, exec save, skip branch, exec restore)
-#pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) {
-                        const bool c = ((cand >> u) & 1u) != 0u;
-                        const unsigned long long cm = __ballot(c);
-                        wq[c ? qtail + cf_rank_in(cm) : (uint32_t)DIST_QCAP + (uint32_t)lane] = T.q_of(bb[u], dd_[u], n_buckets);
-                        qtail += (uint32_t)__popcll(cm);
-                    }
-#else
+                    if (CF_DIST_ABL >= 3) { if (cand == 0xFFu) sh[13] = 1u; return false; }
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         const unsigned long long cm = __ballot((cand >> u) & 1u);
@@ -1238,7 +1235,9 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                             qtail += (uint32_t)__popcll(cm);
                         }
                     }
-#endif
+                    // (measured and not kept: every lane storing — candidates at their rank, the others into a dump word of their own —
+                    // to save the four scalar instructions per entry of the skip branches and the exec save / restore: 325 vs 320 ms,
+                    // the LDS takes four full-wave writes per step instead of 15 % of the lanes)
                     return false;
                 });
 #undef CF_DIST_DRAIN
@@ -1351,7 +1350,8 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     if (late) { T.mark(s); if (pos < A.stage_cap) stage[pos] = (uint16_t)s; }
                 }
             };
-            if (n_hot <= hot_cap) {
+            if (CF_DIST_ABL >= 1) { }
+            else if (n_hot <= hot_cap) {
                 for (uint32_t i0 = 0; i0 < n_hot; i0 += (uint32_t)nt) {
                     const uint32_t i = i0 + (uint32_t)t;
                     bool sel = false;
