@@ -299,8 +299,11 @@ def main():
         n_back = int(min(stored, a.d2h_edge_bytes // 16))
         sr.barrier()
         t1 = time.perf_counter()
+        h2d_s = 0.0
         for _ in range(a.transfer_steps):
+            t_h = time.perf_counter()
             sr.load(pk, 1)
+            h2d_s += time.perf_counter() - t_h
             o2 = sr.run(edge_cap=edge_cap, **PARAMS)
             rare = sr.rare
             mask = sr.unique_mask
@@ -311,7 +314,14 @@ def main():
         el2 = int(sr.allreduce([int(el2 * 1e9)], "max")[0]) / 1e9
         incl = dict(value=n_bases * a.transfer_steps / el2, unit="bases/s", steps=a.transfer_steps, ms_per_step=el2 * 1e3 / a.transfer_steps,
                     h2d_bytes=int(pk.n_bases + 8 * (pk.n_reads + 1) + 24 * E.n_units),
-                    d2h_bytes=int(8 * out["n_rare"] + out["n_rare"] + 16 * n_back), d2h_edges=n_back, edges_stored=int(stored))
+                    d2h_bytes=int(8 * out["n_rare"] + out["n_rare"] + 16 * n_back), d2h_edges=n_back, edges_stored=int(stored),
+                    h2d_gb_per_s=(pk.n_bases + 8 * (pk.n_reads + 1) + 24 * E.n_units) * a.transfer_steps / h2d_s / 1e9,
+                    #  what is NOT in this figure: a complete D2H of every stored edge — the CLI never does it
+                    # (it streams the edges by first-k-mer partition into the text writer, or skips them with --no-edges)
+                    complete_d2h_of_all_edges_bytes=int(16 * stored),
+                    note="the D2H brings back the rare set, the unique mask and d2h_edges edge rows; a complete copy of all stored edges would be "
+                         "complete_d2h_of_all_edges_bytes (about one second at the 55 GB/s this path reaches), which scripts/distance_based_kmer_recruitment.py "
+                         "never needs at once: it writes the edge file partition by partition")
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / max(a.steps, 1)

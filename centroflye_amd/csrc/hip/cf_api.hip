@@ -474,6 +474,8 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
         ctx->dist_stage = (int)value;
     } else if (n == "place_fused") {
         ctx->place_fused = value != 0;
+    } else if (n == "dist_region_bytes") {
+        ctx->dist_region_bytes = value != 0;
     } else if (n == "place_mode") {
         if (value < 1 || value > 2) return cf_fail(ctx, -22, "place_mode out of range (1 = hash map, 2 = per-read regions)");
         ctx->place_mode = (int)value;

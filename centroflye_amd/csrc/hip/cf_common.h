@@ -147,6 +147,7 @@ struct cf_ctx {
     int dist_wide = 0;       // 1 forces the 8-byte-slot table layout (tests)
     int dist_hot_cap = 0;    // > 0: cap on the filter's hot-slot list (tests)
     int dist_regions = 0;    // 1, 2, 4, 8: force the region layout of the 6-byte slots with at least that many regions (tests), 0 = only when the ranks need it
+    int dist_region_bytes = 0; // 1: the region layout streams rank and unit index apart (round 3) even where the 4-byte stream of cf_tab_region26 applies (tests)
     int dist_dbits = 0;      // 5 .. 8: upper limit of the distance-field bits of the 6-byte-slot layout (tests), 0 = as many as the k-mer ranks leave
     int dist_fill_pct = 70;  // a (b,d) table pass is split when more than this share of the slots is in use
     int dist_edge_chunk = 0; // > 0: edge rows a workgroup reserves per global atomic (tests: small chunks cross often), 0 = 8192

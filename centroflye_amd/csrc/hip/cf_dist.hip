@@ -266,7 +266,7 @@ struct cf_tab_wide_t {
 #pragma unroll
         for (int u = 0; u < DIST_UNROLL; ++u) { const uint32_t x = ((ok >> u) & 1u) ? l4 + (uint32_t)u : 0u; out[u] = raw{(uint32_t)pe[x], (uint32_t)pi[x]}; }
     }
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { b = r.b; dd = (r.i - ig) & 0xFFFFu; }   // unit indices are kept mod 65536 and d <= max_d < 65536: the 16-bit difference IS d
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd) { b = r.b; dd = (r.i - ig) & 0xFFFFu; }   // unit indices are kept mod 65536 and d <= max_d < 65536: the 16-bit difference IS d
     // 24 x 24-bit multiplies only (full rate; a 32-bit multiply or a multiply-high is quarter rate): the low 24 bits of b as in
     // the narrow layout, the high 8 bits through a second multiplier
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u + (b >> 24) * 0x85EBCBu; }
@@ -397,7 +397,7 @@ struct cf_tab_narrow_t {
         out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
     }
     // the unit index is kept mod 2^DB and 1 <= d < 2^DB, so the DB-bit difference IS d; no borrow reaches b
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { const uint32_t q = r.v - (ig << kBBits); b = q & kBMask; dd = q >> kBBits; }
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd) { const uint32_t q = r.v - (ig << kBBits); b = q & kBMask; dd = q >> kBBits; }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }               // 24 x 24 -> low 32 bits
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return ((h >> 16) * (n_buckets & 0xFFFFu)) >> 16; }
     static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
@@ -578,7 +578,7 @@ struct cf_tab_region {
 #pragma unroll
         for (int u = 0; u < DIST_UNROLL; ++u) { const uint32_t x = ((ok >> u) & 1u) ? l4 + (uint32_t)u : 0u; out[u] = raw{(uint32_t)pe[x], (uint32_t)pi[x]}; }
     }
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t& b, uint32_t& dd) { b = r.b; dd = (r.i - ig) & 0xFFu; }      // unit indices mod 256, d <= 255
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd) { b = r.b; dd = (r.i - ig) & 0xFFu; }      // unit indices mod 256, d <= 255
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }      // sketch and bitmap: any function of b will do (ranks that differ above bit 23 share counters and bits)
     static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
     __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) const { return (dd << kBBits) | (b >> S); }
@@ -712,6 +712,28 @@ struct cf_tab_region {
     __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&cnt32[s >> 1], 0x8000u << ((s & 1u) * 16u)); }
 };
 
+// The region layout's table behind a FOUR-byte stream, for k-mer sets of 2^24 .. 2^26 ranks whose reads have at most 128 units
+// (8 x 50 000 reads sharded over 8 GPUs sweep a union of 3.7e7 k-mers: tools/rank_emulation.py).  26 bits of rank leave 6 for
+// the unit index — one bit short of the 7 that distances up to 127 need, which is why round 3 streamed rank and index apart
+// (a 16-byte and an 8-byte load per lane and step, a funnel shift, 64-bit queue items: 450 ms against 320 at 50 000 reads).
+// The partner entries of a posting are sorted by unit, so inside an item of 256 entries "d >= 64" begins at ONE position,
+// t64, that the item record carries next to the posting's unit index ([entries : 16 | t64 : 9 | unit index : 7]):
+// d = ((i - ig) mod 64) + 64 * [position >= t64].  Table, keys, regions, filter: cf_tab_region's.
+struct cf_tab_region26 : cf_tab_region {
+    struct raw { uint32_t v; };
+    struct __attribute__((packed, aligned(4))) run4 { uint32_t x, y, z, w; };
+    static __device__ __forceinline__ void load_run(const cf_dist_args& A, uint32_t s_e, uint32_t l4, uint32_t, raw (&out)[DIST_UNROLL]) {
+        static_assert(DIST_UNROLL == 4, "one 16-byte load per lane");
+        const uint32_t* p = A.packed + s_e;         // (padded by DIST_ITEM entries: a run that starts inside the array may be read whole)
+        const run4 r = *(const run4*)(p + l4);
+        out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
+    }
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t igf, uint32_t pos, uint32_t& b, uint32_t& dd) {
+        b = r.v & 0x3FFFFFFu;
+        dd = (((r.v >> 26) - igf) & 63u) + (pos >= (igf >> 7) ? 64u : 0u);      // (igf = t64 << 7 | unit index mod 128: its low 6 bits are all the subtraction keeps)
+    }
+};
+
 
 // lanes below this one whose bit is set in a ballot: v_mbcnt_lo + v_mbcnt_hi (2 instructions; popcount(mask & lanemask_lt) is 4)
 __device__ __forceinline__ uint32_t cf_rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
@@ -820,7 +842,8 @@ cf_items_count_kernel(const int32_t* __restrict__ order, int64_t n_order, const 
 __global__ void __launch_bounds__(256)
 cf_items_fill_kernel(const int32_t* __restrict__ order, int64_t n_order, const int64_t* __restrict__ post_ptr, const int32_t* __restrict__ post,
                      const cf_dist_rec* __restrict__ urange, uint32_t nw, const uint32_t* __restrict__ n_items, const int64_t* __restrict__ ibase,
-                     cf_dist_head* __restrict__ heads, cf_dist_item* __restrict__ items) {
+                     cf_dist_head* __restrict__ heads, cf_dist_item* __restrict__ items, const int64_t* __restrict__ cloud_ptr64, int64_t n_units) {
+    // cloud_ptr64 != null: the 26-bit stream (cf_tab_region26): the item record's low half is [t64 : 9 | unit index mod 128 : 7]
     const int gl = threadIdx.x & 15;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t n_grp = ((int64_t)gridDim.x * blockDim.x) >> 4;
@@ -842,14 +865,21 @@ cf_items_fill_kernel(const int32_t* __restrict__ order, int64_t n_order, const i
         unsigned long long ne = 0;
         for (int64_t q0 = 0; q0 < np_max; q0 += 16) {      // 16 postings at a time, one per lane of the group
             cf_dist_rec r{0, 0u, 0u};
-            if (p0 + q0 + gl < p1) r = urange[post[p0 + q0 + gl]];
+            int64_t e64 = 0;      // (26-bit stream) the first partner entry whose unit lies 64 or more behind the posting's
+            if (p0 + q0 + gl < p1) {
+                const int32_t ux = post[p0 + q0 + gl];
+                r = urange[ux];
+                if (cloud_ptr64) { const int64_t c64 = (int64_t)ux + 64 <= n_units ? cloud_ptr64[(int64_t)ux + 64] : r.e0 + (int64_t)r.len; e64 = min(max(c64, r.e0), r.e0 + (int64_t)r.len); }
+            }
             const uint32_t c = (r.len + DIST_ITEM - 1u) / DIST_ITEM;
             uint32_t inc = c;
             for (int d = 1; d < 16; d <<= 1) { const uint32_t o = __shfl_up(inc, (unsigned)d, 16); if (gl >= d) inc += o; }
             const uint32_t jb = j0 + inc - c;      // the lane's first item
             for (uint32_t x = 0; x < c; ++x) {
                 const uint32_t j = jb + x, off = x * DIST_ITEM;
-                out[(size_t)(j % nw) * per + j / nw] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | (r.ig & 0xFFFFu)};
+                uint32_t low = r.ig & 0xFFFFu;
+                if (cloud_ptr64) low = ((uint32_t)min(max(e64 - (r.e0 + (int64_t)off), (int64_t)0), (int64_t)DIST_ITEM) << 7) | (r.ig & 127u);
+                out[(size_t)(j % nw) * per + j / nw] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | low};
             }
             j0 += (uint32_t)__shfl((int)inc, 15, 16);
             unsigned long long l = r.len;
@@ -912,7 +942,7 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
                 CF_DIST_FETCH(min(j + (uint32_t)D, cnt - 1u), d)
                 uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
 #pragma unroll
-                for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cm & 0xFFFFu, bb[u], dd_[u]);
+                for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cm & 0xFFFFu, l4 + (uint32_t)u, bb[u], dd_[u]);
                 const uint32_t len = cm >> 16;      // entries of the item (wave-uniform); < DIST_ITEM only for the last item of a posting
                 if (body(bb, dd_, len < DIST_ITEM ? ok_of(cm) : (1u << DIST_UNROLL) - 1u, len)) return;
                 ++j;
@@ -1546,7 +1576,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
     uint16_t* d_entry_i = nullptr;
     uint32_t* d_packed = nullptr;
     cf_dist_rec* d_urange = nullptr;
-    bool narrow = false, wide16 = false, region = false;
+    bool narrow = false, wide16 = false, region = false, region26 = false;
     int narrow_db = 8, reg_shift = 0;
     uint8_t* d_entry_i8 = nullptr;
     unsigned long long* d_cnt = nullptr;
@@ -1642,14 +1672,16 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
             region = !wide16 && !ctx->dist_wide && !ctx->dist_dbits && reg_shift <= 3 && ((K - 1) >> reg_shift) <= ((int64_t)1 << 24) - 2 && max_post <= 32767u && K < ((int64_t)1 << 31);
             if (ctx->dist_regions && !region) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_regions does not fit this input"); break; }
             if (region) narrow = false;
+            // up to 2^26 ranks and distances up to 127: the region table behind the 4-byte stream [unit index mod 64 : 6 | rank : 26]
+            region26 = region && !ctx->dist_region_bytes && K <= ((int64_t)1 << 26) && d_need <= 127;
         }
         if (max_post >= (1u << 23) || (wide16 && max_post > 32767u)) { rc = cf_fail(ctx, -34, wide16 ? "cf_dist_edges: distances above 255 with a k-mer of more than 32767 postings" : "cf_dist_edges: a k-mer has more than 2^23 postings"); break; }
-        if (narrow) { if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)v_n_entries + DIST_ITEM, "packed cloud entries"))) break; }
+        if (narrow || region26) { if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)v_n_entries + DIST_ITEM, "packed cloud entries"))) break; }
         else if (region) { if ((rc = cf_alloc_t(ctx, &d_entry_i8, (size_t)v_n_entries + 4 * DIST_ITEM, "entry unit indices (bytes)"))) break; }
         else if ((rc = cf_alloc_t(ctx, &d_entry_i, (size_t)v_n_entries + 1, "entry unit indices"))) break;
         if (U && v_n_entries)
             hipLaunchKernelGGL(cf_entry_unit_kernel, dim3((unsigned)cf_grid_for(U * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               v_cloud_ptr, (const int32_t*)d_rbeg, v_entries, U, d_entry_i, d_packed, 32 - narrow_db, d_entry_i8);
+                               v_cloud_ptr, (const int32_t*)d_rbeg, v_entries, U, d_entry_i, d_packed, region26 ? 26 : 32 - narrow_db, d_entry_i8);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("postings: ") + hipGetErrorString(e)); break; }
@@ -1677,7 +1709,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (wgs == 0) wgs = (block > 512 || per_first > 32768.0) ? 1 : 2;
         if (block == 0) block = wgs == 1 ? 1024 : 512;
         // LDS: everything but the table is fixed; dist_slots (the table budget in 8-byte units) defaults to all the rest
-        const size_t qitem_bytes = narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem);
+        const size_t qitem_bytes = narrow ? sizeof(cf_tab_narrow::qitem) : sizeof(cf_tab_wide::qitem);      // (the region layouts queue 64-bit items, like the wide one)
         const size_t lds_fixed = DIST_LDS_HEAD + (size_t)(2 * DIST_STACK) * 4 + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QSTRIDE + DIST_OVQ) * qitem_bytes + DIST_HOT_CAP * 2;
         const int64_t budget8 = ((int64_t)160 * 1024 / wgs - (int64_t)lds_fixed) / 8;
         if (budget8 < 256) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_wgs leaves no LDS for the table"); break; }
@@ -1724,7 +1756,8 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
             if ((rc = cf_scan_exclusive_u32_to_i64(ctx, d_ialloc, d_ibase, n_order, &n_item_slots))) break;
             if ((rc = cf_alloc_t(ctx, &d_items, (size_t)n_item_slots + 64, "item records"))) break;
             hipLaunchKernelGGL(cf_items_fill_kernel, dim3((unsigned)g_items), dim3(256), 0, ctx->stream, (const int32_t*)d_order, n_order, (const int64_t*)d_post_ptr,
-                               (const int32_t*)d_post, (const cf_dist_rec*)d_urange, nw, (const uint32_t*)d_icnt, (const int64_t*)d_ibase, d_heads, d_items);
+                               (const int32_t*)d_post, (const cf_dist_rec*)d_urange, nw, (const uint32_t*)d_icnt, (const int64_t*)d_ibase, d_heads, d_items,
+                               region26 ? v_cloud_ptr : (const int64_t*)nullptr, U);
         }
         A.heads = d_heads; A.items = d_items;
         const int64_t n_a = n_order;
@@ -1732,7 +1765,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         e = hipGetLastError();
         if (e == hipSuccess) e = hipEventRecord(ctx->ev2, ctx->stream);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("order: ") + hipGetErrorString(e)); break; }
-        void (*kern)(cf_dist_args) = region ? cf_dist_kernel<cf_tab_region> : !narrow ? (wide16 ? cf_dist_kernel<cf_tab_wide16> : cf_dist_kernel<cf_tab_wide>)
+        void (*kern)(cf_dist_args) = region26 ? cf_dist_kernel<cf_tab_region26> : region ? cf_dist_kernel<cf_tab_region> : !narrow ? (wide16 ? cf_dist_kernel<cf_tab_wide16> : cf_dist_kernel<cf_tab_wide>)
                                    : narrow_db == 8 ? cf_dist_kernel<cf_tab_narrow_t<8>> : narrow_db == 7 ? cf_dist_kernel<cf_tab_narrow_t<7>>
                                    : narrow_db == 6 ? cf_dist_kernel<cf_tab_narrow_t<6>> : cf_dist_kernel<cf_tab_narrow_t<5>>;
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -143,11 +143,15 @@ def test_narrow_slots_with_fewer_distance_bits(engine, dbits, n_units):
         engine.set_param("dist_block", 0)
 
 
-@pytest.mark.parametrize("regions", [1, 2, 8])
-def test_region_layout_of_the_six_byte_slots(engine, report, oracle_stage2, regions):
+@pytest.mark.parametrize("regions,stream_bytes", [(1, 0), (2, 0), (8, 0), (2, 1)])
+def test_region_layout_of_the_six_byte_slots(engine, report, oracle_stage2, regions, stream_bytes):
     """Key [d : 8 | rank >> S : 24] in 2^S table regions (k-mer sets of 2^24 .. 2^27 ranks): forced here on small sets, whole
-    stage 2 of a fixture and the synthetic clouds with long posting lists and tiny tables (chains that wrap inside a region)."""
+    stage 2 of a fixture and the synthetic clouds with long posting lists and tiny tables (chains that wrap inside a region).
+    Both streams: four bytes per entry [unit index mod 64 | rank : 26] with the "64 or more" position in the item record
+    (up to 2^26 ranks and 128 units per read: round 4) — the last case below has 250 units and takes the other one — and rank
+    and unit index apart (round 3; stream_bytes = 1 forces it)."""
     engine.set_param("dist_regions", regions)
+    engine.set_param("dist_region_bytes", stream_bytes)
     engine.set_param("dist_block", 128)
     try:
         engine.set_param("dist_slots", 2048)
@@ -158,8 +162,12 @@ def test_region_layout_of_the_six_byte_slots(engine, report, oracle_stage2, regi
         engine.set_param("dist_sketch", 1)
         engine.set_param("dist_slots", 4096)
         pathcheck.check_synthetic_clouds(engine, n_reads=1, n_units=250, cloud=3, n_kmers=25, max_d=240, seed=3)      # distances up to 240
+        # reads of 65 .. 128 units: distances on both sides of 64, items whose "64 or more" position lies inside, before and behind them
+        pathcheck.check_synthetic_clouds(engine, n_reads=3, n_units=128, cloud=5, n_kmers=30, max_d=127, seed=11 + regions)
+        pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=100, cloud=40, n_kmers=300, max_d=99, seed=21 + regions)      # long partner ranges: many items per posting
     finally:
         engine.set_param("dist_regions", 0)
+        engine.set_param("dist_region_bytes", 0)
         engine.set_param("dist_sketch", 1)
         engine.set_param("dist_slots", 0)
         engine.set_param("dist_block", 0)

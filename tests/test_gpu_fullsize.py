@@ -176,7 +176,7 @@ def test_config0_1k_reads_full_stage2_vs_cpu(engine):
     # every layout of the (b, d) table on the same clouds: 6-byte slots with a 7-bit distance field, the region layout
     # (2 and 8 regions), the 8-byte slots, one 1 024-thread workgroup per CU, the filter's in-scan evaluation — the same edges
     # and unique set
-    for knobs in ({"dist_int_thr": 0}, {"dist_dbits": 7}, {"dist_regions": 2}, {"dist_regions": 8}, {"dist_wide": 1}, {"dist_wgs": 1, "dist_block": 1024}, {"dist_hot_cap": 5}):
+    for knobs in ({"dist_int_thr": 0}, {"dist_dbits": 7}, {"dist_regions": 2}, {"dist_regions": 8}, {"dist_regions": 2, "dist_region_bytes": 1}, {"dist_wide": 1}, {"dist_wgs": 1, "dist_block": 1024}, {"dist_hot_cap": 5}):
         try:
             for name, v in knobs.items():
                 engine.set_param(name, v)

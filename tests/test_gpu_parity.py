@@ -139,12 +139,14 @@ def test_kmer_sets_beyond_2_pow_24_keep_the_six_byte_slots(engine):
     # long reads (200 units: distances need 8 bits) with 2^24 + 40 and 2^26 + 40 k-mers: the region layout (2 and 8 regions)
     pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=200, cloud=4, n_kmers=40, seed=9, kmer_base=1 << 24)
     pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=200, cloud=4, n_kmers=40, seed=10, kmer_base=1 << 26)
-    for regions in (1, 4):
-        engine.set_param("dist_regions", regions)
+    for regions, stream_bytes in ((1, 0), (4, 0), (4, 1)):      # (the 4-byte stream of round 4; rank and unit index apart)
+        engine.set_param("dist_regions", regions); engine.set_param("dist_region_bytes", stream_bytes)
         try:
             pathcheck.check_synthetic_clouds(engine, n_reads=3, n_units=100, cloud=4, n_kmers=50, seed=regions)
+            pathcheck.check_synthetic_clouds(engine, n_reads=3, n_units=128, cloud=5, n_kmers=30, max_d=127, seed=11 + regions)
+            pathcheck.check_synthetic_clouds(engine, n_reads=2, n_units=100, cloud=40, n_kmers=300, max_d=99, seed=21 + regions)
         finally:
-            engine.set_param("dist_regions", 0)
+            engine.set_param("dist_regions", 0); engine.set_param("dist_region_bytes", 0)
     for dbits in (5, 6, 7):
         engine.set_param("dist_dbits", dbits)
         try:
