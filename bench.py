@@ -117,7 +117,9 @@ def measured_cpu_whole_run(pk, a):
 
 def pmc_traffic(a, world, stored, out):
     """HBM-side bytes per launch of the dominant kernel from the committed PMC passes — only for the configuration they were taken on."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_dist_kernel.json")
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_dist_kernel.json")))      # the latest round's passes
+    path = cands[-1] if cands else ""
     if world != 1 or a.reads != 50000 or a.seed != 2 or stored != out["local_edges"] or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -350,7 +352,7 @@ def main():
             "value_incl_transfers": incl,
             "roofline": {"bound": "hbm", "kernel": "cf_dist_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a, world, stored, out),
-                         "traffic_note": "HBM-side bytes of ONE launch from the committed rocprofv3 --pmc passes of this configuration (profiles/r03_pmc_dist_kernel.json: "
+                         "traffic_note": "HBM-side bytes of ONE launch from the committed rocprofv3 --pmc passes of this configuration (profiles/r0N_pmc_dist_kernel.json, the latest round's: "
                                          "(2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate passes, tools/profile_round.sh); counters cannot be read inside a timed run; null when the workload differs",
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": mean_k_ms,
                          "pair_emissions_per_s": out["local_emissions"] / (mean_k_ms * 1e-3) if mean_k_ms else 0.0,

@@ -54,7 +54,7 @@
 
 #define PL2_B 1024          // threads per workgroup of the iteration kernel (the tail wants 16 waves)
 #define PL2_LIST 2048       // dirty blocks of 8 reads per round of the tail
-#define PL2_CRES 1024       // touched blocks of 64 reads whose new records go through LDS to the final reduction
+#define PL2_CRES 512        // touched blocks of 64 reads whose new records go through LDS to the final reduction
 
 // Uw = 32-bit words of a slot's cell row: two 16-bit counters per word, rounded up to a multiple of 4 (rows are read 16 bytes at a time)
 struct alignas(16) cf_pl2_rinfo { unsigned long long slot_base, cell_base; uint32_t hmask, Uw, anchor_off1, anchor_slot; };
@@ -343,8 +343,8 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
     uint32_t* n_list = lds32; uint32_t* more = lds32 + 1; uint32_t* n_list2 = lds32 + 2;
     uint32_t* list = lds32 + 4;
     uint32_t* list2 = list + PL2_LIST;
-    unsigned long long* red = (unsigned long long*)(list2 + PL2_LIST);      // 16 waves x {hi, lo, ext, read}
-    unsigned long long* cres = red + 4 * 16;                                 // new records of the touched blocks of 64 (fused last round)
+    unsigned long long* red = (unsigned long long*)(list2 + PL2_LIST);      // the sweeping lanes' bests: up to 8 waves x 64 lanes x {hi, lo, ext, read}
+    unsigned long long* cres = red + 4 * 512;                                 // new records of the touched blocks of 64 (fused last round)
     uint32_t* bb2 = (uint32_t*)(cres + 4 * PL2_CRES);
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
@@ -432,16 +432,18 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
                     const cf_pl2_rec o3 = k3 ? pl2_load(&S.L2[b3]) : none;
                     pl2_take(mine, o0); pl2_take(mine, o1); pl2_take(mine, o2); pl2_take(mine, o3);
                 }
-                for (int d = 1; d <= 32; d <<= 1) pl2_take(mine, pl2_shfl_xor(mine, d));
-                if (lane == 0) { red[4 * wave] = mine.hi; red[4 * wave + 1] = mine.lo; red[4 * wave + 2] = mine.ext; red[4 * wave + 3] = mine.read; }
+                // every lane's best goes to LDS as it is: ONE reduction over the wave's lanes, in the last wave standing, instead of one
+                // per sweeping wave and another over their results (a 64-lane reduction of a record is 42 lane permutes)
+                const uint32_t at = 4u * (uint32_t)(wave * 64 + lane);
+                red[at] = mine.hi; red[at + 1] = mine.lo; red[at + 2] = mine.ext; red[at + 3] = mine.read;
             }
             PL2_TTRACE(5);
             __syncthreads();
             PL2_TTRACE(6);
             PL2_STAMP(6);
-            if (wave == 0) {      // the sweep's wave results and the touched blocks' new records
+            if (wave == 0) {      // the sweeping lanes' results and the touched blocks' new records
                 cf_pl2_rec w{0ull, 0ull, 0ull, 0u, 0u};
-                if (lane < nfw) w = cf_pl2_rec{red[4 * lane], red[4 * lane + 1], red[4 * lane + 2], (uint32_t)red[4 * lane + 3], 0u};
+                for (int k = 0; k < nfw; ++k) { const uint32_t at = 4u * (uint32_t)(k * 64 + lane); pl2_take(w, cf_pl2_rec{red[at], red[at + 1], red[at + 2], (uint32_t)red[at + 3], 0u}); }
                 if (fused)
                     for (uint32_t k = (uint32_t)lane; k < m; k += 64u) pl2_take(w, cf_pl2_rec{cres[4 * k], cres[4 * k + 1], cres[4 * k + 2], (uint32_t)cres[4 * k + 3], 0u});
                 for (int d = 1; d <= 32; d <<= 1) pl2_take(w, pl2_shfl_xor(w, d));
@@ -464,7 +466,7 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
     PL2_STAMP(7);
 }
 
-static size_t pl2_lds_bytes(uint32_t n2) { return (16 + (size_t)PL2_LIST * 8 + 16 * 32 + (size_t)PL2_CRES * 32 + (size_t)((n2 + 31) / 32) * 4 + 16); }
+static size_t pl2_lds_bytes(uint32_t n2) { return (16 + (size_t)PL2_LIST * 8 + 512 * 32 + (size_t)PL2_CRES * 32 + (size_t)((n2 + 31) / 32) * 4 + 16); }
 
 __global__ void __launch_bounds__(PL2_B)
 cf_pl2_tail_kernel(cf_pl2 S) {

@@ -45,6 +45,16 @@ if dist:
     out["counters"] = {c: v["sum"] for c, v in sorted(per_kernel[dist[0]].items())}
     out["dispatches"] = max(v["launches"] for v in per_kernel[dist[0]].values())
     out["traffic_bytes_per_launch"] = traffic(per_kernel[dist[0]])
+    # the ratios that DESIGN.md and profiles/README.md quote, written here so that they cannot drift from the counters
+    line = os.path.join(dst, f"{tag}_bench_line.json")
+    if os.path.exists(line):
+        bl = json.loads(open(line).read().strip().splitlines()[-1])
+        E = bl["counters"]["n_emissions"]
+        c = out["counters"]
+        out["per_pair_emission"] = {"n_emissions": E, "SQ_INSTS_VALU": c.get("SQ_INSTS_VALU", 0) / E, "SQ_INSTS_SALU": c.get("SQ_INSTS_SALU", 0) / E,
+                                    "SQ_INSTS_LDS": c.get("SQ_INSTS_LDS", 0) / E if "SQ_INSTS_LDS" in c else None}
+        out["traffic_over_algorithmic"] = out["traffic_bytes_per_launch"] / bl["roofline"]["algorithmic_bytes_per_launch"] if out["traffic_bytes_per_launch"] else None
+        out["traffic_gb_per_launch"] = out["traffic_bytes_per_launch"] / 1e9 if out["traffic_bytes_per_launch"] else None
 json.dump(out, open(os.path.join(dst, f"{tag}_pmc_dist_kernel.json"), "w"), indent=1)
 others = {k: dict(sorted(v.items()), traffic_bytes=traffic(v)) for k, v in sorted(per_kernel.items()) if k not in dist}
 json.dump({"workload": workload, "notes": notes, "kernels": others}, open(os.path.join(dst, f"{tag}_pmc_other_kernels.json"), "w"), indent=1)

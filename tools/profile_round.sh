@@ -4,7 +4,7 @@
 # Results land under gpurun_out/prof_<tag>/ ; tools/pmc_summary.py turns them into profiles/<tag>_*.
 # usage: bash tools/profile_round.sh <tag>
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
