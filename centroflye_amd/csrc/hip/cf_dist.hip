@@ -286,6 +286,9 @@ struct cf_tab_wide_t {
     // counts one more occurrence of the key in slot i of bucket bk; returns its count after the add
     __device__ __forceinline__ uint32_t add(uint32_t bk, int i) const { return ((uint32_t)atomicAdd(&tab[4 * bk + i], 1ull) & kCntMask) + 1u; }
     static constexpr uint32_t kSlotsPerBucket = 4;
+    static constexpr bool kProbe1 = false;      // (64-bit slots: the drain keeps its match / claim branches)
+    __device__ __forceinline__ void probe1(uint32_t, uint32_t, uint32_t, uint32_t&, uint32_t&, uint32_t&) const {}
+    __device__ __forceinline__ uint32_t key_of(uint32_t, uint32_t) const { return 0u; }
     // claim slot i of bucket bk for (b, dd): 0 = claimed (count 1), 1 = the same key got there first (counted), 2 = another key
     __device__ __forceinline__ unsigned long long claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const {
         return atomicCAS(&tab[4 * bk + i], 0ull, ((unsigned long long)b << 32) | ((unsigned long long)dd << kDShift) | 1ull);
@@ -437,6 +440,29 @@ struct cf_tab_narrow_t {
         if (old == kEmpty) return 0;                        // claimed: the zero count field already means "seen once"
         if (old == key_of(b, dd)) { cnt = add(bk, i); return 1; }  // the same key was claimed by someone else: count it
         return 2;
+    }
+    // ONE probe of the key's home bucket in straight-line code (the drain of the table sweep): match -> count it; no match and a
+    // free slot -> claim the first one (the zero count field of a fresh slot already means "seen once"; the same key claimed by
+    // another lane a moment ago counts as a match); anything else -> park.  Flags are integers made by selects, the count add is
+    // issued by every lane (adding 0 where there is nothing to count): as nested ifs that set booleans on divergent paths the
+    // drain compiled to ~115 scalar instructions of exec-mask bookkeeping per 64 inserts (profiles/r04_dist_phase_insts.md:
+    // the inserts were 0.27 of the kernel's 0.58 scalar instructions per pair).
+    static constexpr bool kProbe1 = true;
+    __device__ __forceinline__ void probe1(uint32_t bk, uint32_t key, uint32_t min_cov, uint32_t& made, uint32_t& park, uint32_t& hot_slot) const {
+        const bucket k = read(bk);
+        const int mt = first_equal(k, key), em = first_equal(k, kEmpty);
+        const bool claim = mt < 0 && em >= 0;
+        const uint32_t s = PB * bk + (uint32_t)(mt >= 0 ? mt : (em >= 0 ? em : 0));
+        uint32_t old = key;
+        if (claim) old = atomicCAS(&keys[s], kEmpty, key);
+        const bool matched = mt >= 0 || (claim && old == key);
+        const bool fresh = claim && old == kEmpty;
+        const uint32_t sh_ = (s & 1u) * 16u;
+        const uint32_t was = atomicAdd(&cnt32[s >> 1], matched ? 1u << sh_ : 0u);
+        const uint32_t cnt = matched ? ((was >> sh_) & 0x7FFFu) + 2u : 1u;
+        made = fresh ? 1u : 0u;
+        park = (matched || fresh) ? 0u : 1u;
+        hot_slot = ((matched || fresh) && cnt == min_cov) ? s : 0xFFFFFFFFu;
     }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
         const uint32_t q = keys[s];
@@ -628,6 +654,23 @@ struct cf_tab_region {
         if (old == key_of(b, dd)) { cnt = add(bk, i); return 1; }
         return 2;
     }
+    static constexpr bool kProbe1 = true;      // (cf_tab_narrow_t::probe1: the drain's one probe in straight-line code)
+    __device__ __forceinline__ void probe1(uint32_t bk, uint32_t key, uint32_t min_cov, uint32_t& made, uint32_t& park, uint32_t& hot_slot) const {
+        const bucket k = read(bk);
+        const int mt = first_equal(k, key), em = first_equal(k, kEmpty);
+        const bool claim = mt < 0 && em >= 0;
+        const uint32_t s = PB * bk + (uint32_t)(mt >= 0 ? mt : (em >= 0 ? em : 0));
+        uint32_t old = key;
+        if (claim) old = atomicCAS(&keys[s], kEmpty, key);
+        const bool matched = mt >= 0 || (claim && old == key);
+        const bool fresh = claim && old == kEmpty;
+        const uint32_t sh_ = (s & 1u) * 16u;
+        const uint32_t was = atomicAdd(&cnt32[s >> 1], matched ? 1u << sh_ : 0u);
+        const uint32_t cnt = matched ? ((was >> sh_) & 0x7FFFu) + 2u : 1u;
+        made = fresh ? 1u : 0u;
+        park = (matched || fresh) ? 0u : 1u;
+        hot_slot = ((matched || fresh) && cnt == min_cov) ? s : 0xFFFFFFFFu;
+    }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
         const uint32_t q = keys[s];
         b = b_of(q, s / (uint32_t)PB); dd = q >> kBBits; cnt = ((cnt32[s >> 1] >> ((s & 1u) * 16u)) & 0x7FFFu) + 1u;
@@ -745,6 +788,9 @@ __device__ __forceinline__ uint32_t cf_rank_in(unsigned long long m) { return __
 // the instruction counters of successive builds differ by ONE phase (results are wrong, what runs before the cut is unchanged)
 #ifndef CF_DIST_ABL
 #define CF_DIST_ABL 0
+#endif
+#ifndef CF_DIST_OLD_DRAIN
+#define CF_DIST_OLD_DRAIN 0      /* 1: the drain's probe as nested match / claim branches (rounds 2-3), for A/B runs */
 #endif
 #define DIST_FULL_BIT 0x80000000u        /* sh[0]: the table is physically full (the pass is void and will be split) */
 
@@ -1195,6 +1241,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                         uint32_t xb, xd, xk;                                                                  \
                         it_ = wq[qtail + (uint32_t)lane];                                                     \
                         T.q_take(it_, n_buckets, xb, xd, xk);                                                 \
+                        if constexpr (Tab::kProbe1 && !CF_DIST_OLD_DRAIN) { T.probe1(xk, T.key_of(xb, xd), A.min_cov, made_, park_, hot_); } else { \
                         const typename Tab::bucket k_ = T.read(xk);                                           \
                         const int mt_ = T.match(k_, xb, xd);                                                  \
                         if (mt_ >= 0) { if (T.add(xk, mt_) == A.min_cov) hot_ = Tab::kSlotsPerBucket * xk + (uint32_t)mt_; } \
@@ -1207,6 +1254,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                                 made_ = (uint32_t)(st_ == 0); park_ = (uint32_t)(st_ == 2);                  \
                                 if (st_ != 2 && cn_ == A.min_cov) hot_ = Tab::kSlotsPerBucket * xk + (uint32_t)em_; \
                             }                                                                                 \
+                        }                                                                                     \
                         }                                                                                     \
                     }                                                                                         \
                     const uint32_t new_ = (uint32_t)__popcll(__ballot(made_ != 0u));                          \
