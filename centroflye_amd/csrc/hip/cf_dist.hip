@@ -789,6 +789,9 @@ __device__ __forceinline__ uint32_t cf_rank_in(unsigned long long m) { return __
 #ifndef CF_DIST_ABL
 #define CF_DIST_ABL 0
 #endif
+#ifndef CF_DIST_PUSH_NOBR
+#define CF_DIST_PUSH_NOBR 0
+#endif
 #ifndef CF_DIST_OLD_DRAIN
 #define CF_DIST_OLD_DRAIN 0      /* 1: the drain's probe as nested match / claim branches (rounds 2-3), for A/B runs */
 #endif
@@ -1308,10 +1311,15 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         const unsigned long long cm = __ballot((cand >> u) & 1u);
+#if CF_DIST_PUSH_NOBR
+                        if ((cand >> u) & 1u) wq[qtail + cf_rank_in(cm)] = T.q_of(bb[u], dd_[u], n_buckets);
+                        qtail += (uint32_t)__popcll(cm);
+#else
                         if (cm) {
                             if ((cand >> u) & 1u) wq[qtail + cf_rank_in(cm)] = T.q_of(bb[u], dd_[u], n_buckets);
                             qtail += (uint32_t)__popcll(cm);
                         }
+#endif
                     }
                     // (measured and not kept: every lane storing — candidates at their rank, the others into a dump word of their own —
                     // to save the four scalar instructions per entry of the skip branches and the exec save / restore: 325 vs 320 ms,

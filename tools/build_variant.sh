@@ -12,5 +12,5 @@ out="$root/centroflye_amd/build_variants"; mkdir -p "$out"
 srcs=()
 for f in "$root"/centroflye_amd/csrc/hip/*.hip; do [[ "$(basename "$f")" == cf_dist.hip ]] || srcs+=("$f"); done
 srcs+=("$dist")
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -mllvm -amdgpu-sched-strategy=max-ilp "${flags[@]}" -I"$root/include" -I"$root/centroflye_amd/csrc/hip" -shared -o "$out/$name.so" "${srcs[@]}" -ldl
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-atomic-optimizer-strategy=None "${flags[@]}" -I"$root/include" -I"$root/centroflye_amd/csrc/hip" -shared -o "$out/$name.so" "${srcs[@]}" -ldl
 echo "$out/$name.so"
