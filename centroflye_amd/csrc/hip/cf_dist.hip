@@ -266,7 +266,8 @@ struct cf_tab_wide_t {
 #pragma unroll
         for (int u = 0; u < DIST_UNROLL; ++u) { const uint32_t x = ((ok >> u) & 1u) ? l4 + (uint32_t)u : 0u; out[u] = raw{(uint32_t)pe[x], (uint32_t)pi[x]}; }
     }
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd) { b = r.b; dd = (r.i - ig) & 0xFFFFu; }   // unit indices are kept mod 65536 and d <= max_d < 65536: the 16-bit difference IS d
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd, uint32_t& qk) { b = r.b; dd = (r.i - ig) & 0xFFFFu; qk = 0u; }
+    __device__ __forceinline__ qitem q_push(uint32_t b, uint32_t dd, uint32_t, uint32_t n_buckets) const { return q_of(b, dd, n_buckets); }   // unit indices are kept mod 65536 and d <= max_d < 65536: the 16-bit difference IS d
     // 24 x 24-bit multiplies only (full rate; a 32-bit multiply or a multiply-high is quarter rate): the low 24 bits of b as in
     // the narrow layout, the high 8 bits through a second multiplier
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u + (b >> 24) * 0x85EBCBu; }
@@ -400,7 +401,9 @@ struct cf_tab_narrow_t {
         out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
     }
     // the unit index is kept mod 2^DB and 1 <= d < 2^DB, so the DB-bit difference IS d; no borrow reaches b
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd) { const uint32_t q = r.v - (ig << kBBits); b = q & kBMask; dd = q >> kBBits; }
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd, uint32_t& qk) { const uint32_t q = r.v - (ig << kBBits); b = q & kBMask; dd = q >> kBBits; qk = q; }
+    // (the queued insert IS the difference decode() made: [d | b]; rebuilt from b and d it cost three more instructions per entry)
+    __device__ __forceinline__ qitem q_push(uint32_t, uint32_t, uint32_t qk, uint32_t) const { return qk; }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }               // 24 x 24 -> low 32 bits
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return ((h >> 16) * (n_buckets & 0xFFFFu)) >> 16; }
     static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
@@ -604,7 +607,8 @@ struct cf_tab_region {
 #pragma unroll
         for (int u = 0; u < DIST_UNROLL; ++u) { const uint32_t x = ((ok >> u) & 1u) ? l4 + (uint32_t)u : 0u; out[u] = raw{(uint32_t)pe[x], (uint32_t)pi[x]}; }
     }
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd) { b = r.b; dd = (r.i - ig) & 0xFFu; }      // unit indices mod 256, d <= 255
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd, uint32_t& qk) { b = r.b; dd = (r.i - ig) & 0xFFu; qk = 0u; }      // unit indices mod 256, d <= 255
+    __device__ __forceinline__ qitem q_push(uint32_t b, uint32_t dd, uint32_t, uint32_t n_buckets) const { return q_of(b, dd, n_buckets); }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }      // sketch and bitmap: any function of b will do (ranks that differ above bit 23 share counters and bits)
     static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
     __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) const { return (dd << kBBits) | (b >> S); }
@@ -771,7 +775,8 @@ struct cf_tab_region26 : cf_tab_region {
         const run4 r = *(const run4*)(p + l4);
         out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
     }
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t igf, uint32_t pos, uint32_t& b, uint32_t& dd) {
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t igf, uint32_t pos, uint32_t& b, uint32_t& dd, uint32_t& qk) {
+        qk = 0u;
         b = r.v & 0x3FFFFFFu;
         dd = (((r.v >> 26) - igf) & 63u) + (pos >= (igf >> 7) ? 64u : 0u);      // (igf = t64 << 7 | unit index mod 128: its low 6 bits are all the subtraction keeps)
     }
@@ -989,11 +994,11 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
                 // loads in flight differs between the paths into the loop head and the compiler waits for ALL of them there
                 // (s_waitcnt vmcnt(0) instead of vmcnt(D - 1))
                 CF_DIST_FETCH(min(j + (uint32_t)D, cnt - 1u), d)
-                uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL];
+                uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL], qq_[DIST_UNROLL];
 #pragma unroll
-                for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cm & 0xFFFFu, l4 + (uint32_t)u, bb[u], dd_[u]);
+                for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cm & 0xFFFFu, l4 + (uint32_t)u, bb[u], dd_[u], qq_[u]);
                 const uint32_t len = cm >> 16;      // entries of the item (wave-uniform); < DIST_ITEM only for the last item of a posting
-                if (body(bb, dd_, len < DIST_ITEM ? ok_of(cm) : (1u << DIST_UNROLL) - 1u, len)) return;
+                if (body(bb, dd_, qq_, len < DIST_ITEM ? ok_of(cm) : (1u << DIST_UNROLL) - 1u, len)) return;
                 ++j;
             }
         }
@@ -1140,7 +1145,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 __syncthreads();      // [sketch cleared]
             }
             {
-                if (CF_DIST_ABL < 6) cf_dist_sweep<Tab, CF_DIST_PF_A>(A, recs, mine, my0, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
+                if (CF_DIST_ABL < 6) cf_dist_sweep<Tab, CF_DIST_PF_A>(A, recs, mine, my0, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], const uint32_t (&qq_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
                     if (CF_DIST_ABL >= 5) { if (bb[0] == 0xFFFFFFF1u && dd_[0] == 77u) sh[13] = 1u; return false; }      // (the loads stay: their data is looked at)
                     // (entries equal to a are counted too: the sketch may only over-count, and the table sweep drops them)
                     uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL], inc_[DIST_UNROLL];
@@ -1283,7 +1288,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                         else if (!(final && otail > 0u)) break;
                         if (otail >= 32u || (final && qtail == 0u && otail > 0u)) { CF_DIST_OVERFLOW(min(otail, 64u)) }
                     }
-                }, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
+                }, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], const uint32_t (&qq_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
                     if (too_full) return true;     // (wave-uniform, set by the drains: the fill only changes there) the pass will be split
                     // Entries equal to a itself are NOT told apart here (round 2 spent 13 vector instructions per step on it): they are
                     // rare (a k-mer twice in one read), the filter never selects a slot whose b is a, and the emission count of the
@@ -1312,11 +1317,11 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         const unsigned long long cm = __ballot((cand >> u) & 1u);
 #if CF_DIST_PUSH_NOBR
-                        if ((cand >> u) & 1u) wq[qtail + cf_rank_in(cm)] = T.q_of(bb[u], dd_[u], n_buckets);
+                        if ((cand >> u) & 1u) wq[qtail + cf_rank_in(cm)] = T.q_push(bb[u], dd_[u], qq_[u], n_buckets);
                         qtail += (uint32_t)__popcll(cm);
 #else
                         if (cm) {
-                            if ((cand >> u) & 1u) wq[qtail + cf_rank_in(cm)] = T.q_of(bb[u], dd_[u], n_buckets);
+                            if ((cand >> u) & 1u) wq[qtail + cf_rank_in(cm)] = T.q_push(bb[u], dd_[u], qq_[u], n_buckets);
                             qtail += (uint32_t)__popcll(cm);
                         }
 #endif
