@@ -273,6 +273,7 @@ struct cf_tab_wide_t {
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u + (b >> 24) * 0x85EBCBu; }
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return ((h >> 16) * (n_buckets & 0xFFFFu)) >> 16; }
     static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
+    static __device__ __forceinline__ uint32_t sk_hash(uint32_t b, uint32_t dd, uint32_t) { return hash(b) + dd * 0x5BD1E9u; }      // the sketch's counter of the pair (b, d): its high bits
     __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u64x2*)&tab[4 * bk], *(const cf_u64x2*)&tab[4 * bk + 2]}; }
     static __device__ __forceinline__ bool is(unsigned long long v, uint32_t b, uint32_t dd) { return (uint32_t)(v >> 32) == b && ((uint32_t)v >> kDShift) == dd; }
     // branch-free: one bit per slot, then find-first-set (nested ?: chains compile to a cascade of exec-mask branches)
@@ -407,6 +408,9 @@ struct cf_tab_narrow_t {
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }               // 24 x 24 -> low 32 bits
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return ((h >> 16) * (n_buckets & 0xFFFFu)) >> 16; }
     static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
+    // the sketch's counter of the pair (b, d), from the decoded difference q = [d | b] itself: one multiply-add (b's low 24 bits times the
+    // constant, plus q: d lands in the counter index's high bits, so the pairs of one b never share a counter)
+    static __device__ __forceinline__ uint32_t sk_hash(uint32_t, uint32_t, uint32_t qk) { return (qk & 0xFFFFFFu) * 0x9E3779u + qk; }
     __device__ __forceinline__ bucket read(uint32_t bk) const {
         bucket r;
 #pragma unroll
@@ -611,6 +615,7 @@ struct cf_tab_region {
     __device__ __forceinline__ qitem q_push(uint32_t b, uint32_t dd, uint32_t, uint32_t n_buckets) const { return q_of(b, dd, n_buckets); }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }      // sketch and bitmap: any function of b will do (ranks that differ above bit 23 share counters and bits)
     static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
+    static __device__ __forceinline__ uint32_t sk_hash(uint32_t b, uint32_t dd, uint32_t) { return hash(b) + dd * 0x5BD1E9u; }      // the sketch's counter of the pair (b, d): its high bits
     __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) const { return (dd << kBBits) | (b >> S); }
     __device__ __forceinline__ uint32_t region_base(uint32_t b) const { return (b & ((1u << S) - 1u)) * nb_r; }
     __device__ __forceinline__ uint32_t home_of(uint32_t b) const { return region_base(b) + (((((b >> S) * 0x9E3779u) >> 16) * (nb_r & 0xFFFFu)) >> 16); }
@@ -793,9 +798,6 @@ __device__ __forceinline__ uint32_t cf_rank_in(unsigned long long m) { return __
 // the instruction counters of successive builds differ by ONE phase (results are wrong, what runs before the cut is unchanged)
 #ifndef CF_DIST_ABL
 #define CF_DIST_ABL 0
-#endif
-#ifndef CF_DIST_PUSH_NOBR
-#define CF_DIST_PUSH_NOBR 0
 #endif
 #ifndef CF_DIST_OLD_DRAIN
 #define CF_DIST_OLD_DRAIN 0      /* 1: the drain's probe as nested match / claim branches (rounds 2-3), for A/B runs */
@@ -1040,11 +1042,12 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
     // every push into a FLAT store followed by a full vmcnt wait (it did: 4 per step in the first version).
     uint32_t* stack = (uint32_t*)(stage + DIST_STAGE_CAP + 8);                   // (P, idx) pairs
     typename Tab::qitem* wq0 = (typename Tab::qitem*)(stack + 2 * DIST_STACK);
-    typename Tab::qitem* wq = wq0 + (size_t)(t >> 6) * DIST_QSTRIDE;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), nw = (uint32_t)nt >> 6;      // (the wave's number in a scalar register: so are the addresses of its queues)
+    typename Tab::qitem* wq = wq0 + (size_t)wv * DIST_QSTRIDE;
     // inserts whose FIRST probe did not finish (bucket full, or another key took the slot it wanted): parked here and run
     // through the probe loop 32 .. 64 at a time (round 2 ran that loop inside every drain: most drains went around twice for
     // one or two of their 64 lanes)
-    typename Tab::qitem* ovq = wq0 + (size_t)(nt >> 6) * DIST_QSTRIDE + (size_t)(t >> 6) * DIST_OVQ;
+    typename Tab::qitem* ovq = wq0 + (size_t)(nt >> 6) * DIST_QSTRIDE + (size_t)wv * DIST_OVQ;
     uint16_t* hotl = (uint16_t*)(wq0 + (size_t)(nt >> 6) * (DIST_QSTRIDE + DIST_OVQ));      // DIST_HOT_CAP slots whose count reached min_cov during the inserts of the pass
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0, acc_edges = 0;  // flushed once per workgroup (thread 0)
@@ -1078,7 +1081,6 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
     long long nx_idx = -1;
     cf_dist_head nx_head{0u, 0u, 0ull, 0u, 0u, 0u, 0u};
     unsigned long long nx_q = 0;
-    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6)), nw = (uint32_t)nt >> 6;
     if (!cf_lds_base_ok()) { if (t == 0) atomicOr(&A.counters[4], 2ull); return; }      // (cf_common.h: cf_lds_at)
     // Barriers.  A first k-mer whose table needs one pass — nearly all — meets the workgroup SEVEN times: [top] the previous
     // one's edge rows are written, [sketch cleared], [sketch swept], [table cleared], [table swept], [filtered], [rows reserved].
@@ -1151,7 +1153,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL], inc_[DIST_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
-                        const uint32_t idx = (Tab::hash(bb[u]) + dd_[u] * 0x5BD1E9u) >> A.sk_shift;
+                        const uint32_t idx = Tab::sk_hash(bb[u], dd_[u], qq_[u]) >> A.sk_shift;
                         sft_[u] = idx << 3;             // (only its low 5 bits are used: the shift and the bit-field extract take them mod 32)
                         inc_[u] = 1u << (sft_[u] & 31u);
                         old_[u] = idx >> 2;
@@ -1168,15 +1170,20 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     // ONE test per step: few adds reach min_cov (each of the four branches of round 2 cost a compare, three scalar
                     // exec-mask instructions and a jump)
                     static_assert(DIST_UNROLL == 4, "max of four");
-                    if (max(max(seen_[0], seen_[1]), max(seen_[2], seen_[3])) >= min_cov_m1) {
+                    const uint32_t seen_max = max(max(seen_[0], seen_[1]), max(seen_[2], seen_[3]));
+                    if (seen_max >= min_cov_m1) {
+                        // The bit is set without looking first (a read, a wait, a test and a second exec mask per entry: the atomic costs the
+                        // LDS what the read did), and lanes past the end of a posting's range (inc 0: they read a counter without adding)
+                        // are not told apart: a bit too many in the bitmap only lets entries into the exact table that are then not
+                        // selected, and a wrap seen by such a lane only sends the first k-mer down the every-b-marked path.
 #pragma unroll
                         for (int u = 0; u < DIST_UNROLL; ++u) {
-                            if (seen_[u] >= min_cov_m1 && inc_[u]) {
+                            if (seen_[u] >= min_cov_m1) {
                                 const uint32_t hbit = Tab::bm_bit(bb[u]);
-                                if (!((bm[hbit >> 5] >> (hbit & 31u)) & 1u)) atomicOr(&bm[hbit >> 5], 1u << (hbit & 31u));
-                                if (seen_[u] == 255u) sh[13] = 1u;
+                                atomicOr(&bm[hbit >> 5], 1u << (hbit & 31u));
                             }
                         }
+                        if (seen_max == 255u) sh[13] = 1u;
                     }
                     return false;
                 });
@@ -1293,38 +1300,41 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     // Entries equal to a itself are NOT told apart here (round 2 spent 13 vector instructions per step on it): they are
                     // rare (a k-mer twice in one read), the filter never selects a slot whose b is a, and the emission count of the
                     // launch has them subtracted on the host (cf_self_pairs_kernel counts them from the posting lists).
-                    uint32_t w_[DIST_UNROLL], hbit_[DIST_UNROLL], live = (1u << DIST_UNROLL) - 1u, cand = 0;
+                    uint32_t w_[DIST_UNROLL], hbit_[DIST_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         hbit_[u] = Tab::bm_bit(bb[u]);
                         w_[u] = bm[hbit_[u] >> 5];
                     }
-                    if (len < DIST_ITEM) live = ok;      // (wave-uniform) only the last item of a posting has lanes past its end
-                    if (pmask) {       // (wave-uniform) only a first k-mer whose table was split tests the partition of b
+                    // Entries that do not exist (only the last item of a posting has lanes past its end) or belong to another partition
+                    // (only a first k-mer whose table was split) get an empty bitmap word, in two wave-uniform branches that are nearly
+                    // never taken: the common path tests one bit per entry and nothing else.
+                    if (len < DIST_ITEM) {
+#pragma unroll
+                        for (int u = 0; u < DIST_UNROLL; ++u) if (!((ok >> u) & 1u)) w_[u] = 0u;
+                    }
+                    if (pmask) {
+                        uint32_t live = len < DIST_ITEM ? ok : (1u << DIST_UNROLL) - 1u;
 #pragma unroll
                         for (int u = 0; u < DIST_UNROLL; ++u) {
                             const uint32_t hb = Tab::hash(bb[u]);
-                            if ((((hb ^ (hb >> 15)) >> 3) & pmask) != pidx) live &= ~(1u << u);
+                            if ((((hb ^ (hb >> 15)) >> 3) & pmask) != pidx) { live &= ~(1u << u); w_[u] = 0u; }
                         }
                         my_e += (uint32_t)__popcll((unsigned long long)live);
                     }
                     s_e += pmask ? 0u : len;      // entries swept, counted on the scalar unit (an `else` here made the compiler keep both
                                                   // counters in a scratch array picked by index: a scratch load + store per step)
+                    bool c_[DIST_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) cand |= (((live >> u) & (w_[u] >> (hbit_[u] & 31u))) & 1u) << u;
-                    if (CF_DIST_ABL >= 3) { if (cand == 0xFFu) sh[13] = 1u; return false; }
+                    for (int u = 0; u < DIST_UNROLL; ++u) c_[u] = __builtin_amdgcn_ubfe(w_[u], Tab::hash(bb[u]) >> 10, 1u) != 0u;      // (v_bfe_u32 takes the offset mod 32: bit bm_bit(b) & 31)
+                    if (CF_DIST_ABL >= 3) { if (c_[0] && c_[1] && c_[2] && c_[3] && bb[0] == 0xFFFFFFF1u) sh[13] = 1u; return false; }
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
-                        const unsigned long long cm = __ballot((cand >> u) & 1u);
-#if CF_DIST_PUSH_NOBR
-                        if ((cand >> u) & 1u) wq[qtail + cf_rank_in(cm)] = T.q_push(bb[u], dd_[u], qq_[u], n_buckets);
-                        qtail += (uint32_t)__popcll(cm);
-#else
+                        const unsigned long long cm = __ballot(c_[u]);
                         if (cm) {
-                            if ((cand >> u) & 1u) wq[qtail + cf_rank_in(cm)] = T.q_push(bb[u], dd_[u], qq_[u], n_buckets);
+                            if (c_[u]) wq[qtail + cf_rank_in(cm)] = T.q_push(bb[u], dd_[u], qq_[u], n_buckets);
                             qtail += (uint32_t)__popcll(cm);
                         }
-#endif
                     }
                     // (measured and not kept: every lane storing — candidates at their rank, the others into a dump word of their own —
                     // to save the four scalar instructions per entry of the skip branches and the exec save / restore: 325 vs 320 ms,
