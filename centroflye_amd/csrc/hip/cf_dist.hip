@@ -266,13 +266,13 @@ struct cf_tab_wide_t {
 #pragma unroll
         for (int u = 0; u < DIST_UNROLL; ++u) { const uint32_t x = ((ok >> u) & 1u) ? l4 + (uint32_t)u : 0u; out[u] = raw{(uint32_t)pe[x], (uint32_t)pi[x]}; }
     }
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd, uint32_t& qk) { b = r.b; dd = (r.i - ig) & 0xFFFFu; qk = 0u; }
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd, uint32_t& qk, uint32_t& lo) { b = r.b; dd = (r.i - ig) & 0xFFFFu; qk = 0u; lo = r.b; }
     __device__ __forceinline__ qitem q_push(uint32_t b, uint32_t dd, uint32_t, uint32_t n_buckets) const { return q_of(b, dd, n_buckets); }   // unit indices are kept mod 65536 and d <= max_d < 65536: the 16-bit difference IS d
     // 24 x 24-bit multiplies only (full rate; a 32-bit multiply or a multiply-high is quarter rate): the low 24 bits of b as in
     // the narrow layout, the high 8 bits through a second multiplier
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u + (b >> 24) * 0x85EBCBu; }
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return ((h >> 16) * (n_buckets & 0xFFFFu)) >> 16; }
-    static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
+    static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return b & (DIST_BM_BITS - 1u); }      // (k-mer ranks: their low bits are as good as a hash of them, and cost nothing)
     static __device__ __forceinline__ uint32_t sk_hash(uint32_t b, uint32_t dd, uint32_t) { return hash(b) + dd * 0x5BD1E9u; }      // the sketch's counter of the pair (b, d): its high bits
     __device__ __forceinline__ bucket read(uint32_t bk) const { return bucket{*(const cf_u64x2*)&tab[4 * bk], *(const cf_u64x2*)&tab[4 * bk + 2]}; }
     static __device__ __forceinline__ bool is(unsigned long long v, uint32_t b, uint32_t dd) { return (uint32_t)(v >> 32) == b && ((uint32_t)v >> kDShift) == dd; }
@@ -402,12 +402,12 @@ struct cf_tab_narrow_t {
         out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
     }
     // the unit index is kept mod 2^DB and 1 <= d < 2^DB, so the DB-bit difference IS d; no borrow reaches b
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd, uint32_t& qk) { const uint32_t q = r.v - (ig << kBBits); b = q & kBMask; dd = q >> kBBits; qk = q; }
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd, uint32_t& qk, uint32_t& lo) { const uint32_t q = r.v - (ig << kBBits); b = q & kBMask; dd = q >> kBBits; qk = q; lo = r.v; }      // (lo: a word whose low 16 bits are b's — the bitmap's index — that costs nothing to make)
     // (the queued insert IS the difference decode() made: [d | b]; rebuilt from b and d it cost three more instructions per entry)
     __device__ __forceinline__ qitem q_push(uint32_t, uint32_t, uint32_t qk, uint32_t) const { return qk; }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }               // 24 x 24 -> low 32 bits
     static __device__ __forceinline__ uint32_t home(uint32_t h, uint32_t n_buckets) { return ((h >> 16) * (n_buckets & 0xFFFFu)) >> 16; }
-    static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
+    static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return b & (DIST_BM_BITS - 1u); }      // (k-mer ranks: their low bits are as good as a hash of them, and cost nothing)
     // the sketch's counter of the pair (b, d), from the decoded difference q = [d | b] itself: one multiply-add (b's low 24 bits times the
     // constant, plus q: d lands in the counter index's high bits, so the pairs of one b never share a counter)
     static __device__ __forceinline__ uint32_t sk_hash(uint32_t, uint32_t, uint32_t qk) { return (qk & 0xFFFFFFu) * 0x9E3779u + qk; }
@@ -611,10 +611,10 @@ struct cf_tab_region {
 #pragma unroll
         for (int u = 0; u < DIST_UNROLL; ++u) { const uint32_t x = ((ok >> u) & 1u) ? l4 + (uint32_t)u : 0u; out[u] = raw{(uint32_t)pe[x], (uint32_t)pi[x]}; }
     }
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd, uint32_t& qk) { b = r.b; dd = (r.i - ig) & 0xFFu; qk = 0u; }      // unit indices mod 256, d <= 255
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd, uint32_t& qk, uint32_t& lo) { b = r.b; dd = (r.i - ig) & 0xFFu; qk = 0u; lo = r.b; }      // unit indices mod 256, d <= 255
     __device__ __forceinline__ qitem q_push(uint32_t b, uint32_t dd, uint32_t, uint32_t n_buckets) const { return q_of(b, dd, n_buckets); }
     static __device__ __forceinline__ uint32_t hash(uint32_t b) { return (b & 0xFFFFFFu) * 0x9E3779u; }      // sketch and bitmap: any function of b will do (ranks that differ above bit 23 share counters and bits)
-    static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return (hash(b) >> 10) & (DIST_BM_BITS - 1u); }
+    static __device__ __forceinline__ uint32_t bm_bit(uint32_t b) { return b & (DIST_BM_BITS - 1u); }      // (k-mer ranks: their low bits are as good as a hash of them, and cost nothing)
     static __device__ __forceinline__ uint32_t sk_hash(uint32_t b, uint32_t dd, uint32_t) { return hash(b) + dd * 0x5BD1E9u; }      // the sketch's counter of the pair (b, d): its high bits
     __device__ __forceinline__ uint32_t key_of(uint32_t b, uint32_t dd) const { return (dd << kBBits) | (b >> S); }
     __device__ __forceinline__ uint32_t region_base(uint32_t b) const { return (b & ((1u << S) - 1u)) * nb_r; }
@@ -780,8 +780,8 @@ struct cf_tab_region26 : cf_tab_region {
         const run4 r = *(const run4*)(p + l4);
         out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
     }
-    static __device__ __forceinline__ void decode(const raw& r, uint32_t igf, uint32_t pos, uint32_t& b, uint32_t& dd, uint32_t& qk) {
-        qk = 0u;
+    static __device__ __forceinline__ void decode(const raw& r, uint32_t igf, uint32_t pos, uint32_t& b, uint32_t& dd, uint32_t& qk, uint32_t& lo) {
+        qk = 0u; lo = r.v;
         b = r.v & 0x3FFFFFFu;
         dd = (((r.v >> 26) - igf) & 63u) + (pos >= (igf >> 7) ? 64u : 0u);      // (igf = t64 << 7 | unit index mod 128: its low 6 bits are all the subtraction keeps)
     }
@@ -789,6 +789,11 @@ struct cf_tab_region26 : cf_tab_region {
 
 
 // lanes below this one whose bit is set in a ballot: v_mbcnt_lo + v_mbcnt_hi (2 instructions; popcount(mask & lanemask_lt) is 4)
+// bit (off mod 32) of w in ONE instruction: v_bfe_u32 takes the low five bits of its offset operand, which the compiler does not use
+// (it masks the offset first, or shifts and masks); the host emulator (tests/emu) defines the macro of the same name
+#ifndef cf_bit_of
+__device__ __forceinline__ uint32_t cf_bit_of(uint32_t w, uint32_t off) { uint32_t r; asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(r) : "v"(w), "v"(off)); return r; }
+#endif
 __device__ __forceinline__ uint32_t cf_rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
 #define DIST_QCAP 320                    /* deferred inserts per wave: fewer than 64 left by the drains before a step + at most 4 x 64 pushed by it */
@@ -996,11 +1001,11 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
                 // loads in flight differs between the paths into the loop head and the compiler waits for ALL of them there
                 // (s_waitcnt vmcnt(0) instead of vmcnt(D - 1))
                 CF_DIST_FETCH(min(j + (uint32_t)D, cnt - 1u), d)
-                uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL], qq_[DIST_UNROLL];
+                uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL], qq_[DIST_UNROLL], lo_[DIST_UNROLL];
 #pragma unroll
-                for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cm & 0xFFFFu, l4 + (uint32_t)u, bb[u], dd_[u], qq_[u]);
+                for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cm & 0xFFFFu, l4 + (uint32_t)u, bb[u], dd_[u], qq_[u], lo_[u]);
                 const uint32_t len = cm >> 16;      // entries of the item (wave-uniform); < DIST_ITEM only for the last item of a posting
-                if (body(bb, dd_, qq_, len < DIST_ITEM ? ok_of(cm) : (1u << DIST_UNROLL) - 1u, len)) return;
+                if (body(bb, dd_, qq_, lo_, len < DIST_ITEM ? ok_of(cm) : (1u << DIST_UNROLL) - 1u, len)) return;
                 ++j;
             }
         }
@@ -1147,7 +1152,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 __syncthreads();      // [sketch cleared]
             }
             {
-                if (CF_DIST_ABL < 6) cf_dist_sweep<Tab, CF_DIST_PF_A>(A, recs, mine, my0, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], const uint32_t (&qq_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
+                if (CF_DIST_ABL < 6) cf_dist_sweep<Tab, CF_DIST_PF_A>(A, recs, mine, my0, [](bool) {}, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], const uint32_t (&qq_)[DIST_UNROLL], const uint32_t (&lo_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
                     if (CF_DIST_ABL >= 5) { if (bb[0] == 0xFFFFFFF1u && dd_[0] == 77u) sh[13] = 1u; return false; }      // (the loads stay: their data is looked at)
                     // (entries equal to a are counted too: the sketch may only over-count, and the table sweep drops them)
                     uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL], inc_[DIST_UNROLL];
@@ -1179,8 +1184,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
 #pragma unroll
                         for (int u = 0; u < DIST_UNROLL; ++u) {
                             if (seen_[u] >= min_cov_m1) {
-                                const uint32_t hbit = Tab::bm_bit(bb[u]);
-                                atomicOr(&bm[hbit >> 5], 1u << (hbit & 31u));
+                                atomicOr(&bm[Tab::bm_bit(lo_[u]) >> 5], 1u << (lo_[u] & 31u));
                             }
                         }
                         if (seen_max == 255u) sh[13] = 1u;
@@ -1295,17 +1299,14 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                         else if (!(final && otail > 0u)) break;
                         if (otail >= 32u || (final && qtail == 0u && otail > 0u)) { CF_DIST_OVERFLOW(min(otail, 64u)) }
                     }
-                }, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], const uint32_t (&qq_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
+                }, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], const uint32_t (&qq_)[DIST_UNROLL], const uint32_t (&lo_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
                     if (too_full) return true;     // (wave-uniform, set by the drains: the fill only changes there) the pass will be split
                     // Entries equal to a itself are NOT told apart here (round 2 spent 13 vector instructions per step on it): they are
                     // rare (a k-mer twice in one read), the filter never selects a slot whose b is a, and the emission count of the
                     // launch has them subtracted on the host (cf_self_pairs_kernel counts them from the posting lists).
-                    uint32_t w_[DIST_UNROLL], hbit_[DIST_UNROLL];
+                    uint32_t w_[DIST_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) {
-                        hbit_[u] = Tab::bm_bit(bb[u]);
-                        w_[u] = bm[hbit_[u] >> 5];
-                    }
+                    for (int u = 0; u < DIST_UNROLL; ++u) w_[u] = bm[Tab::bm_bit(lo_[u]) >> 5];
                     // Entries that do not exist (only the last item of a posting has lanes past its end) or belong to another partition
                     // (only a first k-mer whose table was split) get an empty bitmap word, in two wave-uniform branches that are nearly
                     // never taken: the common path tests one bit per entry and nothing else.
@@ -1326,7 +1327,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                                                   // counters in a scratch array picked by index: a scratch load + store per step)
                     bool c_[DIST_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) c_[u] = __builtin_amdgcn_ubfe(w_[u], Tab::hash(bb[u]) >> 10, 1u) != 0u;      // (v_bfe_u32 takes the offset mod 32: bit bm_bit(b) & 31)
+                    for (int u = 0; u < DIST_UNROLL; ++u) c_[u] = cf_bit_of(w_[u], lo_[u]) != 0u;
                     if (CF_DIST_ABL >= 3) { if (c_[0] && c_[1] && c_[2] && c_[3] && bb[0] == 0xFFFFFFF1u) sh[13] = 1u; return false; }
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
