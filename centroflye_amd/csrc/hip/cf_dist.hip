@@ -38,6 +38,12 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
 #define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
 
+#ifndef cf_ballot
+// the mask of a condition straight from the compare that made it (HIP's __ballot takes an int: the condition goes through a 0 / 1 vector
+// register and a second compare)
+__device__ __forceinline__ unsigned long long cf_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+#endif
+
 // One posting (= one unit g holding the first k-mer): its partner entries — the clouds of the units g+min_d ..
 // min(read end, g+max_d) — are ONE contiguous CSR range [e0, e0 + len); ig is the index of g inside its read.
 struct alignas(16) cf_dist_rec { int64_t e0; uint32_t len; uint32_t ig; };
@@ -149,7 +155,7 @@ cf_order_keys_kernel(const uint32_t* __restrict__ pcnt, const uint32_t* __restri
     for (int64_t rd = 0; rd < rounds; ++rd) {
         const int64_t a = rd * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         const bool take = a < n_kmers && (a % n_parts) == part && pcnt[a] > 0;
-        const unsigned long long m = __ballot(take);
+        const unsigned long long m = cf_ballot(take);
         if (m) {
             unsigned long long base = 0;
             const int leader = __ffsll((long long)m) - 1;
@@ -289,7 +295,7 @@ struct cf_tab_wide_t {
     __device__ __forceinline__ uint32_t add(uint32_t bk, int i) const { return ((uint32_t)atomicAdd(&tab[4 * bk + i], 1ull) & kCntMask) + 1u; }
     static constexpr uint32_t kSlotsPerBucket = 4;
     static constexpr bool kProbe1 = false;      // (64-bit slots: the drain keeps its match / claim branches)
-    __device__ __forceinline__ void probe1(uint32_t, uint32_t, uint32_t, uint32_t&, uint32_t&, uint32_t&) const {}
+    __device__ __forceinline__ void probe1(bool, uint32_t, uint32_t, uint32_t, bool&, bool&, uint32_t&) const {}
     __device__ __forceinline__ uint32_t key_of(uint32_t, uint32_t) const { return 0u; }
     // claim slot i of bucket bk for (b, dd): 0 = claimed (count 1), 1 = the same key got there first (counted), 2 = another key
     __device__ __forceinline__ unsigned long long claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const {
@@ -453,22 +459,32 @@ struct cf_tab_narrow_t {
     // another lane a moment ago counts as a match); anything else -> park.  Flags are integers made by selects, the count add is
     // issued by every lane (adding 0 where there is nothing to count): as nested ifs that set booleans on divergent paths the
     // drain compiled to ~115 scalar instructions of exec-mask bookkeeping per 64 inserts (profiles/r04_dist_phase_insts.md:
-    // the inserts were 0.27 of the kernel's 0.58 scalar instructions per pair).
+    // the inserts were 0.27 of the kernel's 0.58 scalar instructions per pair).  EVERY lane of the wave runs it (active = the lane has
+    // an insert): under `if (lane < n)` the flags crossed the join in vector registers and came back through compares.
     static constexpr bool kProbe1 = true;
-    __device__ __forceinline__ void probe1(uint32_t bk, uint32_t key, uint32_t min_cov, uint32_t& made, uint32_t& park, uint32_t& hot_slot) const {
+    __device__ __forceinline__ void probe1(bool active, uint32_t bk, uint32_t key, uint32_t min_cov, bool& made, bool& park, uint32_t& hot_slot) const {
         const bucket k = read(bk);
-        const int mt = first_equal(k, key), em = first_equal(k, kEmpty);
-        const bool claim = mt < 0 && em >= 0;
-        const uint32_t s = PB * bk + (uint32_t)(mt >= 0 ? mt : (em >= 0 ? em : 0));
+        // the slot of the key, else the first empty one, else PB: two chains of selects over the slots (a compare and a v_cndmask each;
+        // as bit masks + find-first-set the two searches took 26 instructions instead of 16)
+        uint32_t em = (uint32_t)PB;
+#pragma unroll
+        for (int j = PB - 1; j >= 0; --j) em = k.k[j] == kEmpty ? (uint32_t)j : em;
+        uint32_t sl = em;
+        bool mt = false;
+#pragma unroll
+        for (int j = PB - 1; j >= 0; --j) { const bool e = k.k[j] == key; sl = e ? (uint32_t)j : sl; mt |= e; }
+        mt &= active;      // (a lane without an insert — only the last drain of a sweep has any — reads some bucket and changes nothing)
+        const bool claim = active && !mt && em < (uint32_t)PB;
+        const uint32_t s = PB * bk + (sl & (uint32_t)(PB - 1));      // (nothing to do in a full bucket without the key: slot 0's address for the adds of 0 below)
         uint32_t old = key;
         if (claim) old = atomicCAS(&keys[s], kEmpty, key);
-        const bool matched = mt >= 0 || (claim && old == key);
+        const bool matched = mt || (claim && old == key);
         const bool fresh = claim && old == kEmpty;
         const uint32_t sh_ = (s & 1u) * 16u;
         const uint32_t was = atomicAdd(&cnt32[s >> 1], matched ? 1u << sh_ : 0u);
         const uint32_t cnt = matched ? ((was >> sh_) & 0x7FFFu) + 2u : 1u;
-        made = fresh ? 1u : 0u;
-        park = (matched || fresh) ? 0u : 1u;
+        made = fresh;
+        park = active && !(matched || fresh);
         hot_slot = ((matched || fresh) && cnt == min_cov) ? s : 0xFFFFFFFFu;
     }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
@@ -664,20 +680,29 @@ struct cf_tab_region {
         return 2;
     }
     static constexpr bool kProbe1 = true;      // (cf_tab_narrow_t::probe1: the drain's one probe in straight-line code)
-    __device__ __forceinline__ void probe1(uint32_t bk, uint32_t key, uint32_t min_cov, uint32_t& made, uint32_t& park, uint32_t& hot_slot) const {
+    __device__ __forceinline__ void probe1(bool active, uint32_t bk, uint32_t key, uint32_t min_cov, bool& made, bool& park, uint32_t& hot_slot) const {
         const bucket k = read(bk);
-        const int mt = first_equal(k, key), em = first_equal(k, kEmpty);
-        const bool claim = mt < 0 && em >= 0;
-        const uint32_t s = PB * bk + (uint32_t)(mt >= 0 ? mt : (em >= 0 ? em : 0));
+        // the slot of the key, else the first empty one, else PB: two chains of selects over the slots (a compare and a v_cndmask each;
+        // as bit masks + find-first-set the two searches took 26 instructions instead of 16)
+        uint32_t em = (uint32_t)PB;
+#pragma unroll
+        for (int j = PB - 1; j >= 0; --j) em = k.k[j] == kEmpty ? (uint32_t)j : em;
+        uint32_t sl = em;
+        bool mt = false;
+#pragma unroll
+        for (int j = PB - 1; j >= 0; --j) { const bool e = k.k[j] == key; sl = e ? (uint32_t)j : sl; mt |= e; }
+        mt &= active;      // (a lane without an insert — only the last drain of a sweep has any — reads some bucket and changes nothing)
+        const bool claim = active && !mt && em < (uint32_t)PB;
+        const uint32_t s = PB * bk + (sl & (uint32_t)(PB - 1));      // (nothing to do in a full bucket without the key: slot 0's address for the adds of 0 below)
         uint32_t old = key;
         if (claim) old = atomicCAS(&keys[s], kEmpty, key);
-        const bool matched = mt >= 0 || (claim && old == key);
+        const bool matched = mt || (claim && old == key);
         const bool fresh = claim && old == kEmpty;
         const uint32_t sh_ = (s & 1u) * 16u;
         const uint32_t was = atomicAdd(&cnt32[s >> 1], matched ? 1u << sh_ : 0u);
         const uint32_t cnt = matched ? ((was >> sh_) & 0x7FFFu) + 2u : 1u;
-        made = fresh ? 1u : 0u;
-        park = (matched || fresh) ? 0u : 1u;
+        made = fresh;
+        park = active && !(matched || fresh);
         hot_slot = ((matched || fresh) && cnt == min_cov) ? s : 0xFFFFFFFFu;
     }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
@@ -1230,7 +1255,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 // evaluates that list instead of scanning every slot of the table for counts >= min_cov (round 2: 3 scan rounds per
                 // first k-mer, 7 % of the kernel)
 #define CF_DIST_HOT(SLOT) {                                                                                   \
-                    const unsigned long long hm_ = __ballot((SLOT) != 0xFFFFFFFFu);                           \
+                    const unsigned long long hm_ = cf_ballot((SLOT) != 0xFFFFFFFFu);                           \
                     if (hm_) {                                                                                \
                         uint32_t hb_ = 0;                                                                     \
                         if (lane == 0) hb_ = atomicAdd(&sh[11], (uint32_t)__popcll(hm_));                     \
@@ -1246,7 +1271,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                         T.q_take(ovq[otail + (uint32_t)lane], n_buckets, xb, xd, xk);                        \
                         omade_ = cf_dist_insert(T, n_buckets, xk, xb, xd, sh, A.min_cov, ohot_);              \
                     }                                                                                         \
-                    const uint32_t onew_ = (uint32_t)__popcll(__ballot(omade_ != 0u));                        \
+                    const uint32_t onew_ = (uint32_t)__popcll(cf_ballot(omade_ != 0u));                        \
                     if (onew_ && lane == 0) atomicAdd(&sh[0], onew_);                                         \
                     CF_DIST_HOT(ohot_)                                                                        \
                 }
@@ -1254,31 +1279,35 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                     __builtin_amdgcn_wave_barrier();                                                          \
                     const uint32_t n_ = (N); qtail -= n_;                                                     \
-                    uint32_t made_ = 0, park_ = 0, hot_ = 0xFFFFFFFFu;                                        \
+                    bool made_ = false, park_ = false;                                                        \
+                    uint32_t hot_ = 0xFFFFFFFFu;                                                              \
                     typename Tab::qitem it_ = 0;                                                              \
-                    if ((uint32_t)lane < n_) {                                                                \
+                    if constexpr (Tab::kProbe1 && !CF_DIST_OLD_DRAIN) {                                       \
+                        uint32_t xb, xd, xk;                                                                  \
+                        it_ = wq[qtail + (uint32_t)lane];      /* (lanes past n_: a stale word of the queue) */ \
+                        T.q_take(it_, n_buckets, xb, xd, xk);                                                 \
+                        T.probe1((uint32_t)lane < n_, xk, T.key_of(xb, xd), A.min_cov, made_, park_, hot_);   \
+                    } else if ((uint32_t)lane < n_) {                                                         \
                         uint32_t xb, xd, xk;                                                                  \
                         it_ = wq[qtail + (uint32_t)lane];                                                     \
                         T.q_take(it_, n_buckets, xb, xd, xk);                                                 \
-                        if constexpr (Tab::kProbe1 && !CF_DIST_OLD_DRAIN) { T.probe1(xk, T.key_of(xb, xd), A.min_cov, made_, park_, hot_); } else { \
                         const typename Tab::bucket k_ = T.read(xk);                                           \
                         const int mt_ = T.match(k_, xb, xd);                                                  \
                         if (mt_ >= 0) { if (T.add(xk, mt_) == A.min_cov) hot_ = Tab::kSlotsPerBucket * xk + (uint32_t)mt_; } \
                         else {                                                                                \
                             const int em_ = Tab::empty(k_);                                                   \
-                            park_ = 1u;                                                                       \
+                            park_ = true;                                                                     \
                             if (em_ >= 0) {                                                                   \
                                 uint32_t cn_;                                                                 \
                                 const int st_ = T.claim_finish(T.claim_issue(xk, em_, xb, xd), xk, em_, xb, xd, cn_); \
-                                made_ = (uint32_t)(st_ == 0); park_ = (uint32_t)(st_ == 2);                  \
+                                made_ = st_ == 0; park_ = st_ == 2;                                           \
                                 if (st_ != 2 && cn_ == A.min_cov) hot_ = Tab::kSlotsPerBucket * xk + (uint32_t)em_; \
                             }                                                                                 \
                         }                                                                                     \
-                        }                                                                                     \
                     }                                                                                         \
-                    const uint32_t new_ = (uint32_t)__popcll(__ballot(made_ != 0u));                          \
+                    const uint32_t new_ = (uint32_t)__popcll(cf_ballot(made_));                                \
                     if (new_ && lane == 0) atomicAdd(&sh[0], new_);                                           \
-                    const unsigned long long pm_ = __ballot(park_ != 0u);                                     \
+                    const unsigned long long pm_ = cf_ballot(park_);                                           \
                     if (pm_) {                                                                                \
                         if (park_) ovq[otail + cf_rank_in(pm_)] = it_;                                        \
                         otail += (uint32_t)__popcll(pm_);                                                     \
@@ -1331,7 +1360,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     if (CF_DIST_ABL >= 3) { if (c_[0] && c_[1] && c_[2] && c_[3] && bb[0] == 0xFFFFFFF1u) sh[13] = 1u; return false; }
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
-                        const unsigned long long cm = __ballot(c_[u]);
+                        const unsigned long long cm = cf_ballot(c_[u]);
                         if (cm) {
                             if (c_[u]) wq[qtail + cf_rank_in(cm)] = T.q_push(bb[u], dd_[u], qq_[u], n_buckets);
                             qtail += (uint32_t)__popcll(cm);
@@ -1390,17 +1419,17 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 const uint32_t bk = g0 + (uint32_t)t;                       // a group of kScanGroup consecutive slots
                 const uint32_t m = bk < n_groups ? T.hot_mask(bk, A.min_cov) : 0u;
                 const uint32_t cnt = (uint32_t)__popc(m);
-                if (__ballot(cnt != 0u)) {
+                if (cf_ballot(cnt != 0u)) {
                     // positions in the list: lanes hand in their k-th hot slot in round k (most lanes have none, few have
                     // two: one or two rounds, against eight ballots — one per slot of the group — before)
                     uint32_t total = 0;
-                    for (uint32_t k = 0; k < Tab::kScanGroup; ++k) { const unsigned long long bk_ = __ballot(cnt > k); if (!bk_) break; total += (uint32_t)__popcll(bk_); }
+                    for (uint32_t k = 0; k < Tab::kScanGroup; ++k) { const unsigned long long bk_ = cf_ballot(cnt > k); if (!bk_) break; total += (uint32_t)__popcll(bk_); }
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&sh[11], total);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                     uint32_t mm = m;
                     for (uint32_t k = 0; k < Tab::kScanGroup; ++k) {
-                        const unsigned long long bk_ = __ballot(cnt > k);
+                        const unsigned long long bk_ = cf_ballot(cnt > k);
                         if (!bk_) break;
                         if (cnt > k) {
                             const uint32_t bit = (uint32_t)__ffs((int)mm) - 1u;
@@ -1437,14 +1466,14 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
             };
             auto keep = [&](bool sel, uint32_t s, uint32_t b, uint32_t dd, uint32_t cnt) {       // called by all lanes of a wave together
-                const unsigned long long m = __ballot(sel);
+                const unsigned long long m = cf_ballot(sel);
                 if (!m) return;
                 uint32_t row0 = 0;
                 if (lane == 0) { const uint32_t n = (uint32_t)__popcll(m); atomicAdd(&sh[8], n); row0 = atomicAdd(&sh[26], n); }
                 const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0) + (uint32_t)__popcll(m & lt);
                 const bool late = sel && row >= ch_rows;
                 if (sel && !late) put_row(ch_base + row, b, dd, cnt);
-                const unsigned long long ml = __ballot(late);
+                const unsigned long long ml = cf_ballot(late);
                 if (ml) {
                     uint32_t p0 = 0;
                     if (lane == 0) p0 = atomicAdd(&sh[30], (uint32_t)__popcll(ml));
