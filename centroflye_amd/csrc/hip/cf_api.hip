@@ -447,6 +447,8 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
         ctx->dist_slots = (int)value;
     } else if (n == "dist_wide") {
         ctx->dist_wide = value != 0;
+    } else if (n == "dist_post_atomics") {
+        ctx->dist_post_atomics = value != 0;
     } else if (n == "dist_hot_cap") {
         if (value < 0) return cf_fail(ctx, -22, "dist_hot_cap must be >= 0");
         ctx->dist_hot_cap = (int)value;

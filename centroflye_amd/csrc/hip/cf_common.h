@@ -145,6 +145,7 @@ struct cf_ctx {
     int dist_wgs = 0;        // workgroups per CU the LDS is split between; 0 = 2 x 512 threads or 1 x 1024, by the pair emissions per first k-mer
     int dist_slots = 0;      // LDS budget of the (b,d) table in 8-byte units; 0 = all that is left next to the work lists
     int dist_wide = 0;       // 1 forces the 8-byte-slot table layout (tests)
+    int dist_post_atomics = 0;   // 1 builds the postings with the histogram + fill passes of atomics instead of the sort (tests, A/B runs)
     int dist_hot_cap = 0;    // > 0: cap on the filter's hot-slot list (tests)
     int dist_regions = 0;    // 1, 2, 4, 8: force the region layout of the 6-byte slots with at least that many regions (tests), 0 = only when the ranks need it
     int dist_region_bytes = 0; // 1: the region layout streams rank and unit index apart (round 3) even where the 4-byte stream of cf_tab_region26 applies (tests)

@@ -92,18 +92,57 @@ cf_post_recs_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __rest
         for (int64_t e = a + lane; e < b; e += 64) recs[e - e0] = ((unsigned long long)u << kb) | (unsigned long long)(uint32_t)entries[e];
     }
 }
+// The same for ONE partition of the first k-mers (n_parts > 1: a rank of a multi-GPU run scans all clouds and keeps the entries
+// x % n_parts == part, 1 / n_parts of them).  The survivors are compacted in cloud order — per unit a count, a scan, then the fill; one
+// wave per unit, ballots inside — so that the stable sort leaves the units of a k-mer ascending, and the sort key is x / n_parts:
+// fewer bits, often one radix pass fewer.  (Before: one returning device-scope atomic per kept entry in a histogram pass and again
+// in a fill pass, 26 ms per step for a rank of 8 against 19 ms for the whole single-GPU job.)
+__global__ void __launch_bounds__(256)
+cf_post_ucount_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ entries, int64_t u0, int64_t u1, uint32_t part, uint32_t n_parts,
+                      uint32_t* __restrict__ ucnt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = u0 + wave; u < u1; u += n_waves) {
+        const int64_t a = cloud_ptr[u], b = cloud_ptr[u + 1];
+        uint32_t c = 0;
+        for (int64_t e = a + lane; e < b; e += 64) c += (uint32_t)((uint32_t)entries[e] % n_parts == part);
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, (unsigned)d);
+        if (lane == 0) ucnt[u - u0] = c;
+    }
+}
+__global__ void __launch_bounds__(256)
+cf_post_recs_part_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __restrict__ entries, int64_t u0, int64_t u1, uint32_t part, uint32_t n_parts,
+                         const int64_t* __restrict__ uoff, int kb, unsigned long long* __restrict__ recs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = u0 + wave; u < u1; u += n_waves) {
+        const int64_t a = cloud_ptr[u], b = cloud_ptr[u + 1];
+        int64_t o = uoff[u - u0];
+        for (int64_t e0 = a; e0 < b; e0 += 64) {      // (uniform trip count: a ballot inside)
+            const int64_t e = e0 + lane;
+            const uint32_t x = e < b ? (uint32_t)entries[e] : 0u;
+            const bool keep = e < b && x % n_parts == part;
+            const unsigned long long m = cf_ballot(keep);
+            if (keep) recs[o + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)u << kb) | (unsigned long long)(x / n_parts);
+            o += __popcll(m);
+        }
+    }
+}
 // sorted records -> post[] (the units), run starts (rs[x]) / ends (re[x]) of every rank x that occurs, and its first unit
 __global__ void __launch_bounds__(256)
-cf_post_bounds_kernel(const unsigned long long* __restrict__ recs, int64_t n, int kb, int32_t* __restrict__ post, uint32_t* __restrict__ rs,
-                      uint32_t* __restrict__ re, uint32_t* __restrict__ first_unit) {
+cf_post_bounds_kernel(const unsigned long long* __restrict__ recs, int64_t n, int kb, uint32_t part, uint32_t n_parts, int32_t* __restrict__ post,
+                      uint32_t* __restrict__ rs, uint32_t* __restrict__ re, uint32_t* __restrict__ first_unit) {
+    // (the sort key is the rank itself, or — one partition — rank / n_parts: rank = key * n_parts + part)
     const unsigned long long mask = (1ull << kb) - 1ull;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const unsigned long long r = recs[i];
-        const uint32_t x = (uint32_t)(r & mask), u = (uint32_t)(r >> kb);
+        const uint32_t j = (uint32_t)(r & mask), u = (uint32_t)(r >> kb), x = j * n_parts + part;
         post[i] = (int32_t)u;
-        if (i == 0 || (uint32_t)(recs[i - 1] & mask) != x) { rs[x] = (uint32_t)i; first_unit[x] = u; }
-        if (i == n - 1 || (uint32_t)(recs[i + 1] & mask) != x) re[x] = (uint32_t)(i + 1);
+        if (i == 0 || (uint32_t)(recs[i - 1] & mask) != j) { rs[x] = (uint32_t)i; first_unit[x] = u; }
+        if (i == n - 1 || (uint32_t)(recs[i + 1] & mask) != j) re[x] = (uint32_t)(i + 1);
     }
 }
 __global__ void __launch_bounds__(256)
@@ -982,7 +1021,7 @@ cf_items_fill_kernel(const int32_t* __restrict__ order, int64_t n_order, const i
 // 16 * lane.  Software pipeline: D loads in flight per lane.
 // pre(final) runs at ONE site before every step and once more (final = true) after the wave's last step: the table sweep drains
 // its insert queue there (one copy of that code in the loop instead of one per push site).
-// body(bb, dd, ok, len): the decoded entries of a step; ok = per-lane bit mask of the entries that exist (only the last item of
+// body(bb, dd, qk, lo, ok, len): the decoded entries of a step; ok = per-lane bit mask of the entries that exist (only the last item of
 // a posting has lanes past its end: len < DIST_ITEM, wave-uniform, says whether ok needs looking at); returns true to stop the wave.
 template <class Tab, int D, class Pre, class Body>
 __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_dist_item* recs, uint32_t mine, const cf_dist_item& my0, Pre&& pre, Body&& body) {
@@ -1039,7 +1078,7 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
 }
 
 #ifndef CF_DIST_PF_A
-#define CF_DIST_PF_A 1      /* loads in flight per lane in the sketch sweep */
+#define CF_DIST_PF_A 2      /* loads in flight per lane in the sketch sweep (266.2 -> 263.0 ms against one) */
 #endif
 #ifndef CF_DIST_PF_B
 #define CF_DIST_PF_B 2      /* ... and in the table sweep (its body holds the drain code: every copy costs 15 KB of instructions; two fit the
@@ -1708,27 +1747,44 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
                 hipMemcpy(&tmp[1], v_cloud_ptr + u1, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "cloud_ptr read"); break; }
             e0 = tmp[0]; e1 = tmp[1];
         }
-        const bool by_sort = n_parts == 1 && e1 > e0 && (e1 - e0) < ((int64_t)1 << 32) && U < ((int64_t)1 << 31);
+        const bool by_sort = !ctx->dist_post_atomics && e1 > e0 && (e1 - e0) < ((int64_t)1 << 32) && U < ((int64_t)1 << 31);
         if (by_sort) {
-            const int64_t n = e1 - e0;
-            int kb = 1; while (kb < 32 && ((int64_t)1 << kb) < std::max<int64_t>(K, 2)) ++kb;
+            int64_t n = e1 - e0;
+            const int64_t K_part = (K + n_parts - 1) / n_parts;      // sort keys: the rank, or rank / n_parts for one partition
+            int kb = 1; while (kb < 32 && ((int64_t)1 << kb) < std::max<int64_t>(K_part, 2)) ++kb;
             kb = (kb + 7) & ~7;      // whole 8-bit digits: the last radix pass must not reach into the unit bits
             unsigned long long *d_recs = nullptr, *d_rtmp = nullptr, *d_sorted = nullptr;
-            if ((rc = cf_alloc_t(ctx, &d_recs, (size_t)n + 1, "posting records"))) break;
-            if ((rc = cf_alloc_t(ctx, &d_rtmp, (size_t)n + 1, "posting records (sort)"))) { cf_release_t(ctx, d_recs, (size_t)n + 1); break; }
-            hipLaunchKernelGGL(cf_post_recs_kernel, dim3((unsigned)cf_grid_for((u1 - u0) * 64, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               v_cloud_ptr, v_entries, u0, u1, e0, kb, d_recs);
-            rc = cf_radix_sort_u64_any(ctx, d_recs, d_rtmp, n, kb, &d_sorted);
-            if (!rc) rc = cf_alloc_t(ctx, &d_post, (size_t)n, "postings");
-            if (!rc) {
-                n_post = n;
-                hipLaunchKernelGGL(cf_post_bounds_kernel, dim3((unsigned)cf_grid_for(n, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                                   (const unsigned long long*)d_sorted, n, kb, d_post, d_cursor, d_pcnt, d_first);      // (d_cursor = run starts, d_pcnt = run ends)
-                hipLaunchKernelGGL(cf_post_counts_kernel, dim3((unsigned)cf_grid_for(K, 256, max_blocks)), dim3(256), 0, ctx->stream, (const uint32_t*)d_cursor, d_pcnt, K);
-                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = cf_fail(ctx, -5, "postings by sort");
+            uint32_t* d_ucnt = nullptr; int64_t* d_uoff = nullptr;
+            const unsigned g_units = (unsigned)cf_grid_for((u1 - u0) * 64, 256, max_blocks);
+            if (n_parts > 1) {       // what this partition keeps of every unit's cloud, and where its records go
+                if ((rc = cf_alloc_t(ctx, &d_ucnt, (size_t)(u1 - u0) + 1, "kept entries per unit"))) break;
+                if ((rc = cf_alloc_t(ctx, &d_uoff, (size_t)(u1 - u0) + 1, "record offsets per unit"))) { cf_release_t(ctx, d_ucnt, (size_t)(u1 - u0) + 1); break; }
+                if (hipMemsetAsync(d_ucnt + (u1 - u0), 0, 4, ctx->stream) != hipSuccess) rc = cf_fail(ctx, -5, "cf_dist_edges memset");
+                hipLaunchKernelGGL(cf_post_ucount_kernel, dim3(g_units), dim3(256), 0, ctx->stream, v_cloud_ptr, v_entries, u0, u1, (uint32_t)part, (uint32_t)n_parts, d_ucnt);
+                if (!rc) rc = cf_scan_exclusive_u32_to_i64(ctx, d_ucnt, d_uoff, (u1 - u0) + 1, &n);
             }
-            cf_release_t(ctx, d_rtmp, (size_t)n + 1);
-            cf_release_t(ctx, d_recs, (size_t)n + 1);
+            if (!rc && (rc = cf_alloc_t(ctx, &d_recs, (size_t)n + 1, "posting records")) == 0 &&
+                (rc = cf_alloc_t(ctx, &d_rtmp, (size_t)n + 1, "posting records (sort)")) != 0) { cf_release_t(ctx, d_recs, (size_t)n + 1); d_recs = nullptr; }
+            if (!rc) {
+                if (n_parts > 1)
+                    hipLaunchKernelGGL(cf_post_recs_part_kernel, dim3(g_units), dim3(256), 0, ctx->stream,
+                                       v_cloud_ptr, v_entries, u0, u1, (uint32_t)part, (uint32_t)n_parts, (const int64_t*)d_uoff, kb, d_recs);
+                else
+                    hipLaunchKernelGGL(cf_post_recs_kernel, dim3(g_units), dim3(256), 0, ctx->stream, v_cloud_ptr, v_entries, u0, u1, e0, kb, d_recs);
+                if (n) rc = cf_radix_sort_u64_any(ctx, d_recs, d_rtmp, n, kb, &d_sorted);
+                if (!rc) rc = cf_alloc_t(ctx, &d_post, (size_t)n, "postings");
+                if (!rc) {
+                    n_post = n;
+                    if (n) hipLaunchKernelGGL(cf_post_bounds_kernel, dim3((unsigned)cf_grid_for(n, 256, max_blocks)), dim3(256), 0, ctx->stream,
+                                       (const unsigned long long*)d_sorted, n, kb, (uint32_t)part, (uint32_t)n_parts, d_post, d_cursor, d_pcnt, d_first);      // (d_cursor = run starts, d_pcnt = run ends)
+                    hipLaunchKernelGGL(cf_post_counts_kernel, dim3((unsigned)cf_grid_for(K, 256, max_blocks)), dim3(256), 0, ctx->stream, (const uint32_t*)d_cursor, d_pcnt, K);
+                    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) rc = cf_fail(ctx, -5, "postings by sort");
+                }
+                cf_release_t(ctx, d_rtmp, (size_t)n + 1);
+                cf_release_t(ctx, d_recs, (size_t)n + 1);
+            }
+            if (d_uoff) cf_release_t(ctx, d_uoff, (size_t)(u1 - u0) + 1);
+            if (d_ucnt) cf_release_t(ctx, d_ucnt, (size_t)(u1 - u0) + 1);
             if (rc) break;
             int64_t n_chk = 0;
             if ((rc = cf_scan_exclusive_u32_to_i64(ctx, d_pcnt, d_post_ptr, K + 1, &n_chk))) break;

@@ -107,6 +107,18 @@ def test_stage2_spill_and_partition(engine, report, oracle_stage2):
         engine.set_param("dist_edge_chunk", 0)
 
 
+def test_postings_of_one_partition_by_sort_and_by_atomics(engine, report, oracle_stage2):
+    """The postings of a partition of the first k-mers (a % n_parts == part: one rank of a multi-GPU run) are built by compacting the
+    kept cloud entries per unit and sorting them on rank / n_parts; the histogram + fill passes of atomics stay behind a knob."""
+    tup = oracle_stage2("lowcov", max_distance=2)
+    for atomics in (0, 1):
+        engine.set_param("dist_post_atomics", atomics)
+        try:
+            pathcheck.check_stage2(engine, report("lowcov"), tup, n_parts=3, check_table=False)
+        finally:
+            engine.set_param("dist_post_atomics", 0)
+
+
 def test_long_posting_lists_take_the_multi_chunk_path(engine):
     engine.set_param("dist_slots", 4096)
     engine.set_param("dist_block", 128)

@@ -88,10 +88,14 @@ def test_partitions_spill_and_slices(engine, report, oracle_stage2):
         assert engine.stats()["n_spilled"] > 0
         engine.set_param("dist_sketch", 1)      # counting sketch first (the default), same tiny LDS budget
         pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov"), n_parts=3, check_table=False)
+        engine.set_param("dist_post_atomics", 1)    # the partition's postings by histogram + fill passes of atomics (default: compaction + sort)
+        pathcheck.check_stage2(engine, report("lowcov"), oracle_stage2("lowcov"), n_parts=3, check_table=False)
+        engine.set_param("dist_post_atomics", 0)
         engine.set_param("dist_slots", 256)     # 2048 8-bit counters: they wrap -> falls back to "every b marked"
         pathcheck.check_stage2(engine, report("hor2055"), oracle_stage2("hor2055"), check_table=False)
     finally:
         engine.set_param("dist_slots", 0)
+        engine.set_param("dist_post_atomics", 0)
         engine.set_param("dist_stage", 2048)
         engine.set_param("dist_edge_chunk", 0)
         engine.set_param("dist_sketch", 1)

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 for v in full abl1 abl2 abl3 abl4 abl5 abl6 abl7; do
   lib=centroflye_amd/build_variants/$v.so; [ "$v" = full ] && lib=centroflye_amd/libcfhip.so
   [ -f "$lib" ] || continue
-  timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d "$out/$v" -o p -- python3 tools/dist_ab.py 50000 $lib > "$out/$v.log" 2> "$out/$v.err"
+  timeout 400 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -d "$out/$v" -o p -- python3 tools/dist_ab.py 50000 $lib > "$out/$v.log" 2> "$out/$v.err"
   echo "$v rc=$? $(grep -v '^$' "$out/$v.log" | tail -1)"
 done
 find "$out" -name "*counter_collection.csv" | head -10
