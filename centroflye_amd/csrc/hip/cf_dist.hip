@@ -185,22 +185,39 @@ cf_entry_unit_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __res
 }
 
 // keys (first posting unit << 32 | a) of the first k-mers of this partition that have postings
+// A wave takes spans of 64 x 16 consecutive k-mers: it counts what it keeps of a span, reserves the output with ONE atomic and then
+// writes (the keys are sorted afterwards: their order here is free).  An atomic per 64 k-mers on the one counter was 6.9 ms of an
+// emulated rank's 23 ms of set-up (3.7e7 k-mers: 570 000 adds to one address, one after the other).
 __global__ void __launch_bounds__(256)
 cf_order_keys_kernel(const uint32_t* __restrict__ pcnt, const uint32_t* __restrict__ first_unit, int64_t n_kmers, int part, int n_parts,
                      unsigned long long* __restrict__ keys, unsigned long long* __restrict__ n_out) {
     const int lane = threadIdx.x & 63;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t rounds = (n_kmers + stride - 1) / stride;
-    for (int64_t rd = 0; rd < rounds; ++rd) {
-        const int64_t a = rd * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        const bool take = a < n_kmers && (a % n_parts) == part && pcnt[a] > 0;
-        const unsigned long long m = cf_ballot(take);
-        if (m) {
-            unsigned long long base = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if (lane == leader) base = atomicAdd(n_out, (unsigned long long)__popcll(m));
-            base = __shfl(base, leader);
-            if (take) keys[base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)first_unit[a] << 32) | (unsigned long long)a;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr int kRounds = 16;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int64_t s0 = wave * (64 * kRounds); s0 < n_kmers; s0 += n_waves * (64 * kRounds)) {      // (wave-uniform: ballots inside)
+        uint32_t takes = 0, total = 0;      // bit r: this lane keeps its k-mer of round r
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const int64_t a = s0 + (int64_t)r * 64 + lane;
+            const bool take = a < n_kmers && (a % n_parts) == part && pcnt[a] > 0;
+            takes |= (uint32_t)take << r;
+            total += (uint32_t)__popcll(cf_ballot(take));
+        }
+        if (total == 0u) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(n_out, (unsigned long long)total);
+        base = __shfl(base, 0);
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const bool take = (takes >> r) & 1u;
+            const unsigned long long m = cf_ballot(take);
+            if (take) {
+                const int64_t a = s0 + (int64_t)r * 64 + lane;
+                keys[base + (unsigned long long)__popcll(m & lt)] = ((unsigned long long)first_unit[a] << 32) | (unsigned long long)a;
+            }
+            base += (unsigned long long)__popcll(m);
         }
     }
 }
@@ -217,6 +234,12 @@ struct alignas(8) cf_dist_item { uint32_t e, m; };
 // One first k-mer of the launch, in processing order: its rank, its number of items and where its item records start.
 // The records of a first k-mer are laid out per WAVE of the sweeping workgroup (W waves): item j belongs to wave j % W and is its
 // record number j / W; wave w's records are the contiguous run [ibase + w * per, ...), per = ceil(n_items / W).
+// (-DCF_DIST_ITEMS_BLOCKED=1, measured and not kept: wave w sweeps the items [w * per, (w + 1) * per), the records lie in item order
+// and the fill kernel's stores are nearly coalesced — the set-up gains 0.6 ms of 18 and the kernel loses 15 of 263: dealt round robin
+// the waves of a workgroup read neighbouring 1 KB runs of the entry stream at the same time.)
+#ifndef CF_DIST_ITEMS_BLOCKED
+#define CF_DIST_ITEMS_BLOCKED 0
+#endif
 struct alignas(16) cf_dist_head { uint32_t a, n_items; unsigned long long ibase; uint32_t n_entries, pad0, pad1, pad2; };   // n_entries: partner entries (capped at 2^30 - 1)
 
 struct cf_dist_args {
@@ -1004,7 +1027,7 @@ cf_items_fill_kernel(const int32_t* __restrict__ order, int64_t n_order, const i
                 const uint32_t j = jb + x, off = x * DIST_ITEM;
                 uint32_t low = r.ig & 0xFFFFu;
                 if (cloud_ptr64) low = ((uint32_t)min(max(e64 - (r.e0 + (int64_t)off), (int64_t)0), (int64_t)DIST_ITEM) << 7) | (r.ig & 127u);
-                out[(size_t)(j % nw) * per + j / nw] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | low};
+                out[CF_DIST_ITEMS_BLOCKED ? (size_t)j : (size_t)(j % nw) * per + j / nw] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | low};
             }
             j0 += (uint32_t)__shfl((int)inc, 15, 16);
             unsigned long long l = r.len;
@@ -1180,7 +1203,8 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         if (ai < 0) break;
         const uint32_t a = sh[18], n_items = sh[19], n_ent_a = sh[22];
         // this wave's item records: one coalesced load, in flight while the sketch is cleared; both sweeps run on them
-        const uint32_t per_w = (n_items + nw - 1u) / nw, mine = wv < n_items ? (n_items - wv + nw - 1u) / nw : 0u;
+        const uint32_t per_w = (n_items + nw - 1u) / nw;
+        const uint32_t mine = CF_DIST_ITEMS_BLOCKED ? (n_items > wv * per_w ? min(per_w, n_items - wv * per_w) : 0u) : (wv < n_items ? (n_items - wv + nw - 1u) / nw : 0u);
         const cf_dist_item* recs = A.items + ((((unsigned long long)sh[21] << 32) | sh[20]) + (unsigned long long)wv * per_w);
         cf_dist_item my0 = cf_dist_item{0u, 0u};
         if ((uint32_t)lane < min(mine, 64u)) my0 = recs[lane];
