@@ -105,8 +105,17 @@ struct rccl_comm : cf_comm {
 }  // namespace
 
 // What rank 0 publishes: a magic word, the time it was written (ns since the epoch) and the id.
-struct rdv_record { uint64_t magic, written_ns; ncclUniqueId id; };
-static const uint64_t RDV_MAGIC = 0x63666364763033ull;      // "cfcdv03"
+struct rdv_record { uint64_t magic, written_ns, nonce; ncclUniqueId id; };
+static const uint64_t RDV_MAGIC = 0x63666364763034ull;      // "cfcdv04"
+// the launch's nonce: every rank of ONE launch sees the same CF_COMM_NONCE (centroflye_amd/sharded.py derives it from the launcher's
+// pid and start time; a C-ABI user who reuses rendezvous names exports a fresh one per launch); 0 when it is not set
+static uint64_t launch_nonce() {
+    const char* e = std::getenv("CF_COMM_NONCE");
+    if (!e || !*e) return 0;
+    uint64_t h = 1469598103934665603ull;      // FNV-1a
+    for (; *e; ++e) { h ^= (unsigned char)*e; h *= 1099511628211ull; }
+    return h ? h : 1;
+}
 static uint64_t wall_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count(); }
 // when this process started (ns since the epoch), from /proc/self/stat; 0 when it cannot be told
 static uint64_t process_start_ns() {
@@ -133,7 +142,8 @@ static uint64_t process_start_ns() {
 
 // rank 0 writes {magic, time, ncclUniqueId} to `<rendezvous>.<n>` for the n-th communicator of this process (tmp + rename;
 // a leftover of that name is removed first), the others poll for it (2 minutes) and ignore a file written more than
-// CF_RDV_SLACK_S before they started (a leftover of a crashed launch under a reused name); rank 0 removes the file once
+// CF_RDV_SLACK_S before they started or carrying another launch's nonce (a leftover of a crashed launch under a reused name:
+// the time test alone lets a file of the last two minutes through); rank 0 removes the file once
 // ncclCommInitRank has returned (every rank has joined by then).
 static const double CF_RDV_SLACK_S = 120.0;
 cf_comm* cf_comm_open(int device, int rank, int world, const char* rendezvous, std::string& err) {
@@ -161,7 +171,7 @@ cf_comm* cf_comm_open(int device, int rank, int world, const char* rendezvous, s
         const ncclResult_t r = c->api.GetUniqueId(&rec.id);
         if (r != ncclSuccess) { c->fail(r, "ncclGetUniqueId", err); delete c; return nullptr; }
         if (world > 1) {
-            rec.magic = RDV_MAGIC; rec.written_ns = wall_ns();
+            rec.magic = RDV_MAGIC; rec.written_ns = wall_ns(); rec.nonce = launch_nonce();
             const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
             FILE* f = std::fopen(tmp.c_str(), "wb");
             const bool ok = f && std::fwrite(&rec, sizeof rec, 1, f) == 1;
@@ -169,7 +179,7 @@ cf_comm* cf_comm_open(int device, int rank, int world, const char* rendezvous, s
             if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) { err = std::string("cf_comm_init: cannot write ") + path; delete c; return nullptr; }
         }
     } else {
-        const uint64_t born = process_start_ns();
+        const uint64_t born = process_start_ns(), nonce = launch_nonce();
         bool got = false, stale = false;
         for (int i = 0; i < 2400 && !got; ++i) {
             FILE* f = std::fopen(path.c_str(), "rb");
@@ -177,6 +187,7 @@ cf_comm* cf_comm_open(int device, int rank, int world, const char* rendezvous, s
                 got = std::fread(&rec, sizeof rec, 1, f) == 1 && rec.magic == RDV_MAGIC;
                 std::fclose(f);
                 if (got && born && rec.written_ns + (uint64_t)(CF_RDV_SLACK_S * 1e9) < born) { got = false; stale = true; }      // older than this launch: wait for rank 0 to replace it
+                if (got && nonce && rec.nonce != nonce) { got = false; stale = true; }      // another launch's
             }
             if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(50));
         }

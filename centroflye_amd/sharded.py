@@ -48,6 +48,9 @@ class ShardedRecruiter:
         self.engine = Engine(device_index, lib)
         self.local = self.glob = self.dist_engine = self.engine     # one context per GPU
         if self.exchange:
+            # every rank of this launch sees the same nonce (they share the launcher): a rendezvous file left by another launch under a
+            # reused name is not taken for this one's (cf_comm_rccl.hip)
+            os.environ.setdefault("CF_COMM_NONCE", os.path.basename(default_rendezvous()))
             self.engine.comm_init(self.rank, self.world, rendezvous if rendezvous is not None else default_rendezvous())
         self.sections = {}
         self.exchange_bytes = 0
