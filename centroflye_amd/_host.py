@@ -59,6 +59,8 @@ def lib():
     L.cfh_exotic_summary.argtypes = [P, i32, i32, C.c_uint32, C.c_uint32, i64, i64, pi64]
     L.cfh_exotic_list.restype = i64
     L.cfh_exotic_list.argtypes = [P, i32, i64, i64, C.c_void_p, i64]
+    L.cfh_exotic_rare.restype = i64
+    L.cfh_exotic_rare.argtypes = [P, i32, i32, C.c_uint32, C.c_uint32, C.c_void_p, i64]
     for name in ("cfh_bases", "cfh_read_off", "cfh_ids", "cfh_id_off", "cfh_meta"):
         getattr(L, name).argtypes = [P]
         getattr(L, name).restype = C.c_void_p
@@ -176,6 +178,19 @@ class PackedReads:
         if n and lib().cfh_exotic_list(self._h, int(k), int(read_lo), int(hi), rows.ctypes.data, n) != n:
             raise HostError("cfh_exotic_list: the window set changed between two calls")
         return rows
+
+    def exotic_rare(self, k, max_nonuniq, lo, hi):
+        """The rare windows that hold a symbol other than A, C, G, T and no lower-case letter, as strings in ascending order
+        (exotic_summary's n_blocking of them): the reference selects these k-mers like any other."""
+        args = (self._h, int(k), int(max_nonuniq), int(lo), int(min(hi, 2 ** 32 - 1)))
+        n = lib().cfh_exotic_rare(*args, None, 0)
+        if n < 0:
+            raise HostError(f"cfh_exotic_rare failed ({n})")
+        buf = C.create_string_buffer(max(1, n * int(k)))
+        if n and lib().cfh_exotic_rare(*args, buf, n) != n:
+            raise HostError("cfh_exotic_rare: the window set changed between two calls")
+        raw = buf.raw[:n * int(k)].decode("latin-1")
+        return [raw[i * k:(i + 1) * k] for i in range(n)]
 
     def export_read_units(self, rec, pos, outdir, min_pos=0, max_pos=None, n_threads=0):
         """Per-position read-unit FASTA files (reference eltr_polisher.py:53-97).  rec / pos: record indices and

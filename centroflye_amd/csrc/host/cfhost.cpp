@@ -1221,6 +1221,30 @@ int64_t cfh_exotic_list(const cfh_pack* p, int32_t k, int64_t read_lo, int64_t r
         return -5;
     }
 }
+// The windows of cfh_exotic_summary's out[4] themselves: rare (pres in [lo, hi], multi <= max_nonuniq) and free of lower-case letters,
+// as text, in ascending order — the k-mers the caller carries beside the 2-bit set (k bytes each, at most cap of them written).
+int64_t cfh_exotic_rare(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, char* out, int64_t cap) {
+    try {
+        if (!p || k < 1 || (cap > 0 && !out)) return -22;
+        std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> all;
+        int64_t n_pairs = 0;
+        exotic_windows(p, k, 0, (int64_t)p->read_off.size() - 1, all, n_pairs);
+        std::vector<const std::string*> keep;
+        for (const auto& kv : all) {
+            if (max_nonuniq < 0 || kv.second.second > (uint32_t)max_nonuniq || kv.second.first < lo || kv.second.first > hi) continue;
+            bool lower = false;
+            for (char c : kv.first) lower |= (c >= 'a' && c <= 'z');
+            if (!lower) keep.push_back(&kv.first);
+        }
+        std::sort(keep.begin(), keep.end(), [](const std::string* a, const std::string* b) { return *a < *b; });
+        for (int64_t i = 0; i < (int64_t)keep.size() && i < cap; ++i) std::memcpy(out + i * k, keep[(size_t)i]->data(), (size_t)k);
+        return (int64_t)keep.size();
+    } catch (const std::bad_alloc&) {
+        return -12;
+    } catch (...) {
+        return -5;
+    }
+}
 const uint8_t* cfh_bases(const cfh_pack* p) { return (const uint8_t*)p->bases.data(); }
 const int64_t* cfh_read_off(const cfh_pack* p) { return p->read_off.data(); }
 const char* cfh_ids(const cfh_pack* p) { return p->ids.data(); }

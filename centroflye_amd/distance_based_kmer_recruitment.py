@@ -88,25 +88,27 @@ def check_exotic_windows(packed, k, max_nonuniq, lo, hi, verbose=False):
     """Reads with symbols other than upper-case A, C, G, T (N calls, soft-masked stretches): the reference counts the
     windows that hold one as k-mers of their own (reference :47-53, no upper-casing there) — the device path skips them.
     That changes an output only if such a k-mer is rare AND can match a window of an upper-cased unit
-    (read_kmer_cloud.py:25), i.e. holds no lower-case letter; then the input is refused rather than answered differently."""
+    (read_kmer_cloud.py:25), i.e. holds no lower-case letter (the summary's n_blocking): get_rare_kmers then carries those
+    k-mers as strings beside the 2-bit set (kmers.KmerSet.extra).  Returns the summary, or None for plain reads."""
     if not packed.non_acgt:
         return None
     ex = packed.exotic_summary(k, max_nonuniq, lo, hi)
     if verbose:
-        print(f"# k-mers with symbols other than ACGT: {ex['n_distinct']} (rare: {ex['n_rare']})")
-    if ex["n_blocking"]:
-        raise ValueError(f"{ex['n_blocking']} rare k-mer(s) hold a symbol other than A, C, G, T and no lower-case letter (e.g. N): "
-                         "the device path has no code for them; mask or drop those reads")
+        print(f"# k-mers with symbols other than ACGT: {ex['n_distinct']} (rare: {ex['n_rare']}, of them without a lower-case letter: {ex['n_blocking']})")
     return ex
 
 
 def get_rare_kmers(reads_ncrf_report, k, bottom, top, coverage, kmer_survival_rate, max_nonuniq, verbose):
-    e = session.ensure_loaded(reads_ncrf_report.packed, 1)
+    packed = reads_ncrf_report.packed
+    e = session.ensure_loaded(packed, 1)
     e.count_kmers(k)
     lo, hi = rare_window(bottom, top, coverage, kmer_survival_rate)
-    check_exotic_windows(reads_ncrf_report.packed, k, max_nonuniq, lo, hi, verbose)
+    ex = check_exotic_windows(packed, k, max_nonuniq, lo, hi, verbose)
     e.select_rare(max_nonuniq, lo, hi)
-    rare = km.KmerSet(e.kmers(), k)
+    extra = packed.exotic_rare(k, max_nonuniq, lo, hi) if ex and ex["n_blocking"] else []
+    rare = km.KmerSet(e.kmers(), k, extra)
+    if extra:       # the device's list gets their pseudo-codes: ranks, posting lists and edges like any other k-mer's
+        e.set_kmers(rare.codes, k)
     if verbose:
         print(f"# rare kmers: {len(rare)}")
     return rare
@@ -169,15 +171,42 @@ def filter_dist_tuples(dist_cnt, min_coverage, rel_threshold=0.8):
     return set(np.flatnonzero(mask).tolist()), edges
 
 
+def write_kmer_file(path, kset, ranks):
+    """The k-mers of the given ranks, one per line, sorted as strings (reference :157-162)."""
+    ranks = np.asarray(ranks, np.int64)
+    plain = ranks[ranks < kset.n_acgt]
+    _host.write_kmers(path, kset.codes[np.sort(plain)], kset.k)     # ascending codes = sorted strings
+    if plain.size < ranks.size:       # k-mers without a 2-bit code: merged into the sorted lines
+        import heapq
+        more = sorted(kset.strings(ranks[ranks >= kset.n_acgt]))
+        with open(path) as f:
+            lines = f.read().splitlines()
+        with open(path, "w") as f:
+            f.write("".join(ln + "\n" for ln in heapq.merge(lines, more)))
+
+
+def write_edge_file(path, kset, edges, append=False):
+    """Rows (d, a, b, freq) as "d kmer_a kmer_b freq" lines (reference :165-170)."""
+    edges = np.asarray(edges, np.uint32).reshape(-1, 4)
+    odd = (edges[:, 1] >= kset.n_acgt) | (edges[:, 2] >= kset.n_acgt) if kset.extra else None
+    if odd is None or not odd.any():
+        _host.write_edges(path, kset.codes, kset.k, edges, append=append)
+        return
+    _host.write_edges(path, kset.codes, kset.k, np.ascontiguousarray(edges[~odd]), append=append)
+    rows = edges[odd]
+    a, b = kset.strings(rows[:, 1]), kset.strings(rows[:, 2])
+    with open(path, "a") as f:
+        f.write("".join(f"{int(r[0])} {x} {y} {int(r[3])}\n" for r, x, y in zip(rows, a, b)))
+
+
 def output_results(kmer_index, min_coverage, unique_kmers_ind, dist_edges, outdir):
     kset = kmer_index.kset
-    idx = np.array(sorted(unique_kmers_ind), np.int64)
     kfile = os.path.join(outdir, f"unique_kmers_min_edge_cov_{min_coverage}.txt")
-    _host.write_kmers(kfile + ".tmp", kset.codes[idx], kset.k)     # ascending codes = sorted strings
+    write_kmer_file(kfile + ".tmp", kset, np.array(sorted(unique_kmers_ind), np.int64))
     os.replace(kfile + ".tmp", kfile)
     efile = os.path.join(outdir, f"unique_edges_min_edge_cov_{min_coverage}.txt")
     arr = dist_edges.array if getattr(dist_edges, "array", None) is not None else np.array(list(dist_edges), np.uint32).reshape(-1, 4)
-    _host.write_edges(efile + ".tmp", kset.codes, kset.k, arr)
+    write_edge_file(efile + ".tmp", kset, arr)
     os.replace(efile + ".tmp", efile)
 
 
@@ -203,14 +232,14 @@ def main(argv=None):
             if ed is None:
                 open(efile + ".tmp", "w").close()
             else:
-                _host.write_edges(efile + ".tmp", kset.codes, kset.k, ed, append=True)
+                write_edge_file(efile + ".tmp", kset, ed, append=True)
     t1 = time.time()
     mask = _run_dist(dist_cnt, params.min_coverage, 0.8, sink)
     t_dist = time.time() - t1
     if not params.no_edges:
         os.replace(efile + ".tmp", efile)
     kfile = os.path.join(params.outdir, f"unique_kmers_min_edge_cov_{params.min_coverage}.txt")
-    _host.write_kmers(kfile + ".tmp", kset.codes[mask], kset.k)
+    write_kmer_file(kfile + ".tmp", kset, np.flatnonzero(mask))
     os.replace(kfile + ".tmp", kfile)
     if params.verbose:
         print(f"# unique kmers: {int(mask.sum())}; edges: {dist_cnt.stats['n_edges']}")

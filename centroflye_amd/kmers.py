@@ -1,6 +1,12 @@
 """k-mer strings <-> 2-bit codes (A=0 C=1 G=2 T=3, first base most significant) and the
 array-backed containers the drop-in modules hand out in place of the reference's dict / set of
-Python strings (they keep the same mapping / set protocol for small inputs)."""
+Python strings (they keep the same mapping / set protocol for small inputs).
+
+k-mers the 2-bit code does not have — an N or another upper-case symbol in the window, no lower-case letter — are carried beside
+the codes as strings (KmerSet.extra): the reference selects, finds and writes them like any other k-mer
+(distance_based_kmer_recruitment.py:47-53, read_kmer_cloud.py:25).  On the device each of them is a pseudo-code EXOTIC_BASE + j behind
+every real code: it takes a rank, a posting list, edges — and never matches a window by itself; the host adds their cloud entries
+(read_kmer_cloud.py here)."""
 from collections.abc import Mapping, Set
 
 import numpy as np
@@ -9,6 +15,12 @@ _LUT = np.full(256, 255, np.uint8)
 for _i, _c in enumerate(b"ACGT"):
     _LUT[_c] = _i
 _ALPHA = np.frombuffer(b"ACGT", np.uint8)
+EXOTIC_BASE = 1 << 62      # codes of k <= 31 stay below 2^62; bit 63 is the device table's occupancy bit
+
+
+def is_exotic(s, k):
+    """A k-long string that is no ACGT word but could equal a window of an upper-cased unit: no lower-case letter, no white space."""
+    return isinstance(s, str) and len(s) == k and try_encode(s, k) is None and s == s.upper() and not any(c.isspace() for c in s)
 
 
 def encode(strings, k):
@@ -50,11 +62,20 @@ def decode_one(code, k):
 
 
 class KmerSet(Set):
-    """Sorted unique k-mer codes behaving like the reference's ``set`` of k-mer strings."""
+    """Sorted unique k-mer codes behaving like the reference's ``set`` of k-mer strings.  ``extra``: the k-mers without a 2-bit
+    code (sorted strings); ``codes`` ends with one pseudo-code per extra k-mer, so ranks run over both."""
 
-    def __init__(self, codes, k):
-        self.codes = np.ascontiguousarray(codes, np.uint64)
+    def __init__(self, codes, k, extra=()):
+        codes = np.ascontiguousarray(codes, np.uint64)
         self.k = int(k)
+        self.extra = tuple(sorted(set(extra)))
+        if codes.size and int(codes[-1]) >= EXOTIC_BASE:      # (already carries its pseudo-codes: the device's list read back)
+            codes = codes[codes < np.uint64(EXOTIC_BASE)]
+        self.n_acgt = int(codes.size)
+        if self.extra:
+            codes = np.concatenate([codes, np.uint64(EXOTIC_BASE) + np.arange(len(self.extra), dtype=np.uint64)])
+        self.codes = np.ascontiguousarray(codes, np.uint64)
+        self._extra_rank = {s: self.n_acgt + j for j, s in enumerate(self.extra)}
 
     @classmethod
     def _from_iterable(cls, it):   # results of set algebra fall back to plain sets
@@ -64,19 +85,36 @@ class KmerSet(Set):
         return int(self.codes.size)
 
     def __contains__(self, s):
+        if s in self._extra_rank:
+            return True
         c = try_encode(s, self.k)
         if c is None:
             return False
-        i = int(np.searchsorted(self.codes, np.uint64(c)))
-        return i < self.codes.size and int(self.codes[i]) == c
+        i = int(np.searchsorted(self.codes[:self.n_acgt], np.uint64(c)))
+        return i < self.n_acgt and int(self.codes[i]) == c
+
+    def strings(self, ranks=None):
+        """the k-mers of the given ranks (all, in rank order, by default) as strings"""
+        if ranks is None:
+            return decode(self.codes[:self.n_acgt], self.k) + list(self.extra)
+        ranks = np.asarray(ranks, np.int64)
+        out = np.empty(ranks.size, dtype=object)
+        plain = ranks < self.n_acgt
+        if plain.any():
+            out[plain] = decode(self.codes[ranks[plain]], self.k)
+        for i in np.flatnonzero(~plain):
+            out[i] = self.extra[int(ranks[i]) - self.n_acgt]
+        return out.tolist()
 
     def __iter__(self):
-        return iter(decode(self.codes, self.k))
+        return iter(self.strings())
 
     def index(self, s):
+        if s in self._extra_rank:
+            return self._extra_rank[s]
         c = try_encode(s, self.k)
-        i = int(np.searchsorted(self.codes, np.uint64(c))) if c is not None else -1
-        if c is None or i >= self.codes.size or int(self.codes[i]) != c:
+        i = int(np.searchsorted(self.codes[:self.n_acgt], np.uint64(c))) if c is not None else -1
+        if c is None or i >= self.n_acgt or int(self.codes[i]) != c:
             raise KeyError(s)
         return i
 
@@ -132,5 +170,19 @@ def as_kmer_set(kmers, k):
         return KmerSet(np.unique(kmers.astype(np.uint64)), k)
     if kmers is None:
         raise TypeError("a k-mer set is required (the reference would fail on `kmer in None`)")
-    strs = [s for s in kmers if try_encode(s, k) is not None]  # other strings can never match an ACGT window
-    return KmerSet(np.unique(encode(strs, k)), k)
+    kmers = list(kmers)
+    strs = [s for s in kmers if try_encode(s, k) is not None]
+    # other strings match a window of an upper-cased unit only if they hold no lower-case letter (read_kmer_cloud.py:25)
+    return KmerSet(np.unique(encode(strs, k)), k, [s for s in kmers if is_exotic(s, k)])
+
+
+def exotic_lines(path, k):
+    """The lines of a k-mer file (reference read_placer.py:23-25: every stripped line is a k-mer) that are k long, hold a symbol
+    other than A, C, G, T and no lower-case letter; the 2-bit reader (cfh_read_kmers) skips them."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    plain = np.zeros(256, bool)
+    plain[list(b"ACGT\r\n")] = True
+    if plain[raw].all():
+        return []
+    with open(path) as f:
+        return sorted({ln.strip() for ln in f if is_exotic(ln.strip(), k)})

@@ -48,7 +48,7 @@ class KMerClouds(Mapping):
     def __getitem__(self, r_id):
         r = self._row[r_id]
         if self._strings is None:
-            self._strings = np.array(km.decode(self.kset.codes, self.kset.k), dtype=object)
+            self._strings = np.array(self.kset.strings(), dtype=object)
         cp, ent = self.cloud_ptr, self.entries
         units = [set(self._strings[ent[cp[u]:cp[u + 1]]]) for u in range(self.unit_ptr[r], self.unit_ptr[r + 1])]
         return ReadKMerCloud(units, r_id)
@@ -63,12 +63,57 @@ class KMerClouds(Mapping):
         return e
 
 
+_UPPER = np.arange(256, dtype=np.uint8)
+_UPPER[ord("a"):ord("z") + 1] -= 32
+_NOT_ACGT = np.ones(256, bool)
+_NOT_ACGT[list(b"ACGT")] = False
+
+
+def exotic_hits(packed, n, kset):
+    """(unit, rank) pairs, sorted and unique: the units one of whose upper-cased windows (reference :25-29) is a k-mer of
+    ``kset.extra`` — the k-mers the 2-bit lookup of cf_build_clouds cannot find.  Only windows over a symbol that is not A, C, G, T
+    after upper-casing can be one; such symbols are rare (N calls), so this stays on the host."""
+    k = kset.k
+    _, us, ue, _ = packed.units(n)
+    up = _UPPER[np.asarray(packed.bases)]
+    bad = np.flatnonzero(_NOT_ACGT[up])
+    hits = set()
+    if bad.size and len(us):
+        u = np.searchsorted(us, bad, side="right") - 1
+        ok = (u >= 0) & (bad < ue[np.maximum(u, 0)])
+        for b, uu in zip(bad[ok].tolist(), u[ok].tolist()):
+            lo, hi = max(int(us[uu]), b - k + 1), min(b, int(ue[uu]) - k)
+            if hi < lo:
+                continue
+            text = up[lo:hi + k].tobytes().decode("latin-1")
+            for w in range(hi - lo + 1):
+                r = kset._extra_rank.get(text[w:w + k])
+                if r is not None:
+                    hits.add((uu, r))
+    hits = sorted(hits)
+    return np.array([h[0] for h in hits], np.int64), np.array([h[1] for h in hits], np.int64)
+
+
+def add_exotic_entries(packed, n, kset, cloud_ptr, entries):
+    """The cloud CSR with the entries of exotic_hits added (their ranks lie behind every 2-bit k-mer's: the end of the row)."""
+    hu, hr = exotic_hits(packed, n, kset)
+    if not hu.size:
+        return cloud_ptr, entries
+    cloud_ptr = np.asarray(cloud_ptr, np.int64)
+    entries = np.insert(np.asarray(entries), cloud_ptr[hu + 1], hr.astype(np.asarray(entries).dtype))
+    grow = np.concatenate([[0], np.cumsum(np.bincount(hu, minlength=cloud_ptr.size - 1))]).astype(np.int64)
+    return cloud_ptr + grow, entries
+
+
 def get_reads_kmer_clouds(ncrf_report, n, k, genomic_kmers=None):
     kset = km.as_kmer_set(genomic_kmers, k)
     e = session.ensure_loaded(ncrf_report.packed, n)
     e.set_kmers(kset.codes, k)
     e.build_clouds()
     cloud_ptr, entries = e.clouds()
+    if kset.extra:      # k-mers with an N (...): the device finds none of them; their few cloud entries come from the host
+        cloud_ptr, entries = add_exotic_entries(ncrf_report.packed, n, kset, cloud_ptr, entries)
+        e.set_clouds(cloud_ptr, entries)
     unit_ptr = ncrf_report.packed.units(n)[0]
     out = KMerClouds(ncrf_report, n, kset, np.array(unit_ptr), cloud_ptr, entries)
     session.set_clouds_token(out.token)

@@ -14,6 +14,7 @@ import os
 import numpy as np
 
 from . import _host
+from . import kmers as km
 from .ncrf_parser import NCRF_Report
 from .read_kmer_cloud import filter_reads_kmer_clouds, get_reads_kmer_clouds
 
@@ -25,6 +26,9 @@ class ReadPlacer:
         self.k_cloud = params.k_cloud
         if params.genomic_kmers is not None:
             self.genomic_kmers = np.unique(_host.read_kmers(params.genomic_kmers, params.k_cloud))
+            extra = km.exotic_lines(params.genomic_kmers, params.k_cloud)      # k-mers with an N (...): no 2-bit code, kept as strings
+            if extra:
+                self.genomic_kmers = km.KmerSet(self.genomic_kmers, params.k_cloud, extra)
         else:
             self.genomic_kmers = None
         os.makedirs(params.outdir, exist_ok=True)

@@ -87,6 +87,11 @@ int cfh_exotic_summary(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32
  * holds no lower-case letter} — for a caller that must add the counts of several read shards before it can tell which
  * windows are rare (centroflye_amd/sharded.py).  Returns the number of distinct windows (or < 0); fills at most cap rows. */
 int64_t cfh_exotic_list(const cfh_pack* p, int32_t k, int64_t read_lo, int64_t read_hi, int64_t* rows, int64_t cap);
+/* The windows out[4] of cfh_exotic_summary counts, as text: rare and free of lower-case letters — the k-mers with an N (or another
+ * upper-case symbol) that the reference selects, finds again in the upper-cased units (read_kmer_cloud.py:25) and writes
+ * (distance_based_kmer_recruitment.py:47-53, :160-164).  k bytes each, ascending, at most cap written; returns their number (or < 0).
+ * The caller carries them beside the 2-bit set (centroflye_amd/kmers.py: KmerSet.extra). */
+int64_t cfh_exotic_rare(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, char* out, int64_t cap);
 
 /* Flat arrays. */
 const uint8_t* cfh_bases(const cfh_pack* p);     /* ASCII, de-gapped oriented r_al, length N_b */

@@ -47,6 +47,17 @@ EXTRA_FIXTURES = {
         stage2=dict(k=19, coverage=14, min_coverage=3, max_distance=2),
         stage3=dict(prefix_threshold=50000),
     ),
+    # "exotic_rare": the same base of the array turned into N in EVERY read row that holds it (n_shared loci): the windows over it
+    # are k-mers with an N that are RARE — the reference selects them, puts them into clouds (read_kmer_cloud.py:25 upper-cases the
+    # unit, the N stays) and writes them (distance_based_kmer_recruitment.py:47-53, :160-164); plus the random mutations of "exotic".
+    "exotic_rare": dict(
+        synth=dict(seed=23, unit_len=200, monomer_len=50, n_units=60, flank=60000, n_reads=30,
+                   mean_len=6500, sigma=0.2, min_len=6000, max_len=7000, unit_div=0.03,
+                   n_prefix=3, n_suffix=3, prefix_threshold=50000, p_split=0.15),
+        mutate=dict(seed=7, n_lower=6, lower_len=60, n_N=4, n_shared=3, shared_lo=6, shared_hi=13),
+        stage2=dict(k=19, coverage=14, min_coverage=3, max_distance=2),
+        stage3=dict(prefix_threshold=50000),
+    ),
 }
 
 
@@ -54,13 +65,36 @@ def _spec(name):
     return FIXTURES[name] if name in FIXTURES else EXTRA_FIXTURES[name]
 
 
-def mutate_report(path, seed, n_lower, lower_len, n_N):
-    """Lower-case n_lower stretches of lower_len aligned bases and turn n_N bases into N, in the read rows of the report."""
+def mutate_report(path, seed, n_lower, lower_len, n_N, n_shared=0, shared_lo=0, shared_hi=0, shared_len=37):
+    """Lower-case n_lower stretches of lower_len aligned bases and turn n_N bases into N, in the read rows of the report.
+    n_shared: first, n_shared times, the middle base of a stretch of shared_len gap-free row symbols that occurs (once per row) in
+    shared_lo .. shared_hi rows becomes N in every one of those rows."""
     import random
     rng = random.Random(seed)
     with open(path) as f:
         lines = f.read().split("\n")
     recs = [i for i, ln in enumerate(lines) if ln and not ln.startswith("#")][::2]
+    for _ in range(n_shared):
+        rows = {i: lines[i].split(None, 4)[4] for i in recs}
+        count, twice = {}, set()
+        for i, row in rows.items():
+            mine = set()
+            for c in range(len(row) - shared_len + 1):
+                w = row[c:c + shared_len]
+                if w.strip("ACGT"):
+                    continue
+                if w in mine:
+                    twice.add(w)
+                mine.add(w)
+            for w in mine:
+                count[w] = count.get(w, 0) + 1
+        cand = sorted(w for w, n in count.items() if shared_lo <= n <= shared_hi and w not in twice)
+        w = cand[rng.randrange(len(cand))]
+        mut = w[:shared_len // 2] + "N" + w[shared_len // 2 + 1:]
+        for i, row in rows.items():
+            if w in row:
+                head = lines[i].split(None, 4)
+                lines[i] = " ".join(head[:4]) + " " + row.replace(w, mut)
     for what in ["lower"] * n_lower + ["N"] * n_N:
         i = rng.choice(recs)
         head = lines[i].split(None, 4)

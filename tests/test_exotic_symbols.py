@@ -2,8 +2,11 @@
 drop-in CLIs, against files the REFERENCE wrote from the same report (tests/golden/exotic.json, captured by
 make_golden.py under two hash seeds).  Reference semantics: A1 counts the windows of the RAW row
 (distance_based_kmer_recruitment.py:47-53), so a window holding such a symbol is a k-mer of its own; A3 upper-cases the row
-first (read_kmer_cloud.py:25).  Here the device skips those windows in A1 (the host side-path cfh_exotic_summary counts them
-and proves they cannot reach an output), upper-cases in A3, and the files come out identical."""
+first (read_kmer_cloud.py:25).  Here the device skips those windows in A1 (the host side-path cfh_exotic_summary counts them),
+upper-cases in A3, and the files come out identical.  Fixture "exotic": none of those windows can reach an output (rare ones hold
+lower-case letters).  Fixture "exotic_rare": the same base is an N in every read that covers it, so k-mers with an N ARE rare — the
+reference selects them, finds them in the upper-cased units and writes them; here they travel beside the 2-bit set as strings
+(kmers.KmerSet.extra), take ranks on the device through pseudo-codes, and get their cloud entries from the host."""
 import hashlib
 import json
 import os
@@ -99,9 +102,9 @@ def test_presence_and_rare_counts_add_up_to_the_reference(emu_lib, exotic_report
     assert n_rare + ex["n_rare"] == g["rare"]["n"]
 
 
-def test_blocking_rare_kmer_is_refused_not_answered_differently(tmp_path):
-    """A k-mer with an N that IS rare (the same N-holding window in many reads) could match a window of an upper-cased
-    unit: the drop-in refuses the input."""
+def test_rare_kmer_with_an_N_is_carried_as_a_string(emu_lib, tmp_path):
+    """A k-mer with an N that IS rare (the same N-holding window in many reads) matches windows of the upper-cased units: the rare
+    set carries it beside the 2-bit codes, and the clouds of the units that hold it get its rank."""
     unit = "ACGTTGCAAGGCTTAACCGGATCGATTACAGGCATCGGAT"
     lines = []
     for r in range(12):
@@ -112,9 +115,62 @@ def test_blocking_rare_kmer_is_refused_not_answered_differently(tmp_path):
     path.write_text("\n".join(lines) + "\n")
     pk = _host.parse_report(str(path))
     ex = pk.exotic_summary(19, 3, 10, 32)
-    assert ex["n_blocking"] > 0
-    with pytest.raises(ValueError, match="symbol other than"):
-        dbkr.check_exotic_windows(pk, 19, 3, 10, 32)
+    assert ex["n_blocking"] == 19
+    assert dbkr.check_exotic_windows(pk, 19, 3, 10, 32)["n_blocking"] == 19
+    strs = pk.exotic_rare(19, 3, 10, 32)
+    row = (unit * 200)[:333] + "N" + (unit * 200)[334:]
+    assert strs == sorted(row[333 - j:333 - j + 19] for j in range(19))
+    from centroflye_amd import kmers as km, read_kmer_cloud as rkc
+    kset = km.KmerSet(np.zeros(0, np.uint64), 19, strs)
+    hu, hr = rkc.exotic_hits(pk, 1, kset)
+    _, us, ue, _ = pk.units(1)
+    want = sorted((u, kset.index(row[w:w + 19])) for r in range(pk.n_reads) for u in range(pk.units(1)[0][r], pk.units(1)[0][r + 1])
+                  for w in range(333 - 18, 334) if us[u] - pk.read_off[r] <= w and w + 19 <= ue[u] - pk.read_off[r])
+    assert list(zip(hu.tolist(), hr.tolist())) == want and len(want) >= 12
+
+
+@pytest.fixture(scope="module")
+def g_rare():
+    with open(os.path.join(ROOT, "tests", "golden", "exotic_rare.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def exotic_rare_report(fx_dir, g_rare):
+    path = fixtures.make_report("exotic_rare", fx_dir)
+    assert fixtures.sha256_file(path) == g_rare["report_sha256"]
+    return path
+
+
+def test_rare_kmers_with_an_N_reach_the_files_as_in_the_reference_on_emulated_kernels(emu_lib, exotic_rare_report, g_rare, tmp_path):
+    """The reference's own outputs for a report whose N-holding k-mers are rare: 35 of its unique k-mers hold an N."""
+    with open(os.path.join(ROOT, "tests", "golden", "exotic_rare.unique_kmers.txt")) as f:
+        assert sum("N" in ln for ln in f) >= 30
+    session.reset()
+    session._engine = Engine(0, emu_lib)
+    session._engine.set_param("dist_slots", 2048)
+    session._engine.set_param("dist_block", 128)
+    try:
+        out2, out3 = str(tmp_path / "s2"), str(tmp_path / "s3")
+        dbkr.main(_argv2(exotic_rare_report, out2, g_rare["stage2"]))
+        kfile = os.path.join(out2, f"unique_kmers_min_edge_cov_{g_rare['stage2']['min_coverage']}.txt")
+        with open(kfile) as f, open(os.path.join(ROOT, "tests", "golden", "exotic_rare.unique_kmers.txt")) as h:
+            assert f.read() == h.read()
+        read_placer.main(_argv3(exotic_rare_report, kfile, out3, g_rare["stage3"]))
+        _check_files(out2, out3, g_rare)
+    finally:
+        session.reset()
+
+
+@pytest.mark.gpu
+def test_rare_kmers_with_an_N_reach_the_files_as_in_the_reference_on_the_gpu(exotic_rare_report, g_rare, tmp_path):
+    out2, out3 = str(tmp_path / "s2"), str(tmp_path / "s3")
+    subprocess.check_call([sys.executable, "-u", os.path.join(ROOT, "scripts", "distance_based_kmer_recruitment.py")] + _argv2(exotic_rare_report, out2, g_rare["stage2"]),
+                          stdout=subprocess.DEVNULL)
+    kfile = os.path.join(out2, f"unique_kmers_min_edge_cov_{g_rare['stage2']['min_coverage']}.txt")
+    subprocess.check_call([sys.executable, "-u", os.path.join(ROOT, "scripts", "read_placer.py")] + _argv3(exotic_rare_report, kfile, out3, g_rare["stage3"]),
+                          stdout=subprocess.DEVNULL)
+    _check_files(out2, out3, g_rare)
 
 
 def test_cli_files_equal_the_reference_on_emulated_kernels(emu_lib, exotic_report, g, tmp_path):
