@@ -127,8 +127,8 @@ class ShardedRecruiter:
                 upper = np.bincount(inv, weights=rows[:, 4]) > 0
                 blocking = int(((multi <= max_nonuniq) & (pres >= lo) & (pres <= hi) & upper).sum())
             if blocking:
-                raise ValueError(f"{blocking} rare k-mer(s) hold a symbol other than A, C, G, T and no lower-case letter (e.g. N): "
-                                 "the device path has no code for them; mask or drop those reads")
+                raise ValueError(f"{blocking} rare k-mer(s) hold a symbol other than A, C, G, T and no lower-case letter (e.g. N): the multi-GPU "
+                                 "path does not carry them (one GPU does: scripts/distance_based_kmer_recruitment.py); mask or drop those reads")
         lap("exotic_windows")
         if self.exchange:
             self.exchange_bytes = E.exchange_table()
