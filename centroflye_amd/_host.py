@@ -59,6 +59,8 @@ def lib():
     L.cfh_exotic_summary.argtypes = [P, i32, i32, C.c_uint32, C.c_uint32, i64, i64, pi64]
     L.cfh_exotic_list.restype = i64
     L.cfh_exotic_list.argtypes = [P, i32, i64, i64, C.c_void_p, i64]
+    L.cfh_exotic_kept.restype = i64
+    L.cfh_exotic_kept.argtypes = [P, i32, i32, C.c_void_p, C.c_void_p, i64]
     L.cfh_exotic_rare.restype = i64
     L.cfh_exotic_rare.argtypes = [P, i32, i32, C.c_uint32, C.c_uint32, C.c_void_p, i64]
     for name in ("cfh_bases", "cfh_read_off", "cfh_ids", "cfh_id_off", "cfh_meta"):
@@ -178,6 +180,19 @@ class PackedReads:
         if n and lib().cfh_exotic_list(self._h, int(k), int(read_lo), int(hi), rows.ctypes.data, n) != n:
             raise HostError("cfh_exotic_list: the window set changed between two calls")
         return rows
+
+    def exotic_kept(self, k, max_nonuniq):
+        """{window text: reads holding it} for every window with a symbol other than upper-case A, C, G, T that the reference's table
+        keeps (twice in at most max_nonuniq reads)."""
+        n = lib().cfh_exotic_kept(self._h, int(k), int(max_nonuniq), None, None, 0)
+        if n < 0:
+            raise HostError(f"cfh_exotic_kept failed ({n})")
+        buf = C.create_string_buffer(max(1, n * int(k)))
+        pres = np.zeros(max(1, n), np.int64)
+        if n and lib().cfh_exotic_kept(self._h, int(k), int(max_nonuniq), buf, pres.ctypes.data, n) != n:
+            raise HostError("cfh_exotic_kept: the window set changed between two calls")
+        raw = buf.raw[:n * int(k)].decode("latin-1")
+        return {raw[i * k:(i + 1) * k]: int(pres[i]) for i in range(n)}
 
     def exotic_rare(self, k, max_nonuniq, lo, hi):
         """The rare windows that hold a symbol other than A, C, G, T and no lower-case letter, as strings in ascending order

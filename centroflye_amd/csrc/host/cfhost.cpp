@@ -1245,6 +1245,29 @@ int64_t cfh_exotic_rare(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint3
         return -5;
     }
 }
+// Every such window the reference's table keeps (twice in at most max_nonuniq reads; distance_based_kmer_recruitment.py:39-63), as
+// text in ascending order with the number of reads that hold it: the keys the 2-bit table of cf_count_kmers cannot have.
+int64_t cfh_exotic_kept(const cfh_pack* p, int32_t k, int32_t max_nonuniq, char* out, int64_t* pres, int64_t cap) {
+    try {
+        if (!p || k < 1 || (cap > 0 && (!out || !pres))) return -22;
+        std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> all;
+        int64_t n_pairs = 0;
+        exotic_windows(p, k, 0, (int64_t)p->read_off.size() - 1, all, n_pairs);
+        std::vector<const std::pair<const std::string, std::pair<uint32_t, uint32_t>>*> keep;
+        for (const auto& kv : all)
+            if (max_nonuniq >= 0 && kv.second.second <= (uint32_t)max_nonuniq) keep.push_back(&kv);
+        std::sort(keep.begin(), keep.end(), [](auto* a, auto* b) { return a->first < b->first; });
+        for (int64_t i = 0; i < (int64_t)keep.size() && i < cap; ++i) {
+            std::memcpy(out + i * k, keep[(size_t)i]->first.data(), (size_t)k);
+            pres[i] = (int64_t)keep[(size_t)i]->second.first;
+        }
+        return (int64_t)keep.size();
+    } catch (const std::bad_alloc&) {
+        return -12;
+    } catch (...) {
+        return -5;
+    }
+}
 const uint8_t* cfh_bases(const cfh_pack* p) { return (const uint8_t*)p->bases.data(); }
 const int64_t* cfh_read_off(const cfh_pack* p) { return p->read_off.data(); }
 const char* cfh_ids(const cfh_pack* p) { return p->ids.data(); }

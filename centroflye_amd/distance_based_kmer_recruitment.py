@@ -68,20 +68,15 @@ def rare_window(bottom, top, coverage, kmer_survival_rate):
 
 def get_kmer_freqs_from_ncrf_report(reads_ncrf_report, k, verbose, max_nonuniq):
     """{k-mer: number of reads holding it} without the k-mers that occur twice in more than max_nonuniq reads (reference :39-63).
-    The reference's dict also holds the windows with a symbol other than upper-case A, C, G, T as string keys of their own; this
-    mapping has no key for them (no 2-bit code), so a read set that has such windows is refused here rather than answered with
-    keys missing (get_rare_kmers, which only needs to know whether one of them is rare, accepts it: check_exotic_windows)."""
+    The reference's dict also holds the windows with a symbol other than upper-case A, C, G, T as string keys of their own (it counts
+    the raw text): those come from the host side path (cfh_exotic_kept) and ride along as a plain dict (KmerFreqs.extra)."""
     packed = reads_ncrf_report.packed
-    if packed.non_acgt:
-        ex = packed.exotic_summary(k, max_nonuniq, 0, 2 ** 32 - 1)
-        if ex["n_distinct"]:
-            raise ValueError(f"{ex['n_distinct']} distinct k-mer window(s) hold a symbol other than upper-case A, C, G, T: "
-                             "get_kmer_freqs_from_ncrf_report cannot return them (the device path has no code for them)")
+    extra = packed.exotic_kept(k, max_nonuniq) if packed.non_acgt else None
     e = session.ensure_loaded(packed, 1)
     e.count_kmers(k)
     keys, pres, multi = e.table()
     keep = multi.astype(np.int64) <= max_nonuniq
-    return km.KmerFreqs(keys[keep], pres[keep], k)
+    return km.KmerFreqs(keys[keep], pres[keep], k, extra)
 
 
 def check_exotic_windows(packed, k, max_nonuniq, lo, hi, verbose=False):

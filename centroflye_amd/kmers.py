@@ -7,6 +7,7 @@ the codes as strings (KmerSet.extra): the reference selects, finds and writes th
 (distance_based_kmer_recruitment.py:47-53, read_kmer_cloud.py:25).  On the device each of them is a pseudo-code EXOTIC_BASE + j behind
 every real code: it takes a rank, a posting list, edges — and never matches a window by itself; the host adds their cloud entries
 (read_kmer_cloud.py here)."""
+import itertools
 from collections.abc import Mapping, Set
 
 import numpy as np
@@ -136,20 +137,24 @@ class KmerIndex(Mapping):
 
 
 class KmerFreqs(Mapping):
-    """kmer string -> number of reads containing it (the reference's ``all_kmers`` dict)."""
+    """kmer string -> number of reads containing it (the reference's ``all_kmers`` dict).  ``extra``: the keys without a 2-bit code
+    (windows with an N, soft-masked stretches: the reference counts the raw text) as a plain dict."""
 
-    def __init__(self, codes, pres, k):
+    def __init__(self, codes, pres, k, extra=None):
         self.codes = np.ascontiguousarray(codes, np.uint64)
         self.pres = np.ascontiguousarray(pres, np.int64)
         self.k = int(k)
+        self.extra = dict(extra or {})
 
     def __len__(self):
-        return int(self.codes.size)
+        return int(self.codes.size) + len(self.extra)
 
     def __iter__(self):
-        return iter(decode(self.codes, self.k))
+        return itertools.chain(decode(self.codes, self.k), self.extra)
 
     def __getitem__(self, s):
+        if s in self.extra:
+            return self.extra[s]
         c = try_encode(s, self.k)
         i = int(np.searchsorted(self.codes, np.uint64(c))) if c is not None else -1
         if c is None or i >= self.codes.size or int(self.codes[i]) != c:
@@ -157,7 +162,7 @@ class KmerFreqs(Mapping):
         return int(self.pres[i])
 
     def items(self):
-        return zip(decode(self.codes, self.k), (int(v) for v in self.pres))
+        return itertools.chain(zip(decode(self.codes, self.k), (int(v) for v in self.pres)), self.extra.items())
 
 
 def as_kmer_set(kmers, k):

@@ -173,6 +173,30 @@ def test_rare_kmers_with_an_N_reach_the_files_as_in_the_reference_on_the_gpu(exo
     _check_files(out2, out3, g_rare)
 
 
+@pytest.mark.parametrize("name", ["exotic", "exotic_rare"])
+def test_presence_mapping_and_rare_set_equal_the_reference_key_by_key(emu_lib, fx_dir, name):
+    """G1 and G2 of the reference on reads with N calls and soft-masked stretches: the mapping k-mer -> reads holding it (keys with such
+    symbols are strings of the raw text, reference :47-53) and the rare set, digests over every key."""
+    from centroflye_amd.ncrf_parser import NCRF_Report
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.json")) as f:
+        gg = json.load(f)
+    p2 = gg["stage2"]
+    session.reset()
+    session._engine = Engine(0, emu_lib)
+    try:
+        rep = NCRF_Report(fixtures.make_report(name, fx_dir), keep_rows=False)
+        freqs = dbkr.get_kmer_freqs_from_ncrf_report(rep, k=p2["k"], verbose=False, max_nonuniq=p2["max_nonuniq"])
+        assert len(freqs) == gg["presence"]["n"] and canon.presence_digest(freqs.items()) == gg["presence"]["digest"]
+        rare = dbkr.get_rare_kmers(rep, k=p2["k"], bottom=p2["bottom"], top=p2["top"], coverage=p2["coverage"],
+                                   kmer_survival_rate=p2["kmer_survival_rate"], max_nonuniq=p2["max_nonuniq"], verbose=False)
+        # the reference's rare set also holds rare windows WITH lower-case letters: they can match nothing downstream and are not carried
+        lo, hi = dbkr.rare_window(p2["bottom"], p2["top"], p2["coverage"], p2["kmer_survival_rate"])
+        inert = [s for s, v in freqs.extra.items() if lo <= v <= hi and s != s.upper()]
+        assert len(rare) + len(inert) == gg["rare"]["n"] and canon.set_digest(list(rare) + inert) == gg["rare"]["digest"]
+    finally:
+        session.reset()
+
+
 def test_cli_files_equal_the_reference_on_emulated_kernels(emu_lib, exotic_report, g, tmp_path):
     session.reset()
     session._engine = Engine(0, emu_lib)
