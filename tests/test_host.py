@@ -219,3 +219,27 @@ def test_pack_cache_round_trip_and_refusals(tmp_path, monkeypatch):
         e = _host.parse_report(path, keep_rows=False, cache_dir=cache)      # falls back to parsing, rewrites the cache
         assert not e.from_cache and np.array_equal(e.bases, d.bases)
         assert open(fn, "rb").read() == blob
+
+
+@pytest.mark.parametrize("name", ["exotic", "exotic_rare"])
+def test_windows_without_a_2bit_code_are_listed_consistently(name, fx_dir):
+    """The four views of the windows that hold a symbol other than upper-case A, C, G, T — summary counts, hashed rows, the kept keys
+    with their read counts, the rare upper-case ones as text — agree with each other and with a count over the raw rows."""
+    pk = _host.parse_report(fixtures.make_report(name, fx_dir))
+    k, max_nonuniq, lo, hi = 19, 3, 5, 14
+    ex = pk.exotic_summary(k, max_nonuniq, lo, hi)
+    rows = pk.exotic_list(k)
+    kept = pk.exotic_kept(k, max_nonuniq)
+    rare = pk.exotic_rare(k, max_nonuniq, lo, hi)
+    assert rows.shape == (ex["n_distinct"], 5) and int(rows[:, 2].sum()) == ex["n_read_kmers"]
+    assert len(kept) == ex["n_kept"] == int((rows[:, 3] <= max_nonuniq).sum())
+    assert len(rare) == ex["n_blocking"] and rare == sorted(rare)
+    assert rare == sorted(s for s, v in kept.items() if lo <= v <= hi and s == s.upper())
+    raw = pk.bases.tobytes()
+    seen = {}
+    for r in range(pk.n_reads):
+        s = raw[pk.read_off[r]:pk.read_off[r + 1]]
+        for x in {s[w:w + k] for w in range(len(s) - k + 1) if s[w:w + k].strip(b"ACGT")}:
+            seen[x] = seen.get(x, 0) + 1
+    assert {kk.encode("latin-1"): v for kk, v in kept.items()} == {x: v for x, v in seen.items() if x.decode("latin-1") in kept} and len(seen) == ex["n_distinct"]
+    assert (name == "exotic_rare") == bool(rare)
