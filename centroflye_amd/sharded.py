@@ -20,7 +20,9 @@ import time
 
 import numpy as np
 
+from . import kmers as km
 from .engine import Engine
+from .read_kmer_cloud import add_exotic_entries
 
 
 def default_rendezvous():
@@ -85,6 +87,35 @@ class ShardedRecruiter:
     def allreduce(self, values, op="sum"):
         return self.engine.allreduce(values, op) if self.exchange else np.asarray(values, np.int64)
 
+    def _exotic_strings(self, packed, k, rare_keys):
+        """The text of the windows whose (hash, hash) rows turned out rare over ALL shards: every rank looks its own windows up and the
+        ranks exchange the bytes (7 per int64, so that the sum of the one rank that fills a word stays its value) — each window is held
+        by at least one shard."""
+        want = {(int(a), int(b)): i for i, (a, b) in enumerate(rare_keys.tolist())}
+        words = (k + 6) // 7
+        slab = np.zeros((len(want), 1 + words), np.int64)
+        for s_ in packed.exotic_rare(k, 2 ** 31 - 1, 0, 2 ** 32 - 1):      # this shard's windows without a lower-case letter, whatever their counts
+            raw = s_.encode("latin-1")
+            h1, h2 = 0xcbf29ce484222325, 0x9E3779B97F4A7C15      # the two hashes of cfh_exotic_list (cfhost.cpp)
+            for c in raw:
+                h1 = ((h1 ^ c) * 0x100000001b3) & (2 ** 64 - 1)
+                h2 = ((h2 + c) * 0xff51afd7ed558ccd) & (2 ** 64 - 1)
+                h2 ^= h2 >> 29
+            i = want.get((h1 >> 1, h2 >> 1))
+            if i is not None:
+                slab[i, 0] = 1
+                for w in range(words):
+                    slab[i, 1 + w] = int.from_bytes(raw[7 * w:7 * w + 7].ljust(7, b"\0"), "big")
+        if self.exchange and self.world > 1:
+            slab = np.asarray(self.allreduce(slab.reshape(-1), "sum"), np.int64).reshape(len(want), 1 + words)
+        if (slab[:, 0] < 1).any():
+            raise ValueError(f"{int((slab[:, 0] < 1).sum())} rare k-mer window(s) with a symbol other than A, C, G, T: their text was found on no shard")
+        out = []
+        for row in slab.tolist():
+            n = row[0]
+            out.append(b"".join(int(v // n).to_bytes(7, "big") for v in row[1:])[:k].decode("latin-1"))      # (held by n shards: n equal words added)
+        return sorted(out)
+
     # ------------------------------------------------------------------ one step
     def run(self, k=19, max_nonuniq=3, lo=10, hi=32, min_d=1, max_d=150, min_cov=4, rel_threshold=0.8, edge_cap=0):
         E = self.engine
@@ -102,9 +133,10 @@ class ShardedRecruiter:
         # Windows with symbols other than upper-case A, C, G, T are skipped on the device; the reference counts them as k-mers of
         # their own (distance_based_kmer_recruitment.py:47-53).  One of them changes an output only if it is rare over ALL
         # shards and could match a window of an upper-cased unit: decided on GLOBAL counts, exactly as the single-GPU entry
-        # point decides (check_exotic_windows) — presence and multiplicity of a window add over disjoint read shards — and
-        # before the table exchange is paid for.
+        # point decides (check_exotic_windows) — presence and multiplicity of a window add over disjoint read shards.  Those that
+        # are rare travel as strings from here on (round 4; round 3 stopped the run).
         packed = getattr(self, "packed", None)
+        self._exotic = []
         if packed is not None:
             rows = packed.exotic_list(k) if packed.non_acgt else np.zeros((0, 5), np.int64)
             if self.exchange and self.world > 1:
@@ -118,17 +150,17 @@ class ShardedRecruiter:
                     rows[:, 2] -= 1
                 else:
                     rows = np.zeros((0, 5), np.int64)
-            blocking = 0
+            extra = []
             if rows.shape[0]:
-                _, inv = np.unique(np.stack([rows[:, 0], rows[:, 1]], 1), axis=0, return_inverse=True)
+                keys, inv = np.unique(np.stack([rows[:, 0], rows[:, 1]], 1), axis=0, return_inverse=True)
                 inv = np.asarray(inv).reshape(-1)
                 pres = np.bincount(inv, weights=rows[:, 2]).astype(np.int64)
                 multi = np.bincount(inv, weights=rows[:, 3]).astype(np.int64)
                 upper = np.bincount(inv, weights=rows[:, 4]) > 0
-                blocking = int(((multi <= max_nonuniq) & (pres >= lo) & (pres <= hi) & upper).sum())
-            if blocking:
-                raise ValueError(f"{blocking} rare k-mer(s) hold a symbol other than A, C, G, T and no lower-case letter (e.g. N): the multi-GPU "
-                                 "path does not carry them (one GPU does: scripts/distance_based_kmer_recruitment.py); mask or drop those reads")
+                rare_keys = keys[(multi <= max_nonuniq) & (pres >= lo) & (pres <= hi) & upper]
+                if rare_keys.shape[0]:
+                    extra = self._exotic_strings(packed, k, rare_keys)
+            self._exotic = extra
         lap("exotic_windows")
         if self.exchange:
             self.exchange_bytes = E.exchange_table()
@@ -136,8 +168,19 @@ class ShardedRecruiter:
         E.select_rare(max_nonuniq, lo, hi)
         st_owner = E.stats()
         n_rare = E.allgather_kmers() if self.exchange else st_owner["n_kmers"]
+        self.kset = None
+        if getattr(self, "_exotic", None):
+            # rare k-mers with an N (...): carried as strings beside the codes (kmers.KmerSet.extra, as the single-GPU entry point does);
+            # every rank installs the same pseudo-codes behind the gathered list, so ranks agree over all ranks
+            self.kset = km.KmerSet(E.kmers(), k, self._exotic)
+            E.set_kmers(self.kset.codes, k)
+            n_rare = len(self.kset)
         lap("select")
         n_ce_local = E.build_clouds()
+        if self.kset is not None:      # their cloud entries (windows over a non-ACGT symbol of this rank's units) come from the host
+            cloud_ptr, entries = add_exotic_entries(packed, 1, self.kset, *E.clouds())
+            E.set_clouds(cloud_ptr, entries)
+            n_ce_local = int(entries.size)
         lap("clouds")
         dist_ce = n_ce_local
         if self.exchange:

@@ -24,6 +24,56 @@ PARAMS = dict(k=19, max_nonuniq=3, lo=4, hi=14, min_d=1, max_d=2, min_cov=2, rel
 READS_PER_RANK = 12
 
 
+def exotic_real(rank, world, rdv, lib):
+    """Fixture "exotic_rare" (k-mers with an N that ARE rare) dealt record by record to the ranks: the sharded run must carry those
+    k-mers exactly as the single-process path does on the whole report (same rare set, same edges, same unique k-mers)."""
+    import fixtures
+    from centroflye_amd import kmers as km
+    from centroflye_amd.engine import Engine
+    from centroflye_amd.read_kmer_cloud import add_exotic_entries
+    full = fixtures.make_report("exotic_rare", rdv)      # (both ranks write the same bytes through tmp + rename)
+    with open(full) as f:
+        lines = f.read().split("\n")
+    recs = [i for i, ln in enumerate(lines) if ln and not ln.startswith("#")]
+    mine = set()
+    for j in range(0, len(recs), 2):
+        if (j // 2) % world == rank:
+            mine.update(recs[j:j + 2])
+    part = os.path.join(rdv, f"part{rank}.ncrf")
+    with open(part, "w") as f:
+        f.write("\n".join(ln for i, ln in enumerate(lines) if i in mine or ln.startswith("#") or not ln))
+    P = dict(PARAMS, lo=5, hi=14)
+    pk = _host.parse_report(part)
+    sr = ShardedRecruiter(0, lib=lib, rank=rank, world=world, rendezvous=rdv)
+    sr.engine.set_param("dist_slots", 2048); sr.engine.set_param("dist_block", 128)
+    sr.load(pk, 1)
+    out = sr.run(edge_cap=400000, **P)
+    edges = sr.engine.edges(out["local_edges"])
+    chk = cport.edge_checksum(edges)
+    total_chk = int(sum(int(x) for x in sr.allreduce([chk & 0xFFFFFFFF, chk >> 32], "sum") * np.array([1, 2 ** 32], dtype=object)) % 2 ** 64)
+    n_odd = int(sr.allreduce([int(((edges[:, 1] >= sr.kset.n_acgt) | (edges[:, 2] >= sr.kset.n_acgt)).sum())], "sum")[0])
+    if rank == 0:
+        pf = _host.parse_report(full)
+        with Engine(0, lib) as e:
+            e.set_param("dist_slots", 2048); e.set_param("dist_block", 128)
+            e.load(pf, 1)
+            e.count_kmers(P["k"]); e.select_rare(P["max_nonuniq"], P["lo"], P["hi"])
+            kset = km.KmerSet(e.kmers(), P["k"], pf.exotic_rare(P["k"], P["max_nonuniq"], P["lo"], P["hi"]))
+            e.set_kmers(kset.codes, P["k"])
+            e.build_clouds()
+            e.set_clouds(*add_exotic_entries(pf, 1, kset, *e.clouds()))
+            e.reset_unique()
+            n = e.dist_edges(0, 2 ** 62, P["min_d"], P["max_d"], P["min_cov"], P["rel_threshold"], 0, 1, 400000)
+            want = dict(n_edges=n, checksum=cport.edge_checksum(e.edges(n)), unique=e.unique_mask(), st=e.stats())
+        ok = dict(n_extra=len(kset.extra), same_strings=list(sr.kset.extra) == list(kset.extra), same_codes=bool(np.array_equal(sr.kset.codes, kset.codes)),
+                  n_rare=out["n_rare"] == len(kset), n_edges=out["n_edges"] == want["n_edges"], edge_checksum=total_chk == want["checksum"],
+                  unique=bool(np.array_equal(sr.unique_mask, want["unique"])), n_emissions=out["n_emissions"] == want["st"]["n_emissions"],
+                  n_cloud_entries=out["n_cloud_entries"] == want["st"]["n_cloud_entries"], edges_with_such_a_kmer=n_odd)
+        print("EXOTIC_REAL " + json.dumps(ok), flush=True)
+    sr.barrier()
+    sr.close()
+
+
 def main():
     rank, world, rdv = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     lib = _lib.load(os.path.join(ROOT, "tests", "emu", "libcfhip_emu.so"))
@@ -35,6 +85,8 @@ def main():
     if len(sys.argv) > 5:
         sr.engine.set_param("comm_self_p2p", int(sys.argv[5]))
     sr.load(pk, 1)
+    if len(sys.argv) > 6 and sys.argv[6] == "exotic_real":
+        return exotic_real(rank, world, rdv, lib)
     if len(sys.argv) > 6:       # exotic windows (symbols other than upper-case ACGT): the decision is made on counts ADDED over the shards
         mode = sys.argv[6]
 

@@ -62,3 +62,27 @@ def test_exotic_windows_are_judged_on_counts_added_over_the_shards(emu_lib, tmp_
         assert p.returncode == 0, so[-3000:] + se[-3000:]
         res = json.loads([ln for ln in so.splitlines() if ln.startswith("EXOTIC_RESULT ")][0].split(" ", 1)[1])
         assert res["refused"] == refused, res
+
+
+def test_rare_kmers_with_an_N_travel_through_the_sharded_path(emu_lib, tmp_path):
+    """Fixture "exotic_rare" dealt over two ranks: the windows with an N are rare only on the ADDED counts; their text is exchanged,
+    every rank installs the same pseudo-codes behind the gathered rare list and adds its own units' cloud entries — rare set, edges
+    (checksum over all ranks), unique k-mers and counters equal the single-process run on the whole report."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    rdv = tmp_path / "rdv"
+    rdv.mkdir()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"), str(r), "2", str(rdv), str(1 << 28), "0", "exotic_real"],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=1500))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-3000:] + se[-3000:]
+    res = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("EXOTIC_REAL ")][0].split(" ", 1)[1])
+    assert res["n_extra"] >= 30 and res["edges_with_such_a_kmer"] > 0
+    assert all(res[k] is True for k in ("same_strings", "same_codes", "n_rare", "n_edges", "edge_checksum", "unique", "n_emissions", "n_cloud_entries")), res
