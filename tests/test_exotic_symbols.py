@@ -197,6 +197,34 @@ def test_presence_mapping_and_rare_set_equal_the_reference_key_by_key(emu_lib, f
         session.reset()
 
 
+def _sharded_counts(lib, report, g_, tmp_path):
+    """the exchange path (bucketing, all-to-all, all-gathers) on ONE rank: edges and unique k-mers of the reference's files"""
+    from centroflye_amd.sharded import ShardedRecruiter
+    p2 = g_["stage2"]
+    lo, hi = dbkr.rare_window(p2["bottom"], p2["top"], p2["coverage"], p2["kmer_survival_rate"])
+    sr = ShardedRecruiter(0, lib=lib, rank=0, world=1, rendezvous=str(tmp_path / "rdv"), force_exchange=True)
+    try:
+        if lib is not None:
+            sr.engine.set_param("dist_slots", 2048); sr.engine.set_param("dist_block", 128)
+        sr.load(_host.parse_report(report), 1)
+        out = sr.run(k=p2["k"], max_nonuniq=p2["max_nonuniq"], lo=lo, hi=hi, min_d=p2["min_distance"], max_d=p2["max_distance"],
+                     min_cov=p2["min_coverage"], rel_threshold=0.8, edge_cap=0)
+        assert out["n_edges"] == g_["edges"]["n"] and out["n_unique"] == g_["unique_kmers"]["n"] == int(sr.unique_mask.sum())
+        assert len(sr.kset.extra) >= 30 and sorted(sr.kset.strings(np.flatnonzero(sr.unique_mask))) == open(
+            os.path.join(ROOT, "tests", "golden", "exotic_rare.unique_kmers.txt")).read().split()
+    finally:
+        sr.close()
+
+
+def test_sharded_entry_point_carries_the_rare_N_kmers_on_emulated_kernels(emu_lib, exotic_rare_report, g_rare, tmp_path):
+    _sharded_counts(emu_lib, exotic_rare_report, g_rare, tmp_path)
+
+
+@pytest.mark.gpu
+def test_sharded_entry_point_carries_the_rare_N_kmers_on_the_gpu(exotic_rare_report, g_rare, tmp_path):
+    _sharded_counts(None, exotic_rare_report, g_rare, tmp_path)
+
+
 def test_cli_files_equal_the_reference_on_emulated_kernels(emu_lib, exotic_report, g, tmp_path):
     session.reset()
     session._engine = Engine(0, emu_lib)
