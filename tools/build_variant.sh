@@ -1,6 +1,8 @@
 #!/usr/bin/env bash
 # Developer tool: build a variant of libcfhip into centroflye_amd/build_variants/<name>.so
 # usage: tools/build_variant.sh <name> [-DFLAG ...] [--dist <alternative cf_dist.hip>]
+# (centroflye_amd/build_variants/ is listed in .gpurunignore so that left-over builds do not travel with every GPU lease: take the line out
+#  for the A/B runs of tools/dist_ab.py / count_ab.py / dist_ablation.sh, delete the builds afterwards)
 set -euo pipefail
 root="$(cd "$(dirname "$0")/.." && pwd)"
 name=$1; shift
