@@ -479,7 +479,7 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "dist_region_bytes") {
         ctx->dist_region_bytes = value != 0;
     } else if (n == "place_mode") {
-        if (value < 1 || value > 2) return cf_fail(ctx, -22, "place_mode out of range (1 = hash map, 2 = per-read regions)");
+        if (value < 1 || value > 3) return cf_fail(ctx, -22, "place_mode out of range (1 = hash map, 2 = per-read regions unless min_inters < 4, 3 = per-read regions always)");
         ctx->place_mode = (int)value;
     } else if (n == "place_block") {
         if (value != 0 && (value < 128 || value > 1024 || value % 128)) return cf_fail(ctx, -22, "place_block must be 0 or a multiple of 128 in 128 .. 1024");

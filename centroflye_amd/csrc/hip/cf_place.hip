@@ -501,7 +501,12 @@ int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int3
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     const int64_t R = ctx->n_reads;
     for (int64_t r = 0; r < R; ++r) if (cls[r] > 2) return cf_fail(ctx, -22, "cf_place_reads: class must be 0, 1 or 2");
-    if (ctx->place_mode == 2 && cf_place2_fits(ctx)) {      // round 4: per-read score regions, one kernel per greedy iteration (cf_place2.hip)
+    // round 4: per-read score regions, one kernel per greedy iteration (cf_place2.hip).  Its rescans look at the rows that have
+    // max(1, min_inters) hits: with a threshold that nearly every row reaches (--min-inters 1 .. 3) that is every row of every read a
+    // placement touches — measured at 10 000 reads, min_inters 1 / 2 / 3 / 5: 2 256 / 619 / 267 / 164 ms against 220 for the hash-map
+    // path (35 s with --min-cloud-kmer-freq 1 on top: tools/place_sweep_check.py) — so small thresholds take the rounds 1-3 path.
+    // (place_mode 3 forces the regions whatever the threshold: tests.)
+    if ((ctx->place_mode == 3 || (ctx->place_mode == 2 && min_inters >= 4)) && cf_place2_fits(ctx)) {
         std::vector<int64_t> o_read, o_pos;
         std::vector<int32_t> o_s0, o_s1;
         CF_TRY(cf_place2_run(ctx, cls, id_rank, min_cloud_kmer_freq, min_unit, min_inters, min_prop, o_read, o_pos, o_s0, o_s1));

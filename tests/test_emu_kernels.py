@@ -223,6 +223,26 @@ def test_stage3_launch_shapes_and_region_restart(engine, report, golden, knobs):
             engine.set_param(k, v)
 
 
+@pytest.mark.parametrize("mode", [2, 3, 1])
+def test_stage3_small_thresholds_on_both_paths(engine, report, golden, mode):
+    """--min-inters below 4 makes nearly every score row a candidate row: the default (place_mode 2) sends such runs down the hash-map
+    path, place_mode 3 keeps the per-read regions; both give the oracle's lines (with --min-cloud-kmer-freq 1 and --min-unit 1 on top)."""
+    from centroflye_amd import _host
+    from oracle import ncrf
+    name = "lowcov"
+    g = golden(name)
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.unique_kmers.txt")) as f:
+        gk = np.array(sorted(recruit.encode_kmer(x.strip()) for x in f if x.strip()), dtype=np.uint64)
+    records, alns, lens = ncrf.parse_report(report(name))
+    pk = _host.parse_report(report(name))
+    p3 = dict(g["stage3"], min_inters=2, min_unit=1, min_cloud_kmer_freq=1)
+    engine.set_param("place_mode", mode)
+    try:
+        pathcheck.check_stage3(engine, pk, records, alns, lens, gk, p3)
+    finally:
+        engine.set_param("place_mode", 2)
+
+
 def test_unit_kmer_occurrences_and_top_n(engine, report):
     import json
     with open(os.path.join(ROOT, "tests", "golden", "lowcov.unit_kmers.json")) as f:
