@@ -243,6 +243,22 @@ def test_stage3_small_thresholds_on_both_paths(engine, report, golden, mode):
         engine.set_param("place_mode", 2)
 
 
+def test_stage3_with_units_of_two_motifs(engine, report, golden):
+    """--n-motif 2 (reference ncrf_parser.py get_motif_alignments(n=2): units of two stuck-together motifs): clouds, filter and every line
+    of the placement against the oracle (whose unit split is pinned to the reference's G0 unit_cols_n2)."""
+    from centroflye_amd import _host
+    from oracle import ncrf
+    name = "lowcov"
+    g = golden(name)
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.unique_kmers.txt")) as f:
+        gk = np.array(sorted(recruit.encode_kmer(x.strip()) for x in f if x.strip()), dtype=np.uint64)
+    records, alns, lens = ncrf.parse_report(report(name))
+    pk = _host.parse_report(report(name), keep_rows=True)
+    p3 = dict(g["stage3"], n_motif=2, min_inters=40)
+    lines = pathcheck.check_stage3(engine, pk, records, alns, lens, gk, p3)
+    assert sum(1 for ln in lines if not ln.endswith(" None")) >= 5
+
+
 def test_unit_kmer_occurrences_and_top_n(engine, report):
     import json
     with open(os.path.join(ROOT, "tests", "golden", "lowcov.unit_kmers.json")) as f:
