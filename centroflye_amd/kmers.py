@@ -184,10 +184,8 @@ def as_kmer_set(kmers, k):
 def exotic_lines(path, k):
     """The lines of a k-mer file (reference read_placer.py:23-25: every stripped line is a k-mer) that are k long, hold a symbol
     other than A, C, G, T and no lower-case letter; the 2-bit reader (cfh_read_kmers) skips them."""
-    raw = np.fromfile(path, dtype=np.uint8)
-    plain = np.zeros(256, bool)
-    plain[list(b"ACGT\r\n")] = True
-    if plain[raw].all():
-        return []
+    with open(path, "rb") as f:
+        if not f.read().translate(None, b"ACGT\r\n"):      # (nothing but k-mers of the 2-bit alphabet: the usual file)
+            return []
     with open(path) as f:
         return sorted({ln.strip() for ln in f if is_exotic(ln.strip(), k)})

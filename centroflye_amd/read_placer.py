@@ -25,7 +25,9 @@ class ReadPlacer:
         self.ncrf_report = NCRF_Report(params.ncrf, keep_rows=getattr(params, "n_motif", 1) != 1)
         self.k_cloud = params.k_cloud
         if params.genomic_kmers is not None:
-            self.genomic_kmers = np.unique(_host.read_kmers(params.genomic_kmers, params.k_cloud))
+            self.genomic_kmers = _host.read_kmers(params.genomic_kmers, params.k_cloud)
+            if self.genomic_kmers.size > 1 and not (self.genomic_kmers[1:] > self.genomic_kmers[:-1]).all():      # (stage 2 writes them sorted)
+                self.genomic_kmers = np.unique(self.genomic_kmers)
             extra = km.exotic_lines(params.genomic_kmers, params.k_cloud)      # k-mers with an N (...): no 2-bit code, kept as strings
             if extra:
                 self.genomic_kmers = km.KmerSet(self.genomic_kmers, params.k_cloud, extra)
