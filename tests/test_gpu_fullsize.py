@@ -59,6 +59,28 @@ def test_config3_share_200k_reads_count_clouds_and_one_distance_partition_vs_cpu
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("other", [dict(k=31), dict(k=11, lo=20, hi=200, max_d=20), dict(rel_threshold=0.6, min_cov=2, max_d=40),
+                                   dict(max_nonuniq=0, lo=6, hi=20, min_d=3, max_d=300, min_cov=6)])
+def test_other_parameters_at_3k_reads_vs_cpu(other):
+    """Parameter sets other than the benchmark's at a size with real table pressure (tools/param_sweep_check.py runs them at 20 000 reads:
+    profiles/r04_param_sweep.json): the 2-bit code's longest and a short k, the threshold that takes the double division, a low minimum
+    coverage, another rare window, distances from 3 to 300 — A1 table, A2 rare set, A3 CSR and one first-k-mer partition of A5/A6 against
+    the OpenMP oracle."""
+    import bigparity
+    pk = synth(3000, 3)
+    base = dict(bigparity.P)
+    e = Engine(0)
+    try:
+        bigparity.P.update(other)
+        rec = bigparity.check(e, pk, 1, 4)
+    finally:
+        bigparity.P.clear(); bigparity.P.update(base)
+        e.close()
+    assert rec["identical"], (other, rec["checks"])
+    assert rec["n_emissions_partition"] > 1e8 and rec["n_edges_partition"] > 1000
+
+
+@pytest.mark.timeout(900)
 def test_config1_50k_reads_count_and_rare_filter_vs_cpu(engine):
     pk = synth(50000, 2)                      # the bench workload itself
     assert pk.n_bases > 9e8
