@@ -55,6 +55,12 @@
 #define PL2_B 1024          // threads per workgroup of the iteration kernel (the tail wants 16 waves)
 #define PL2_LIST 2048       // dirty blocks of 8 reads per round of the tail
 #define PL2_CRES 512        // touched blocks of 64 reads whose new records go through LDS to the final reduction
+#ifndef PL2_DW
+#define PL2_DW 8            // dirty-bitmap words per thread and round of the tail's scan (16: 50 000 reads + 3.5 %, 500 000 - 3.3 %)
+#endif
+#ifndef PL2_SW
+#define PL2_SW 4            // block records per lane and round of the tail's sweep over all blocks of 64 reads
+#endif
 
 // Uw = 32-bit words of a slot's cell row: two 16-bit counters per word, rounded up to a multiple of 4 (rows are read 16 bytes at a time)
 struct alignas(16) cf_pl2_rinfo { unsigned long long slot_base, cell_base; uint32_t hmask, Uw, anchor_off1, anchor_slot; };
@@ -343,8 +349,8 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
     uint32_t* n_list = lds32; uint32_t* more = lds32 + 1; uint32_t* n_list2 = lds32 + 2;
     uint32_t* list = lds32 + 4;
     uint32_t* list2 = list + PL2_LIST;
-    unsigned long long* red = (unsigned long long*)(list2 + PL2_LIST);      // the sweeping lanes' bests: up to 8 waves x 64 lanes x {hi, lo, ext, read}
-    unsigned long long* cres = red + 4 * 512;                                 // new records of the touched blocks of 64 (fused last round)
+    unsigned long long* red = (unsigned long long*)(list2 + PL2_LIST);      // the sweeping lanes' bests: up to 16 waves x 64 lanes x {hi, lo, ext, read}
+    unsigned long long* cres = red + 4 * 1024;                                 // new records of the touched blocks of 64 (fused last round)
     uint32_t* bb2 = (uint32_t*)(cres + 4 * PL2_CRES);
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
@@ -354,12 +360,17 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
     while (again) {
         if (tid == 0) { *n_list = 0u; *more = 0u; *n_list2 = 0u; }
         __syncthreads();
-        for (uint32_t w0 = tid; w0 < S.n_dirty_words; w0 += 2u * nthr) {      // every workgroup has arrived: plain traffic on the bitmap
-            const uint32_t w1 = w0 + nthr;
-            const uint32_t b0 = cf_ld_agent(&S.dirty[w0]), b1 = w1 < S.n_dirty_words ? cf_ld_agent(&S.dirty[w1]) : 0u;
-            for (int t = 0; t < 2; ++t) {
-                uint32_t bits = t ? b1 : b0;
-                const uint32_t wi = t ? w1 : w0;
+        // every workgroup has arrived: plain traffic on the bitmap.  A thread takes PL2_DW words per round, ALL loaded before the first is
+        // looked at: the bitmap is one bit per read, and a round trip per pair of words made this scan 8 dependent round trips at 500 000
+        // reads (one at 50 000).
+        for (uint32_t w0 = tid; w0 < S.n_dirty_words; w0 += (uint32_t)PL2_DW * nthr) {
+            uint32_t bw[PL2_DW];
+#pragma unroll
+            for (int t = 0; t < PL2_DW; ++t) { const uint32_t wi = w0 + (uint32_t)t * nthr; bw[t] = wi < S.n_dirty_words ? cf_ld_agent(&S.dirty[wi]) : 0u; }
+#pragma unroll
+            for (int t = 0; t < PL2_DW; ++t) {
+                uint32_t bits = bw[t];
+                const uint32_t wi = w0 + (uint32_t)t * nthr;
                 if (!bits) continue;
                 const uint32_t cnt = (uint32_t)__popc(bits);
                 const uint32_t k0 = atomicAdd(n_list, cnt);
@@ -391,7 +402,7 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
         // ones, whose new records come through LDS — so the two levels cost one round trip and one barrier, not two of each.
         const uint32_t m = *n_list2;
         const bool fused = !again && m <= PL2_CRES;
-        const int nfw = (int)min((uint32_t)(nw / 2), (S.n2 + 255u) >> 8);      // waves of the sweep over all blocks
+        const int nfw = (int)min((uint32_t)(S.n2 > 2048u ? nw - nw / 4 : nw / 2), (S.n2 + 255u) >> 8);      // waves of the sweep over all blocks (three quarters of the workgroup for large read sets: the touched blocks need few)
         const int w_first = fused ? nfw : 0, w_n = nw - w_first;
         if (wave >= w_first)
             for (uint32_t k = (uint32_t)(wave - w_first) * 8u; k < m; k += (uint32_t)w_n * 8u) {
@@ -419,18 +430,17 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
             if (wave < nfw) {
                 cf_pl2_rec mine{0ull, 0ull, 0ull, 0u, 0u};
                 const uint32_t stride = (uint32_t)nfw * 64u;
-                for (uint32_t b = (uint32_t)(wave * 64 + lane); b < S.n2; b += 4u * stride) {
+                for (uint32_t b = (uint32_t)(wave * 64 + lane); b < S.n2; b += (uint32_t)PL2_SW * stride) {      // (PL2_SW loads in flight per lane)
                     const cf_pl2_rec none{0ull, 0ull, 0ull, 0u, 0u};
-                    const uint32_t b1 = b + stride, b2 = b + 2u * stride, b3 = b + 3u * stride;
-                    const bool k0 = !fused || !((bb2[b >> 5] >> (b & 31)) & 1u);
-                    const bool k1 = b1 < S.n2 && (!fused || !((bb2[b1 >> 5] >> (b1 & 31)) & 1u));
-                    const bool k2 = b2 < S.n2 && (!fused || !((bb2[b2 >> 5] >> (b2 & 31)) & 1u));
-                    const bool k3 = b3 < S.n2 && (!fused || !((bb2[b3 >> 5] >> (b3 & 31)) & 1u));
-                    const cf_pl2_rec o0 = k0 ? pl2_load(&S.L2[b]) : none;
-                    const cf_pl2_rec o1 = k1 ? pl2_load(&S.L2[b1]) : none;
-                    const cf_pl2_rec o2 = k2 ? pl2_load(&S.L2[b2]) : none;
-                    const cf_pl2_rec o3 = k3 ? pl2_load(&S.L2[b3]) : none;
-                    pl2_take(mine, o0); pl2_take(mine, o1); pl2_take(mine, o2); pl2_take(mine, o3);
+                    cf_pl2_rec o[PL2_SW];
+#pragma unroll
+                    for (int t = 0; t < PL2_SW; ++t) {
+                        const uint32_t bt = b + (uint32_t)t * stride;
+                        const bool kt = bt < S.n2 && (!fused || !((bb2[bt >> 5] >> (bt & 31)) & 1u));
+                        o[t] = kt ? pl2_load(&S.L2[bt]) : none;
+                    }
+#pragma unroll
+                    for (int t = 0; t < PL2_SW; ++t) pl2_take(mine, o[t]);
                 }
                 // every lane's best goes to LDS as it is: ONE reduction over the wave's lanes, in the last wave standing, instead of one
                 // per sweeping wave and another over their results (a 64-lane reduction of a record is 42 lane permutes)
@@ -466,7 +476,7 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
     PL2_STAMP(7);
 }
 
-static size_t pl2_lds_bytes(uint32_t n2) { return (16 + (size_t)PL2_LIST * 8 + 512 * 32 + (size_t)PL2_CRES * 32 + (size_t)((n2 + 31) / 32) * 4 + 16); }
+static size_t pl2_lds_bytes(uint32_t n2) { return (16 + (size_t)PL2_LIST * 8 + 1024 * 32 + (size_t)PL2_CRES * 32 + (size_t)((n2 + 31) / 32) * 4 + 16); }
 
 __global__ void __launch_bounds__(PL2_B)
 cf_pl2_tail_kernel(cf_pl2 S) {
