@@ -200,9 +200,10 @@ def parse_args():
 def launch_ranks(a):
     """`python bench.py --gpus N` outside a launcher: start the N ranks as children (this process never initialises HIP)."""
     idf = os.path.join(tempfile.gettempdir(), f"cfcomm_{os.getuid()}_{os.getpid()}_{int(time.time() * 1e3)}.id")
+    nonce = os.urandom(8).hex()      # a fresh token per launch: a stale rendezvous record under a reused name is another launch's
     procs = []
     for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), CF_COMM_ID_FILE=idf)
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), CF_COMM_ID_FILE=idf, CF_COMM_NONCE=nonce)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     # fail fast: a rank that dies leaves the others waiting in a collective — end them, exit non-zero (this process never
     # touches a GPU, so it may kill its children)

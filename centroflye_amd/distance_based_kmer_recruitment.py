@@ -206,6 +206,20 @@ def output_results(kmer_index, min_coverage, unique_kmers_ind, dist_edges, outdi
 
 
 def main(argv=None):
+    # N GPUs behind the same command line (centroflye_amd/sharded_cli.py): CF_GPUS=N starts N ranks from this process — which then
+    # never touches a GPU —; under a launcher (RANK / WORLD_SIZE > 1 in the environment, e.g. torch.distributed.run) or with
+    # CF_SHARDED=1 this process IS a rank
+    world = int(os.environ.get("WORLD_SIZE", "1") or 1)
+    if (world > 1 and "RANK" in os.environ) or os.environ.get("CF_SHARDED") == "1":
+        from . import sharded_cli
+        return sharded_cli.rank_main(argv)
+    n_gpus = int(os.environ.get("CF_GPUS", "0") or 0)
+    if n_gpus > 1:
+        from . import sharded_cli
+        rc = sharded_cli.launch(argv, n_gpus)
+        if rc:
+            raise SystemExit(rc)
+        return 0
     params = parse_args(argv)
     smart_makedirs(params.outdir)
     t0 = time.time()

@@ -260,6 +260,14 @@ class Engine:
         self._check(self._lib.cf_edges_checksum(self._ctx, int(n), C.byref(out)), "cf_edges_checksum")
         return int(out.value)
 
+    def checksum(self, what):
+        """(sum, items) of the order-independent device-side checksum of "table" (A1), "kmers" (the installed set), "clouds"
+        (the CSR) or "unique" (the k-mers whose unique bit is set) — the oracle's figures (cfhip.h: cf_checksum)."""
+        out, n = C.c_uint64(), C.c_int64()
+        sel = {"table": 0, "kmers": 1, "clouds": 2, "unique": 3}[what]
+        self._check(self._lib.cf_checksum(self._ctx, sel, C.byref(out), C.byref(n)), "cf_checksum")
+        return int(out.value), int(n.value)
+
     def unique_mask(self):
         n = self.stats()["n_kmers"]
         out = np.zeros(n, np.uint8)

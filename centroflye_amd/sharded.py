@@ -41,6 +41,35 @@ def default_rendezvous():
                         f"cfcomm_{os.getuid()}_{os.environ.get('MASTER_PORT', '0')}_{ppid}_{born}.id")
 
 
+def new_launch_token():
+    """A fresh token for CF_COMM_NONCE: a launcher (bench.py --gpus N, the CF_GPUS entry of the stage script) exports it to every rank
+    it starts, so that a rendezvous file left by another launch under a reused name is never taken for this one's."""
+    return os.urandom(8).hex()
+
+
+def set_launch_nonce(explicit_rendezvous):
+    """CF_COMM_NONCE for cf_comm_init (cf_comm_rccl.hip), from values that are EQUAL on all ranks of this launch and FRESH per launch
+     — or left unset (no nonce check; the record's age rule still applies) when no such value is known:
+      * a launcher's token (already in the environment): kept;
+      * the ranks share a parent and the rendezvous name is derived from it (no CF_COMM_ID_FILE, no explicit path): that name, which
+        holds the parent's pid and start time;
+      * an explicit rendezvous / CF_COMM_ID_FILE (mpirun, srun, one launcher per node: parents differ, the name may be reused):
+        the job's id as the launcher publishes it (TORCHELASTIC_RUN_ID other than torchrun's default "none", SLURM_JOB_ID + SLURM_STEP_ID,
+        OMPI / PMIx job ids), else nothing."""
+    if os.environ.get("CF_COMM_NONCE"):
+        return
+    if explicit_rendezvous is None and not os.environ.get("CF_COMM_ID_FILE"):
+        os.environ["CF_COMM_NONCE"] = os.path.basename(default_rendezvous())
+        return
+    run_id = os.environ.get("TORCHELASTIC_RUN_ID", "")
+    if run_id and run_id != "none":
+        os.environ["CF_COMM_NONCE"] = f"torchelastic:{run_id}:{os.environ.get('MASTER_ADDR', '')}:{os.environ.get('MASTER_PORT', '')}"
+    elif os.environ.get("SLURM_JOB_ID"):
+        os.environ["CF_COMM_NONCE"] = f"slurm:{os.environ['SLURM_JOB_ID']}:{os.environ.get('SLURM_STEP_ID', '')}"
+    elif os.environ.get("PMIX_NAMESPACE") or os.environ.get("OMPI_MCA_ess_base_jobid"):
+        os.environ["CF_COMM_NONCE"] = "mpi:" + (os.environ.get("PMIX_NAMESPACE") or os.environ["OMPI_MCA_ess_base_jobid"])
+
+
 class ShardedRecruiter:
     def __init__(self, device_index=0, lib=None, rank=0, world=1, rendezvous=None, force_exchange=False):
         self.rank, self.world = int(rank), int(world)
@@ -50,11 +79,9 @@ class ShardedRecruiter:
         self.engine = Engine(device_index, lib)
         self.local = self.glob = self.dist_engine = self.engine     # one context per GPU
         if self.exchange:
-            # every rank of this launch sees the same nonce (they share the launcher): a rendezvous file left by another launch under a
-            # reused name is not taken for this one's (cf_comm_rccl.hip)
-            os.environ.setdefault("CF_COMM_NONCE", os.path.basename(default_rendezvous()))
+            set_launch_nonce(rendezvous)
             self.engine.comm_init(self.rank, self.world, rendezvous if rendezvous is not None else default_rendezvous())
-        self.sections = {}
+        self.sections, self._t_last = {}, time.perf_counter()
         self.exchange_bytes = 0
         self._cache = {}
 
@@ -78,6 +105,7 @@ class ShardedRecruiter:
 
     def load(self, packed, n_motif=1):
         self.packed = packed
+        self.n_motif = int(n_motif)
         self.engine.load(packed, n_motif)
 
     def barrier(self):
@@ -118,14 +146,22 @@ class ShardedRecruiter:
 
     # ------------------------------------------------------------------ one step
     def run(self, k=19, max_nonuniq=3, lo=10, hi=32, min_d=1, max_d=150, min_cov=4, rel_threshold=0.8, edge_cap=0):
-        E = self.engine
-        sec, t_last = {}, [time.perf_counter()]
+        """One step: prepare() (A1-A3 with their exchanges), one distance launch on this rank's first k-mers, combine()."""
+        self.prepare(k, max_nonuniq, lo, hi)
+        self.dist(min_d, max_d, min_cov, rel_threshold, edge_cap)
+        return self.combine()
 
-        def lap(name):      # every library call returns with its work done
-            now = time.perf_counter()
-            sec[name] = round(sec.get(name, 0.0) + now - t_last[0], 4)
-            t_last[0] = now
-        self.sections = sec
+    def _lap(self, name):      # every library call returns with its work done
+        now = time.perf_counter()
+        self.sections[name] = round(self.sections.get(name, 0.0) + now - self._t_last, 4)
+        self._t_last = now
+
+    def prepare(self, k=19, max_nonuniq=3, lo=10, hi=32):
+        """A1 on the shard, table exchange, A2 on the owned keys, rare-list gather, A3 on the shard, cloud gather: afterwards every rank
+        holds the rare set and the clouds of ALL reads (units in rank order) and dist() may run any first-k-mer partition."""
+        E = self.engine
+        self.sections, self._t_last = {}, time.perf_counter()
+        lap = self._lap
         self._cache = {}
         E.count_kmers(k)
         st_local = E.stats()
@@ -139,6 +175,10 @@ class ShardedRecruiter:
         self._exotic = []
         if packed is not None:
             rows = packed.exotic_list(k) if packed.non_acgt else np.zeros((0, 5), np.int64)
+            # a window's text decides its flag (column 4: no lower-case letter), the same on every shard; windows with a lower-case letter
+            # can never be selected (they match no upper-cased unit) — on soft-masked read sets they are nearly all rows, so they are
+            # dropped before the exchange
+            rows = rows[rows[:, 4] != 0]
             if self.exchange and self.world > 1:
                 n_max = int(self.allreduce([rows.shape[0]], "max")[0])
                 if n_max:
@@ -178,7 +218,7 @@ class ShardedRecruiter:
         lap("select")
         n_ce_local = E.build_clouds()
         if self.kset is not None:      # their cloud entries (windows over a non-ACGT symbol of this rank's units) come from the host
-            cloud_ptr, entries = add_exotic_entries(packed, 1, self.kset, *E.clouds())
+            cloud_ptr, entries = add_exotic_entries(packed, getattr(self, "n_motif", 1), self.kset, *E.clouds())
             E.set_clouds(cloud_ptr, entries)
             n_ce_local = int(entries.size)
         lap("clouds")
@@ -186,21 +226,46 @@ class ShardedRecruiter:
         if self.exchange:
             dist_ce = E.allgather_clouds()
             lap("cloud_gather")
-        E.reset_unique()
-        n_edges = E.dist_edges(0, 2 ** 62, min_d, max_d, min_cov, rel_threshold, self.rank, self.world, edge_cap)
+        self._prep = dict(st_local=st_local, st_owner=st_owner, n_rare=n_rare, n_ce_local=n_ce_local, dist_ce=dist_ce)
+        self.reset_dist()
+        return n_rare
+
+    def reset_dist(self):
+        """Forget the distance launches since prepare(): empty unique bitmap, counters at zero."""
+        self.engine.reset_unique()
+        self._dist = dict(n_edges=0, n_emissions=0, kernel_ms=0.0, n_spilled=0, n_dist_passes=0)
+
+    def dist(self, min_d=1, max_d=150, min_cov=4, rel_threshold=0.8, edge_cap=0, sub=0, n_sub=1, min_n=0, max_n=2 ** 62):
+        """A5 + A6 for this rank's first k-mers, a % world == rank — or for the sub-partition `sub` of `n_sub` of them
+        (a % (world * n_sub) == rank + sub * world: the stage script streams a rank's edges in pieces it can hold).  The unique bitmap
+        and the counters accumulate over calls until the next prepare().  Returns the edges selected by this call (up to edge_cap of
+        them are stored: Engine.edges / sort_edges)."""
+        E = self.engine
+        n_edges = E.dist_edges(min_n, max_n, min_d, max_d, min_cov, rel_threshold, self.rank + sub * self.world, self.world * n_sub, edge_cap)
         st_d = E.stats()
-        lap("dist")
-        c = [n_edges, st_d["n_emissions"], st_local["n_bases"], st_local["n_windows"], st_local["n_read_kmers"],
-             st_owner["n_distinct"], st_owner["n_kept"], n_ce_local]
+        d = self._dist
+        d["n_edges"] += n_edges; d["n_emissions"] += st_d["n_emissions"]; d["kernel_ms"] += E.times()["dist_kernel_ms"]
+        d["n_spilled"] += st_d["n_spilled"]; d["n_dist_passes"] += st_d["n_dist_passes"]
+        d["n_unique_local"] = st_d["n_unique"]
+        self._lap("dist")
+        return n_edges
+
+    def combine(self):
+        """OR of the unique masks and sums of the counters over ranks: the figures of the whole read set."""
+        E, p, d = self.engine, self._prep, self._dist
+        st_local, st_owner = p["st_local"], p["st_owner"]
+        c = [d["n_edges"], d["n_emissions"], st_local["n_bases"], st_local["n_windows"], st_local["n_read_kmers"],
+             st_owner["n_distinct"], st_owner["n_kept"], p["n_ce_local"]]
         if self.exchange:
             n_unique = E.allreduce_unique()
             c = E.allreduce(c, "sum").tolist()
         else:
-            n_unique = st_d["n_unique"]
-        lap("combine")
-        self.local_edges = n_edges
+            n_unique = d.get("n_unique_local", 0)
+        self._lap("combine")
+        self._cache.pop("mask", None)
+        self.local_edges = d["n_edges"]
         return dict(n_edges=c[0], n_emissions=c[1], n_bases=c[2], n_windows=c[3], n_read_kmers=c[4], n_distinct=c[5],
-                    n_kept=c[6], n_cloud_entries=c[7], n_rare=n_rare, n_unique=n_unique,
-                    local_emissions=st_d["n_emissions"], local_edges=n_edges, local_bases=st_local["n_bases"],
-                    local_cloud_entries=n_ce_local, dist_cloud_entries=dist_ce,
-                    dist_kernel_ms=E.times()["dist_kernel_ms"], n_spilled=st_d["n_spilled"], n_dist_passes=st_d["n_dist_passes"])
+                    n_kept=c[6], n_cloud_entries=c[7], n_rare=p["n_rare"], n_unique=n_unique,
+                    local_emissions=d["n_emissions"], local_edges=d["n_edges"], local_bases=st_local["n_bases"],
+                    local_cloud_entries=p["n_ce_local"], dist_cloud_entries=p["dist_ce"],
+                    dist_kernel_ms=d["kernel_ms"], n_spilled=d["n_spilled"], n_dist_passes=d["n_dist_passes"])

@@ -130,6 +130,17 @@ int cf_sort_edges(cf_ctx* ctx);
  * same figure the oracle reports; full-size parity checks compare every selected edge of
  * distance_based_kmer_recruitment.py:131-149 without copying tens of GB to the host). */
 int cf_edges_checksum(cf_ctx* ctx, int64_t n, uint64_t* out);
+/* Order-independent checksums of the other resident results, computed on the device (sums mod 2^64 of the oracle's per-element
+ * mixes, oracle/c/cf_oracle_mt.c; mix = the 64-bit finaliser of MurmurHash3): what =
+ *   CF_CHECKSUM_TABLE   every (key, pres, multi) of the A1 table (distance_based_kmer_recruitment.py:39-63):
+ *                       mix(mix(mix(key + 0x7AB1E) ^ pres) ^ (multi << 1));
+ *   CF_CHECKSUM_KMERS   the installed k-mer set, after cf_select_rare the rare set (:66-82): mix(kmer ^ 0xABCDEF);
+ *   CF_CHECKSUM_CLOUDS  every (unit, entry) of the cloud CSR (read_kmer_cloud.py:17-40): mix(mix(unit + 0x51ED) ^ entry);
+ *   CF_CHECKSUM_UNIQUE  the k-mers of the set whose unique bit is set (:145-148), same mix as CF_CHECKSUM_KMERS.
+ * n_items (may be NULL): how many elements went into the sum.  Full-size parity checks (BASELINE configs[3]: 1.3e9 table
+ * entries, 6.5e8 cloud entries) compare these figures with a committed oracle record instead of copying the arrays back. */
+enum { CF_CHECKSUM_TABLE = 0, CF_CHECKSUM_KMERS = 1, CF_CHECKSUM_CLOUDS = 2, CF_CHECKSUM_UNIQUE = 3 };
+int cf_checksum(cf_ctx* ctx, int32_t what, uint64_t* sum, int64_t* n_items);
 int cf_get_unique_mask(cf_ctx* ctx, uint8_t* mask /* n_kmers bytes of 0/1 */);
 int cf_or_unique_mask(cf_ctx* ctx, const uint8_t* mask);
 int cf_reset_unique(cf_ctx* ctx);

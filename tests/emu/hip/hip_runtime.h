@@ -89,6 +89,9 @@ template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMall
 inline hipError_t hipFree(void* p) { cfemu::dev_free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+enum { hipHostRegisterDefault = 0 };
+inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 enum hipMemoryType { hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
 struct hipPointerAttribute_t { hipMemoryType type; };
 inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { a->type = hipMemoryTypeHost; return hipSuccess; }   // "device" memory is host memory here

@@ -1,0 +1,132 @@
+"""The sharded path behind the reference's command line: `CF_GPUS=N python
+scripts/distance_based_kmer_recruitment.py ...` starts N ranks (centroflye_amd/sharded_cli.py) that shard the parsed report,
+run A1-A6 with the exchanges of centroflye_amd/sharded.py and write the reference's two files
+(distance_based_kmer_recruitment.py:152-171).  CPU: two / three ranks on the host-emulated kernels with the file transport —
+k-mer file byte for byte and the edge lines as a set against the REFERENCE's goldens (fixture exotic_rare, whose goldens were
+taken with --max-distance 2, a size the emulator runs) and against the numpy oracle (lowcov); GPU (-m gpu): one rank through
+the whole exchange path (RCCL communicator of one rank) on every fixture against the reference's goldens."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import canon
+import fixtures
+from centroflye_amd import _host, sharded_cli
+from oracle import recruit
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = [sys.executable, os.path.join(ROOT, "tests", "sharded_cli_worker.py")]
+
+
+def _argv(report, outdir, p2, extra=()):
+    return ["--ncrf", report, "--coverage", str(p2["coverage"]), "--min-coverage", str(p2["min_coverage"]), "--outdir", outdir, "-k", str(p2["k"]),
+            "--max-distance", str(p2["max_distance"]), "--min-distance", str(p2["min_distance"])] + list(extra)
+
+
+def _launch(argv, n, monkeypatch, sub_edges=0):
+    monkeypatch.setenv("OMP_NUM_THREADS", "1")
+    monkeypatch.setenv("CF_TEST_SUB_EDGES", str(sub_edges))
+    monkeypatch.delenv("CF_PACK_CACHE", raising=False)
+    return sharded_cli.launch(argv, n, rank_cmd=WORKER)
+
+
+def test_shards_are_contiguous_runs_of_reads_with_equal_bases(report):
+    pk = _host.parse_report(report("lowcov"), keep_rows=False)
+    for world in (1, 2, 3, 7, 64):
+        cuts = sharded_cli.shard_bounds(pk.read_off, world)
+        assert cuts[0] == 0 and cuts[-1] == pk.n_reads and all(a <= b for a, b in zip(cuts, cuts[1:]))
+        shards = [sharded_cli.ReadShard(pk, cuts[r], cuts[r + 1]) for r in range(world)]
+        assert np.array_equal(np.concatenate([s.bases for s in shards]), pk.bases)
+        assert sum(s.n_reads for s in shards) == pk.n_reads
+        up, us, ue, _ = pk.units(1)
+        assert sum(s.units(1)[1].size for s in shards) == us.size
+        for s in shards:
+            sup, sus, sue, _ = s.units(1)
+            assert sup[0] == 0 and sup[-1] == sus.size and s.read_off[0] == 0 and s.read_off[-1] == s.n_bases
+            if sus.size:
+                assert sus.min() >= 0 and sue.max() <= s.n_bases
+                u0 = int(up[s.lo])
+                assert np.array_equal(s.bases[sus[0]:sue[0]], pk.bases[us[u0]:ue[u0]])
+        if world <= 3:
+            sizes = [s.n_bases for s in shards]
+            assert max(sizes) - min(sizes) < 3 * int(np.diff(pk.read_off).max())
+
+
+@pytest.mark.parametrize("world,sub_edges", [(2, 0), (3, 700)])
+def test_cf_gpus_ranks_write_the_oracles_files_on_emulated_kernels(emu_lib, report, oracle_stage2, tmp_path, monkeypatch, world, sub_edges):
+    """lowcov with --max-distance 2; sub_edges = 700: every rank streams its first k-mers in several sub-partitions (a partition that
+    does not fit is started over with more of them)."""
+    name = "lowcov"
+    p2 = fixtures.stage2_params(name)
+    p2["max_distance"] = 2
+    assert _launch(_argv(report(name), str(tmp_path), p2, ["--metrics"]), world, monkeypatch, sub_edges) == 0
+    records, alns, lens, res, _ = oracle_stage2(name, max_distance=2)
+    with open(tmp_path / f"unique_kmers_min_edge_cov_{p2['min_coverage']}.txt") as f:
+        assert f.read() == recruit.kmers_file_text(res["rare"], res["unique"], p2["k"])
+    with open(tmp_path / f"unique_edges_min_edge_cov_{p2['min_coverage']}.txt") as f:
+        lines = f.read().splitlines()
+    assert sorted(lines) == recruit.edges_file_lines(res["rare"], res["edges"], p2["k"]) and len(lines) > 2 * max(sub_edges, 300)
+    with open(tmp_path / "stage2_metrics.json") as f:
+        m = json.load(f)
+    assert m["world"] == world and sum(m["shard_reads"]) == len(records) and m["pack_from_cache"] and m["exchange_bytes"] > 0
+    assert m["stats"]["n_edges"] == len(lines) and m["stats"]["n_unique"] == int(np.count_nonzero(res["unique"]) if res["unique"].dtype == bool else len(res["unique"]))
+    assert not [p for p in os.listdir(tmp_path) if ".tmp" in p or p.startswith(".cfpack")]
+
+
+def test_cf_gpus_2_reproduces_the_reference_files_with_rare_N_kmers_on_emulated_kernels(emu_lib, fx_dir, tmp_path, monkeypatch):
+    """Fixture exotic_rare (goldens written by the reference itself): 35 of the unique k-mers hold an N; they travel through the
+    sharded path as strings and reach both files."""
+    with open(os.path.join(ROOT, "tests", "golden", "exotic_rare.json")) as f:
+        g = json.load(f)
+    rep = fixtures.make_report("exotic_rare", fx_dir)
+    assert fixtures.sha256_file(rep) == g["report_sha256"]
+    p2 = g["stage2"]
+    assert _launch(_argv(rep, str(tmp_path), p2), 2, monkeypatch) == 0
+    with open(tmp_path / f"unique_kmers_min_edge_cov_{p2['min_coverage']}.txt", "rb") as f:
+        data = f.read()
+    assert hashlib.sha256(data).hexdigest() == g["unique_kmers"]["sha256"] and data.count(b"N") >= 30
+    with open(tmp_path / f"unique_edges_min_edge_cov_{p2['min_coverage']}.txt") as f:
+        elines = f.read().splitlines()
+    assert len(elines) == g["edges"]["n"] and canon.edge_lines_digest(elines) == g["edges"]["digest"]
+
+
+def test_cf_gpus_no_edges_and_a_dead_rank(emu_lib, report, tmp_path, monkeypatch):
+    name = "lowcov"
+    p2 = fixtures.stage2_params(name)
+    p2["max_distance"] = 2
+    out = tmp_path / "ok"
+    assert _launch(_argv(report(name), str(out), p2, ["--no-edges"]), 2, monkeypatch) == 0
+    assert sorted(os.listdir(out)) == [f"unique_kmers_min_edge_cov_{p2['min_coverage']}.txt"]
+    # a rank that dies (here: every rank, on a report that does not exist for them) ends the launch with a non-zero code
+    monkeypatch.setenv("CF_TEST_SUB_EDGES", "0")
+    bad = sharded_cli.launch(_argv(report(name), str(tmp_path / "bad"), p2), 2, rank_cmd=[sys.executable, "-c", "import sys; sys.exit(3)"])
+    assert bad == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(fixtures.FIXTURES) + ["exotic_rare"])
+def test_sharded_stage_script_reproduces_the_reference_files_on_the_gpu(name, fx_dir, tmp_path):
+    """`CF_SHARDED=1 python -u scripts/distance_based_kmer_recruitment.py ...`: this process is rank 0 of 1 and goes through the whole
+    exchange path (a one-rank RCCL communicator, the message to itself through ncclSend / ncclRecv); `CF_GPUS=1` must be the plain path."""
+    with open(os.path.join(ROOT, "tests", "golden", f"{name}.json")) as f:
+        g = json.load(f)
+    rep = fixtures.make_report(name, fx_dir)
+    p2 = dict(fixtures.STAGE2_DEFAULTS)
+    p2.update(g["stage2"] if "stage2" in g else fixtures.stage2_params(name))
+    out = str(tmp_path / "sharded")
+    env = dict(os.environ, CF_SHARDED="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    subprocess.check_call([sys.executable, "-u", os.path.join(ROOT, "scripts", "distance_based_kmer_recruitment.py")] + _argv(rep, out, p2, ["--metrics"]),
+                          stdout=subprocess.DEVNULL, env=env)
+    with open(os.path.join(out, f"unique_kmers_min_edge_cov_{p2['min_coverage']}.txt"), "rb") as f:
+        assert hashlib.sha256(f.read()).hexdigest() == g["unique_kmers"]["sha256"]
+    with open(os.path.join(out, f"unique_edges_min_edge_cov_{p2['min_coverage']}.txt")) as f:
+        elines = f.read().splitlines()
+    assert len(elines) == g["edges"]["n"] and canon.edge_lines_digest(elines) == g["edges"]["digest"]
+    with open(os.path.join(out, "stage2_metrics.json")) as f:
+        m = json.load(f)
+    assert m["world"] == 1 and m["exchange_bytes"] >= 0 and "table_exchange" in m["sections_s"] and "cloud_gather" in m["sections_s"]
