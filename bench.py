@@ -30,6 +30,13 @@ Rank 0 prints ONE JSON line (contract in the task brief) with these extra object
   parity_vs_committed_oracle   counters + device-side checksum of every stored edge against the 64/64
                         CPU run of the oracle on the same reads (profiles/r03_full_parity.json)
   end_to_end            stage 2 + A4 + greedy placement of the same reads (BASELINE configs[2])
+  workload_b            (N = 1) the same 50 000 reads with POINT substitutions as copy-specific variants (var_len 1: SURVEY §8(d)'s
+                        literal model, simulate_tandem_repeat.py:15-30 — few copy-specific k-mers, E per base collapses): its own
+                        ms_per_step, stage split, counters and roofline figures, and every figure of the step (A1 table, rare set,
+                        clouds, all pair emissions, every selected edge, the unique k-mers) against the committed oracle record of
+                        those reads (profiles/r05_parity_50k_varlen1.json, tools/parity_record.py)
+
+`python bench.py --gpus 8 --reads 62500` is BASELINE configs[3]'s line: 500 000 reads sharded 8 ways.
 """
 import argparse
 import json
@@ -99,6 +106,32 @@ def cpu_baseline(a, pk, engine):
     out["host_cpus"] = os.cpu_count()
     out["legs"] = [one, allc]
     return out
+
+
+def cpu_baseline_weak(a):
+    """N > 1: the CPU leg on rank 0's host for the per-GPU workload of this weak-scaling line — the N = 1
+    configuration's reads (a.reads reads of the array sized for them; the shard of an N-times longer array has 1 / N of the coverage
+    and no rare window of its own, so it is no workload by itself).  Same bounded sample as at N = 1: A1-A3 whole + one first-k-mer
+    partition x n_parts, every core; the other ranks wait in the closing barrier meanwhile."""
+    from centroflye_amd import _host
+    from oracle import cport
+    pk = _host.synth(n_reads=a.reads, **synth_kwargs(a.reads, a.seed))
+    up, us, ue, _ = pk.units(1)
+    ncpu = os.cpu_count()
+    try:
+        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    n_parts, part = a.cpu_parts, a.cpu_parts // 3
+    with cport.Stage2State(pk.bases, pk.read_off, up, us, ue, K, PARAMS["max_nonuniq"], PARAMS["lo"], PARAMS["hi"], threads=0) as st:
+        w = st.dist_part(part, n_parts, 0, 2 ** 62, PARAMS["min_d"], PARAMS["max_d"], PARAMS["min_cov"], PARAMS["rel_threshold"], threads=0)
+        t_a13 = st.secs_count_select + st.secs_clouds + w["secs_postings"]
+        t_all = t_a13 + n_parts * w["secs"]
+    return dict(value=pk.n_bases / t_all, unit="bases/s", cores=ncpu, kind="port", host_cpus=os.cpu_count(), extrapolated=True, scale_factor=n_parts,
+                emissions_per_s=w["n_emissions"] / w["secs"],
+                sample=f"rank 0's host, the per-GPU workload of this weak-scaling line = the N = 1 configuration ({pk.n_reads} reads / {pk.n_bases} bases): A1-A3 whole "
+                       f"({t_a13:.1f} s) + A5/A6 for the first k-mers a % {n_parts} == {part} ({w['n_emissions']} pair emissions, {w['secs']:.1f} s) x {n_parts}; "
+                       f"oracle/c/cf_oracle_mt.c OpenMP, {ncpu} threads; compare with value / n_gpus")
 
 
 def measured_cpu_whole_run(pk, a):
@@ -175,6 +208,93 @@ def rr_leg(engine, pk, no_cpu):
     return out
 
 
+def timed_steps(sr, steps, warmup, edge_cap):
+    """`warmup` untimed steps, then exactly `steps` timed ones between barriers; seconds = max over ranks."""
+    E = sr.engine
+    outs = []
+    for _ in range(warmup):
+        outs.append(sr.run(edge_cap=edge_cap, **PARAMS))
+    sr.barrier()            # (every library call returns with its stream drained)
+    t0 = time.perf_counter()
+    kernel_ms = []
+    stage_ms = dict(count=0.0, select=0.0, clouds=0.0, postings=0.0, dist=0.0)
+    sections = {}
+    for _ in range(steps):
+        out = sr.run(edge_cap=edge_cap, **PARAMS)
+        outs.append(out)
+        kernel_ms.append(out["dist_kernel_ms"])
+        tm = E.times()
+        for k_ in ("count", "select", "clouds", "postings", "dist"):
+            stage_ms[k_] += tm[k_ + "_ms"]
+        for k_, v in sr.sections.items():
+            sections[k_] = sections.get(k_, 0.0) + v
+    sr.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = int(sr.allreduce([int(elapsed * 1e9)], "max")[0]) / 1e9       # max over ranks
+    return outs, elapsed, kernel_ms, {k: v / max(steps, 1) for k, v in stage_ms.items()}, {k: round(v * 1e3 / max(steps, 1), 3) for k, v in sections.items()}
+
+
+def pmc_derived():
+    """What the committed PMC passes of the dominant kernel say binds it (tools/pmc_summary.py writes `derived` into
+    profiles/r0N_pmc_dist_kernel.json from the counters of the bench's own command): the label of roofline.bound and the LDS / L2 /
+    HBM-side figures SURVEY §8(d) asks to see next to the HBM fraction."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_dist_kernel.json")))
+    if not cands:
+        return None, None
+    with open(cands[-1]) as f:
+        d = json.load(f).get("derived")
+    return (d, os.path.relpath(cands[-1], ROOT)) if d else (None, None)
+
+
+def workload_b(a, sr, rank, world):
+    """The bench's reads with point substitutions (var_len 1) through the same step; checked against the committed oracle record."""
+    from centroflye_amd import _host
+    E = sr.engine
+    kw = dict(synth_kwargs(a.reads * world, a.seed), var_len=1)
+    pk = _host.synth(n_reads=a.reads, cand_offset=rank, cand_stride=world, **kw)
+    sr.load(pk, 1)
+    first = sr.run(edge_cap=0, **PARAMS)
+    edge_cap = int(first["local_edges"]) + 1024
+    outs, elapsed, kernel_ms, stage_ms, sections = timed_steps(sr, a.steps_b, 1, edge_cap)
+    out = outs[-1]
+    stored = min(out["local_edges"], edge_cap)
+    ms = elapsed * 1e3 / max(a.steps_b, 1)
+    mean_k = float(np.mean(kernel_ms)) if kernel_ms else 0.0
+    alg = 4 * out["dist_cloud_entries"] + 4 * out["local_emissions"] + 16 * stored
+    b_alg = (out["n_bases"] + 16 * out["n_read_kmers"]) + 16 * out["n_distinct"] + (out["n_bases"] + 8 * out["n_windows"] + 4 * out["n_cloud_entries"]) \
+        + (4 * out["n_cloud_entries"] + 4 * out["n_emissions"]) + 16 * min(out["n_edges"], edge_cap * world)
+    res = {"workload": f"{a.reads} reads per GPU, the same generator and seed with var_len 1 (point substitutions as copy-specific variants, SURVEY §8(d)'s literal model): "
+                       f"{out['n_bases']} bases, {out['n_rare']} rare k-mers, {out['n_emissions'] / max(out['n_bases'], 1):.1f} pair emissions per base",
+           "value": out["n_bases"] * a.steps_b / elapsed, "unit": "bases/s", "steps": a.steps_b, "ms_per_step": ms,
+           "stage_ms_per_step": stage_ms, "host_section_ms_per_step": sections,
+           "counters": {k: out[k] for k in ("n_bases", "n_windows", "n_read_kmers", "n_distinct", "n_kept", "n_rare", "n_cloud_entries", "n_emissions", "n_edges", "n_unique", "n_dist_passes")},
+           "roofline": {"kernel": "cf_dist_kernel", "kernel_ms": mean_k, "algorithmic_bytes_per_launch": alg, "achieved": alg / (mean_k * 1e-3) / 1e9 if mean_k else 0.0,
+                        "unit": "GB/s", "frac": alg / (mean_k * 1e-3) / 1e9 / HBM_PEAK_GBS if mean_k else 0.0,
+                        "pair_emissions_per_s": out["local_emissions"] / (mean_k * 1e-3) if mean_k else 0.0,
+                        "whole_step_algorithmic_bytes": b_alg, "whole_step_frac": b_alg / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+                        "dist_kernel_share_of_step": mean_k / ms if ms else 0.0},
+           "steps_identical": bool(all(all(o[k] == out[k] for k in ("n_edges", "n_emissions", "n_rare", "n_unique", "n_cloud_entries")) for o in outs))}
+    path = os.path.join(ROOT, "profiles", "r05_parity_50k_varlen1.json")
+    res["parity_vs_committed_oracle"] = None
+    if world == 1 and os.path.exists(path):
+        with open(path) as f:
+            rec = json.load(f)
+        wl, part = rec["workload"], rec["partition"]
+        if (wl["reads"], wl["seed"], wl["var_len"], wl["n_units"], rec["params"], part["n_parts"]) == (a.reads, a.seed, 1, kw["n_units"], PARAMS, 1) and rec["n_bases"] == out["n_bases"]:
+            # the timed steps left the table, the rare set, the clouds, the edges and the unique bitmap of the last step resident
+            got = dict(n_windows=out["n_windows"], n_read_kmers=out["n_read_kmers"], n_distinct=out["n_distinct"], n_kept=out["n_kept"], n_rare=out["n_rare"],
+                       n_cloud_entries=out["n_cloud_entries"], rare_checksum=E.checksum("kmers")[0], cloud_checksum=E.checksum("clouds")[0])
+            gp = dict(n_emissions=out["n_emissions"], n_edges=out["n_edges"], n_unique=out["n_unique"], edge_checksum=E.edges_checksum(),
+                      unique_kmers_checksum=E.checksum("unique")[0])
+            E.count_kmers(K)          # (select_rare compacts the table it reads: the A1 table of the step is rebuilt for its checksum)
+            got["table_checksum"] = E.checksum("table")[0]
+            res["parity_vs_committed_oracle"] = dict(
+                against="profiles/r05_parity_50k_varlen1.json (oracle/c/cf_oracle_mt.c: A1-A3 whole and every first k-mer of these reads)",
+                checked=sorted(got) + sorted(gp), match=bool(all(got[k] == rec[k] for k in got) and all(gp[k] == part[k] for k in gp)))
+    return res
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +313,7 @@ def parse_args():
     ap.add_argument("--rr", action="store_true", help="also time read recruitment (SURVEY 8(f) rank 4) on the same reads + as many random ones (N = 1)")
     ap.add_argument("--param", action="append", default=[], help="library knob name=value (cf_set_param)")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1 only: run the multi-GPU exchange path (bucketing, all-to-all, all-gathers, gathered view) through a one-rank RCCL communicator, to price it without wire time")
+    ap.add_argument("--steps-b", type=int, default=3, help="timed steps of workload_b (the same reads with var_len 1); 0 = skip")
     ap.add_argument("--lib", default=None, help="test hook: another build of libcfhip (the CPU suite passes the host-emulated one to check this harness)")
     return ap.parse_args()
 
@@ -269,26 +390,7 @@ def main():
     if edge_cap < 0:
         first = sr.run(edge_cap=0, **PARAMS)
         edge_cap = int(first["local_edges"]) + 1024
-    outs = []
-    for _ in range(a.warmup):
-        outs.append(sr.run(edge_cap=edge_cap, **PARAMS))
-    sr.barrier()            # (every library call returns with its stream drained)
-    t0 = time.perf_counter()
-    kernel_ms = []
-    stage_ms = dict(count=0.0, select=0.0, clouds=0.0, postings=0.0, dist=0.0)
-    sections = {}
-    for _ in range(a.steps):
-        out = sr.run(edge_cap=edge_cap, **PARAMS)
-        outs.append(out)
-        kernel_ms.append(out["dist_kernel_ms"])
-        tm = E.times()
-        for k_ in ("count", "select", "clouds", "postings", "dist"):
-            stage_ms[k_] += tm[k_ + "_ms"]
-        for k_, v in sr.sections.items():
-            sections[k_] = sections.get(k_, 0.0) + v
-    sr.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = int(sr.allreduce([int(elapsed * 1e9)], "max")[0]) / 1e9       # max over ranks
+    outs, elapsed, kernel_ms, stage_ms, sections = timed_steps(sr, a.steps, a.warmup, edge_cap)
 
     out = outs[-1]
     same = all(all(o[k] == out[k] for k in ("n_edges", "n_emissions", "n_rare", "n_unique", "n_cloud_entries")) for o in outs)
@@ -336,6 +438,7 @@ def main():
         # B_alg of the whole step, all ranks: [N_b + 16 N_rk] + [16 K_dist] + [N_b + 8 N_w + 4 N_ce] + [4 N_ce + 4 E] + [16 edges stored]
         b_alg = (n_bases + 16 * out["n_read_kmers"]) + 16 * out["n_distinct"] + (n_bases + 8 * out["n_windows"] + 4 * out["n_cloud_entries"]) \
             + (4 * out["n_cloud_entries"] + 4 * out["n_emissions"]) + 16 * min(out["n_edges"], edge_cap * world)
+        derived, derived_from = pmc_derived()
         res = {
             "metric": "long-read bases/sec through rare-k-mer recruit+distance",
             "value": n_bases * a.steps / elapsed,
@@ -351,8 +454,13 @@ def main():
                        "reads_per_gpu": a.reads, "k": K, "var_len": VAR_LEN, "edges_stored": int(stored), "edges_selected": int(out["local_edges"]),
                        "parallelism": f"reads sharded x{world}, first k-mers partitioned x{world}"},
             "value_incl_transfers": incl,
-            "roofline": {"bound": "hbm", "kernel": "cf_dist_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `frac` prices the kernel's ALGORITHMIC bytes against the HBM peak (the contract's definition); `bound` names what the
+            # counters of the committed PMC passes say limits it — for this kernel LDS round-trip latency at 4 waves per SIMD, not HBM
+            # ("the roofline label is formal; say what binds"): `lds`, `l2_hit`, `hbm_side_gbps` are those counters
+            "roofline": {"bound": (derived or {}).get("bound", "hbm"), "bound_by_contract": "hbm", "kernel": "cf_dist_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(a, world, stored, out),
+                         "lds": (derived or {}).get("lds"), "l2_hit": (derived or {}).get("l2_hit"), "hbm_side_gbps": (derived or {}).get("hbm_side_gbps"),
+                         "issue_per_cycle_per_cu": (derived or {}).get("issue_per_cycle_per_cu"), "counters_from": derived_from,
                          "traffic_note": "HBM-side bytes of ONE launch from the committed rocprofv3 --pmc passes of this configuration (profiles/r0N_pmc_dist_kernel.json, the latest round's: "
                                          "(2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate passes, tools/profile_round.sh); counters cannot be read inside a timed run; null when the workload differs",
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": mean_k_ms,
@@ -361,8 +469,8 @@ def main():
                          "whole_step_frac": b_alg / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)},
             "counters": {k: out[k] for k in ("n_bases", "n_windows", "n_read_kmers", "n_distinct", "n_kept", "n_rare", "n_cloud_entries",
                                              "n_emissions", "n_edges", "n_unique", "n_dist_passes")},
-            "stage_ms_per_step": {k: v / max(a.steps, 1) for k, v in stage_ms.items()},
-            "host_section_ms_per_step": {k: round(v * 1e3 / max(a.steps, 1), 3) for k, v in sections.items()},
+            "stage_ms_per_step": stage_ms,
+            "host_section_ms_per_step": sections,
             "exchange_bytes_per_step": int(sr.exchange_bytes),
             "setup_s": {"synth": round(t_synth, 2), "load_h2d": round(t_load, 3)},
             "steps_identical": bool(same),
@@ -393,8 +501,13 @@ def main():
             sr.load(pk, 1)       # (stage 3 installed the placer's k-mer set and clouds)
             sr.run(edge_cap=0, **PARAMS)
             res["cpu_baseline"] = cpu_baseline(a, pk, E)
+        elif not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_weak(a)
         else:
             res["cpu_baseline"] = None
+    wb = workload_b(a, sr, rank, world) if a.steps_b > 0 else None      # (every rank: its steps hold collectives)
+    if rank == 0:
+        res["workload_b"] = wb
         print(json.dumps(res), flush=True)
     sr.barrier()
     sr.close()

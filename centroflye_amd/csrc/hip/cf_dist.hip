@@ -33,7 +33,7 @@ int cf_refresh_unique_count(cf_ctx* ctx);  // cf_clouds.hip
 #define DIST_BM_BITS 65536u              /* bitmap over hash(b): k-mers that may have a selected edge */
 #define DIST_HOT_CAP 2048u               /* slots the insert path can hand to the filter per pass (more: the filter scans the table) */
 #define DIST_EDGE_CHUNK 8192ull          /* edge rows a workgroup reserves per global atomic */
-#define DIST_OVQ 96u                     /* per-wave list of inserts whose first probe did not finish (drained with the probe loop at >= 32) */
+#define DIST_OVQ 160u                    /* per-wave list of inserts whose first probe did not finish (run through the probe loop down to < 32 after every drain: 31 + the 128 a drain can park) */
 #define DIST_LDS_HEAD (DIST_BM_BITS / 8 + 128)  /* bitmap + sh (32 words): the fixed head of the kernel's LDS */
 #define DIST_CNT_MASK 0x7FFFFFu          /* 23-bit count */
 #define DIST_SEL_BIT (1ull << 23)        /* slot selected by the A6 filter */
@@ -279,6 +279,27 @@ struct cf_dist_args {
     uint32_t* unique_bits;
 };
 
+// The 4-byte entry stream of the narrow / region26 layouts: 16 bytes per lane from entry s_e (wave-uniform) on.  Through a BUFFER
+// load (round 5): the array's descriptor sits in four scalar registers, the item's byte offset is the instruction's scalar offset and
+// the lane's share the constant 16 x lane — no vector instruction per fetch.  As a global load through a pointer the compiler folded
+// the lane's offset into a 64-bit pointer per lane and added the item's offset with a v_lshl_add_u64 whose DESTINATION pair it then
+// reused for the loaded data: the loop head had to wait for every load in flight before it could write the address
+// (s_waitcnt vmcnt(0) once per D + 1 steps).  The scalar offset is 32 bits of bytes: streams of 2^30 entries and more
+// take the layouts that stream rank and unit index apart (cf_dist_edges).  (The host emulator of tests/emu defines CF_NO_BUFFER_LOAD.)
+typedef uint32_t cf_raw4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) cf_run4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ void cf_load_packed4(const cf_dist_args& A, uint32_t s_e, uint32_t l4, uint32_t& x, uint32_t& y, uint32_t& z, uint32_t& w) {
+#if !defined(CF_NO_BUFFER_LOAD)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)A.packed, 0, (int)0xFFFFFFFFu, 0x00020000);
+    const cf_raw4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(l4 * 4u), (int)(s_e << 2), 0);
+    x = v.x; y = v.y; z = v.z; w = v.w;
+#else
+    const uint32_t* p = A.packed + s_e;
+    const cf_run4 r = *(const cf_run4*)(p + l4);
+    x = r.x; y = r.y; z = r.z; w = r.w;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------
 // The (b, d) table lives in LDS and is organised in 32-byte buckets read with two ds_read_b128: a probe
 // inspects a whole bucket with straight-line code, so a wave does not run a per-lane probe loop in the
@@ -358,6 +379,7 @@ struct cf_tab_wide_t {
     static constexpr uint32_t kSlotsPerBucket = 4;
     static constexpr bool kProbe1 = false;      // (64-bit slots: the drain keeps its match / claim branches)
     __device__ __forceinline__ void probe1(bool, uint32_t, uint32_t, uint32_t, bool&, bool&, uint32_t&) const {}
+    __device__ __forceinline__ void probe2(bool, uint32_t, uint32_t, bool, uint32_t, uint32_t, uint32_t, bool&, bool&, uint32_t&, bool&, bool&, uint32_t&) const {}
     __device__ __forceinline__ uint32_t key_of(uint32_t, uint32_t) const { return 0u; }
     // claim slot i of bucket bk for (b, dd): 0 = claimed (count 1), 1 = the same key got there first (counted), 2 = another key
     __device__ __forceinline__ unsigned long long claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const {
@@ -437,6 +459,41 @@ typedef cf_tab_wide_t<16> cf_tab_wide16;
 #ifndef CF_NARROW_PB
 #define CF_NARROW_PB 4      /* keys per bucket of the 6-byte-slot layout: 4 (one 16-byte read of keys; 453 -> 441 ms) or 8 */
 #endif
+// Two probes of the 6-byte-slot tables side by side (the drain of the table sweep with CF_DIST_DRAIN2: two queued inserts per lane).
+// The same straight line as probe1 below, written stage by stage for both inserts — both bucket reads, both slot searches, both
+// claims, both count adds — so that the two chains of LDS round trips are in flight together.  Two inserts of one lane may meet in
+// one bucket: they then behave like two lanes that do (the second claim of the same key sees the key and counts; another key's parks).
+template <class Tab>
+__device__ __forceinline__ void cf_probe2(const Tab& T, bool act0, uint32_t bk0, uint32_t key0, bool act1, uint32_t bk1, uint32_t key1, uint32_t min_cov,
+                                          bool& made0, bool& park0, uint32_t& hot0, bool& made1, bool& park1, uint32_t& hot1) {
+    constexpr int PB_ = (int)Tab::kPerBucket;
+    const typename Tab::bucket k0 = T.read(bk0), k1 = T.read(bk1);
+    uint32_t em0 = (uint32_t)PB_, em1 = (uint32_t)PB_;
+#pragma unroll
+    for (int j = PB_ - 1; j >= 0; --j) { em0 = k0.k[j] == Tab::kEmpty ? (uint32_t)j : em0; em1 = k1.k[j] == Tab::kEmpty ? (uint32_t)j : em1; }
+    uint32_t sl0 = em0, sl1 = em1;
+    bool mt0 = false, mt1 = false;
+#pragma unroll
+    for (int j = PB_ - 1; j >= 0; --j) {
+        const bool e0 = k0.k[j] == key0, e1 = k1.k[j] == key1;
+        sl0 = e0 ? (uint32_t)j : sl0; mt0 |= e0; sl1 = e1 ? (uint32_t)j : sl1; mt1 |= e1;
+    }
+    mt0 &= act0; mt1 &= act1;
+    const bool claim0 = act0 && !mt0 && em0 < (uint32_t)PB_, claim1 = act1 && !mt1 && em1 < (uint32_t)PB_;
+    const uint32_t s0 = (uint32_t)PB_ * bk0 + (sl0 & (uint32_t)(PB_ - 1)), s1 = (uint32_t)PB_ * bk1 + (sl1 & (uint32_t)(PB_ - 1));
+    uint32_t old0 = key0, old1 = key1;
+    if (claim0) old0 = atomicCAS(&T.keys[s0], Tab::kEmpty, key0);
+    if (claim1) old1 = atomicCAS(&T.keys[s1], Tab::kEmpty, key1);
+    const bool matched0 = mt0 || (claim0 && old0 == key0), fresh0 = claim0 && old0 == Tab::kEmpty;
+    const bool matched1 = mt1 || (claim1 && old1 == key1), fresh1 = claim1 && old1 == Tab::kEmpty;
+    const uint32_t sh0 = (s0 & 1u) * 16u, sh1 = (s1 & 1u) * 16u;
+    const uint32_t was0 = atomicAdd(&T.cnt32[s0 >> 1], matched0 ? 1u << sh0 : 0u);
+    const uint32_t was1 = atomicAdd(&T.cnt32[s1 >> 1], matched1 ? 1u << sh1 : 0u);
+    const uint32_t cnt0 = matched0 ? ((was0 >> sh0) & 0x7FFFu) + 2u : 1u, cnt1 = matched1 ? ((was1 >> sh1) & 0x7FFFu) + 2u : 1u;
+    made0 = fresh0; park0 = act0 && !(matched0 || fresh0); hot0 = ((matched0 || fresh0) && cnt0 == min_cov) ? s0 : 0xFFFFFFFFu;
+    made1 = fresh1; park1 = act1 && !(matched1 || fresh1); hot1 = ((matched1 || fresh1) && cnt1 == min_cov) ? s1 : 0xFFFFFFFFu;
+}
+
 template <int DB, int PB = CF_NARROW_PB>
 struct cf_tab_narrow_t {
     static_assert(PB == 4 || PB == 8, "a bucket is one or two 16-byte reads of keys");
@@ -465,9 +522,7 @@ struct cf_tab_narrow_t {
     struct __attribute__((packed, aligned(4))) run4 { uint32_t x, y, z, w; };
     static __device__ __forceinline__ void load_run(const cf_dist_args& A, uint32_t s_e, uint32_t l4, uint32_t, raw (&out)[DIST_UNROLL]) {
         static_assert(DIST_UNROLL == 4, "one 16-byte load per lane");
-        const uint32_t* p = A.packed + s_e;         // scalar base + 32-bit lane offset: global_load_dwordx4 v, v_off, s[base]
-        const run4 r = *(const run4*)(p + l4);
-        out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
+        cf_load_packed4(A, s_e, l4, out[0].v, out[1].v, out[2].v, out[3].v);
     }
     // the unit index is kept mod 2^DB and 1 <= d < 2^DB, so the DB-bit difference IS d; no borrow reaches b
     static __device__ __forceinline__ void decode(const raw& r, uint32_t ig, uint32_t, uint32_t& b, uint32_t& dd, uint32_t& qk, uint32_t& lo) { const uint32_t q = r.v - (ig << kBBits); b = q & kBMask; dd = q >> kBBits; qk = q; lo = r.v; }      // (lo: a word whose low 16 bits are b's — the bitmap's index — that costs nothing to make)
@@ -548,6 +603,10 @@ struct cf_tab_narrow_t {
         made = fresh;
         park = active && !(matched || fresh);
         hot_slot = ((matched || fresh) && cnt == min_cov) ? s : 0xFFFFFFFFu;
+    }
+    __device__ __forceinline__ void probe2(bool act0, uint32_t bk0, uint32_t key0, bool act1, uint32_t bk1, uint32_t key1, uint32_t min_cov,
+                                           bool& made0, bool& park0, uint32_t& hot0, bool& made1, bool& park1, uint32_t& hot1) const {
+        cf_probe2(*this, act0, bk0, key0, act1, bk1, key1, min_cov, made0, park0, hot0, made1, park1, hot1);
     }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
         const uint32_t q = keys[s];
@@ -767,6 +826,10 @@ struct cf_tab_region {
         park = active && !(matched || fresh);
         hot_slot = ((matched || fresh) && cnt == min_cov) ? s : 0xFFFFFFFFu;
     }
+    __device__ __forceinline__ void probe2(bool act0, uint32_t bk0, uint32_t key0, bool act1, uint32_t bk1, uint32_t key1, uint32_t min_cov,
+                                           bool& made0, bool& park0, uint32_t& hot0, bool& made1, bool& park1, uint32_t& hot1) const {
+        cf_probe2(*this, act0, bk0, key0, act1, bk1, key1, min_cov, made0, park0, hot0, made1, park1, hot1);
+    }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
         const uint32_t q = keys[s];
         b = b_of(q, s / (uint32_t)PB); dd = q >> kBBits; cnt = ((cnt32[s >> 1] >> ((s & 1u) * 16u)) & 0x7FFFu) + 1u;
@@ -863,9 +926,7 @@ struct cf_tab_region26 : cf_tab_region {
     struct __attribute__((packed, aligned(4))) run4 { uint32_t x, y, z, w; };
     static __device__ __forceinline__ void load_run(const cf_dist_args& A, uint32_t s_e, uint32_t l4, uint32_t, raw (&out)[DIST_UNROLL]) {
         static_assert(DIST_UNROLL == 4, "one 16-byte load per lane");
-        const uint32_t* p = A.packed + s_e;         // (padded by DIST_ITEM entries: a run that starts inside the array may be read whole)
-        const run4 r = *(const run4*)(p + l4);
-        out[0].v = r.x; out[1].v = r.y; out[2].v = r.z; out[3].v = r.w;
+        cf_load_packed4(A, s_e, l4, out[0].v, out[1].v, out[2].v, out[3].v);
     }
     static __device__ __forceinline__ void decode(const raw& r, uint32_t igf, uint32_t pos, uint32_t& b, uint32_t& dd, uint32_t& qk, uint32_t& lo) {
         qk = 0u; lo = r.v;
@@ -883,13 +944,31 @@ __device__ __forceinline__ uint32_t cf_bit_of(uint32_t w, uint32_t off) { uint32
 #endif
 __device__ __forceinline__ uint32_t cf_rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 
-#define DIST_QCAP 320                    /* deferred inserts per wave: fewer than 64 left by the drains before a step + at most 4 x 64 pushed by it */
+#define DIST_QCAP 384                    /* deferred inserts per wave: fewer than 128 (64 without CF_DIST_DRAIN2) left by the drains before a step + at most 4 x 64 pushed by it */
 #define DIST_QSTRIDE DIST_QCAP
 // Diagnostic builds only (tools/dist_ablation.sh): -DCF_DIST_ABL=n removes the kernel's phases from the END — 1 no filter / rows, 2 also no
 // inserts (the drains drop their queue), 3 no pushes, 4 no table sweep, 5 no sketch arithmetic, 6 no sketch sweep, 7 no clears — so that
 // the instruction counters of successive builds differ by ONE phase (results are wrong, what runs before the cut is unchanged)
 #ifndef CF_DIST_ABL
 #define CF_DIST_ABL 0
+#endif
+// Round 5: three changes to the insert path of the table sweep, each behind a switch for A/B builds (tools/build_variant.sh):
+//  CF_DIST_HOTBLK  the slots whose count reaches min_cov go to the filter's list through blocks of 64 entries that a WAVE reserves with
+//                  one LDS atomic per 64 entries (cursor and block end live in scalar registers) — it was one returning LDS atomic,
+//                  a wait and a readfirstlane per DRAIN (nearly every drain of 64 inserts brings some slot to min_cov);
+//  CF_DIST_FILLRD  the table's fill level is read INSIDE the drain (the load is issued with the queue read and looked at after the
+//                  bucket came back: no round trip of its own) instead of twice in front of every drain;
+//  CF_DIST_DRAIN2  a drain takes up to 128 queued inserts, two per lane: two independent chains (queue word, bucket, claim, count)
+//                  in flight per lane — the inserts are bound by that chain of LDS round trips at four waves per SIMD, not by
+//                  instruction issue (profiles/r04_dist_phase_insts_after_cuts.md).
+#ifndef CF_DIST_HOTBLK
+#define CF_DIST_HOTBLK 1
+#endif
+#ifndef CF_DIST_FILLRD
+#define CF_DIST_FILLRD 1
+#endif
+#ifndef CF_DIST_DRAIN2
+#define CF_DIST_DRAIN2 1
 #endif
 #ifndef CF_DIST_OLD_DRAIN
 #define CF_DIST_OLD_DRAIN 0      /* 1: the drain's probe as nested match / claim branches (rounds 2-3), for A/B runs */
@@ -1054,8 +1133,13 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
         const uint32_t cnt = min(64u, mine - j0);
         cf_dist_item my = my0;
         if (j0) { my = cf_dist_item{0u, 0u}; if (lane < cnt) my = recs[j0 + lane]; }
-        // D loads in flight per lane: a ring of D register sets, the loop unrolled D times so that every set has fixed registers
-        typename Tab::raw ring[D][DIST_UNROLL];
+        // D loads in flight per lane WHILE a step is worked on: D + 1 register sets, the loop unrolled D + 1 times so that every set has
+        // fixed registers — at position p the step's data is set p, and the load of the step D ahead goes into set (p + D) mod (D + 1), the
+        // one the previous position has just finished with.  (Rounds 3-4 kept D sets, copied the step's set aside and re-filled it at once:
+        // the compiler made the copy a chain of v_mov at the END of the unrolled body, behind an s_waitcnt vmcnt(0) — every wave waited
+        // out the loads it had just issued, every D steps, whatever D was; round 5, read off the ISA.)
+        constexpr int NS = D + 1;
+        typename Tab::raw ring[NS][DIST_UNROLL];
         auto ok_of = [&](uint32_t m) -> uint32_t {      // per-lane mask of the entries of an item that exist
             uint32_t ok = (1u << DIST_UNROLL) - 1u;
             if ((m >> 16) < DIST_ITEM) {      // (wave-uniform) the last item of a posting
@@ -1072,30 +1156,34 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
         }
 #pragma unroll
         for (int d = 0; d < D; ++d) CF_DIST_FETCH(min((uint32_t)d, cnt - 1u), d)      // (unconditional, see below)
-        uint32_t j = 0;
-        bool more = true;
-        while (more) {
+        // the steps of this round: a lambda, so that "the wave's items are through" leaves the unrolled loop by a plain return — with a flag
+        // tested at the loop head the compiler saw a path from every exit back into the loop and made the head wait for every load
+        // in flight (s_waitcnt vmcnt(0) in front of the first fetch of every D + 1 steps)
+        const bool stop = [&]() -> bool {
+            uint32_t j = 0;
+            for (;;) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                if (!more) break;
-                pre(j == cnt && j0 + 64u >= mine);
-                if (j == cnt) { more = false; break; }
-                typename Tab::raw cx_[DIST_UNROLL];
+                for (int p = 0; p < NS; ++p) {
+                    // The fetch of the step D ahead comes FIRST, in front of pre(): the table sweep's drain runs there, and with a register
+                    // set of the ring free at that point the compiler used it for the drain's temporaries — a write to a register that an
+                    // earlier load had as its destination, which its wait-count pass could only make safe by waiting for every load in
+                    // flight (s_waitcnt vmcnt(0) in every drain).  With all D + 1 sets spoken for the drain gets registers of its own.
+                    // Unconditional: a wave past its last item fetches that one again — with a fetch under a condition the number of
+                    // loads in flight differs between the paths into the loop head and the compiler waits for ALL of them there.
+                    CF_DIST_FETCH(min(j + (uint32_t)D, cnt - 1u), (p + D) % NS)
+                    pre(j == cnt && j0 + 64u >= mine);
+                    if (j == cnt) return false;
+                    const uint32_t cm = (uint32_t)__builtin_amdgcn_readlane((int)my.m, (int)j);
+                    uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL], qq_[DIST_UNROLL], lo_[DIST_UNROLL];
 #pragma unroll
-                for (int u = 0; u < DIST_UNROLL; ++u) cx_[u] = ring[d][u];
-                const uint32_t cm = (uint32_t)__builtin_amdgcn_readlane((int)my.m, (int)j);
-                // unconditional: a wave past its last item fetches that one again — with a fetch under a condition the number of
-                // loads in flight differs between the paths into the loop head and the compiler waits for ALL of them there
-                // (s_waitcnt vmcnt(0) instead of vmcnt(D - 1))
-                CF_DIST_FETCH(min(j + (uint32_t)D, cnt - 1u), d)
-                uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL], qq_[DIST_UNROLL], lo_[DIST_UNROLL];
-#pragma unroll
-                for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(cx_[u], cm & 0xFFFFu, l4 + (uint32_t)u, bb[u], dd_[u], qq_[u], lo_[u]);
-                const uint32_t len = cm >> 16;      // entries of the item (wave-uniform); < DIST_ITEM only for the last item of a posting
-                if (body(bb, dd_, qq_, lo_, len < DIST_ITEM ? ok_of(cm) : (1u << DIST_UNROLL) - 1u, len)) return;
-                ++j;
+                    for (int u = 0; u < DIST_UNROLL; ++u) Tab::decode(ring[p][u], cm & 0xFFFFu, l4 + (uint32_t)u, bb[u], dd_[u], qq_[u], lo_[u]);
+                    const uint32_t len = cm >> 16;      // entries of the item (wave-uniform); < DIST_ITEM only for the last item of a posting
+                    if (body(bb, dd_, qq_, lo_, len < DIST_ITEM ? ok_of(cm) : (1u << DIST_UNROLL) - 1u, len)) return true;
+                    ++j;
+                }
             }
-        }
+        }();
+        if (stop) return;
 #undef CF_DIST_FETCH
     }
 }
@@ -1317,6 +1405,25 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 // slots whose count just reached min_cov go to the filter's list (one LDS atomic per wave and drain): the filter then
                 // evaluates that list instead of scanning every slot of the table for counts >= min_cov (round 2: 3 scan rounds per
                 // first k-mer, 7 % of the kernel)
+#if CF_DIST_HOTBLK
+                uint32_t hcur = 0, hend = 0;      // wave-uniform: this wave's block of the hot list [hcur, hend)
+#define CF_DIST_HOT(SLOT) {                                                                                   \
+                    const unsigned long long hm_ = cf_ballot((SLOT) != 0xFFFFFFFFu);                           \
+                    if (hm_) {                                                                                \
+                        const uint32_t hn_ = (uint32_t)__popcll(hm_), room_ = hend - hcur;                    \
+                        uint32_t hp_ = hcur + cf_rank_in(hm_);                                                \
+                        if (hn_ > room_) {      /* (wave-uniform) the rest goes to a new block of 64: entries the wave never fills stay 0xFFFF */ \
+                            uint32_t nb_ = 0;                                                                 \
+                            if (lane == 0) nb_ = atomicAdd(&sh[11], 64u);                                     \
+                            nb_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb_);                         \
+                            if (nb_ + (uint32_t)lane < DIST_HOT_CAP) hotl[nb_ + (uint32_t)lane] = (uint16_t)0xFFFFu; \
+                            hp_ = hp_ < hend ? hp_ : nb_ + (hp_ - hend);                                      \
+                            hcur = nb_ + (hn_ - room_); hend = nb_ + 64u;                                     \
+                        } else hcur += hn_;                                                                   \
+                        if ((SLOT) != 0xFFFFFFFFu && hp_ < DIST_HOT_CAP) hotl[hp_] = (uint16_t)(SLOT);        \
+                    }                                                                                         \
+                }
+#else
 #define CF_DIST_HOT(SLOT) {                                                                                   \
                     const unsigned long long hm_ = cf_ballot((SLOT) != 0xFFFFFFFFu);                           \
                     if (hm_) {                                                                                \
@@ -1326,6 +1433,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                         if ((SLOT) != 0xFFFFFFFFu && hb_ < DIST_HOT_CAP) hotl[hb_] = (uint16_t)(SLOT);        \
                     }                                                                                         \
                 }
+#endif
 #define CF_DIST_OVERFLOW(N) {                                                                                 \
                     const uint32_t m_ = (N); otail -= m_;                                                     \
                     uint32_t omade_ = 0, ohot_ = 0xFFFFFFFFu;                                                 \
@@ -1338,6 +1446,13 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     if (onew_ && lane == 0) atomicAdd(&sh[0], onew_);                                         \
                     CF_DIST_HOT(ohot_)                                                                        \
                 }
+#if CF_DIST_FILLRD
+#define CF_DIST_FILL_ISSUE const uint32_t fl_ = sh[0];
+#define CF_DIST_FILL_LOOK too_full = too_full || (uint32_t)__builtin_amdgcn_readfirstlane((int)fl_) > A.fill_limit;
+#else
+#define CF_DIST_FILL_ISSUE
+#define CF_DIST_FILL_LOOK
+#endif
 #define CF_DIST_DRAIN(N) {                                                                                    \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                     __builtin_amdgcn_wave_barrier();                                                          \
@@ -1345,6 +1460,29 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     bool made_ = false, park_ = false;                                                        \
                     uint32_t hot_ = 0xFFFFFFFFu;                                                              \
                     typename Tab::qitem it_ = 0;                                                              \
+                    CF_DIST_FILL_ISSUE                                                                        \
+                    if constexpr (Tab::kProbe1 && !CF_DIST_OLD_DRAIN && CF_DIST_DRAIN2) {                     \
+                        /* two queued inserts per lane, their probes side by side (lanes past n_: stale words of the queue) */ \
+                        bool made2_ = false, park2_ = false;                                                  \
+                        uint32_t hot2_ = 0xFFFFFFFFu;                                                         \
+                        uint32_t xb, xd, xk, yb, yd, yk;                                                      \
+                        it_ = wq[qtail + (uint32_t)lane];                                                     \
+                        const typename Tab::qitem it2_ = wq[qtail + 64u + (uint32_t)lane];                    \
+                        T.q_take(it_, n_buckets, xb, xd, xk);                                                 \
+                        T.q_take(it2_, n_buckets, yb, yd, yk);                                                \
+                        T.probe2((uint32_t)lane < n_, xk, T.key_of(xb, xd), (uint32_t)lane + 64u < n_, yk, T.key_of(yb, yd), A.min_cov, made_, park_, hot_, made2_, park2_, hot2_); \
+                        const uint32_t new_ = (uint32_t)__popcll(cf_ballot(made_)) + (uint32_t)__popcll(cf_ballot(made2_)); \
+                        if (new_ && lane == 0) atomicAdd(&sh[0], new_);                                       \
+                        const unsigned long long pm_ = cf_ballot(park_), pm2_ = cf_ballot(park2_);              \
+                        if (pm_ | pm2_) {                                                                     \
+                            if (park_) ovq[otail + cf_rank_in(pm_)] = it_;                                    \
+                            otail += (uint32_t)__popcll(pm_);                                                 \
+                            if (park2_) ovq[otail + cf_rank_in(pm2_)] = it2_;                                 \
+                            otail += (uint32_t)__popcll(pm2_);                                                \
+                        }                                                                                     \
+                        CF_DIST_HOT(hot_)                                                                     \
+                        CF_DIST_HOT(hot2_)                                                                    \
+                    } else {                                                                                  \
                     if constexpr (Tab::kProbe1 && !CF_DIST_OLD_DRAIN) {                                       \
                         uint32_t xb, xd, xk;                                                                  \
                         it_ = wq[qtail + (uint32_t)lane];      /* (lanes past n_: a stale word of the queue) */ \
@@ -1376,6 +1514,8 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                         otail += (uint32_t)__popcll(pm_);                                                     \
                     }                                                                                         \
                     CF_DIST_HOT(hot_)                                                                         \
+                    }                                                                                         \
+                    CF_DIST_FILL_LOOK                                                                         \
                     __builtin_amdgcn_wave_barrier();                                                          \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                 }
@@ -1383,13 +1523,18 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     if (CF_DIST_ABL >= 2) { qtail = 0; return; }
                     // a step pushes at most 4 x 64 inserts: the queue is brought below 64 first; after the wave's last step
                     // both lists are emptied (a pass whose table got too full is void and drops them)
-                    const uint32_t lim = final ? 1u : 64u;
+                    constexpr uint32_t kDrain = (Tab::kProbe1 && !CF_DIST_OLD_DRAIN && CF_DIST_DRAIN2) ? 128u : 64u;      // queued inserts per drain
+                    const uint32_t lim = final ? 1u : kDrain;
                     if (qtail < lim && !(final && otail > 0u)) return;      // nothing to drain: no look at the fill level either
                     for (;;) {
+#if CF_DIST_FILLRD
+                        if (too_full) break;      // (seen by the last drain; the limit leaves room for the drains of all waves that run meanwhile)
+#else
                         if (sh[0] > A.fill_limit) { too_full = true; break; }
-                        if (qtail >= lim) { CF_DIST_DRAIN(min(qtail, 64u)) }
+#endif
+                        if (qtail >= lim) { CF_DIST_DRAIN(min(qtail, kDrain)) }
                         else if (!(final && otail > 0u)) break;
-                        if (otail >= 32u || (final && qtail == 0u && otail > 0u)) { CF_DIST_OVERFLOW(min(otail, 64u)) }
+                        while (otail >= 32u || (final && qtail == 0u && otail > 0u)) { CF_DIST_OVERFLOW(min(otail, 64u)) }
                     }
                 }, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], const uint32_t (&qq_)[DIST_UNROLL], const uint32_t (&lo_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
                     if (too_full) return true;     // (wave-uniform, set by the drains: the fill only changes there) the pass will be split
@@ -1437,6 +1582,8 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
 #undef CF_DIST_DRAIN
 #undef CF_DIST_OVERFLOW
 #undef CF_DIST_HOT
+#undef CF_DIST_FILL_ISSUE
+#undef CF_DIST_FILL_LOOK
                 CF_STAMP(3);   // table sweep + inserts (wave 0's own items)
             }
             __syncthreads();      // [table swept]
@@ -1550,8 +1697,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     const uint32_t i = i0 + (uint32_t)t;
                     bool sel = false;
                     uint32_t s = 0, eb = 0, ed = 0, ec = 0;
-                    if (i < n_hot) {
-                        s = hot[i];
+                    if (i < n_hot && (s = hot[i]) != 0xFFFFu) {      // (0xFFFF: an entry of a wave's block of the list that the wave did not fill)
                         T.eval_slot(s, n_buckets, A.min_cov, [&](uint32_t, uint32_t b, uint32_t dd, uint32_t cnt, unsigned long long total) { sel = b != a && dominant(cnt, total); eb = b; ed = dd; ec = cnt; });
                     }
                     keep(sel, s, eb, ed, ec);
@@ -1843,7 +1989,9 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         int kb = 24; while (kb < 32 && K >= ((int64_t)1 << kb) - 1) ++kb;       // ranks 0 .. K - 1 and the all-ones key stays free
         narrow_db = 32 - kb;                                                       // the widest distance field the ranks leave
         if (ctx->dist_dbits) narrow_db = std::min(narrow_db, ctx->dist_dbits);
-        narrow = !wide16 && !ctx->dist_wide && narrow_db >= 5 && narrow_db >= need_bits && max_post <= 32767u;
+        // (the 4-byte stream is read with buffer loads whose scalar byte offset has 32 bits: 2^30 entries and more take the other layouts)
+        const bool stream4_ok = v_n_entries + (int64_t)DIST_ITEM < ((int64_t)1 << 30);
+        narrow = !wide16 && !ctx->dist_wide && narrow_db >= 5 && narrow_db >= need_bits && max_post <= 32767u && stream4_ok;
         if (ctx->dist_dbits && !narrow) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_dbits does not fit this input (distances or k-mer ranks need more bits)"); break; }
         // ranks that do not fit next to the distance: the 6-byte slots in 2^S table regions (the key drops the rank's low S bits)
         if (!narrow || ctx->dist_regions) {
@@ -1854,7 +2002,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
             if (ctx->dist_regions && !region) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_regions does not fit this input"); break; }
             if (region) narrow = false;
             // up to 2^26 ranks and distances up to 127: the region table behind the 4-byte stream [unit index mod 64 : 6 | rank : 26]
-            region26 = region && !ctx->dist_region_bytes && K <= ((int64_t)1 << 26) && d_need <= 127;
+            region26 = region && !ctx->dist_region_bytes && K <= ((int64_t)1 << 26) && d_need <= 127 && stream4_ok;
         }
         if (max_post >= (1u << 23) || (wide16 && max_post > 32767u)) { rc = cf_fail(ctx, -34, wide16 ? "cf_dist_edges: distances above 255 with a k-mer of more than 32767 postings" : "cf_dist_edges: a k-mer has more than 2^23 postings"); break; }
         if (narrow || region26) { if ((rc = cf_alloc_t(ctx, &d_packed, (size_t)v_n_entries + DIST_ITEM, "packed cloud entries"))) break; }
@@ -1897,6 +2045,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (ctx->dist_slots > budget8) { rc = cf_fail(ctx, -22, "cf_dist_edges: dist_slots does not fit the 160 KiB LDS next to the work lists"); break; }
         const int64_t slots8 = ctx->dist_slots ? ctx->dist_slots : budget8;
         A.slots = (int32_t)((slots8 * 8 / slot_bytes) & ~(region ? (int64_t)(32 << reg_shift) - 1 : 7ll));      // (regions: equal parts of whole 8-slot groups)
+        if (A.slots >= 0xFFFF) { rc = cf_fail(ctx, -22, "cf_dist_edges: more than 65534 table slots (16-bit slot indices; 0xFFFF marks an unused entry of the hot list)"); break; }
         A.fill_limit = (uint32_t)((int64_t)A.slots * ctx->dist_fill_pct / 100);   // checked once per wave step: leave slack below the physical size
         A.est_limit = (uint32_t)((int64_t)A.fill_limit * 100 / ctx->dist_est_pct);
         A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;

@@ -157,6 +157,7 @@ inline uint2 make_uint2(unsigned x, unsigned y) { uint2 v; v.x = x; v.y = y; ret
 #define cf_lds_at(off) (cf_lds + (off))
 #define cf_lds_base_ok() true
 #define cf_ld_agent(p) (*(p))          /* cf_place2.hip: device-scope loads / the wave's drain of its memory operations */
+#define CF_NO_BUFFER_LOAD 1      /* cf_dist.hip: the entry stream through pointer loads (no buffer descriptors on the host) */
 #define cf_ballot(p) __ballot((p) ? 1 : 0)      /* cf_dist.hip: __builtin_amdgcn_ballot_w64 */
 #define cf_bit_of(w, off) (((w) >> ((off) & 31u)) & 1u)      /* cf_dist.hip: v_bfe_u32 w, off, 1 (the offset's low five bits) */
 #define cf_drain_vm() ((void)0)

@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "emu", "libcfhip_emu.so")
-ARGS = ["--lib", EMU, "--reads", "6", "--steps", "1", "--warmup", "0", "--edge-cap", "1000", "--transfer-steps", "1", "--no-cpu-baseline"]
+ARGS = ["--lib", EMU, "--reads", "6", "--steps", "1", "--warmup", "0", "--edge-cap", "1000", "--transfer-steps", "1", "--no-cpu-baseline", "--steps-b", "1"]
 
 
 def _line(stdout):
@@ -29,6 +29,10 @@ def _check(res, n):
     assert "workload" in res["config"] and "var_len" in res["config"]["workload"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "whole_step_frac")) <= set(res["roofline"]) and res["roofline"]["traffic"] is None
     assert res["steps_identical"] and res["counters"]["n_bases"] > 100000 * n
+    assert set(("bound_by_contract", "lds", "l2_hit", "hbm_side_gbps")) <= set(res["roofline"]) and res["roofline"]["bound_by_contract"] == "hbm"
+    wb = res["workload_b"]      # the same reads with point substitutions (var_len 1), its own timed steps
+    assert wb["steps"] == 1 and wb["value"] > 0 and wb["steps_identical"] and "var_len 1" in wb["workload"] and wb["counters"]["n_bases"] > 100000 * n
+    assert set(("count", "select", "clouds", "postings", "dist")) <= set(wb["stage_ms_per_step"]) and wb["parity_vs_committed_oracle"] is None
 
 
 def test_single_process(emu_lib, tmp_path):

@@ -10,10 +10,11 @@
     against a full GPU launch here and by bench.py every run;
   * placement (A4 + A8/A9) of 3 000 reads vs the C restatement of the greedy loop: identical lines; and of the 50 000
     reads of configs[2] vs the same C placer (the arg-max scan threaded).
-  * BASELINE configs[3]'s single-GPU-feasible share — 200 000 reads (~4 Gb): A1 (three bucket passes, 18 read-id bits), A2, A3 and
-    one first-k-mer partition of A5/A6 (2.2e7 rare k-mers: the 6-byte table slots with a 7-bit distance field) vs the CPU
-    path (tests/bigparity.py; the same check at 400 000 reads — the region layout — is tools/rank_emulation.py --check,
-    record in profiles/r04_rank_emulation.json).
+  * BASELINE configs[3] at its own size — 500 000 reads (~10 Gb) resident on one GPU: A1, A2, A3 of all reads and ONE WHOLE rank of 8
+    (a % 8 == 3, through the exchange path and the gathered view) against the committed oracle record
+    profiles/r05_parity_500k_rank3.json (tools/parity_record.py); 200 000 reads the same way (profiles/r05_parity_200k.json);
+  * two more workload families at size: point substitutions (var_len 1, SURVEY 8(d)'s literal model) on the bench's 50 000 reads, and
+    reads of up to ~195 units with more than 2^24 rare k-mers.
 The oracle side is pinned on CPU (tests/test_oracle_golden.py).  Reference: distance_based_kmer_recruitment.py:39-149,
 read_placer.py:42-94."""
 import os
@@ -40,22 +41,78 @@ def engine():
     e.close()
 
 
-@pytest.mark.timeout(1500)
-def test_config3_share_200k_reads_count_clouds_and_one_distance_partition_vs_cpu():
+def _record(name):
+    import json
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)) as f:
+        return json.load(f)
+
+
+def _against_record(name, out_name, **kw):
+    """The GPU against a COMMITTED oracle record (tools/parity_record.py ran oracle/c/cf_oracle_mt.c once on the GPU box's 256 host threads;
+    the record holds the workload's generator parameters, every counter and the checksums of the A1 table, the rare set, the cloud CSR and
+    of one first-k-mer partition): the same seeded reads, device-side checksums of every element (cf_checksum, cf_edges_checksum)."""
     import json
     import bigparity
-    pk = synth(200000, 2)
-    assert pk.n_bases > 3.5e9
+    rec = _record(name)
+    pk = bigparity.synth_workload(rec["workload"])
+    assert pk.n_reads == rec["reads"] and pk.n_bases == rec["n_bases"]
     e = Engine(0)
     try:
-        rec = bigparity.check(e, pk, 21, 64)
+        res = bigparity.check_record(e, pk, rec, **kw)
     finally:
         e.close()
-    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
-    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_200k.json"), "w") as f:
-        json.dump(rec, f, indent=1)
-    assert rec["identical"], rec["checks"]
-    assert rec["n_rare"] > (1 << 24) and rec["n_emissions_partition"] > 3e9      # (ranks beyond 24 bits: not the bench's table layout)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", out_name), "w") as f:
+        json.dump(res, f, indent=1)
+    assert res["identical"], res["checks"]
+    return rec, res
+
+
+@pytest.mark.timeout(900)
+def test_config3_500k_reads_count_clouds_and_one_whole_rank_of_8_vs_committed_oracle():
+    """BASELINE configs[3] at its own size: 500 000 reads (9.96 Gb) resident on the one GPU; A1 (1.27e9 table entries), A2 (4.46e7 rare
+    k-mers), A3 (6.5e8 cloud entries) of ALL reads, then ONE WHOLE rank of 8 — first k-mers a % 8 == 3: 6.3e10 pair emissions, 2.9e9
+    selected edges — run the way a rank runs it: A1 on the rank's read shard, table exchange, rare-list and cloud gathers through a
+    one-rank RCCL communicator with the message to itself going through ncclSend / ncclRecv, the distance stage over the gathered view in
+    the table layout every rank of 8 takes (cf_tab_region26).  Oracle side: profiles/r05_parity_500k_rank3.json (561 s of A1-A3 + 650 s for
+    the 16 sub-partitions a % 128 == 3 + 8 j on 256 host threads; the GPU equalled it when the record was taken)."""
+    rec, res = _against_record("r05_parity_500k_rank3.json", "parity_500k_rank3.json", through_exchange=True)
+    assert rec["reads"] == 500000 and rec["n_rare"] > (1 << 25) and rec["partition"]["n_parts"] == 8 and rec["partition"]["n_emissions"] > 6e10
+    assert res["got"]["gathered_cloud_entries"] == rec["n_cloud_entries"]
+
+
+@pytest.mark.timeout(600)
+def test_config3_share_200k_reads_count_clouds_and_one_distance_partition_vs_committed_oracle():
+    """200 000 reads (3.98 Gb): three bucket passes of the counting sort, 18 read-id bits, 2.2e7 rare k-mers (the 6-byte table slots with a
+    7-bit distance field); oracle side: profiles/r05_parity_200k.json (round 4 ran the oracle inside the test: 224 s of every GPU suite)."""
+    rec, res = _against_record("r05_parity_200k.json", "parity_200k.json")
+    assert rec["n_rare"] > (1 << 24) and res["got"]["n_emissions_partition"] > 3e9      # (ranks beyond 24 bits: not the bench's table layout)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("what,kw,part,n_parts", [
+    ("point substitutions (var_len 1), 50 000 reads", dict(reads=50000, seed=2, var_len=1, n_units=15000, synth={}), 0, 1),
+    ("long reads (> 128 units), 2^24+ rare k-mers", dict(reads=30000, seed=6, var_len=8, n_units=36000, synth=dict(mean_len=80000.0, max_len=400000)), 21, 256)])
+def test_other_workload_families_at_size_vs_cpu(what, kw, part, n_parts):
+    """Round 4's at-size tests all used one generator family (var_len 8, reads of ~10 units).  Two more: SURVEY 8(d)'s LITERAL model —
+    copy-specific variants are point substitutions as simulate_tandem_repeat.py:15-30 makes them, so few k-mers are copy-specific, the
+    clouds are small and E per base collapses (what a real HOR array looks like) — the bench's own 50 000 reads, every first k-mer; and
+    reads of ~40 and up to ~195 units with more than 2^24 rare k-mers: distances up to 150 next to ranks beyond 24 bits, the table layout
+    that streams rank and unit index apart, at size.  Oracle: oracle/c/cf_oracle_mt.c in the test (these finish in about a minute)."""
+    import bigparity
+    pk = bigparity.synth_workload(kw)
+    e = Engine(0)
+    try:
+        rec = bigparity.check(e, pk, part, n_parts)
+    finally:
+        e.close()
+    assert rec["identical"], (what, rec["checks"])
+    if kw["var_len"] == 1:
+        assert rec["n_bases"] > 9e8 and rec["n_emissions_partition"] > 1e9
+    else:
+        up = pk.units(1)[0]
+        assert int(np.diff(up).max()) > 128 and rec["n_rare"] > (1 << 24) and rec["n_emissions_partition"] > 1e9
 
 
 @pytest.mark.timeout(900)
