@@ -7,7 +7,7 @@
 #include <thread>
 
 #ifndef CF_COPY_MODE_DEFAULT
-#define CF_COPY_MODE_DEFAULT 0      // staged: see cf_copy_mode() and profiles/r05_copy_modes.log for the measurement behind the default
+#define CF_COPY_MODE_DEFAULT 1      // auto: H2D of 64 MB and more through hipHostRegister, everything else staged (profiles/r05_copy_modes.log)
 #endif
 struct alignas(16) cf_u32x4_api { uint32_t x, y, z, w; };
 
@@ -123,7 +123,7 @@ static bool cf_is_host_pointer(const void* p) {
 // item 7).  Which way is faster depends on the host (pinning costs page-table work per 4-KB page; the staged path costs a memcpy
 // through the pinned slots on copy_threads cores): CF_COPY_MODE = "staged" | "register" | "auto" (register from CF_REG_MIN bytes on);
 // a registration that fails (locked-memory limit, memory that cannot be pinned) falls back to the staged path.
-static const size_t CF_REG_MIN = (size_t)256 << 20;
+static const size_t CF_REG_MIN = (size_t)64 << 20;
 static int cf_copy_mode() {      // 0 staged, 1 register (from CF_REG_MIN on), 2 register whatever the size above CF_PIN_MIN
     static const int mode = [] {
         const char* e = std::getenv("CF_COPY_MODE");
@@ -149,7 +149,10 @@ static int cf_copy_staged(cf_ctx* ctx, void* dst, const void* src, size_t bytes,
         return 0;
     }
     CF_HIP(hipStreamSynchronize(ctx->stream));      // what the copy reads / overwrites is settled
-    if (cf_copy_mode() == 2 || (cf_copy_mode() == 1 && bytes >= CF_REG_MIN)) {
+    // measured on an MI355X box (gpurun_out/c1_copy_modes.log, 0.4 GB of reads / 4 GB of edge rows): H2D 52.7 GB/s registered against 34.9
+    // (8 copy threads) / 46.8 (16) staged; D2H 12.9 - 29 GB/s registered (pinning the fresh pages of an output buffer costs more than
+    // the copy) against 54 staged with 16 threads.  So "auto" registers host memory for H2D only.
+    if (cf_copy_mode() == 2 || (cf_copy_mode() == 1 && to_device && bytes >= CF_REG_MIN)) {
         const int rc = cf_copy_registered(ctx, dst, src, bytes, to_device);
         if (rc <= 0) return rc;      // 1: could not pin — the staged path below
     }
@@ -536,6 +539,12 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "place_row_words") {
         if (value != 0 && value != 32 && value != 64) return cf_fail(ctx, -22, "place_row_words must be 0 (auto), 32 or 64");
         ctx->place_row_words = (int)value;
+    } else if (n == "place_l3") {
+        if (value < 0 || value > 2) return cf_fail(ctx, -22, "place_l3 must be 0 (auto), 1 (always) or 2 (never)");
+        ctx->place_l3 = (int)value;
+    } else if (n == "place_l3_shift") {
+        if (value < 0 || value > 6) return cf_fail(ctx, -22, "place_l3_shift must be 0 (= 6) .. 6");
+        ctx->place_l3_shift = (int)value;
     } else if (n == "place_slots_per_unit") {
         if (value < 0 || value > 65536) return cf_fail(ctx, -22, "place_slots_per_unit out of range (0 = default, 1 .. 65536)");
         ctx->place_slots_per_unit = (int)value;

@@ -131,11 +131,11 @@ struct cf_ctx {
 
     // host <-> device copies of the caller's (pageable) buffers go through pinned staging slots, one per copy thread
     // (cf_api.hip: cf_copy_h2d / cf_copy_d2h)
-    static constexpr int kCopyThreads = 16;      // slots; CF_COPY_THREADS (1 .. 16, default 8) picks how many are used
+    static constexpr int kCopyThreads = 16;      // slots; CF_COPY_THREADS (1 .. 16, default 16) picks how many are used
     void* pin_slot[kCopyThreads] = {nullptr};
     hipStream_t pin_stream[kCopyThreads] = {nullptr};
     size_t pin_bytes = 0;
-    int copy_threads = 8;        // CF_COPY_THREADS (1 .. 16), read once by cf_create
+    int copy_threads = 16;       // CF_COPY_THREADS (1 .. 16), read once by cf_create (round 5: 16 staged threads move 54 GB/s D2H, 8 moved 34 - 40)
 
     cf_stats stats{};
     cf_times times{};
@@ -162,6 +162,8 @@ struct cf_ctx {
     int place_block = 0;         // cf_place2: threads per workgroup of the iteration kernel (128 .. 1024, a multiple of 128; 0 = 1024)
     int place_row_words = 0;     // cf_place2: 32-bit words of a posting row (32 or 64); 0 = the smaller one that holds the longest posting list
     int place_slots_per_unit = 0; // cf_place2: score-region slots per unit of a read (0 = 48); doubled-up automatically when a region fills
+    int place_l3 = 0;            // cf_place2: third level of the arg-max (best candidate per group of 64-read blocks): 0 = for read sets of more than 2 048 blocks, 1 = always, 2 = never
+    int place_l3_shift = 0;      // cf_place2: log2 of the blocks per group (0 = 6: groups of 64 blocks = 4 096 reads; tests use small groups at small read sets)
     int count_mode = 1;          // 1: sort and reduce (cf_count2.hip) when it applies; 0: the atomic table of round 1 (cf_count.hip)
     int count_bits = 0;          // bucket bits of the sort-and-reduce path; 0 = from the number of windows (tests force small / large values)
     int count_slots = 4096;

@@ -962,7 +962,10 @@ __device__ __forceinline__ uint32_t cf_rank_in(unsigned long long m) { return __
 //                  in flight per lane — the inserts are bound by that chain of LDS round trips at four waves per SIMD, not by
 //                  instruction issue (profiles/r04_dist_phase_insts_after_cuts.md).
 #ifndef CF_DIST_HOTBLK
-#define CF_DIST_HOTBLK 1
+#define CF_DIST_HOTBLK 0      /* measured (gpurun_out/c1_dist_ab.log): 257.4 ms with the blocks, 251.3 without — the unused entries of every wave's last block lengthen the filter's list by up to 64 x waves entries */
+#endif
+#ifndef CF_DIST_PUSH_FLAT
+#define CF_DIST_PUSH_FLAT 0
 #endif
 #ifndef CF_DIST_FILLRD
 #define CF_DIST_FILLRD 1
@@ -1566,6 +1569,18 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) c_[u] = cf_bit_of(w_[u], lo_[u]) != 0u;
                     if (CF_DIST_ABL >= 3) { if (c_[0] && c_[1] && c_[2] && c_[3] && bb[0] == 0xFFFFFFF1u) sh[13] = 1u; return false; }
+#if CF_DIST_PUSH_FLAT
+                    // no test for "no candidate in the wave" (with 15 % of the entries candidates there always is one: the test was a
+                    // compare of the ballot and a branch per entry slot), rank and queue word made by every lane, only the store under the mask
+#pragma unroll
+                    for (int u = 0; u < DIST_UNROLL; ++u) {
+                        const unsigned long long cm = cf_ballot(c_[u]);
+                        const uint32_t at = qtail + cf_rank_in(cm);
+                        const typename Tab::qitem qv = T.q_push(bb[u], dd_[u], qq_[u], n_buckets);
+                        if (c_[u]) wq[at] = qv;
+                        qtail += (uint32_t)__popcll(cm);
+                    }
+#else
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
                         const unsigned long long cm = cf_ballot(c_[u]);
@@ -1574,6 +1589,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                             qtail += (uint32_t)__popcll(cm);
                         }
                     }
+#endif
                     // (measured and not kept: every lane storing — candidates at their rank, the others into a dump word of their own —
                     // to save the four scalar instructions per entry of the skip branches and the exec save / restore: 325 vs 320 ms,
                     // the LDS takes four full-wave writes per step instead of 15 % of the lanes)

@@ -58,6 +58,8 @@
 #ifndef PL2_DW
 #define PL2_DW 8            // dirty-bitmap words per thread and round of the tail's scan (16: 50 000 reads + 3.5 %, 500 000 - 3.3 %)
 #endif
+#define PL2_G3MAX 1024      // groups of the third level that the tail keeps bitmaps and per-wave lists for (more groups: the level is not used)
+#define PL2_REFRESH 2       // third-level records a sweeping wave brings up to date per tail (a 64-lane reduction each)
 #ifndef PL2_SW
 #define PL2_SW 4            // block records per lane and round of the tail's sweep over all blocks of 64 reads
 #endif
@@ -86,6 +88,8 @@ struct cf_pl2 {
     uint32_t* hotbits;               // one bit per slot: the row has reached hot_thr hits (it may qualify: rescans look at it)
     uint32_t* dirty; uint32_t n_dirty_words;
     cf_pl2_rec* RB; cf_pl2_rec* L2;      // best candidate per read, per 64 reads
+    cf_pl2_rec* L3; uint32_t* l3_stale;  // (large read sets) best candidate per GROUP of 2^g3s blocks, and one bit per group: its record is out of date
+    uint32_t n3, g3s;                    // groups (0: the level is not used), log2 of the blocks per group
     uint32_t n_reads, n2;
     cf_pl2_rec* win;                 // the read the next launch lays down (hi == 0: none, the stage is over)
     uint32_t hot_thr;
@@ -272,7 +276,7 @@ __device__ __forceinline__ void pl2_row(const cf_pl2& S, const cf_pl2_rinfo& ri,
 }
 
 // ---- one dirty read by one LANE: recomputed from its hot rows (RB, anchor); its block of 64 is marked (LDS)
-__device__ __forceinline__ void pl2_rescan_read(const cf_pl2& S, uint32_t r, uint32_t* bb2, uint32_t* list2, uint32_t* n_list2) {
+__device__ __forceinline__ void pl2_rescan_read(const cf_pl2& S, uint32_t r, uint32_t* bb2, uint32_t* list2, uint32_t* n_list2, uint32_t* bb3) {
     const cf_pl2_rinfo ri = S.rinfo[r];
     const bool used = S.C.used[r] != 0;
     const uint32_t rank = (uint32_t)S.C.id_rank[r];
@@ -322,7 +326,10 @@ __device__ __forceinline__ void pl2_rescan_read(const cf_pl2& S, uint32_t r, uin
     pl2_store(&S.RB[r], rec);
     if (anchor) { S.rinfo[r].anchor_slot = (uint32_t)(anchor - 1ull); S.rinfo[r].anchor_off1 = anchor_off1; }
     const uint32_t i2 = r >> 6, bit = 1u << (i2 & 31);
-    if (!(atomicOr(&bb2[i2 >> 5], bit) & bit)) list2[atomicAdd(n_list2, 1u)] = i2;
+    if (!(atomicOr(&bb2[i2 >> 5], bit) & bit)) {
+        list2[atomicAdd(n_list2, 1u)] = i2;
+        if (S.n3) { const uint32_t g = i2 >> S.g3s; atomicOr(&bb3[g >> 5], 1u << (g & 31)); }      // the block's group of the third level is touched
+    }
 }
 
 #ifdef CF_PL2_STAMPS
@@ -355,7 +362,14 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
     const uint32_t n_b2words = (S.n2 + 31u) >> 5;
+    // third level (S.n3 > 0): bb3 = groups with a touched block, st3 = the groups whose record is out of date (a copy of S.l3_stale,
+    // written back at the end), glist = per sweeping wave the groups whose blocks it has to look at one by one
+    uint32_t* bb3 = bb2 + n_b2words;
+    uint32_t* st3 = bb3 + PL2_G3MAX / 32;
+    uint16_t* glist = (uint16_t*)(st3 + PL2_G3MAX / 32);      // 16 waves x (PL2_G3MAX / 8) entries
+    const uint32_t n_b3words = (S.n3 + 31u) >> 5;
     for (uint32_t i = tid; i < n_b2words; i += nthr) bb2[i] = 0u;
+    for (uint32_t i = tid; i < n_b3words; i += nthr) { bb3[i] = 0u; st3[i] = S.l3_stale[i]; }
     bool again = true;
     while (again) {
         if (tid == 0) { *n_list = 0u; *more = 0u; *n_list2 = 0u; }
@@ -391,7 +405,7 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
         again = *more != 0u;
         for (uint32_t k = tid; k < n; k += nthr) {
             const uint32_t r = list[k];
-            if (r < S.n_reads && r != 0xFFFFFFFFu) pl2_rescan_read(S, r, bb2, list2, n_list2);
+            if (r < S.n_reads && r != 0xFFFFFFFFu) pl2_rescan_read(S, r, bb2, list2, n_list2, bb3);
         }
         PL2_TTRACE(3);
         __syncthreads();
@@ -427,7 +441,66 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
         if (again || !fused) { __syncthreads(); PL2_STAMP(5); }
         if (!again) {
             // all blocks of 64: lanes take 4 records at a time (the loads of a batch are in flight together)
-            if (wave < nfw) {
+            if (wave < nfw && S.n3 && fused) {
+                // Third level (read sets of more than 2 048 blocks; round 5: the sweep over ALL blocks made the tail grow with the read set —
+                // 7 800 records of 32 bytes through one CU at 500 000 reads, three rounds of loads).  L3[g] = the best candidate of the blocks
+                // of group g, kept LAZILY: a group with a block touched in this tail is marked out of date (its blocks' new records are
+                // being written right now) and is looked at block by block — as are the groups still out of date from earlier tails —,
+                // every other group is ONE record.  A sweeping wave brings up to PL2_REFRESH out-of-date groups that were NOT touched
+                // this time up to date (all their block records are in its lanes: one 64-lane reduction each).  A busy tail touches
+                // every group and sweeps like before; the light tails that follow (most are: a handful of dirty reads) mend the level
+                // a few groups at a time and then read n3 + 64 x (touched groups) records instead of n2.
+                cf_pl2_rec mine{0ull, 0ull, 0ull, 0u, 0u};
+                const cf_pl2_rec none{0ull, 0ull, 0ull, 0u, 0u};
+                const uint32_t gb = 1u << S.g3s;      // blocks per group (<= 64: a lane per block)
+                // (a) this wave's groups that need their blocks: a wave-private list (lane 0 writes, the wave reads)
+                uint16_t* gl = glist + (size_t)wave * (PL2_G3MAX / 8);
+                uint32_t n_gl = 0;
+                for (uint32_t g = (uint32_t)wave; g < S.n3; g += (uint32_t)nfw) {      // (wave-uniform)
+                    const uint32_t bt = 1u << (g & 31);
+                    if ((st3[g >> 5] | bb3[g >> 5]) & bt) { if (lane == 0) gl[n_gl] = (uint16_t)g; ++n_gl; }
+                }
+                // (b) groups that are up to date and untouched: one record per lane (all in flight together)
+                {
+                    cf_pl2_rec o[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {      // (two per lane: the host uses the level only when n3 <= 128 x the sweeping waves)
+                        const uint32_t g = (uint32_t)(wave * 64 + lane) + (uint32_t)t * (uint32_t)nfw * 64u;
+                        const bool kt = g < S.n3 && !(((st3[g >> 5] | bb3[g >> 5]) >> (g & 31)) & 1u);
+                        o[t] = kt ? pl2_load(&S.L3[g]) : none;
+                    }
+                    // (c) block by block, PL2_SW groups in flight
+                    uint32_t refreshed = 0;
+                    for (uint32_t i0 = 0; i0 < n_gl; i0 += (uint32_t)PL2_SW) {
+                        cf_pl2_rec q[PL2_SW];
+                        uint32_t gq[PL2_SW];
+#pragma unroll
+                        for (int t = 0; t < PL2_SW; ++t) {
+                            gq[t] = i0 + (uint32_t)t < n_gl ? (uint32_t)gl[i0 + (uint32_t)t] : 0xFFFFFFFFu;
+                            const uint32_t b = (gq[t] << S.g3s) + (uint32_t)lane;
+                            const bool kt = gq[t] != 0xFFFFFFFFu && (uint32_t)lane < gb && b < S.n2 && !((bb2[b >> 5] >> (b & 31)) & 1u);
+                            q[t] = kt ? pl2_load(&S.L2[b]) : none;
+                        }
+#pragma unroll
+                        for (int t = 0; t < PL2_SW; ++t) {
+                            pl2_take(mine, q[t]);
+                            if (gq[t] == 0xFFFFFFFFu) continue;      // (wave-uniform)
+                            const uint32_t g = gq[t], bt = 1u << (g & 31);
+                            if ((bb3[g >> 5] & bt)) { if (lane == 0) atomicOr(&st3[g >> 5], bt); }      // touched now: out of date from here on
+                            else if (refreshed < (uint32_t)PL2_REFRESH) {      // out of date, untouched: every block record of the group is in q[t]
+                                cf_pl2_rec w = q[t];
+                                for (int d = 1; d <= 32; d <<= 1) pl2_take(w, pl2_shfl_xor(w, d));
+                                if (lane == 0) { pl2_store(&S.L3[g], w); atomicAnd(&st3[g >> 5], ~bt); }
+                                ++refreshed;
+                            }
+                        }
+                    }
+                    pl2_take(mine, o[0]); pl2_take(mine, o[1]);
+                }
+                const uint32_t at = 4u * (uint32_t)(wave * 64 + lane);
+                red[at] = mine.hi; red[at + 1] = mine.lo; red[at + 2] = mine.ext; red[at + 3] = mine.read;
+            } else if (wave < nfw) {
+                if (S.n3) for (uint32_t i = (uint32_t)(wave * 64 + lane); i < n_b3words; i += (uint32_t)nfw * 64u) st3[i] = 0xFFFFFFFFu;      // (a tail whose touched blocks went through several rounds: every group out of date)
                 cf_pl2_rec mine{0ull, 0ull, 0ull, 0u, 0u};
                 const uint32_t stride = (uint32_t)nfw * 64u;
                 for (uint32_t b = (uint32_t)(wave * 64 + lane); b < S.n2; b += (uint32_t)PL2_SW * stride) {      // (PL2_SW loads in flight per lane)
@@ -470,13 +543,14 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
                     S.C.ctl[3] = 0u;
                 }
             }
+            if (S.n3 && wave == 1) for (uint32_t i = (uint32_t)lane; i < n_b3words; i += 64u) S.l3_stale[i] = st3[i];      // (behind the sweep's barrier: the bits are final)
         }
     }
     PL2_TTRACE(7);
     PL2_STAMP(7);
 }
 
-static size_t pl2_lds_bytes(uint32_t n2) { return (16 + (size_t)PL2_LIST * 8 + 1024 * 32 + (size_t)PL2_CRES * 32 + (size_t)((n2 + 31) / 32) * 4 + 16); }
+static size_t pl2_lds_bytes(uint32_t n2) { return (16 + (size_t)PL2_LIST * 8 + 1024 * 32 + (size_t)PL2_CRES * 32 + (size_t)((n2 + 31) / 32) * 4 + 2 * (PL2_G3MAX / 32) * 4 + 16 * (PL2_G3MAX / 8) * 2 + 16); }
 
 __global__ void __launch_bounds__(PL2_B)
 cf_pl2_tail_kernel(cf_pl2 S) {
@@ -698,6 +772,20 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
     CF_TRY(B.get(&S.dirty, (size_t)S.n_dirty_words + 1, "dirty bits"));
     CF_TRY(B.get(&S.RB, (size_t)S.n2 * 64 + 64, "read candidates"));
     CF_TRY(B.get(&S.L2, (size_t)S.n2 + 1, "candidates per 64 reads"));
+    {
+        // the third level: for read sets of more than 2 048 blocks (131 072 reads) — below, the sweep over all blocks is one round of
+        // loads anyway — and only when the tail's per-wave lists and the two-records-per-lane pass hold its groups
+        const int blk = ctx->place_block > 0 ? ctx->place_block : PL2_B;
+        const uint32_t nw_ = (uint32_t)blk / 64u;
+        const uint32_t nfw_ = std::max(1u, std::min(S.n2 > 2048u ? nw_ - nw_ / 4u : nw_ / 2u, (S.n2 + 255u) >> 8));
+        S.g3s = ctx->place_l3_shift > 0 ? (uint32_t)ctx->place_l3_shift : 6u;
+        uint32_t n3 = (S.n2 + (1u << S.g3s) - 1u) >> S.g3s;
+        const bool want = ctx->place_l3 == 1 || (ctx->place_l3 == 0 && S.n2 > 2048u);
+        if (!want || n3 > PL2_G3MAX || n3 > 128u * nfw_) n3 = 0;
+        S.n3 = n3;
+        CF_TRY(B.get(&S.L3, (size_t)n3 + 1, "candidates per group of blocks"));
+        CF_TRY(B.get(&S.l3_stale, (size_t)(PL2_G3MAX / 32), "out-of-date groups"));
+    }
     CF_TRY(B.get(&S.win, 1, "winner"));
     CF_TRY(B.get(&S.C.ctl, 8, "control"));
     CF_TRY(B.get(&S.stamps, 16, "phase stamps"));
@@ -805,6 +893,8 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
             CF_HIP(hipMemsetAsync(S.dirty, 0, (size_t)S.n_dirty_words * 4, st));
             CF_HIP(hipMemsetAsync(S.RB, 0, (size_t)S.n2 * 64 * sizeof(cf_pl2_rec), st));
             CF_HIP(hipMemsetAsync(S.L2, 0, (size_t)S.n2 * sizeof(cf_pl2_rec), st));
+            CF_HIP(hipMemsetAsync(S.L3, 0, ((size_t)S.n3 + 1) * sizeof(cf_pl2_rec), st));
+            CF_HIP(hipMemsetAsync(S.l3_stale, 0xFF, (size_t)(PL2_G3MAX / 32) * 4, st));      // every group out of date: the first tails sweep block by block and mend it
             CF_HIP(hipMemsetAsync(S.win, 0, sizeof(cf_pl2_rec), st));
             CF_HIP(hipMemsetAsync(S.C.ctl, 0, 8, st));         // done = 0, n_out = 0 (error flags kept)
             CF_HIP(hipMemsetAsync(S.C.ctl + 3, 0, 4, st));

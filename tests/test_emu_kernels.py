@@ -200,7 +200,7 @@ def test_stage3_against_reference_golden(engine, report, golden):
 
 
 @pytest.mark.parametrize("knobs", [{"place_grid": 3, "place_block": 256}, {"place_row_words": 64, "place_grid": 1}, {"place_slots_per_unit": 1},
-                                   {"place_mode": 1}, {"place_mode": 1, "place_fused": 0}])
+                                   {"place_mode": 1}, {"place_mode": 1, "place_fused": 0}, {"place_l3": 1}, {"place_slots_per_unit": 1 << 16}])
 def test_stage3_launch_shapes_and_region_restart(engine, report, golden, knobs):
     """The greedy placement in other shapes of the round-4 path (cf_place2.hip: odd grids, 4-wave tails, wide posting rows,
     score regions that start too small: the seed of a stage, then the whole run, start over with larger ones) and on the round
@@ -213,7 +213,9 @@ def test_stage3_launch_shapes_and_region_restart(engine, report, golden, knobs):
         gk = np.array(sorted(recruit.encode_kmer(x.strip()) for x in f if x.strip()), dtype=np.uint64)
     records, alns, lens = ncrf.parse_report(report(name))
     pk = _host.parse_report(report(name))
-    defaults = {"place_mode": 2, "place_grid": 0, "place_block": 0, "place_row_words": 0, "place_slots_per_unit": 0, "place_fused": 1}
+    # ({"place_l3": 1}: the third level of the arg-max on a read set of one block; {"place_slots_per_unit": 65536}: regions that would need
+    # more than 2^32 slots give up BEFORE allocating — ADVICE round 4 — and the hash-map path takes over: the same lines)
+    defaults = {"place_mode": 2, "place_grid": 0, "place_block": 0, "place_row_words": 0, "place_slots_per_unit": 0, "place_fused": 1, "place_l3": 0}
     try:
         for k, v in knobs.items():
             engine.set_param(k, v)
@@ -221,6 +223,41 @@ def test_stage3_launch_shapes_and_region_restart(engine, report, golden, knobs):
     finally:
         for k, v in defaults.items():
             engine.set_param(k, v)
+
+
+def test_placement_third_level_of_the_argmax_on_several_groups(engine):
+    """cf_place2's third level (the best candidate per GROUP of 64-read blocks, kept lazily: groups touched by a tail go out of date and
+    are mended a few per tail) is used for read sets of more than 131 072 reads; here it is forced onto 150 reads = 3 blocks with groups
+    of 1 and 2 blocks, against the C placer line by line.  (GPU: 3 000 and 50 000 reads, tests/test_gpu_fullsize.py.)"""
+    from centroflye_amd import _host
+    from conftest import lines_from_placement
+    from oracle import cport
+    pk = _host.synth(seed=5, n_units=60, n_reads=150, var_len=8)
+    up, _, _, _ = pk.units(1)
+    engine.set_param("dist_block", 128); engine.set_param("dist_slots", 2048)
+    try:
+        engine.load(pk, 1)
+        engine.count_kmers(19); engine.select_rare(3, 10, 32); engine.build_clouds(); engine.reset_unique()
+        engine.dist_edges(0, 2 ** 62, 1, 2, 4, 0.8, 0, 1, 0)
+        gk = engine.kmers()[engine.unique_mask()]
+        assert gk.size > 3000
+        engine.set_kmers(gk, 19); engine.build_clouds(); engine.filter_clouds(2)
+        cp, ent = engine.clouds()
+        cls = pk.classify(50000)
+        rank = np.argsort(np.argsort(np.array(pk.ids, dtype=object), kind="stable"), kind="stable").astype(np.int32)
+        want = lines_from_placement(pk.ids, *[x.tolist() for x in cport.place_reads(cls, rank, up, cp, ent, gk.size, 2, 2, 10, 3)])
+        assert sum(1 for x in want if not x.endswith("None")) > 100
+        for knobs in ({"place_l3": 1, "place_l3_shift": 1}, {"place_l3": 1, "place_l3_shift": 1, "place_block": 256, "place_grid": 3}, {"place_l3": 1, "place_l3_shift": 2, "place_grid": 5}):
+            try:
+                for k, v in knobs.items():
+                    engine.set_param(k, v)
+                got = lines_from_placement(pk.ids, *[x.tolist() for x in engine.place_reads(cls, rank, 2, 2, 10, 3)])
+            finally:
+                for k in knobs:
+                    engine.set_param(k, 0)
+            assert got == want, knobs
+    finally:
+        engine.set_param("dist_block", 0); engine.set_param("dist_slots", 0)
 
 
 @pytest.mark.parametrize("mode", [2, 3, 1])

@@ -231,6 +231,13 @@ def test_config2_50k_reads_placement_vs_c_placer(engine):
     wl = lines_from_placement(pk.ids, *[x.tolist() for x in want])
     assert sum(1 for x in gl if not x.endswith("None")) > 45000
     assert gl == wl
+    # the same with the third level of the arg-max that read sets of more than 131 072 reads get: 782 blocks in 98 groups of 8
+    engine.set_param("place_l3", 1); engine.set_param("place_l3_shift", 3)
+    try:
+        again = engine.place_reads(cls, rank, 2, 2, 10, 3)
+    finally:
+        engine.set_param("place_l3", 0); engine.set_param("place_l3_shift", 0)
+    assert all(np.array_equal(a, b) for a, b in zip(again, got))
 
 
 @pytest.mark.timeout(900)
@@ -300,8 +307,12 @@ def test_placement_3k_reads_vs_c_placer(engine):
     # 256-thread workgroups (a 4-wave tail), 32-word posting rows (longer posting lists continue in the CSR arrays), regions that
     # start too small (the seed of a stage and then the whole run start over with larger ones) — and the round 1-3 path (hash
     # map + seen set: two kernels per iteration, three with an event list, other chunk / grid shapes): the same placement
-    defaults = {"place_mode": 2, "place_grid": 0, "place_block": 0, "place_row_words": 0, "place_slots_per_unit": 0, "place_fused": 1, "place_chunk": 2}
+    # round 5: the third level of the arg-max (groups of 64-read blocks, kept lazily; by itself only for more than 131 072 reads) forced
+    # onto these 47 blocks in groups of 4 and 2; regions that would need more than 2^32 slots (they give up before allocating and the
+    # hash-map path takes over)
+    defaults = {"place_mode": 2, "place_grid": 0, "place_block": 0, "place_row_words": 0, "place_slots_per_unit": 0, "place_fused": 1, "place_chunk": 2, "place_l3": 0, "place_l3_shift": 0}
     for knobs in ({"place_grid": 13, "place_block": 256}, {"place_row_words": 32, "place_grid": 7}, {"place_row_words": 64}, {"place_slots_per_unit": 2},
+                  {"place_l3": 1, "place_l3_shift": 2}, {"place_l3": 1, "place_l3_shift": 1, "place_block": 256, "place_grid": 13}, {"place_slots_per_unit": 1 << 16},
                   {"place_mode": 1}, {"place_mode": 1, "place_fused": 0}, {"place_mode": 1, "place_chunk": 7, "place_grid": 13},
                   {"place_mode": 1, "place_chunk": 64, "place_grid": 512}):
         try:
