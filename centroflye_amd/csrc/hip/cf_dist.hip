@@ -1192,11 +1192,10 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
 }
 
 #ifndef CF_DIST_PF_A
-#define CF_DIST_PF_A 2      /* loads in flight per lane in the sketch sweep (266.2 -> 263.0 ms against one) */
+#define CF_DIST_PF_A 1      /* loads in flight per lane while a step of the sketch sweep is worked on (round 5, with the pipeline that really keeps them in flight: 1 / 2 / 3 = 250.6 / 251.7 / 257.6 ms) */
 #endif
 #ifndef CF_DIST_PF_B
-#define CF_DIST_PF_B 2      /* ... and in the table sweep (its body holds the drain code: every copy costs 15 KB of instructions; two fit the
-                               registers since the filter writes the edge rows itself — 125 VGPRs, no spill: 322.4 -> 320.7 ms) */
+#define CF_DIST_PF_B 1      /* ... and of the table sweep (1 / 2 / 3 = 250.7 / 251.7 / 255.5 ms; both at 1: 250.1) */
 #endif
 
 // registers per lane: the default bound (1024 threads, one workgroup per CU) gives 128 = four waves per SIMD; diagnostic builds

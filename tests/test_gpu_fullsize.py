@@ -93,7 +93,7 @@ def test_config3_share_200k_reads_count_clouds_and_one_distance_partition_vs_com
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("what,kw,part,n_parts", [
     ("point substitutions (var_len 1), 50 000 reads", dict(reads=50000, seed=2, var_len=1, n_units=15000, synth={}), 5, 16),
-    ("long reads (> 128 units), 2^24+ rare k-mers", dict(reads=30000, seed=6, var_len=8, n_units=36000, synth=dict(mean_len=80000.0, max_len=400000)), 21, 256)])
+    ("long reads (> 128 units), 2^24+ rare k-mers", dict(reads=34000, seed=6, var_len=8, n_units=41000, synth=dict(mean_len=80000.0, max_len=400000)), 21, 256)])
 def test_other_workload_families_at_size_vs_cpu(what, kw, part, n_parts):
     """Round 4's at-size tests all used one generator family (var_len 8, reads of ~10 units).  Two more: SURVEY 8(d)'s LITERAL model —
     copy-specific variants are point substitutions as simulate_tandem_repeat.py:15-30 makes them, so few k-mers are copy-specific, the

@@ -3,12 +3,16 @@
 clouds or over the gathered view (cf_allgather_clouds through a one-rank communicator), with a small edge cap or with every selected
 edge stored — to tell apart what made the partition of profiles/r05_parity_500k_rank3.json take 1 368 ms where the emulated rank of
 round 4 (local clouds, 2^20 edges stored) took 186 ms.
-usage: tools/gview_probe.py [reads=500000] [part=3] [n_parts=8]"""
+With --shapes: the same partition (local clouds, 2^20 edges stored) in other launch shapes of cf_dist_kernel (workgroups per CU x threads):
+a rank of 8 at this size has 11 000 pair emissions per first k-mer, half of the single-GPU bench's.
+usage: tools/gview_probe.py [reads=500000] [part=3] [n_parts=8] [--shapes]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from centroflye_amd import _host
 from centroflye_amd.engine import Engine
+shapes = "--shapes" in sys.argv
+sys.argv = [a for a in sys.argv if a != "--shapes"]
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
 part = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 n_parts = int(sys.argv[3]) if len(sys.argv) > 3 else 8
@@ -33,6 +37,16 @@ def run(tag, cap):
 
 
 n = run("local clouds, 2^20 edges stored", 1 << 20)
+if shapes:
+    for wgs, block in ((2, 512), (3, 320), (4, 256), (2, 384), (1, 1024)):
+        e.set_param("dist_wgs", wgs); e.set_param("dist_block", block)
+        try:
+            run(f"local clouds, 2^20 edges stored, {wgs} workgroups of {block} threads per CU", 1 << 20)
+        except Exception as ex:      # a shape the LDS carve-up does not allow
+            print(json.dumps(dict(case=f"{wgs} x {block}", error=str(ex)[:200])), flush=True)
+    e.set_param("dist_wgs", 0); e.set_param("dist_block", 0)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "gview_probe_shapes.json"), "w"), indent=1)
+    e.close(); sys.exit(0)
 run("local clouds, every edge stored", n + 16)
 run("local clouds, 2^20 edges stored (again, after the large edge buffer)", 1 << 20)
 e.set_param("comm_self_p2p", 1)
