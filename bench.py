@@ -127,8 +127,8 @@ def cpu_baseline_weak(a):
         w = st.dist_part(part, n_parts, 0, 2 ** 62, PARAMS["min_d"], PARAMS["max_d"], PARAMS["min_cov"], PARAMS["rel_threshold"], threads=0)
         t_a13 = st.secs_count_select + st.secs_clouds + w["secs_postings"]
         t_all = t_a13 + n_parts * w["secs"]
-    return dict(value=pk.n_bases / t_all, unit="bases/s", cores=ncpu, kind="port", host_cpus=os.cpu_count(), extrapolated=True, scale_factor=n_parts,
-                emissions_per_s=w["n_emissions"] / w["secs"],
+    return dict(value=pk.n_bases / max(t_all, 1e-9), unit="bases/s", cores=ncpu, kind="port", host_cpus=os.cpu_count(), extrapolated=True, scale_factor=n_parts,
+                emissions_per_s=w["n_emissions"] / max(w["secs"], 1e-9),
                 sample=f"rank 0's host, the per-GPU workload of this weak-scaling line = the N = 1 configuration ({pk.n_reads} reads / {pk.n_bases} bases): A1-A3 whole "
                        f"({t_a13:.1f} s) + A5/A6 for the first k-mers a % {n_parts} == {part} ({w['n_emissions']} pair emissions, {w['secs']:.1f} s) x {n_parts}; "
                        f"oracle/c/cf_oracle_mt.c OpenMP, {ncpu} threads; compare with value / n_gpus")
@@ -501,13 +501,13 @@ def main():
             sr.load(pk, 1)       # (stage 3 installed the placer's k-mer set and clouds)
             sr.run(edge_cap=0, **PARAMS)
             res["cpu_baseline"] = cpu_baseline(a, pk, E)
-        elif not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline_weak(a)
         else:
             res["cpu_baseline"] = None
     wb = workload_b(a, sr, rank, world) if a.steps_b > 0 else None      # (every rank: its steps hold collectives)
     if rank == 0:
         res["workload_b"] = wb
+        if world > 1 and not a.no_cpu_baseline:      # (behind the last collective of the other ranks: they wait in the closing barrier)
+            res["cpu_baseline"] = cpu_baseline_weak(a)
         print(json.dumps(res), flush=True)
     sr.barrier()
     sr.close()

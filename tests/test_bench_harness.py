@@ -49,6 +49,19 @@ def test_spawns_its_own_ranks(emu_lib, tmp_path):
     assert res["exchange_bytes_per_step"] > 0
 
 
+def test_two_ranks_carry_a_cpu_baseline(emu_lib, tmp_path):
+    """N > 1 lines have a cpu_baseline too: rank 0 times the per-GPU workload of the weak-scaling line on its host
+    after the last collective; the other ranks wait in the closing barrier."""
+    args = [x for x in ARGS if x != "--no-cpu-baseline"] + ["--cpu-parts", "2"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, capture_output=True, text=True, timeout=600, cwd=tmp_path,
+                       env=dict(os.environ, OMP_NUM_THREADS="2"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    res = _line(p.stdout)
+    _check(res, 2)
+    cb = res["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["extrapolated"] and "N = 1 configuration" in cb["sample"]
+
+
 def test_under_torch_distributed_run(emu_lib, tmp_path):
     pytest.importorskip("torch")        # only the LAUNCHER is torch's; bench.py itself imports none of it
     with socket.socket() as s:
