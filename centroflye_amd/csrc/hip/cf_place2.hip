@@ -342,7 +342,9 @@ __device__ __forceinline__ void pl2_rescan_read(const cf_pl2& S, uint32_t r, uin
 // winner.  One workgroup.  A busy iteration dirties a thousand reads scattered over the read numbers: they are packed into
 // a dense list so that every lane of the workgroup has one (rescans by blocks of 8 left most lanes of a pass without work
 // and needed eight passes).
-__device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
+// out_idx: the line of the output this tail's winner gets = the number of reads this stage has placed so far, which the HOST knows (one
+// per launch): it comes as a kernel argument — round 4 kept it in memory and the lane that publishes the winner paid a dependent load for it
+__device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, unsigned long long t_last = 0ull) {
     (void)t_last;
 #ifdef CF_PL2_STAMPS2
     const bool ttr = S.C.ctl[1] == S.trace_iter && (threadIdx.x & 63) == 0;
@@ -521,7 +523,8 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
                 red[at] = mine.hi; red[at + 1] = mine.lo; red[at + 2] = mine.ext; red[at + 3] = mine.read;
             }
             PL2_TTRACE(5);
-            __syncthreads();
+            cf_barrier_lds();      // (what the last wave reads — the sweeping lanes' bests, the touched blocks' new records — is in LDS: the stores of the
+                                   // new block records to memory need not have been acknowledged; round 4 waited for them here, in every tail)
             PL2_TTRACE(6);
             PL2_STAMP(6);
             if (wave == 0) {      // the sweeping lanes' results and the touched blocks' new records
@@ -529,12 +532,23 @@ __device__ void pl2_tail(const cf_pl2& S, unsigned long long t_last = 0ull) {
                 for (int k = 0; k < nfw; ++k) { const uint32_t at = 4u * (uint32_t)(k * 64 + lane); pl2_take(w, cf_pl2_rec{red[at], red[at + 1], red[at + 2], (uint32_t)red[at + 3], 0u}); }
                 if (fused)
                     for (uint32_t k = (uint32_t)lane; k < m; k += 64u) pl2_take(w, cf_pl2_rec{cres[4 * k], cres[4 * k + 1], cres[4 * k + 2], (uint32_t)cres[4 * k + 3], 0u});
-                for (int d = 1; d <= 32; d <<= 1) pl2_take(w, pl2_shfl_xor(w, d));
+                {   // 64 lanes -> 1: the KEY (hi, lo) goes through the butterfly (4 dwords per step instead of 7), the payload comes from the lane that holds it
+                    unsigned long long khi = w.hi, klo = w.lo;
+                    for (int d = 1; d <= 32; d <<= 1) {
+                        const unsigned long long ohi = __shfl_xor(khi, d), olo = __shfl_xor(klo, d);
+                        const bool bt = ohi > khi || (ohi == khi && olo > klo);
+                        khi = bt ? ohi : khi; klo = bt ? olo : klo;
+                    }
+                    const unsigned long long mine_m = __ballot(w.hi == khi && w.lo == klo);      // (equal keys are equal candidates: lo holds the read's id rank; all-empty: every lane)
+                    const int src = __ffsll((long long)mine_m) - 1;
+                    w.ext = __shfl(w.ext, src); w.read = (uint32_t)__shfl((int)w.read, src); w.hi = khi; w.lo = klo;
+                }
                 if (lane == 0) {
                     pl2_store(S.win, w);
                     if (!w.hi) S.C.ctl[0] = 1u;
                     else {
-                        const unsigned int o = S.C.ctl[1]++;
+                        const unsigned int o = out_idx;
+                        S.C.ctl[1] = o + 1u;      // (the host reads the number of placements from here)
                         S.C.out_read[o] = (int64_t)w.read; S.C.out_pos[o] = (int64_t)(w.lo >> 32);
                         S.C.out_s0[o] = (int32_t)((w.hi - 1ull) >> 32); S.C.out_s1[o] = (int32_t)(uint32_t)(w.hi - 1ull);
                         S.C.used[w.read] = 1;
@@ -555,9 +569,9 @@ static size_t pl2_lds_bytes(uint32_t n2) { return (16 + (size_t)PL2_LIST * 8 + 1
 __global__ void __launch_bounds__(PL2_B)
 cf_pl2_tail_kernel(cf_pl2 S) {
 #ifdef CF_PL2_STAMPS
-    pl2_tail(S, wall_clock64());
+    pl2_tail(S, 0u, wall_clock64());
 #else
-    pl2_tail(S);
+    pl2_tail(S, 0u);
 #endif
 }
 
@@ -565,7 +579,7 @@ cf_pl2_tail_kernel(cf_pl2 S) {
 // PW = 32-bit words of a posting row (32 or 64: the smallest that holds the longest posting list; longer lists continue in the CSR arrays)
 template <int PW>
 __global__ void __launch_bounds__(PL2_B)
-cf_pl2_iter_kernel(cf_pl2 S) {
+cf_pl2_iter_kernel(cf_pl2 S, uint32_t it /* greedy iteration of the stage, 0-based: its winner was published as line `it` */) {
 #ifdef CF_PL2_STAMPS
     unsigned long long t_last = wall_clock64();
 #endif
@@ -641,9 +655,9 @@ cf_pl2_iter_kernel(cf_pl2 S) {
 #ifdef CF_PL2_STAMPS
     if (threadIdx.x == 0) { atomicAdd(&S.stamps[1], t_loop - t_last); atomicAdd(&S.stamps[8], t_win - t_last); atomicAdd(&S.stamps[9], t_body - t_win); atomicAdd(&S.stamps[10], t_loop - t_body); t_last = t_loop; atomicAdd(&S.stamps[0], 1ull); }
     PL2_STAMP(2);
-    pl2_tail(S, t_last);
+    pl2_tail(S, it + 1u, t_last);
 #else
-    pl2_tail(S);
+    pl2_tail(S, it + 1u);
 #endif
 }
 
@@ -911,8 +925,8 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
         CF_KERNEL_CHECK("cf_pl2_tail_kernel");
         const int64_t n_iter = (int64_t)stage_reads.size();
         for (int64_t it = 0; it < n_iter; ++it) {
-            if (pw == 32) hipLaunchKernelGGL(cf_pl2_iter_kernel<32>, dim3((unsigned)grid), dim3((unsigned)block), lds, st, S);
-            else hipLaunchKernelGGL(cf_pl2_iter_kernel<64>, dim3((unsigned)grid), dim3((unsigned)block), lds, st, S);
+            if (pw == 32) hipLaunchKernelGGL(cf_pl2_iter_kernel<32>, dim3((unsigned)grid), dim3((unsigned)block), lds, st, S, (uint32_t)it);
+            else hipLaunchKernelGGL(cf_pl2_iter_kernel<64>, dim3((unsigned)grid), dim3((unsigned)block), lds, st, S, (uint32_t)it);
             if ((it & 511) == 511 || it + 1 == n_iter) {
                 CF_KERNEL_CHECK("placement iteration");
                 CF_HIP(hipMemcpyAsync(h_ctl, S.C.ctl, 16, hipMemcpyDeviceToHost, st));
