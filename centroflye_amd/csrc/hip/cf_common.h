@@ -162,7 +162,7 @@ struct cf_ctx {
     int place_block = 0;         // cf_place2: threads per workgroup of the iteration kernel (128 .. 1024, a multiple of 128; 0 = 1024)
     int place_row_words = 0;     // cf_place2: 32-bit words of a posting row (32 or 64); 0 = the smaller one that holds the longest posting list
     int place_slots_per_unit = 0; // cf_place2: score-region slots per unit of a read (0 = 48); doubled-up automatically when a region fills
-    int place_l3 = 0;            // cf_place2: third level of the arg-max (best candidate per group of 64-read blocks): 0 = for read sets of more than 2 048 blocks, 1 = always, 2 = never
+    int place_l3 = 0;            // cf_place2: third level of the arg-max (best candidate per group of 64-read blocks): 1 = on; 0 / 2 = off (measured: no gain at 500 000 reads)
     int place_l3_shift = 0;      // cf_place2: log2 of the blocks per group (0 = 6: groups of 64 blocks = 4 096 reads; tests use small groups at small read sets)
     int count_mode = 1;          // 1: sort and reduce (cf_count2.hip) when it applies; 0: the atomic table of round 1 (cf_count.hip)
     int count_bits = 0;          // bucket bits of the sort-and-reduce path; 0 = from the number of windows (tests force small / large values)
