@@ -227,27 +227,27 @@ def test_stage3_launch_shapes_and_region_restart(engine, report, golden, knobs):
 
 def test_placement_third_level_of_the_argmax_on_several_groups(engine):
     """cf_place2's third level (the best candidate per GROUP of 64-read blocks, kept lazily: groups touched by a tail go out of date and
-    are mended a few per tail) is used for read sets of more than 131 072 reads; here it is forced onto 150 reads = 3 blocks with groups
-    of 1 and 2 blocks, against the C placer line by line.  (GPU: 3 000 and 50 000 reads, tests/test_gpu_fullsize.py.)"""
+    are mended a few per tail; off by default: measured neutral at 500 000 reads) forced onto 130 reads = 3 blocks with groups of 1 and
+    2 blocks, against the C placer line by line.  (GPU: 3 000 and 50 000 reads, tests/test_gpu_fullsize.py.)"""
     from centroflye_amd import _host
     from conftest import lines_from_placement
     from oracle import cport
-    pk = _host.synth(seed=5, n_units=60, n_reads=150, var_len=8)
+    pk = _host.synth(seed=5, n_units=52, n_reads=130, var_len=8)
     up, _, _, _ = pk.units(1)
     engine.set_param("dist_block", 128); engine.set_param("dist_slots", 2048)
     try:
+        us, ue = pk.units(1)[1], pk.units(1)[2]
+        _, a = cport.stage2(pk.bases, pk.read_off, up, us, ue, 19, 3, 10, 32, 0, 2 ** 62, 1, 2, 4, 0.8, want_arrays=True)      # (stage 2 by the C oracle: the
+        gk = a["rare"][a["unique"]]                                                                                      # emulated count + dist kernels take a minute here)
+        assert gk.size > 2000
         engine.load(pk, 1)
-        engine.count_kmers(19); engine.select_rare(3, 10, 32); engine.build_clouds(); engine.reset_unique()
-        engine.dist_edges(0, 2 ** 62, 1, 2, 4, 0.8, 0, 1, 0)
-        gk = engine.kmers()[engine.unique_mask()]
-        assert gk.size > 3000
         engine.set_kmers(gk, 19); engine.build_clouds(); engine.filter_clouds(2)
         cp, ent = engine.clouds()
         cls = pk.classify(50000)
         rank = np.argsort(np.argsort(np.array(pk.ids, dtype=object), kind="stable"), kind="stable").astype(np.int32)
         want = lines_from_placement(pk.ids, *[x.tolist() for x in cport.place_reads(cls, rank, up, cp, ent, gk.size, 2, 2, 10, 3)])
-        assert sum(1 for x in want if not x.endswith("None")) > 100
-        for knobs in ({"place_l3": 1, "place_l3_shift": 1}, {"place_l3": 1, "place_l3_shift": 1, "place_block": 256, "place_grid": 3}, {"place_l3": 1, "place_l3_shift": 2, "place_grid": 5}):
+        assert sum(1 for x in want if not x.endswith("None")) > 90
+        for knobs in ({"place_l3": 1, "place_l3_shift": 1, "place_block": 256, "place_grid": 3}, {"place_l3": 1, "place_l3_shift": 2, "place_grid": 5}):
             try:
                 for k, v in knobs.items():
                     engine.set_param(k, v)
