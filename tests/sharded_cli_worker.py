@@ -11,6 +11,11 @@ from centroflye_amd import _lib, sharded_cli  # noqa: E402
 
 if __name__ == "__main__":
     lib = _lib.load(os.path.join(ROOT, "tests", "emu", "libcfhip_emu.so"))
-    os.makedirs(os.environ["CF_COMM_ID_FILE"], exist_ok=True)
+    # the emulator's file transport wants a DIRECTORY as the rendezvous: the launcher's file name (sharded_cli.launch) or, under a
+    # launcher that only exports RANK / WORLD_SIZE (torch.distributed.run), the name the ranks derive from their common parent
+    from centroflye_amd.sharded import default_rendezvous
+    rdv = default_rendezvous()
+    os.environ["CF_COMM_ID_FILE"] = rdv
+    os.makedirs(rdv, exist_ok=True)
     sys.exit(sharded_cli.rank_main(sys.argv[1:], lib=lib, device=0, sub_edges=int(os.environ.get("CF_TEST_SUB_EDGES", "0")) or None,
                                    knobs={"dist_slots": 2048, "dist_block": 128}))

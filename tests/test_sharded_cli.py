@@ -95,6 +95,30 @@ def test_cf_gpus_2_reproduces_the_reference_files_with_rare_N_kmers_on_emulated_
     assert len(elines) == g["edges"]["n"] and canon.edge_lines_digest(elines) == g["edges"]["digest"]
 
 
+def test_ranks_of_a_launcher_write_the_same_files(emu_lib, report, oracle_stage2, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 <stage script> ...`: the ranks find RANK / WORLD_SIZE / LOCAL_RANK in their
+    environment (no CF_GPUS parent, no pack cache: every rank parses the report itself) and derive the rendezvous from their common
+    parent; torch is only the launcher."""
+    pytest.importorskip("torch")
+    import socket
+    name = "lowcov"
+    p2 = fixtures.stage2_params(name)
+    p2["max_distance"] = 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           WORKER[1]] + _argv(report(name), str(tmp_path), p2)
+    env = {k: v for k, v in os.environ.items() if k not in ("CF_PACK_CACHE", "CF_COMM_ID_FILE", "CF_COMM_NONCE", "CF_GPUS")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, OMP_NUM_THREADS="1"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    records, alns, lens, res, _ = oracle_stage2(name, max_distance=2)
+    with open(tmp_path / f"unique_kmers_min_edge_cov_{p2['min_coverage']}.txt") as f:
+        assert f.read() == recruit.kmers_file_text(res["rare"], res["unique"], p2["k"])
+    with open(tmp_path / f"unique_edges_min_edge_cov_{p2['min_coverage']}.txt") as f:
+        assert sorted(f.read().splitlines()) == recruit.edges_file_lines(res["rare"], res["edges"], p2["k"])
+
+
 def test_cf_gpus_no_edges_and_a_dead_rank(emu_lib, report, tmp_path, monkeypatch):
     name = "lowcov"
     p2 = fixtures.stage2_params(name)
