@@ -18,7 +18,7 @@ for v in names:
     log = os.path.join(src, v + ".log")
     if os.path.exists(log):
         for ln in open(log):
-            m = re.search(r"\[([\d.]+), ([\d.]+)\]", ln)
+            m = re.search(r"\[([\d.]+), ([\d.]+)", ln)
             if m:
                 ms = float(m.group(2))
     c = {}
@@ -31,7 +31,7 @@ for v in names:
         rows[v] = dict(ms=ms, **{k: sum(x) / len(x) for k, x in c.items()})      # mean over the launches (two per run)
 if "full" not in rows:
     sys.exit("no counters under gpurun_out/abl")
-out = ["# cf_dist_kernel: instructions and time per phase, by ablation (round 4)", "",
+out = ["# cf_dist_kernel: instructions and time per phase, by ablation", "",
        "`tools/dist_ablation.sh` on an MI355X: `rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT` of",
        "`tools/dist_ab.py 50000 <library>` for the shipped library and for builds with `-DCF_DIST_ABL=n` (cf_dist.hip), which remove the kernel's phases from",
        "the END: what runs before the cut is unchanged, so successive builds differ by one phase.  Kernel ms are the tool's HIP-event times WITHOUT the",
