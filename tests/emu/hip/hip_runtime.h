@@ -83,7 +83,13 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->clockRate = 1000000;
     return hipSuccess;
 }
-inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *tot = (size_t)64 << 30; *fr = *tot - cfemu::g_bytes_live; return hipSuccess; }
+// (CFEMU_TOTAL_MB: the size of the emulated device, for tests of the "would not fit" paths; read at every call)
+inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) {
+    const char* mb = std::getenv("CFEMU_TOTAL_MB");
+    *tot = mb && *mb ? (size_t)std::strtoull(mb, nullptr, 10) << 20 : (size_t)64 << 30;
+    *fr = *tot > cfemu::g_bytes_live ? *tot - cfemu::g_bytes_live : 0;
+    return hipSuccess;
+}
 inline hipError_t hipMalloc(void** p, size_t n) { *p = cfemu::dev_alloc(n); return (*p || !n) ? hipSuccess : hipErrorOutOfMemory; }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 inline hipError_t hipFree(void* p) { cfemu::dev_free(p); return hipSuccess; }

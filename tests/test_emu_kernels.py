@@ -216,11 +216,21 @@ def test_stage3_launch_shapes_and_region_restart(engine, report, golden, knobs):
     # ({"place_l3": 1}: the third level of the arg-max on a read set of one block; {"place_slots_per_unit": 65536}: regions that would need
     # more than 2^32 slots give up BEFORE allocating — ADVICE round 4 — and the hash-map path takes over: the same lines)
     defaults = {"place_mode": 2, "place_grid": 0, "place_block": 0, "place_row_words": 0, "place_slots_per_unit": 0, "place_fused": 1, "place_l3": 0}
+    # (the emulated device is made small for that case — 65 536 slots per unit of this fixture's few reads are 1 GB, which a 64 GB device
+    # takes: 46 s of clearing on the host — and place_mode 3, which never falls back, must say why it gives up)
+    small_device = knobs.get("place_slots_per_unit") == 1 << 16
     try:
+        if small_device:
+            os.environ["CFEMU_TOTAL_MB"] = "256"
+            engine.set_param("place_mode", 3); engine.set_param("place_slots_per_unit", 1 << 16)
+            with pytest.raises(DeviceError, match="more than the device has free"):
+                pathcheck.check_stage3(engine, pk, records, alns, lens, gk, g["stage3"], expect_lines=g["read_positions"])
+            engine.set_param("place_mode", 2)
         for k, v in knobs.items():
             engine.set_param(k, v)
         pathcheck.check_stage3(engine, pk, records, alns, lens, gk, g["stage3"], expect_lines=g["read_positions"])
     finally:
+        os.environ.pop("CFEMU_TOTAL_MB", None)
         for k, v in defaults.items():
             engine.set_param(k, v)
 

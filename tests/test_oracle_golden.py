@@ -55,7 +55,14 @@ def test_G1_to_G5_stage2(name, oracle_stage2, golden):
     assert res["counters"]["E"] == g["hist"]["E"] and len(a) == g["hist"]["n_keys"]
     if name == "lowcov":   # the full (a, b, d, cnt) histogram, 2.4e7 keys: one fixture keeps the CPU suite short;
         # for the others E, the key count and every selected edge (below) pin the same histogram
-        assert canon.hist_digest((rare_s[x], rare_s[y], int(z), int(w)) for x, y, z, w in zip(a, b, d, cnt)) == g["hist"]["digest"]
+        # (built from the 2-bit codes with numpy — canon.hist_digest_codes; the generic string form on a slice of it below)
+        # (one sort by a packed (a, b, d) key — the rare list is ascending, so index order is string order — instead of a four-key lexsort)
+        o = np.argsort((a.astype(np.uint64) << np.uint64(40)) | (b.astype(np.uint64) << np.uint64(16)) | d.astype(np.uint64), kind="stable")
+        assert len(rare_s) < 1 << 24 and int(d.max()) < 1 << 16
+        assert canon.hist_digest_codes(res["rare"][a[o]], res["rare"][b[o]], d[o], cnt[o], k, presorted=True) == g["hist"]["digest"]
+        sl = slice(0, 50000)
+        assert canon.hist_digest((rare_s[x], rare_s[y], int(z), int(w)) for x, y, z, w in zip(a[sl], b[sl], d[sl], cnt[sl])) == \
+            canon.hist_digest_codes(res["rare"][a[sl]], res["rare"][b[sl]], d[sl], cnt[sl], k)
     assert res["edges"].shape[0] == g["edges"]["n"]
     assert canon.edge_lines_digest(recruit.edges_file_lines(res["rare"], res["edges"], k)) == g["edges"]["digest"]
     text = recruit.kmers_file_text(res["rare"], res["unique"], k)
