@@ -545,6 +545,9 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "place_l3_shift") {
         if (value < 0 || value > 6) return cf_fail(ctx, -22, "place_l3_shift must be 0 (= 6) .. 6");
         ctx->place_l3_shift = (int)value;
+    } else if (n == "place_cmap_bits") {
+        if (value < 0 || value > 30) return cf_fail(ctx, -22, "place_cmap_bits out of range (0 = default, 1 .. 30)");
+        ctx->place_cmap_bits = (int)value;
     } else if (n == "place_slots_per_unit") {
         if (value < 0 || value > 65536) return cf_fail(ctx, -22, "place_slots_per_unit out of range (0 = default, 1 .. 65536)");
         ctx->place_slots_per_unit = (int)value;

@@ -41,7 +41,7 @@ struct cf_place_state {
     unsigned long long* seen; uint64_t seen_mask;
     // events (kmer << 32 | pos)
     unsigned long long* events; unsigned long long* n_events;  // n_events[0] = count
-    // control: [0] done, [1] n_out, [2] error flags, [3] thr
+    // control: [0] done, [1] n_out, [2] error flags (1: the contig's map is full, 2: a score region / the score map, 4: ...), [3] thr, [4] score-map entries, [5] contig-map entries
     unsigned int* ctl;
     const uint8_t* used_in; uint8_t* used;
     const int32_t* id_rank;
@@ -52,13 +52,21 @@ struct cf_place_state {
     uint32_t thr, min_unit, min_inters, min_prop;
 };
 
+// The contig's (k-mer, position) map is open-addressed.  Round 5 (tools/fuzz_place.py: 500 reads placed in 183 s): a map that had
+// filled up was noticed only by an add that had probed EVERY slot — 131 072 compare-and-swaps per add, for up to 512 greedy iterations
+// until the host looked at the flag.  Now the claims are counted ([5] of the control words; the map lives as long as the contig, so the
+// count is never reset) and the flag goes up at half load, and no add probes more than CF_CONTIG_PROBES slots (at half load the longest
+// run of an open-addressed table of 10^9 slots is about a hundred).
+#define CF_CONTIG_PROBES 512
+
 // ---- add one read at a position: thread-block grid over units of the read
 __device__ __forceinline__ void cf_contig_add(const cf_place_state& S, uint32_t x, uint32_t q) {
     const unsigned long long want = (((unsigned long long)q << 32) | x) | CF_OCC;
     uint64_t h = cf_mix64(want) & S.cmask;
-    for (uint64_t probe = 0; probe <= S.cmask; ++probe) {
+    for (uint64_t probe = 0; probe <= min(S.cmask, (uint64_t)CF_CONTIG_PROBES); ++probe) {
         const unsigned long long cur = atomicCAS(&S.ckeys[h], 0ull, want);      // (the claim IS the look: one round trip, not load + claim)
         if (cur == 0ull || cur == want) {
+            if (cur == 0ull && atomicAdd(&S.ctl[5], 1u) > (unsigned int)(S.cmask >> 1)) atomicOr(&S.ctl[2], 1u);      // load > 0.5: the host starts over with a larger map
             const uint32_t c = atomicAdd(&S.ccnt[h], 1u) + 1u;
             if (c == S.thr) {
                 S.freq_flag[x] = 1;
@@ -76,9 +84,10 @@ __device__ __forceinline__ void cf_contig_add(const cf_place_state& S, uint32_t 
 __device__ __forceinline__ bool cf_contig_add_hit(const cf_place_state& S, uint32_t x, uint32_t q) {
     const unsigned long long want = (((unsigned long long)q << 32) | x) | CF_OCC;
     uint64_t h = cf_mix64(want) & S.cmask;
-    for (uint64_t probe = 0; probe <= S.cmask; ++probe) {
+    for (uint64_t probe = 0; probe <= min(S.cmask, (uint64_t)CF_CONTIG_PROBES); ++probe) {
         const unsigned long long cur = atomicCAS(&S.ckeys[h], 0ull, want);
         if (cur == 0ull || cur == want) {
+            if (cur == 0ull && atomicAdd(&S.ctl[5], 1u) > (unsigned int)(S.cmask >> 1)) atomicOr(&S.ctl[2], 1u);
             const uint32_t c = atomicAdd(&S.ccnt[h], 1u) + 1u;
             if (c == S.thr) { S.freq_flag[x] = 1; return true; }
             return false;

@@ -752,7 +752,7 @@ cf_pl2_seed_kernel(cf_pl2 S, int64_t n_kmers) {
 
 // One attempt with regions of `slots_per_unit` x units slots per read; returns 1 when a region or the contig map overflowed.
 static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int32_t min_freq, int32_t min_unit, int32_t min_inters, int32_t min_prop,
-                       int slots_per_unit, std::vector<int64_t>& o_read, std::vector<int64_t>& o_pos, std::vector<int32_t>& o_s0, std::vector<int32_t>& o_s1) {
+                       int slots_per_unit, int cmap_grow, std::vector<int64_t>& o_read, std::vector<int64_t>& o_pos, std::vector<int32_t>& o_s0, std::vector<int32_t>& o_s1) {
     const int64_t R = ctx->n_reads, N = ctx->n_entries, K = ctx->n_kmers;
     const std::vector<int64_t>& up = ctx->h_unit_ptr;
     Bufs B{ctx, {}};
@@ -767,7 +767,14 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
     S.ib = 1; while ((1ll << S.ib) < max_u) ++S.ib;
     uint2* d_ent = nullptr; int64_t* d_read_e = nullptr; uint8_t* d_cls = nullptr; uint32_t* d_pcnt = nullptr; int64_t* d_post_ptr = nullptr;
     unsigned long long* d_post = nullptr; uint32_t* d_prow = nullptr; int32_t* d_rank = nullptr;
-    const uint64_t ccap = cf_pow2_ceil((uint64_t)std::max<int64_t>(N / 8, 1 << 16));      // only the fifth and later positions of a k-mer land here
+    // only the fifth and later positions of a k-mer land here; `cmap_grow`: times four per attempt that filled it (k-mers that are NOT
+    // unique to one place of the array — small read sets, thin coverage — have many positions)
+    const uint64_t ccap = (ctx->place_cmap_bits > 0 ? 1ull << ctx->place_cmap_bits : cf_pow2_ceil((uint64_t)std::max<int64_t>(N / 8, 1 << 16))) << (2 * cmap_grow);
+    {
+        size_t free_b = 0, total_b = 0;
+        if (ccap >= (1ull << 33) || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ccap * 12ull > (unsigned long long)free_b + (unsigned long long)ctx->pooled))
+            return cf_fail(ctx, -34, "cf_place_reads: the contig's overflow map would not fit the device");
+    }
     CF_TRY(B.get(&d_ent, (size_t)N + 1, "entry records"));
     CF_TRY(B.get(&d_read_e, (size_t)R + 2, "read entry offsets"));
     CF_TRY(B.get(&d_cls, (size_t)R + 1, "classes"));
@@ -921,7 +928,7 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
             CF_HIP(hipMemcpyAsync(h_ctl, S.C.ctl, 16, hipMemcpyDeviceToHost, st));
             CF_HIP(hipStreamSynchronize(st));
             if (std::getenv("CF_DEBUG")) std::fprintf(stderr, "[cf_place2] stage %d: %lld reads, %llu slots, %llu cells, %d slots per unit, flags after the seed %u\n", stage_cls, (long long)stage_reads.size(), n_slots, n_cells, spu, h_ctl[2]);
-            if (h_ctl[2] & 1u) return 1;
+            if (h_ctl[2] & 1u) return 2;      // the contig's overflow map: another attempt with a larger one
             if (!(h_ctl[2] & 2u)) break;
             CF_HIP(hipMemsetAsync(S.C.ctl + 2, 0, 4, st));
         }
@@ -936,7 +943,7 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
                 CF_HIP(hipMemcpyAsync(h_ctl, S.C.ctl, 16, hipMemcpyDeviceToHost, st));
                 CF_HIP(hipStreamSynchronize(st));
                 if (std::getenv("CF_DEBUG") && ((it & 8191) == 8191 || h_ctl[2] || h_ctl[0])) std::fprintf(stderr, "[cf_place2] stage %d iter %lld/%lld ctl=%u,%u,%u\n", stage_cls, (long long)it, (long long)n_iter, h_ctl[0], h_ctl[1], h_ctl[2]);
-                if (h_ctl[2]) return 1;
+                if (h_ctl[2]) return (h_ctl[2] & 1u) ? 2 : 1;
                 if (h_ctl[0]) break;
             }
         }
@@ -1000,7 +1007,7 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
                                    h_st[14], (double)h_st[11] / 100.0 / (double)h_st[14], (double)h_st[12] / 100.0 / (double)h_st[14], (double)h_st[13] / 100.0 / (double)h_st[14]);
     }
 #endif
-    if (h_ctl[2]) return 1;
+    if (h_ctl[2]) return (h_ctl[2] & 1u) ? 2 : 1;
     return 0;
 }
 
@@ -1019,13 +1026,16 @@ bool cf_place2_fits(const cf_ctx* ctx) {
 
 int cf_place2_run(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, int32_t min_freq, int32_t min_unit, int32_t min_inters, int32_t min_prop,
                   std::vector<int64_t>& o_read, std::vector<int64_t>& o_pos, std::vector<int32_t>& o_s0, std::vector<int32_t>& o_s1) {
+    // an attempt ends with 1 when a score region filled up (the next one gets four times the slots per unit) and with 2 when the contig's
+    // overflow map did (round 5: that flag used to enlarge the REGIONS, six times over, and then give the run to the hash-map path)
     int spu = ctx->place_slots_per_unit > 0 ? ctx->place_slots_per_unit : 48;
-    int rc = 1;
-    for (int attempt = 0; attempt < 6 && rc == 1; ++attempt) {
-        rc = pl2_attempt(ctx, cls, id_rank, min_freq, min_unit, min_inters, min_prop, spu, o_read, o_pos, o_s0, o_s1);
-        if (std::getenv("CF_DEBUG")) std::fprintf(stderr, "[cf_place2] attempt %d rc=%d slots per unit %d\n", attempt, rc, spu);
+    int rc = 1, cmap_grow = 0;
+    for (int attempt = 0; attempt < 8 && (rc == 1 || rc == 2); ++attempt) {
+        rc = pl2_attempt(ctx, cls, id_rank, min_freq, min_unit, min_inters, min_prop, spu, cmap_grow, o_read, o_pos, o_s0, o_s1);
+        if (std::getenv("CF_DEBUG")) std::fprintf(stderr, "[cf_place2] attempt %d rc=%d slots per unit %d, contig map x 4^%d\n", attempt, rc, spu, cmap_grow);
         if (rc == 1) spu *= 4;
+        if (rc == 2) ++cmap_grow;
     }
-    if (rc == 1) return cf_fail(ctx, -34, "cf_place_reads: score regions kept overflowing");
+    if (rc == 1 || rc == 2) return cf_fail(ctx, -34, rc == 1 ? "cf_place_reads: score regions kept overflowing" : "cf_place_reads: the contig's overflow map kept overflowing");
     return rc;
 }

@@ -200,7 +200,8 @@ def test_stage3_against_reference_golden(engine, report, golden):
 
 
 @pytest.mark.parametrize("knobs", [{"place_grid": 3, "place_block": 256}, {"place_row_words": 64, "place_grid": 1}, {"place_slots_per_unit": 1},
-                                   {"place_mode": 1}, {"place_mode": 1, "place_fused": 0}, {"place_l3": 1}, {"place_slots_per_unit": 1 << 16}])
+                                   {"place_mode": 1}, {"place_mode": 1, "place_fused": 0}, {"place_l3": 1}, {"place_slots_per_unit": 1 << 16},
+                                   {"place_cmap_bits": 3}, {"place_cmap_bits": 5, "place_slots_per_unit": 1, "place_grid": 2}])
 def test_stage3_launch_shapes_and_region_restart(engine, report, golden, knobs):
     """The greedy placement in other shapes of the round-4 path (cf_place2.hip: odd grids, 4-wave tails, wide posting rows,
     score regions that start too small: the seed of a stage, then the whole run, start over with larger ones) and on the round
@@ -215,7 +216,9 @@ def test_stage3_launch_shapes_and_region_restart(engine, report, golden, knobs):
     pk = _host.parse_report(report(name))
     # ({"place_l3": 1}: the third level of the arg-max on a read set of one block; {"place_slots_per_unit": 65536}: regions that would need
     # more than 2^32 slots give up BEFORE allocating — ADVICE round 4 — and the hash-map path takes over: the same lines)
-    defaults = {"place_mode": 2, "place_grid": 0, "place_block": 0, "place_row_words": 0, "place_slots_per_unit": 0, "place_fused": 1, "place_l3": 0}
+    # ({"place_cmap_bits": 3}: the contig's overflow map starts with 8 slots and has to grow — round 5: a full map used to enlarge the score
+    # regions instead, probing every slot at every add meanwhile; with regions that start too small on top, both kinds of restart in one run)
+    defaults = {"place_mode": 2, "place_grid": 0, "place_block": 0, "place_row_words": 0, "place_slots_per_unit": 0, "place_fused": 1, "place_l3": 0, "place_cmap_bits": 0}
     # (the emulated device is made small for that case — 65 536 slots per unit of this fixture's few reads are 1 GB, which a 64 GB device
     # takes: 46 s of clearing on the host — and place_mode 3, which never falls back, must say why it gives up)
     small_device = knobs.get("place_slots_per_unit") == 1 << 16
