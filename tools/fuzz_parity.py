@@ -91,13 +91,14 @@ with Engine(0, lib) as e:
                 e.set_param(kk, vv)
             r = bigparity.check(e, pk, part=part, n_parts=n_parts)
             rec.update(identical=bool(r["identical"]), checks=r["checks"], n_rare=r["n_rare"], n_emissions=r["n_emissions_partition"], n_edges=r["n_edges_partition"],
-                       passes=r["n_dist_passes"], n_bases=r["n_bases"])
+                       passes=r["n_dist_passes"], n_bases=r["n_bases"], dist_kernel_ms=r["dist_kernel_ms"], oracle_s=round(r["oracle_A1_A3_s"] + r["oracle_partition_s"], 1),
+                       device_ms={k: round(float(v), 1) for k, v in e.times().items() if k.endswith("_ms") and v})
         except DeviceError as ex:
             refused = "(-22)" in str(ex) or "(-12)" in str(ex)      # (a knob combination the library does not take; a case too large for the device)
             rec.update(identical=None if refused else False, refused=str(ex)[:200])
         rec["s"] = round(time.time() - t0, 2)
         recs.append(rec)
-        print(json.dumps({k: rec.get(k) for k in ("case", "identical", "refused", "params", "partition", "knobs", "n_rare", "n_emissions", "n_edges", "passes", "s")}), flush=True)
+        print(json.dumps({k: rec.get(k) for k in ("case", "identical", "refused", "params", "partition", "knobs", "n_rare", "n_emissions", "n_edges", "passes", "dist_kernel_ms", "oracle_s", "s")}), flush=True)
         if rec["identical"] is False:
             print("DIFFERENCE:", json.dumps(rec), flush=True)
 bad = [r for r in recs if r["identical"] is False]
