@@ -5,9 +5,10 @@ coverage, read lengths, error rates, divergence, variant model), the script's pa
 device knobs that force the rarely taken paths (small tables: partition splits and overflow lists; other workgroup shapes; no sketch;
 the wide / region layouts; a small hot list; the atomic posting and counting paths), and compares the device with the OpenMP oracle
 through tests/bigparity.check: counters, A1 table checksum, rare set, clouds, the partition's emissions / edges / edge checksum /
-unique bits.  A knob combination the library refuses (-22) is recorded as refused; any difference is a failure.
+unique bits.  A quarter of the partitioned cases go the way one RANK of n_parts goes (bigparity.check_record, through_exchange: shard
+count, table exchange, gathers and the gathered view through a one-rank communicator that sends to itself, in rounds of a few KB).  A knob combination the library refuses (-22) is recorded as refused; any difference is a failure.
 usage: tools/fuzz_parity.py [cases] [--seed S] [--seconds T] [--out gpurun_out/fuzz_parity.json]"""
-import json, os, sys, time
+import json, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -24,10 +25,11 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1
 seed = arg("--seed", 1)
 budget = arg("--seconds", 10 ** 9, float)
 out = arg("--out", os.path.join(ROOT, "gpurun_out", "fuzz_parity.json"), str)
+only = arg("--only", -1)
 rng = np.random.default_rng(seed)
 BASE = dict(bigparity.P)
 KNOB_DEFAULTS = dict(dist_slots=0, dist_block=0, dist_wgs=0, dist_sketch=1, dist_wide=0, dist_regions=0, dist_region_bytes=0, dist_dbits=0, dist_hot_cap=0,
-                     dist_post_atomics=0, dist_fill_pct=70, dist_stage=2048, dist_int_thr=1, count_mode=1, count_bits=0)
+                     dist_post_atomics=0, dist_fill_pct=70, dist_stage=2048, dist_int_thr=1, count_mode=1, count_bits=0, comm_round_bytes=1 << 28)
 
 
 def draw_case():
@@ -80,7 +82,10 @@ with Engine(0, lib) as e:
         if time.time() - t_start > budget:
             break
         sy, p, part, n_parts, knobs = draw_case()
-        rec = dict(case=i, synth=sy, params=p, partition=[part, n_parts], knobs=knobs)
+        exchange = bool(rng.random() < 0.25) and n_parts >= 2
+        rec = dict(case=i, synth=sy, params=p, partition=[part, n_parts], knobs=knobs, exchange=exchange)
+        if only >= 0 and i != only:      # (--only i: the i-th case of this seed alone)
+            continue
         t0 = time.time()
         try:
             pk = _host.synth(**sy)
@@ -89,7 +94,24 @@ with Engine(0, lib) as e:
                 e.set_param(kk, vv)
             for kk, vv in knobs.items():
                 e.set_param(kk, vv)
-            r = bigparity.check(e, pk, part=part, n_parts=n_parts)
+            # (a look at the size first, on the device: a case whose partition has more than 4e9 pair emissions or 2e8 edges is minutes of oracle time
+            # and gigabytes of edge rows — dropped, not run)
+            e.load(pk, 1); e.count_kmers(p["k"]); e.select_rare(p["max_nonuniq"], p["lo"], p["hi"]); e.build_clouds(); e.reset_unique()
+            ne0 = e.dist_edges(0, 2 ** 62, p["min_d"], p["max_d"], p["min_cov"], p["rel_threshold"], part, n_parts, edge_cap=0)
+            if e.stats()["n_emissions"] > 4e9 or ne0 > 2e8:
+                raise DeviceError(f"case too large (-12): {e.stats()['n_emissions']} pair emissions, {ne0} edges")
+            if exchange:
+                # the way ONE rank of n_parts runs its partition: A1 on its read shard, table exchange / rare gather / cloud gather through a one-rank
+                # communicator that sends to itself (bucketing, rounds of comm_round_bytes, merge, gathered view), A5 / A6 over the gathered view
+                e.set_param("comm_round_bytes", int(rng.choice([1 << 12, 1 << 16, 1 << 28])))
+                orec = bigparity.oracle_record(pk, part, n_parts)
+                x = bigparity.check_record(e, pk, orec, through_exchange=True, rendezvous=tempfile.mkdtemp() if lib else None)      # (the emulator's file transport meets in a directory)
+                e.set_param("comm_round_bytes", 1 << 28)
+                r = dict(identical=x["identical"], checks=x["checks"], n_rare=orec["n_rare"], n_emissions_partition=x["got"]["n_emissions_partition"],
+                         n_edges_partition=x["got"]["n_edges_partition"], n_dist_passes=x["got"]["n_dist_passes"], n_bases=orec["n_bases"],
+                         dist_kernel_ms=x["got"]["dist_kernel_ms"], oracle_A1_A3_s=orec["oracle_A1_A3_s"], oracle_partition_s=orec["partition"]["oracle_s"])
+            else:
+                r = bigparity.check(e, pk, part=part, n_parts=n_parts)
             rec.update(identical=bool(r["identical"]), checks=r["checks"], n_rare=r["n_rare"], n_emissions=r["n_emissions_partition"], n_edges=r["n_edges_partition"],
                        passes=r["n_dist_passes"], n_bases=r["n_bases"], dist_kernel_ms=r["dist_kernel_ms"], oracle_s=round(r["oracle_A1_A3_s"] + r["oracle_partition_s"], 1),
                        device_ms={k: round(float(v), 1) for k, v in e.times().items() if k.endswith("_ms") and v})
@@ -98,12 +120,12 @@ with Engine(0, lib) as e:
             rec.update(identical=None if refused else False, refused=str(ex)[:200])
         rec["s"] = round(time.time() - t0, 2)
         recs.append(rec)
-        print(json.dumps({k: rec.get(k) for k in ("case", "identical", "refused", "params", "partition", "knobs", "n_rare", "n_emissions", "n_edges", "passes", "dist_kernel_ms", "oracle_s", "s")}), flush=True)
+        print(json.dumps({k: rec.get(k) for k in ("case", "identical", "refused", "params", "partition", "exchange", "knobs", "n_rare", "n_emissions", "n_edges", "passes", "dist_kernel_ms", "oracle_s", "s")}), flush=True)
         if rec["identical"] is False:
             print("DIFFERENCE:", json.dumps(rec), flush=True)
 bad = [r for r in recs if r["identical"] is False]
 summary = dict(seed=seed, cases=len(recs), identical=sum(1 for r in recs if r["identical"]), refused=sum(1 for r in recs if r["identical"] is None), different=len(bad),
-               with_edges=sum(1 for r in recs if r.get("n_edges")), pair_emissions=int(sum(r.get("n_emissions") or 0 for r in recs)), seconds=round(time.time() - t_start, 1))
+               with_edges=sum(1 for r in recs if r.get("n_edges")), through_exchange=sum(1 for r in recs if r.get("exchange") and r["identical"]), pair_emissions=int(sum(r.get("n_emissions") or 0 for r in recs)), seconds=round(time.time() - t_start, 1))
 json.dump(dict(summary=summary, cases=recs), open(out, "w"), indent=1)
 print(json.dumps(summary))
 sys.exit(1 if bad else 0)
