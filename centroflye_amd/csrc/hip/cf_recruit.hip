@@ -89,7 +89,13 @@ extern "C" int cf_rr_distances(cf_ctx* ctx, const uint8_t* unit, int32_t unit_le
                                int64_t n_reads, int32_t threshold, int32_t* dist_fwd, int32_t* dist_rc) {
     if (!ctx) return -22;
     if (!unit || unit_len < 1 || unit_len > 64 * RR_MAX_BLOCKS) return cf_fail(ctx, -22, "cf_rr_distances: the unit must have 1 .. 4096 bases");
-    if (n_reads < 0 || (n_reads && (!reads || !read_off || !dist_fwd || !dist_rc))) return cf_fail(ctx, -22, "cf_rr_distances: bad arguments");
+    if (n_reads < 0 || (n_reads && (!read_off || !dist_fwd || !dist_rc))) return cf_fail(ctx, -22, "cf_rr_distances: bad arguments");
+    // (round 5, tools/fuzz_rr.py: a batch of EMPTY reads has no bytes — `reads` may then be null; the offsets are looked at before they are trusted)
+    if (n_reads) {
+        if (read_off[0] != 0) return cf_fail(ctx, -22, "cf_rr_distances: read_off[0] must be 0");
+        for (int64_t r = 0; r < n_reads; ++r) if (read_off[r + 1] < read_off[r]) return cf_fail(ctx, -22, "cf_rr_distances: read offsets must not decrease");
+        if (read_off[n_reads] > 0 && !reads) return cf_fail(ctx, -22, "cf_rr_distances: bad arguments (no read bytes)");
+    }
     // match masks of the unit and of its reverse complement (the reference asserts upper-case ACGT, rr.cpp:11-26)
     std::vector<unsigned long long> peq((size_t)2 * 4 * RR_MAX_BLOCKS, 0ull);
     for (int32_t i = 0; i < unit_len; ++i) {

@@ -78,6 +78,11 @@ def test_kernel_source_on_the_host_emulator(emu_lib):
             e.rr_distances(b"ACGN", np.zeros(0, np.uint8), np.zeros(1, np.int64), 3)
         fwd, rc = e.rr_distances(b"ACGT", np.zeros(0, np.uint8), np.zeros(1, np.int64), 3)
         assert fwd.size == 0 and rc.size == 0
+        # a batch of EMPTY reads has no bytes at all (round 5, tools/fuzz_rr.py: the library called that "bad arguments")
+        fwd, rc = e.rr_distances(b"ACGTA", np.zeros(0, np.uint8), np.zeros(4, np.int64), 5)
+        assert fwd.tolist() == [5, 5, 5] == rc.tolist() and e.rr_distances(b"ACGTA", np.zeros(0, np.uint8), np.zeros(3, np.int64), 4)[0].tolist() == [-1, -1]
+        with pytest.raises(Exception, match="decrease"):
+            e.rr_distances(b"ACGT", np.frombuffer(b"ACGTACGT", np.uint8), np.array([0, 6, 4, 8], np.int64), 3)
     finally:
         e.close()
 
