@@ -1,5 +1,6 @@
 """-m gpu: the randomised differential runs of tools/fuzz_parity.py (stage 2 against the OpenMP oracle) and tools/fuzz_place.py (stage 3
-against the C placer) with fixed seeds and small read sets — a minute and a half of cases nobody wrote down: other unit lengths, coverages,
+against the C placer), tools/fuzz_rr.py (read recruitment against the C restatement and the reference's edlib) and tools/fuzz_unit_kmers.py
+(occurrence counts and top-n against the numpy oracle) with fixed seeds and small inputs — two and a half minutes of cases nobody wrote down: other unit lengths, coverages,
 error rates, k, rare windows, distances, thresholds, partitions, placer thresholds, and the device knobs that force the rarely taken paths.
 Round 5: the first run of the placement one found 500 reads that took 183 s (the contig's overflow map, profiles/
 r05_fuzz_place_contig_map_bug.log); longer runs: profiles/r05_fuzz_*.json."""
@@ -37,3 +38,15 @@ def test_stage3_random_cases_equal_the_c_placer(tmp_path):
     slow = [(c["case"], c["synth"]["n_reads"], c["place_ms"]) for c in d["cases"] if c.get("place_ms") and c["knobs"].get("place_grid", 128) >= 16
             and c["place_ms"] > 20.0 * c["synth"]["n_reads"]]
     assert not slow, slow
+
+
+def test_read_recruitment_random_batches_equal_the_restatement_and_edlib(tmp_path):
+    d = run_tool("fuzz_rr.py", ["100000", "--seed", "7", "--seconds", "20"], "", tmp_path, 300)
+    s = d["summary"]
+    assert s["different"] == 0 and s["identical"] == s["cases"] >= 300 and s["distances_within_threshold"] > 1000, s
+
+
+def test_occurrence_counts_and_top_n_random_cases_equal_the_oracle(tmp_path):
+    d = run_tool("fuzz_unit_kmers.py", ["1000", "--seed", "7", "--seconds", "25"], "20,100,400", tmp_path, 300)
+    s = d["summary"]
+    assert s["different"] == 0 and s["identical"] >= 8, s

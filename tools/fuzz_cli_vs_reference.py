@@ -38,6 +38,14 @@ session._engine.set_param("dist_slots", 2048); session._engine.set_param("dist_b
 from centroflye_amd import %(module)s as M
 M.main(%(argv)r)
 '''
+# (c) in a third of the cases: stage 2 once more as CF_GPUS = 2 or 3 ranks on the emulator (centroflye_amd/sharded_cli.py through tests/sharded_cli_worker.py)
+SHARD_RUN = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+os.environ["OMP_NUM_THREADS"] = "1"; os.environ["CF_TEST_SUB_EDGES"] = %(sub)r; os.environ.pop("CF_PACK_CACHE", None)
+from centroflye_amd import sharded_cli
+sys.exit(sharded_cli.launch(%(argv)r, %(world)d, rank_cmd=[sys.executable, %(worker)r]))
+'''
 
 
 def run(code, timeout):
@@ -82,7 +90,8 @@ def main():
             a2 += ["--min-nreads", str(lo_r), "--max-nreads", str(lo_r + rng.choice([1, 6, 100]))]
         a3 = ["--n-motif", str(rng.choice([1, 1, 2])), "--k-cloud", str(k), "--min-cloud-kmer-freq", str(rng.choice([1, 2, 2, 3])), "--min-kmer-mult", str(rng.choice([1, 2, 2, 3])),
               "--min-unit", str(rng.choice([1, 2, 2, 3])), "--min-inters", str(rng.choice([1, 4, 10, 10, 30])), "--prefix-threshold", str(sy["prefix_threshold"])]
-        rec = dict(case=i, synth=sy, mutate=mut, stage2=a2, stage3=a3)
+        sharded = (rng.choice([2, 3]), rng.choice([0, 0, 500])) if rng.random() < 0.33 else None      # (ranks, edge rows per sub-partition)
+        rec = dict(case=i, synth=sy, mutate=mut, stage2=a2, stage3=a3, sharded=sharded)
         if only >= 0 and i != only:
             continue
         work = tempfile.mkdtemp(prefix="cf_fuzz_cli_")
@@ -119,6 +128,19 @@ def main():
                 lines = open(pf).read().splitlines()
                 outs[who] = dict(kmers=open(kf, "rb").read(), edges=sorted(open(ef).read().splitlines()), placed=[x for x in lines if not x.endswith(" None")],
                                  none=sorted(x for x in lines if x.endswith(" None")))
+            if sharded and not outs["ref"].get("failed") == "stage 2":
+                o2 = os.path.join(work, "sharded", "s2")
+                rc, log = run(SHARD_RUN % dict(root=ROOT, sub=str(sharded[1]), world=sharded[0], worker=os.path.join(ROOT, "tests", "sharded_cli_worker.py"),
+                                               argv=["--ncrf", report, "--outdir", o2] + a2), 1800)
+                minc = a2[a2.index("--min-coverage") + 1]
+                kf, ef = os.path.join(o2, f"unique_kmers_min_edge_cov_{minc}.txt"), os.path.join(o2, f"unique_edges_min_edge_cov_{minc}.txt")
+                if rc or not os.path.exists(kf) or not os.path.exists(ef):
+                    diffs.append("sharded run failed: " + log[-400:])
+                else:
+                    if open(kf, "rb").read() != outs["ref"]["kmers"]:
+                        diffs.append("sharded kmers")
+                    if sorted(open(ef).read().splitlines()) != outs["ref"]["edges"]:
+                        diffs.append("sharded edges")
             r, o = outs["ref"], outs["our"]
             if r.get("failed") or o.get("failed"):
                 # both may refuse the same input (an empty k-mer set makes the reference's placer fail too); one side only is a difference
@@ -138,9 +160,9 @@ def main():
             shutil.copytree(work, os.path.join(keep, f"case{i}"), dirs_exist_ok=True)
         shutil.rmtree(work, ignore_errors=True)
         recs.append(rec)
-        print(json.dumps({k: rec.get(k) for k in ("case", "identical", "differences", "ref_failed", "our_failed", "n_kmers", "n_edges", "n_placed", "n_none", "stage2", "stage3", "mutate", "s")}), flush=True)
+        print(json.dumps({k: rec.get(k) for k in ("case", "identical", "differences", "ref_failed", "our_failed", "n_kmers", "n_edges", "n_placed", "n_none", "stage2", "stage3", "mutate", "sharded", "s")}), flush=True)
     bad = [r for r in recs if not r["identical"]]
-    summary = dict(seed=seed, cases=len(recs), identical=len(recs) - len(bad), different=len(bad), both_refused=sum(1 for r in recs if r.get("ref_failed") and r["identical"]),
+    summary = dict(seed=seed, cases=len(recs), identical=len(recs) - len(bad), different=len(bad), both_refused=sum(1 for r in recs if r.get("ref_failed") and r["identical"]), sharded=sum(1 for r in recs if r.get("sharded") and r["identical"] and not r.get("skipped")),
                    placed=sum(r.get("n_placed", 0) for r in recs), edges=sum(r.get("n_edges", 0) for r in recs), seconds=round(time.time() - t_start, 1))
     out = arg("--out", os.path.join(ROOT, "gpurun_out", "fuzz_cli_vs_reference.json"), str)
     os.makedirs(os.path.dirname(out), exist_ok=True)
