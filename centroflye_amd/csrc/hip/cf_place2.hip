@@ -769,7 +769,7 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
     unsigned long long* d_post = nullptr; uint32_t* d_prow = nullptr; int32_t* d_rank = nullptr;
     // only the fifth and later positions of a k-mer land here; `cmap_grow`: times four per attempt that filled it (k-mers that are NOT
     // unique to one place of the array — small read sets, thin coverage — have many positions)
-    const uint64_t ccap = (ctx->place_cmap_bits > 0 ? 1ull << ctx->place_cmap_bits : cf_pow2_ceil((uint64_t)std::max<int64_t>(N / 8, 1 << 16))) << (2 * cmap_grow);
+    const uint64_t ccap = (ctx->place_cmap_bits > 0 ? 1ull << ctx->place_cmap_bits : cf_pow2_ceil((uint64_t)std::max<int64_t>(N / 8, 1 << 21))) << (2 * cmap_grow);      // (2^21 slots = 25 MB: small read sets, whose k-mers are the least unique, start with room)
     {
         size_t free_b = 0, total_b = 0;
         if (ccap >= (1ull << 33) || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ccap * 12ull > (unsigned long long)free_b + (unsigned long long)ctx->pooled))

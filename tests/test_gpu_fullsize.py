@@ -91,29 +91,23 @@ def test_config3_share_200k_reads_count_clouds_and_one_distance_partition_vs_com
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("what,kw,part,n_parts", [
-    ("point substitutions (var_len 1), 50 000 reads", dict(reads=50000, seed=2, var_len=1, n_units=15000, synth={}), 5, 16),
-    ("long reads (> 128 units), 2^24+ rare k-mers", dict(reads=34000, seed=6, var_len=8, n_units=41000, synth=dict(mean_len=80000.0, max_len=400000)), 21, 256)])
-def test_other_workload_families_at_size_vs_cpu(what, kw, part, n_parts):
+@pytest.mark.parametrize("what,record", [("point substitutions (var_len 1), 50 000 reads", "r05_parity_50k_varlen1.json"),
+                                         ("long reads (> 128 units), 2^24+ rare k-mers", "r05_parity_long_reads.json")])
+def test_other_workload_families_at_size_vs_committed_oracle(what, record):
     """Round 4's at-size tests all used one generator family (var_len 8, reads of ~10 units).  Two more: SURVEY 8(d)'s LITERAL model —
     copy-specific variants are point substitutions as simulate_tandem_repeat.py:15-30 makes them, so few k-mers are copy-specific, the
-    clouds are small and E per base collapses (what a real HOR array looks like) — the bench's own 50 000 reads (bench.py's workload_b
-    checks the WHOLE of that step against a committed record), one first-k-mer partition of 16; and
-    reads of ~40 and up to ~195 units with more than 2^24 rare k-mers: distances up to 150 next to ranks beyond 24 bits, the table layout
-    that streams rank and unit index apart, at size.  Oracle: oracle/c/cf_oracle_mt.c in the test (these finish in about a minute)."""
-    import bigparity
-    pk = bigparity.synth_workload(kw)
-    e = Engine(0)
-    try:
-        rec = bigparity.check(e, pk, part, n_parts)
-    finally:
-        e.close()
-    assert rec["identical"], (what, rec["checks"])
-    if kw["var_len"] == 1:
-        assert rec["n_bases"] > 9e8 and rec["n_emissions_partition"] > 1e7
+    clouds are small and E per base collapses (what a real HOR array looks like) — the bench's own 50 000 reads, A1-A3 and EVERY first
+    k-mer (1.07e11 pair emissions; the record bench.py's workload_b asserts too); and 34 000 reads of ~40 and up to ~195 units (2.7 Gb) with
+    more than 2^24 rare k-mers: distances up to 150 next to ranks beyond 24 bits, the table layout that streams rank and unit index apart,
+    one first-k-mer partition of 256 (5.2e9 pair emissions, 1.3e8 edges).  Oracle side: committed records (tools/parity_record.py; the
+    oracle ran inside this test until round 5: 210 s of every GPU suite)."""
+    rec, res = _against_record(record, "parity_" + record[len("r05_parity_"):])
+    if rec["workload"]["var_len"] == 1:
+        assert rec["n_bases"] > 9e8 and res["got"]["n_emissions_partition"] > 1e11 and rec["partition"]["n_parts"] == 1
     else:
-        up = pk.units(1)[0]
-        assert int(np.diff(up).max()) > 128 and rec["n_rare"] > (1 << 24) and rec["n_emissions_partition"] > 1e9
+        import bigparity
+        up = bigparity.synth_workload(rec["workload"]).units(1)[0]
+        assert int(np.diff(up).max()) > 128 and rec["n_rare"] > (1 << 24) and res["got"]["n_emissions_partition"] > 1e9
 
 
 @pytest.mark.timeout(900)

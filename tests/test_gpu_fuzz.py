@@ -24,9 +24,9 @@ def run_tool(name, args, env_reads, tmp_path, timeout):
 
 
 def test_stage2_random_cases_equal_the_oracle(tmp_path):
-    d = run_tool("fuzz_parity.py", ["200", "--seed", "7", "--seconds", "60"], "300,600,1200", tmp_path, 600)
+    d = run_tool("fuzz_parity.py", ["200", "--seed", "7", "--seconds", "40"], "300,600,1200", tmp_path, 600)
     s = d["summary"]
-    assert s["different"] == 0 and s["identical"] >= 12 and s["with_edges"] >= 8, s
+    assert s["different"] == 0 and s["identical"] >= 8 and s["with_edges"] >= 5, s
     assert s["identical"] + s["refused"] == s["cases"]
 
 
@@ -41,12 +41,12 @@ def test_stage3_random_cases_equal_the_c_placer(tmp_path):
 
 
 def test_read_recruitment_random_batches_equal_the_restatement_and_edlib(tmp_path):
-    d = run_tool("fuzz_rr.py", ["100000", "--seed", "7", "--seconds", "20"], "", tmp_path, 300)
+    d = run_tool("fuzz_rr.py", ["100000", "--seed", "7", "--seconds", "10"], "", tmp_path, 300)
     s = d["summary"]
-    assert s["different"] == 0 and s["identical"] == s["cases"] >= 300 and s["distances_within_threshold"] > 1000, s
+    assert s["different"] == 0 and s["identical"] == s["cases"] >= 150 and s["distances_within_threshold"] > 500, s
 
 
 def test_occurrence_counts_and_top_n_random_cases_equal_the_oracle(tmp_path):
-    d = run_tool("fuzz_unit_kmers.py", ["1000", "--seed", "7", "--seconds", "25"], "20,100,400", tmp_path, 300)
+    d = run_tool("fuzz_unit_kmers.py", ["1000", "--seed", "7", "--seconds", "15"], "20,100,400", tmp_path, 300)
     s = d["summary"]
-    assert s["different"] == 0 and s["identical"] >= 8, s
+    assert s["different"] == 0 and s["identical"] >= 4, s
