@@ -38,6 +38,40 @@ session._engine.set_param("dist_slots", 2048); session._engine.set_param("dist_b
 from centroflye_amd import %(module)s as M
 M.main(%(argv)r)
 '''
+# (d) SURVEY 8(f) rank 3: the per-position read-unit FASTA files the polisher writes before it calls Flye (eltr_polisher.py:53-97), from the
+# REFERENCE's read_positions.csv, by the reference's ELTR_Polisher (edlib / Biopython stubbed, the unit FASTA is not used by the export) and by
+# this repo's eltr_polisher; --min-pos / --max-pos drawn
+POL_REF = r'''
+import sys, types, math
+sys.dont_write_bytecode = True
+for mod in ("Bio", "Bio.SeqIO", "edlib"):
+    sys.modules.setdefault(mod, types.ModuleType(mod))
+sys.modules["Bio"].SeqIO = sys.modules["Bio.SeqIO"]
+sys.path.insert(0, %(ref)r)
+import eltr_polisher as E
+E.read_bio_seq = lambda fn: "ACGT"
+params = types.SimpleNamespace(unit=%(unit)r, ncrf=%(report)r, outdir=%(out)r, read_placement=%(csv)r, min_pos=%(lo)d, max_pos=%(hi)s)
+pol = E.ELTR_Polisher(params)
+pol.export_read_units(pol.map_pos2read())
+'''
+POL_OUR = r'''
+import sys
+sys.path.insert(0, %(root)r)
+from centroflye_amd import eltr_polisher as M
+sys.argv = ["eltr_polisher", "--ncrf", %(report)r, "--read-placement", %(csv)r, "--unit", %(unit)r, "--outdir", %(out)r, "--export-only", "--min-pos", str(%(lo)d)] + %(hi_arg)r
+M.main()
+'''
+
+
+def digest_tree(outdir):
+    import hashlib
+    res = {}
+    for d in sorted(os.listdir(outdir)) if os.path.isdir(outdir) else []:
+        if d.startswith("pos_"):
+            res[d] = [hashlib.sha256(open(os.path.join(outdir, d, fn), "rb").read()).hexdigest() for fn in ("read_units.fasta", "median_read_unit.fasta")]
+    return res
+
+
 # (c) in a third of the cases: stage 2 once more as CF_GPUS = 2 or 3 ranks on the emulator (centroflye_amd/sharded_cli.py through tests/sharded_cli_worker.py)
 SHARD_RUN = r'''
 import os, sys
@@ -98,7 +132,8 @@ def main():
         a3 = ["--n-motif", str(rng.choice([1, 1, 2])), "--k-cloud", str(k), "--min-cloud-kmer-freq", str(rng.choice([1, 2, 2, 3])), "--min-kmer-mult", str(rng.choice([1, 2, 2, 3])),
               "--min-unit", str(rng.choice([1, 2, 2, 3])), "--min-inters", str(rng.choice([1, 4, 10, 10, 30])), "--prefix-threshold", str(sy["prefix_threshold"])]
         sharded = (rng.choice([2, 3]), rng.choice([0, 0, 500])) if rng.random() < 0.33 else None      # (ranks, edge rows per sub-partition)
-        rec = dict(case=i, synth=sy, mutate=mut, stage2=a2, stage3=a3, sharded=sharded)
+        polish = (rng.choice([0, 0, 1, 3]), rng.choice([None, None, 4, 9])) if rng.random() < 0.6 else None      # (--min-pos, --max-pos) of the export
+        rec = dict(case=i, synth=sy, mutate=mut, stage2=a2, stage3=a3, sharded=sharded, polish=polish)
         if only >= 0 and i != only:
             continue
         work = tempfile.mkdtemp(prefix="cf_fuzz_cli_")
@@ -149,6 +184,17 @@ def main():
                         diffs.append("sharded kmers")
                     if sorted(open(ef).read().splitlines()) != outs["ref"]["edges"]:
                         diffs.append("sharded edges")
+            if "placed" in outs["ref"] and polish is not None:
+                csv, unit = os.path.join(work, "ref", "s3", "read_positions.csv"), os.path.join(work, "unit.fasta")
+                open(unit, "w").write(">u\nACGT\n")
+                lo, hi = polish
+                pr, po = os.path.join(work, "ref", "pol"), os.path.join(work, "our", "pol")
+                rc1, log1 = run(POL_REF % dict(ref=REF, unit=unit, report=report, out=pr, csv=csv, lo=lo, hi="math.inf" if hi is None else str(hi)), 600)
+                rc2, log2 = run(POL_OUR % dict(root=ROOT, unit=unit, report=report, out=po, csv=csv, lo=lo, hi_arg=[] if hi is None else ["--max-pos", str(hi)]), 600)
+                tr, to = digest_tree(pr), digest_tree(po)
+                rec["polisher"] = dict(window=polish, positions=len(tr), ref_rc=rc1, our_rc=rc2)
+                if bool(rc1) != bool(rc2) or (not rc1 and tr != to):
+                    diffs.append("polisher export: ref rc=%s (%d positions) our rc=%s (%d positions) %s" % (rc1, len(tr), rc2, len(to), (log1[-300:] + " | " + log2[-300:]) if (rc1 or rc2) else ""))
             r, o = outs["ref"], outs["our"]
             if r.get("failed") or o.get("failed"):
                 # both may refuse the same input (an empty k-mer set makes the reference's placer fail too); one side only is a difference
@@ -170,9 +216,9 @@ def main():
             shutil.copytree(work, os.path.join(keep, f"case{i}"), dirs_exist_ok=True)
         shutil.rmtree(work, ignore_errors=True)
         recs.append(rec)
-        print(json.dumps({k: rec.get(k) for k in ("case", "identical", "differences", "ref_failed", "our_failed", "n_kmers", "n_edges", "n_placed", "n_none", "stage2", "stage3", "mutate", "sharded", "s")}), flush=True)
+        print(json.dumps({k: rec.get(k) for k in ("case", "identical", "differences", "ref_failed", "our_failed", "n_kmers", "n_edges", "n_placed", "n_none", "stage2", "stage3", "mutate", "sharded", "polisher", "s")}), flush=True)
     bad = [r for r in recs if not r["identical"]]
-    summary = dict(seed=seed, cases=len(recs), identical=len(recs) - len(bad), different=len(bad), both_refused=sum(1 for r in recs if r.get("ref_failed") and r["identical"]), sharded=sum(1 for r in recs if r.get("sharded") and r["identical"] and not r.get("skipped")),
+    summary = dict(seed=seed, cases=len(recs), identical=len(recs) - len(bad), different=len(bad), both_refused=sum(1 for r in recs if r.get("ref_failed") and r["identical"]), sharded=sum(1 for r in recs if r.get("sharded") and r["identical"] and not r.get("skipped")), polisher_exports=sum(1 for r in recs if r.get("polisher")),
                    placed=sum(r.get("n_placed", 0) for r in recs), edges=sum(r.get("n_edges", 0) for r in recs), seconds=round(time.time() - t_start, 1))
     out = arg("--out", os.path.join(ROOT, "gpurun_out", "fuzz_cli_vs_reference.json"), str)
     os.makedirs(os.path.dirname(out), exist_ok=True)
