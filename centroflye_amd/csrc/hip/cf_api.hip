@@ -545,6 +545,9 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "place_l3_shift") {
         if (value < 0 || value > 6) return cf_fail(ctx, -22, "place_l3_shift must be 0 (= 6) .. 6");
         ctx->place_l3_shift = (int)value;
+    } else if (n == "place_long_rescans") {
+        if (value < -1 || value > 1000000) return cf_fail(ctx, -22, "place_long_rescans out of range (-1, 0 .. 1000000)");
+        ctx->place_long_rescans = (int)value;
     } else if (n == "place_cmap_bits") {
         if (value < 0 || value > 30) return cf_fail(ctx, -22, "place_cmap_bits out of range (0 = default, 1 .. 30)");
         ctx->place_cmap_bits = (int)value;

@@ -161,6 +161,7 @@ struct cf_ctx {
     int place_mode = 2;          // 2: per-read score regions, one kernel per greedy iteration (cf_place2.hip); 1: the hash-map path of rounds 1-3 (cf_place.hip)
     int place_block = 0;         // cf_place2: threads per workgroup of the iteration kernel (128 .. 1024, a multiple of 128; 0 = 1024)
     int place_row_words = 0;     // cf_place2: 32-bit words of a posting row (32 or 64); 0 = the smaller one that holds the longest posting list
+    int place_long_rescans = 2;  // cf_place2: long rescans (reads with more than four candidate rows) per greedy iteration above which the run goes to the hash-map path (-1: at the first look, tests)
     int place_cmap_bits = 0;     // cf_place2: log2 of the first capacity of the contig's overflow map (0 = entries / 8, at least 2^21; tests force tiny maps that have to grow)
     int place_slots_per_unit = 0; // cf_place2: score-region slots per unit of a read (0 = 48); doubled-up automatically when a region fills
     int place_l3 = 0;            // cf_place2: third level of the arg-max (best candidate per group of 64-read blocks): 1 = on; 0 / 2 = off (measured: no gain at 500 000 reads)

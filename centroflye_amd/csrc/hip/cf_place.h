@@ -41,7 +41,7 @@ struct cf_place_state {
     unsigned long long* seen; uint64_t seen_mask;
     // events (kmer << 32 | pos)
     unsigned long long* events; unsigned long long* n_events;  // n_events[0] = count
-    // control: [0] done, [1] n_out, [2] error flags (1: the contig's map is full, 2: a score region / the score map, 4: ...), [3] thr, [4] score-map entries, [5] contig-map entries
+    // control: [0] done, [1] n_out, [2] error flags (1: the contig's map is full, 2: a score region / the score map, 4: ...), [3] thr, [4] score-map entries, [5] contig-map entries, [6] cf_place2: rescans of reads with more than four candidate rows
     unsigned int* ctl;
     const uint8_t* used_in; uint8_t* used;
     const int32_t* id_rank;

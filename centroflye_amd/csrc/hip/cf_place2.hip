@@ -313,7 +313,8 @@ __device__ __forceinline__ void pl2_rescan_read(const cf_pl2& S, uint32_t r, uin
         if (np > 1) pl2_row(S, ri, p1, rank, r, rec, anchor, anchor_off1);
         if (np > 2) pl2_row(S, ri, p2, rank, r, rec, anchor, anchor_off1);
         if (np > 3) pl2_row(S, ri, p3, rank, r, rec, anchor, anchor_off1);
-        if (np > 4) {      // more than four: the rest, word by word (never seen at the default thresholds)
+        if (np > 4) {      // more than four: the rest, word by word (never seen at the default thresholds on reads of unique k-mers)
+            atomicAdd(&S.C.ctl[6], 1u);      // (counted: a run whose reads keep having many candidate rows is handed to the hash-map path, cf_place2_run)
             uint32_t seen = 0;
             for (uint32_t w = 0; w < n_w; ++w)
                 for (unsigned long long b = cf_ld_agent(hb + w); b; b &= b - 1ull) {
@@ -883,7 +884,7 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
         // regions of this stage's reads, then the seed.  The seed changes nothing but the scores: when it fills a region (a
         // late stage's few reads meet every position of a long contig) only this step is repeated with larger regions.
         Bufs SB{ctx, {}};      // the stage's score memory
-        unsigned int h_ctl[4] = {0, 0, 0, 0};
+        unsigned int h_ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int spu = slots_per_unit, tries = 0;; spu *= 4, ++tries) {
             if (tries == 6) return cf_fail(ctx, -34, "cf_place_reads: the seed of a stage kept overflowing the score regions");
             unsigned long long n_slots = 0, n_cells = 0;
@@ -923,6 +924,7 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
             CF_HIP(hipMemsetAsync(S.win, 0, sizeof(cf_pl2_rec), st));
             CF_HIP(hipMemsetAsync(S.C.ctl, 0, 8, st));         // done = 0, n_out = 0 (error flags kept)
             CF_HIP(hipMemsetAsync(S.C.ctl + 3, 0, 4, st));
+            CF_HIP(hipMemsetAsync(S.C.ctl + 6, 0, 4, st));     // long rescans of this stage
             hipLaunchKernelGGL(cf_pl2_seed_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, S, K);
             CF_KERNEL_CHECK("cf_pl2_seed_kernel");
             CF_HIP(hipMemcpyAsync(h_ctl, S.C.ctl, 16, hipMemcpyDeviceToHost, st));
@@ -938,10 +940,16 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
         for (int64_t it = 0; it < n_iter; ++it) {
             if (pw == 32) hipLaunchKernelGGL(cf_pl2_iter_kernel<32>, dim3((unsigned)grid), dim3((unsigned)block), lds, st, S, (uint32_t)it);
             else hipLaunchKernelGGL(cf_pl2_iter_kernel<64>, dim3((unsigned)grid), dim3((unsigned)block), lds, st, S, (uint32_t)it);
-            if ((it & 511) == 511 || it + 1 == n_iter) {
+            if ((it & 511) == 511 || it == 63 || it + 1 == n_iter) {
                 CF_KERNEL_CHECK("placement iteration");
-                CF_HIP(hipMemcpyAsync(h_ctl, S.C.ctl, 16, hipMemcpyDeviceToHost, st));
+                CF_HIP(hipMemcpyAsync(h_ctl, S.C.ctl, 32, hipMemcpyDeviceToHost, st));
                 CF_HIP(hipStreamSynchronize(st));
+                // Round 5 (tools/fuzz_place.py, thin coverage: 15 000 reads over 45 000 units): where the k-mers are NOT unique to one place of
+                // the array a read meets the contig at many offsets, many of its score rows are candidate rows, and the lane that rescans
+                // the read walks them one by one — 254 us of a 270 us iteration, against 39 us per iteration on the hash-map path.  More than
+                // two such rescans per iteration so far: this path gives the run up (place_mode 3 keeps it)
+                if (ctx->place_mode != 3 && it + 1 < n_iter && (ctx->place_long_rescans < 0 || (unsigned long long)h_ctl[6] > (unsigned long long)ctx->place_long_rescans * (unsigned long long)(it + 1)))
+                    return cf_fail(ctx, -34, "cf_place_reads: reads with many candidate score rows (" + std::to_string(h_ctl[6]) + " long rescans in " + std::to_string(it + 1) + " iterations)");
                 if (std::getenv("CF_DEBUG") && ((it & 8191) == 8191 || h_ctl[2] || h_ctl[0])) std::fprintf(stderr, "[cf_place2] stage %d iter %lld/%lld ctl=%u,%u,%u\n", stage_cls, (long long)it, (long long)n_iter, h_ctl[0], h_ctl[1], h_ctl[2]);
                 if (h_ctl[2]) return (h_ctl[2] & 1u) ? 2 : 1;
                 if (h_ctl[0]) break;

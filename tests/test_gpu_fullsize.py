@@ -304,8 +304,12 @@ def test_placement_3k_reads_vs_c_placer(engine):
     # round 5: the third level of the arg-max (groups of 64-read blocks, kept lazily; by itself only for more than 131 072 reads) forced
     # onto these 47 blocks in groups of 4 and 2; regions that would need more than 2^32 slots (they give up before allocating and the
     # hash-map path takes over)
-    defaults = {"place_mode": 2, "place_grid": 0, "place_block": 0, "place_row_words": 0, "place_slots_per_unit": 0, "place_fused": 1, "place_chunk": 2, "place_l3": 0, "place_l3_shift": 0}
-    for knobs in ({"place_grid": 13, "place_block": 256}, {"place_row_words": 32, "place_grid": 7}, {"place_row_words": 64}, {"place_slots_per_unit": 2},
+    # ("place_long_rescans": 1 000 000 keeps the region path on these shapes whatever this read set's candidate rows look like — round 5: runs
+    # whose reads keep having more than four candidate rows are handed to the hash-map path; -1: handed over at the first look, at iteration 64)
+    defaults = {"place_mode": 2, "place_grid": 0, "place_block": 0, "place_row_words": 0, "place_slots_per_unit": 0, "place_fused": 1, "place_chunk": 2, "place_l3": 0, "place_l3_shift": 0,
+                "place_long_rescans": 1000000}
+    engine.set_param("place_long_rescans", 1000000)
+    for knobs in ({"place_grid": 13, "place_block": 256}, {"place_long_rescans": -1}, {"place_row_words": 32, "place_grid": 7}, {"place_row_words": 64}, {"place_slots_per_unit": 2},
                   {"place_l3": 1, "place_l3_shift": 2}, {"place_l3": 1, "place_l3_shift": 1, "place_block": 256, "place_grid": 13}, {"place_slots_per_unit": 1 << 16},
                   {"place_mode": 1}, {"place_mode": 1, "place_fused": 0}, {"place_mode": 1, "place_chunk": 7, "place_grid": 13},
                   {"place_mode": 1, "place_chunk": 64, "place_grid": 512}):
@@ -317,3 +321,4 @@ def test_placement_3k_reads_vs_c_placer(engine):
             for k, v in defaults.items():
                 engine.set_param(k, v)
         assert all(np.array_equal(a, b) for a, b in zip(again, got)), knobs
+    engine.set_param("place_long_rescans", 2)

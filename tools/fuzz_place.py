@@ -49,26 +49,32 @@ with Engine(0, lib) as e:
                                   ("place_l3", [1]), ("place_l3_shift", [1, 2, 3]), ("place_mode", [1, 3]), ("place_fused", [0])):
                 if rng.random() < 0.25:
                     knobs[name] = int(rng.choice(choices))
-        rec = dict(case=i, synth=sy, params=s, knobs=knobs)
+        for kv in filter(None, os.environ.get("CF_FUZZ_KNOBS", "").split(",")):      # (knobs forced on every case, e.g. place_mode=1: one case again on the other path)
+            knobs[kv.split("=")[0]] = int(kv.split("=")[1])
+        n_motif = int(rng.choice([1, 1, 1, 2]))      # (--n-motif: units of n motif copies, ncrf_parser.py:28-59)
+        rec = dict(case=i, synth=sy, params=s, knobs=knobs, n_motif=n_motif)
         if only >= 0 and i != only:      # (--only i: the i-th case of this seed alone; the draws before it are made and dropped)
             continue
         t0 = time.time()
         try:
-            pk = _host.synth(**sy)
+            pk = _host.synth(keep_rows=n_motif != 1, **sy)      # (units of n > 1 motif copies are cut from the alignment rows)
             cls = pk.classify(s["prefix_threshold"])
             rank = np.argsort(np.argsort(np.array(pk.ids, dtype=object), kind="stable"), kind="stable").astype(np.int32)
-            up = pk.units(1)[0]
+            up = pk.units(n_motif)[0]
             for kk, vv in KNOB_DEFAULTS.items():
                 e.set_param(kk, vv)
             e.load(pk, 1); e.count_kmers(19); e.select_rare(3, 10, 32); e.build_clouds(); e.reset_unique()
             e.dist_edges(0, 2 ** 62, 1, 150, 4, 0.8, 0, 1, 0)
             gk = e.kmers()[e.unique_mask()]
+            if n_motif != 1:
+                e.load(pk, n_motif)
             rec.update(n_kmers=int(gk.size), classes=[int((cls == c).sum()) for c in range(3)])
             if gk.size == 0:
                 rec.update(identical=None, refused="no unique k-mers")
             else:
                 e.set_kmers(gk, 19); e.build_clouds(); e.filter_clouds(s["min_mult"])
                 cp, ent = e.clouds()
+                rec["n_entries"] = int(ent.size)
                 tc = time.time()
                 want = lines_from_placement(pk.ids, *[x.tolist() for x in cport.place_reads(cls, rank, up, cp, ent, gk.size, s["freq"], s["min_unit"], s["min_inters"], 3)])
                 rec["oracle_s"] = round(time.time() - tc, 2)
@@ -83,7 +89,7 @@ with Engine(0, lib) as e:
             rec.update(identical=None if refused else False, refused=str(ex)[:200])
         rec["s"] = round(time.time() - t0, 2)
         recs.append(rec)
-        print(json.dumps({k: rec.get(k) for k in ("case", "identical", "refused", "params", "knobs", "n_kmers", "classes", "placed", "place_ms", "oracle_s", "s")}), flush=True)
+        print(json.dumps({k: rec.get(k) for k in ("case", "identical", "refused", "params", "n_motif", "knobs", "n_kmers", "n_entries", "classes", "placed", "place_ms", "oracle_s", "s")}), flush=True)
         if rec["identical"] is False:
             print("DIFFERENCE:", json.dumps(rec), flush=True)
 bad = [r for r in recs if r["identical"] is False]
