@@ -937,6 +937,7 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
         hipLaunchKernelGGL(cf_pl2_tail_kernel, dim3(1), dim3(PL2_B), lds, st, S);
         CF_KERNEL_CHECK("cf_pl2_tail_kernel");
         const int64_t n_iter = (int64_t)stage_reads.size();
+        unsigned long long long_seen = 0, iters_seen = 0;
         for (int64_t it = 0; it < n_iter; ++it) {
             if (pw == 32) hipLaunchKernelGGL(cf_pl2_iter_kernel<32>, dim3((unsigned)grid), dim3((unsigned)block), lds, st, S, (uint32_t)it);
             else hipLaunchKernelGGL(cf_pl2_iter_kernel<64>, dim3((unsigned)grid), dim3((unsigned)block), lds, st, S, (uint32_t)it);
@@ -948,8 +949,11 @@ static int pl2_attempt(cf_ctx* ctx, const uint8_t* cls, const int32_t* id_rank, 
                 // the array a read meets the contig at many offsets, many of its score rows are candidate rows, and the lane that rescans
                 // the read walks them one by one — 254 us of a 270 us iteration, against 39 us per iteration on the hash-map path.  More than
                 // two such rescans per iteration so far: this path gives the run up (place_mode 3 keeps it)
-                if (ctx->place_mode != 3 && it + 1 < n_iter && (ctx->place_long_rescans < 0 || (unsigned long long)h_ctl[6] > (unsigned long long)ctx->place_long_rescans * (unsigned long long)(it + 1)))
-                    return cf_fail(ctx, -34, "cf_place_reads: reads with many candidate score rows (" + std::to_string(h_ctl[6]) + " long rescans in " + std::to_string(it + 1) + " iterations)");
+                // (counted per window between two looks: the contig of a stage's first iterations is short, the rows come later)
+                const unsigned long long win_long = (unsigned long long)h_ctl[6] - long_seen, win_iters = (unsigned long long)(it + 1) - iters_seen;
+                long_seen = h_ctl[6]; iters_seen = (unsigned long long)(it + 1);
+                if (ctx->place_mode != 3 && it + 1 < n_iter && (ctx->place_long_rescans < 0 || win_long > (unsigned long long)ctx->place_long_rescans * win_iters))
+                    return cf_fail(ctx, -34, "cf_place_reads: reads with many candidate score rows (" + std::to_string(win_long) + " long rescans in the last " + std::to_string(win_iters) + " of " + std::to_string(it + 1) + " iterations)");
                 if (std::getenv("CF_DEBUG") && ((it & 8191) == 8191 || h_ctl[2] || h_ctl[0])) std::fprintf(stderr, "[cf_place2] stage %d iter %lld/%lld ctl=%u,%u,%u\n", stage_cls, (long long)it, (long long)n_iter, h_ctl[0], h_ctl[1], h_ctl[2]);
                 if (h_ctl[2]) return (h_ctl[2] & 1u) ? 2 : 1;
                 if (h_ctl[0]) break;
