@@ -26,6 +26,25 @@ def test_cfhip_exports_every_declared_symbol():
     assert sorted(_lib.PROTOTYPES) == names  # the binding covers exactly the header
 
 
+def test_the_device_library_knows_every_knob_the_header_lists():
+    """The in-tree libcfhip.so travels to the GPU box as it is: one built BEFORE the last edit of the sources fails there, not here (round 5:
+    a knob added after the last build — 'unknown parameter' in the GPU suite).  Every knob name of cf_set_param's comment in the header must
+    be a string of the built library, and the library must not be older than its sources."""
+    with open(os.path.join(ROOT, "include", "cfhip.h")) as f:
+        text = f.read()
+    doc = text[text.index("/* Tuning knobs"):text.index("int cf_set_param")]
+    knobs = sorted(set(re.findall(r'"((?:dist|place|count|comm)_[a-z0-9_]+)"', doc)))
+    assert len(knobs) >= 32 and "place_long_rescans" in knobs and "dist_slots" in knobs
+    with open(_lib.LIB_PATH, "rb") as f:
+        blob = f.read()
+    missing = [k for k in knobs if k.encode() not in blob]
+    assert not missing, f"libcfhip.so does not know {missing}: rebuild it (python -c 'import __graft_entry__ as g; g.build()')"
+    src_dir = os.path.join(ROOT, "centroflye_amd", "csrc", "hip")
+    newest = max(os.path.getmtime(os.path.join(src_dir, fn)) for fn in os.listdir(src_dir) if fn.endswith((".hip", ".h")))
+    newest = max(newest, os.path.getmtime(os.path.join(ROOT, "include", "cfhip.h")))
+    assert os.path.getmtime(_lib.LIB_PATH) >= newest, "libcfhip.so is older than its sources: rebuild it (python -c 'import __graft_entry__ as g; g.build()')"
+
+
 def test_cfhost_exports_every_declared_symbol():
     names = declared("cfhost.h", "cfh_")
     lib = _host.lib()
