@@ -141,7 +141,8 @@ def dist_histogram(unit_ptr, cloud_ptr, entries, n_kmers, min_n, max_n, min_d, m
         w = np.concatenate([acc_cnt] + [np.ones(p.size, np.int64) for p in pend])
         order = np.argsort(allk, kind="stable")
         allk, w = allk[order], w[order]
-        acc_keys, start = np.unique(allk, return_index=True)
+        start = np.flatnonzero(np.concatenate(([True], allk[1:] != allk[:-1]))) if allk.size else np.zeros(0, np.int64)      # (allk is sorted: run starts)
+        acc_keys = allk[start]
         acc_cnt = np.add.reduceat(w, start) if acc_keys.size else np.zeros(0, np.int64)
         pend, pend_n = [], 0
 
