@@ -431,12 +431,20 @@ bool skip_ws1(const char*& p, const char* end) {  // \s+
 }
 
 // ^([^ ]+)\s+(\d+)\s+(\d+)bp\s+(\d+)-(\d+)\s+(.+)$
+static bool parse_first_from(const char* b, const char* p, const char* e, FileRecord& fr, const char*& al_b, const char*& al_e);
 bool parse_first(const char* b, const char* e, FileRecord& fr, const char*& al_b, const char*& al_e) {
     const char* p = b;
     while (p < e && *p != ' ') ++p;
     if (p == b) return false;
-    // [^ ]+ is greedy but must be followed by \s+; with tabs inside the id the regex would
-    // backtrack — ids with embedded whitespace other than ' ' are not produced by NCRF.
+    // [^ ]+ is greedy but must be followed by \s+ and the rest of the pattern: the id ends at the first blank — or, when the rest does not
+    // match from there, at the LAST tab (or other white space that is not a blank) inside that stretch from which it does: the regex
+    // backtracks (round 5, tools/fuzz_parser_vs_reference.py: a tab between the id and the read length).  NCRF itself pads with blanks.
+    if (parse_first_from(b, p, e, fr, al_b, al_e)) return true;
+    for (const char* q = p - 1; q > b; --q)
+        if (is_ws(*q) && parse_first_from(b, q, e, fr, al_b, al_e)) return true;
+    return false;
+}
+static bool parse_first_from(const char* b, const char* p, const char* e, FileRecord& fr, const char*& al_b, const char*& al_e) {
     fr.r_id.assign(b, p);
     if (!skip_ws1(p, e)) return false;
     if (!parse_int(p, e, fr.r_len)) return false;

@@ -94,6 +94,13 @@ def test_short_and_comment_lines(tmp_path):
     assert pk.n_reads == 1 and pk.ids == ["r1"] and pk.bases.tobytes() == b"ACGT"
     up, us, ue, uc = pk.units(1)
     assert up.tolist() == [0, 1] and uc.tolist() == [[0, 4]]
+    # white space the reference's regexes take (\s+ between the fields; the id is [^ ]+ and BACKTRACKS to a tab when the rest does not match from
+    # the first blank; the line is stripped): round 5, tools/fuzz_parser_vs_reference.py — a tab right after the id was "malformed" here
+    p.write_text("r1\t100 4bp\t 0-4   ACGT  \r\nACGT+\t4bp  score=4\tACGT\r\nr2\t\t50 4bp 0-4 AC-T\nACGT- 4bp score=3 ACGT\n")
+    pk = _host.parse_report(str(p), min_record_len=1, keep_rows=True)
+    assert pk.ids == ["r1", "r2\t"] and pk.row(0, 0) == "ACGT"      # (the longest id the rest still matches behind: the reference's r_id keeps the first tab)
+    assert True and [int(x) for x in pk.meta[0][:4]] == [100, 4, 0, 4]
+    assert pk.row(1, 0) == "A-GT" and [int(x) for x in pk.meta[1][:5]] == [50, 4, 46, 50, 1]
 
 
 def test_kmer_text_io_roundtrip(tmp_path):
