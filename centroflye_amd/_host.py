@@ -63,6 +63,8 @@ def lib():
     L.cfh_exotic_kept.argtypes = [P, i32, i32, C.c_void_p, C.c_void_p, i64]
     L.cfh_exotic_rare.restype = i64
     L.cfh_exotic_rare.argtypes = [P, i32, i32, C.c_uint32, C.c_uint32, C.c_void_p, i64]
+    L.cfh_exotic_rare_lower.restype = i64
+    L.cfh_exotic_rare_lower.argtypes = [P, i32, i32, C.c_uint32, C.c_uint32, C.c_void_p, i64]
     for name in ("cfh_bases", "cfh_read_off", "cfh_ids", "cfh_id_off", "cfh_meta"):
         getattr(L, name).argtypes = [P]
         getattr(L, name).restype = C.c_void_p
@@ -193,6 +195,19 @@ class PackedReads:
             raise HostError("cfh_exotic_kept: the window set changed between two calls")
         raw = buf.raw[:n * int(k)].decode("latin-1")
         return {raw[i * k:(i + 1) * k]: int(pres[i]) for i in range(n)}
+
+    def exotic_rare_lower(self, k, max_nonuniq, lo, hi):
+        """The rare windows that hold a lower-case letter, as strings in ascending order: members of the reference's rare SET only (they
+        never equal a window of an upper-cased unit)."""
+        args = (self._h, int(k), int(max_nonuniq), int(lo), int(min(hi, 2 ** 32 - 1)))
+        n = lib().cfh_exotic_rare_lower(*args, None, 0)
+        if n < 0:
+            raise HostError(f"cfh_exotic_rare_lower failed ({n})")
+        buf = C.create_string_buffer(max(1, n * int(k)))
+        if n and lib().cfh_exotic_rare_lower(*args, buf, n) != n:
+            raise HostError("cfh_exotic_rare_lower: the window set changed between two calls")
+        raw = buf.raw[:n * int(k)].decode("latin-1")
+        return [raw[i * k:(i + 1) * k] for i in range(n)]
 
     def exotic_rare(self, k, max_nonuniq, lo, hi):
         """The rare windows that hold a symbol other than A, C, G, T and no lower-case letter, as strings in ascending order

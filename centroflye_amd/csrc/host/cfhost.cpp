@@ -1231,7 +1231,16 @@ int64_t cfh_exotic_list(const cfh_pack* p, int32_t k, int64_t read_lo, int64_t r
 }
 // The windows of cfh_exotic_summary's out[4] themselves: rare (pres in [lo, hi], multi <= max_nonuniq) and free of lower-case letters,
 // as text, in ascending order — the k-mers the caller carries beside the 2-bit set (k bytes each, at most cap of them written).
+static int64_t exotic_rare_impl(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, char* out, int64_t cap, bool want_lower);
 int64_t cfh_exotic_rare(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, char* out, int64_t cap) {
+    return exotic_rare_impl(p, k, max_nonuniq, lo, hi, out, cap, false);
+}
+// The rare windows that DO hold a lower-case letter: the reference's get_rare_kmers returns them too (:66-82 on the raw text of :47-53); they
+// can never equal a window of an upper-cased unit (read_kmer_cloud.py:25), so no output depends on them — members of the returned set only.
+int64_t cfh_exotic_rare_lower(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, char* out, int64_t cap) {
+    return exotic_rare_impl(p, k, max_nonuniq, lo, hi, out, cap, true);
+}
+static int64_t exotic_rare_impl(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, char* out, int64_t cap, bool want_lower) {
     try {
         if (!p || k < 1 || (cap > 0 && !out)) return -22;
         std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> all;
@@ -1242,7 +1251,7 @@ int64_t cfh_exotic_rare(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint3
             if (max_nonuniq < 0 || kv.second.second > (uint32_t)max_nonuniq || kv.second.first < lo || kv.second.first > hi) continue;
             bool lower = false;
             for (char c : kv.first) lower |= (c >= 'a' && c <= 'z');
-            if (!lower) keep.push_back(&kv.first);
+            if (lower == want_lower) keep.push_back(&kv.first);
         }
         std::sort(keep.begin(), keep.end(), [](const std::string* a, const std::string* b) { return *a < *b; });
         for (int64_t i = 0; i < (int64_t)keep.size() && i < cap; ++i) std::memcpy(out + i * k, keep[(size_t)i]->data(), (size_t)k);

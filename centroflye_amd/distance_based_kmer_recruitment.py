@@ -101,7 +101,9 @@ def get_rare_kmers(reads_ncrf_report, k, bottom, top, coverage, kmer_survival_ra
     ex = check_exotic_windows(packed, k, max_nonuniq, lo, hi, verbose)
     e.select_rare(max_nonuniq, lo, hi)
     extra = packed.exotic_rare(k, max_nonuniq, lo, hi) if ex and ex["n_blocking"] else []
-    rare = km.KmerSet(e.kmers(), k, extra)
+    # (the rare windows WITH a lower-case letter: the reference's set holds them too — members only, no cloud can)
+    inert = packed.exotic_rare_lower(k, max_nonuniq, lo, hi) if ex and ex["n_rare"] > ex["n_blocking"] else []
+    rare = km.KmerSet(e.kmers(), k, extra, inert)
     if extra:       # the device's list gets their pseudo-codes: ranks, posting lists and edges like any other k-mer's
         e.set_kmers(rare.codes, k)
     if verbose:

@@ -66,10 +66,13 @@ class KmerSet(Set):
     """Sorted unique k-mer codes behaving like the reference's ``set`` of k-mer strings.  ``extra``: the k-mers without a 2-bit
     code (sorted strings); ``codes`` ends with one pseudo-code per extra k-mer, so ranks run over both."""
 
-    def __init__(self, codes, k, extra=()):
+    def __init__(self, codes, k, extra=(), inert=()):
         codes = np.ascontiguousarray(codes, np.uint64)
         self.k = int(k)
         self.extra = tuple(sorted(set(extra)))
+        # members only: k-mers with a lower-case letter (rare windows of soft-masked stretches — the reference's get_rare_kmers returns them,
+        # no cloud can hold them); they have no code, their indices lie behind every rank
+        self.inert = tuple(sorted(set(inert)))
         if codes.size and int(codes[-1]) >= EXOTIC_BASE:      # (already carries its pseudo-codes: the device's list read back)
             codes = codes[codes < np.uint64(EXOTIC_BASE)]
         self.n_acgt = int(codes.size)
@@ -77,16 +80,17 @@ class KmerSet(Set):
             codes = np.concatenate([codes, np.uint64(EXOTIC_BASE) + np.arange(len(self.extra), dtype=np.uint64)])
         self.codes = np.ascontiguousarray(codes, np.uint64)
         self._extra_rank = {s: self.n_acgt + j for j, s in enumerate(self.extra)}
+        self._inert_rank = {s: int(self.codes.size) + j for j, s in enumerate(self.inert)}
 
     @classmethod
     def _from_iterable(cls, it):   # results of set algebra fall back to plain sets
         return set(it)
 
     def __len__(self):
-        return int(self.codes.size)
+        return int(self.codes.size) + len(self.inert)
 
     def __contains__(self, s):
-        if s in self._extra_rank:
+        if s in self._extra_rank or s in self._inert_rank:
             return True
         c = try_encode(s, self.k)
         if c is None:
@@ -97,14 +101,15 @@ class KmerSet(Set):
     def strings(self, ranks=None):
         """the k-mers of the given ranks (all, in rank order, by default) as strings"""
         if ranks is None:
-            return decode(self.codes[:self.n_acgt], self.k) + list(self.extra)
+            return decode(self.codes[:self.n_acgt], self.k) + list(self.extra) + list(self.inert)
         ranks = np.asarray(ranks, np.int64)
         out = np.empty(ranks.size, dtype=object)
         plain = ranks < self.n_acgt
         if plain.any():
             out[plain] = decode(self.codes[ranks[plain]], self.k)
         for i in np.flatnonzero(~plain):
-            out[i] = self.extra[int(ranks[i]) - self.n_acgt]
+            j = int(ranks[i]) - self.n_acgt
+            out[i] = self.extra[j] if j < len(self.extra) else self.inert[j - len(self.extra)]
         return out.tolist()
 
     def __iter__(self):
@@ -113,6 +118,8 @@ class KmerSet(Set):
     def index(self, s):
         if s in self._extra_rank:
             return self._extra_rank[s]
+        if s in self._inert_rank:
+            return self._inert_rank[s]
         c = try_encode(s, self.k)
         i = int(np.searchsorted(self.codes[:self.n_acgt], np.uint64(c))) if c is not None else -1
         if c is None or i >= self.n_acgt or int(self.codes[i]) != c:

@@ -92,6 +92,9 @@ int64_t cfh_exotic_list(const cfh_pack* p, int32_t k, int64_t read_lo, int64_t r
  * (distance_based_kmer_recruitment.py:47-53, :160-164).  k bytes each, ascending, at most cap written; returns their number (or < 0).
  * The caller carries them beside the 2-bit set (centroflye_amd/kmers.py: KmerSet.extra). */
 int64_t cfh_exotic_rare(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, char* out, int64_t cap);
+/* The rare windows that hold a lower-case letter (the rest of cfh_exotic_summary's out[3]): members of the set the reference's
+ * get_rare_kmers returns (distance_based_kmer_recruitment.py:66-82), never of a cloud (read_kmer_cloud.py:25 upper-cases the unit). */
+int64_t cfh_exotic_rare_lower(const cfh_pack* p, int32_t k, int32_t max_nonuniq, uint32_t lo, uint32_t hi, char* out, int64_t cap);
 /* Every such window that the reference's table keeps (twice in at most max_nonuniq reads, :56-62), lower case included: text (k bytes
  * each, ascending) and the number of reads holding it — the keys of get_kmer_freqs_from_ncrf_report's mapping that have no 2-bit code. */
 int64_t cfh_exotic_kept(const cfh_pack* p, int32_t k, int32_t max_nonuniq, char* out, int64_t* pres, int64_t cap);

@@ -129,6 +129,39 @@ def test_rare_kmer_with_an_N_is_carried_as_a_string(emu_lib, tmp_path):
     assert list(zip(hu.tolist(), hr.tolist())) == want and len(want) >= 12
 
 
+def test_rare_soft_masked_windows_are_members_of_the_rare_set_only(emu_lib, tmp_path):
+    """The same soft-masked stretch in twelve reads: its windows are RARE k-mers of the reference's get_rare_kmers (the raw text, :47-53 / :66-82)
+    and keys of its kmer_index — and of nothing else: no cloud holds them (read_kmer_cloud.py:25 upper-cases the unit), so no edge and no line
+    of the k-mer file.  Round 5 (tools/fuzz_api2_vs_reference.py): the returned set left them out."""
+    from centroflye_amd import read_kmer_cloud as rkc
+    from centroflye_amd.ncrf_parser import NCRF_Report
+    unit = "ACGTTGCAAGGCTTAACCGGATCGATTACAGGCATCGGAT"
+    lines = []
+    for r in range(12):
+        row = unit * 200
+        row = row[:333] + row[333:363].lower() + row[363:]
+        lines += [f"read{r} {len(row) + 50} {len(row)}bp 10-{10 + len(row)} {row}", f"{unit}+ {len(row)}bp score=9 {row}"]
+    path = tmp_path / "lower.ncrf"
+    path.write_text("\n".join(lines) + "\n")
+    session.reset()
+    session._engine = Engine(0, emu_lib)
+    try:
+        rep = NCRF_Report(str(path))
+        rare = dbkr.get_rare_kmers(rep, k=19, bottom=0.9, top=3.0, coverage=32, kmer_survival_rate=0.34, max_nonuniq=3, verbose=False)
+        row = (unit * 200)[:333] + (unit * 200)[333:363].lower() + (unit * 200)[363:]
+        want = sorted({row[w:w + 19] for w in range(333 - 18, 363) if row[w:w + 19] != row[w:w + 19].upper()})
+        assert list(rare.inert) == want and len(want) == 48 and all(x in rare for x in want) and len(rare) == rare.codes.size + 48
+        assert "acgttgcaaggcttaaccg" not in rare and set(rare) >= set(want)
+        clouds = rkc.get_reads_kmer_clouds(rep, n=1, k=19, genomic_kmers=rare)
+        assert not any(x in want for c in clouds.values() for u in c.kmers for x in u)
+        dist_cnt, kmer_index = dbkr.get_kmer_dist_map(clouds, rare, 0, 2 ** 62, 1, 2, False)
+        assert len(kmer_index) == len(rare) and sorted(kmer_index[x] for x in want) == list(range(rare.codes.size, rare.codes.size + 48))
+        uniq, edges = dbkr.filter_dist_tuples(dist_cnt, 4)
+        assert all(max(a, b) < rare.codes.size for _, a, b, _ in edges) and all(u < rare.codes.size for u in uniq)
+    finally:
+        session.reset()
+
+
 @pytest.fixture(scope="module")
 def g_rare():
     with open(os.path.join(ROOT, "tests", "golden", "exotic_rare.json")) as f:
@@ -189,10 +222,11 @@ def test_presence_mapping_and_rare_set_equal_the_reference_key_by_key(emu_lib, f
         assert len(freqs) == gg["presence"]["n"] and canon.presence_digest(freqs.items()) == gg["presence"]["digest"]
         rare = dbkr.get_rare_kmers(rep, k=p2["k"], bottom=p2["bottom"], top=p2["top"], coverage=p2["coverage"],
                                    kmer_survival_rate=p2["kmer_survival_rate"], max_nonuniq=p2["max_nonuniq"], verbose=False)
-        # the reference's rare set also holds rare windows WITH lower-case letters: they can match nothing downstream and are not carried
+        # (the reference's rare set also holds rare windows WITH lower-case letters: members of the returned set since round 5 —
+        # tools/fuzz_api2_vs_reference.py —, they can match nothing downstream)
+        assert len(rare) == gg["rare"]["n"] and canon.set_digest(list(rare)) == gg["rare"]["digest"]
         lo, hi = dbkr.rare_window(p2["bottom"], p2["top"], p2["coverage"], p2["kmer_survival_rate"])
-        inert = [s for s, v in freqs.extra.items() if lo <= v <= hi and s != s.upper()]
-        assert len(rare) + len(inert) == gg["rare"]["n"] and canon.set_digest(list(rare) + inert) == gg["rare"]["digest"]
+        assert sorted(rare.inert) == sorted(s for s, v in freqs.extra.items() if lo <= v <= hi and s != s.upper())
     finally:
         session.reset()
 
