@@ -56,6 +56,7 @@ def main():
     import ncrf_parser as RP
     import numpy as np
     from centroflye_amd import _host
+    from centroflye_amd.ncrf_parser import NCRF_Report as ONR
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100
     seed, budget, keep = arg("--seed", 1), arg("--seconds", 10 ** 9, float), arg("--keep", "", str)
     rng = random.Random(seed)
@@ -112,6 +113,22 @@ def main():
                         diffs.append(f"class {c}")
             if sorted(pk.discarded_reads) != sorted(ref.discarded_reads):
                 diffs.append("discarded reads")
+            # the same through the drop-in class (centroflye_amd.ncrf_parser.NCRF_Report): records, their attributes, the MotifAlignment tuples
+            mir = ONR(report)
+            if list(mir.records) != list(ref.records) or sorted(mir.discarded_reads) != sorted(ref.discarded_reads):
+                diffs.append("mirror: records / discarded")
+            else:
+                for r_id, x in ref.records.items():
+                    y = mir.records[r_id]
+                    if (y.r_id, y.r_len, y.r_al_len, y.r_st, y.r_en, y.strand, y.motif, y.r_al, y.m_al) != (x.r_id, x.r_len, x.r_al_len, x.r_st, x.r_en, x.strand, x.motif, x.r_al, x.m_al):
+                        diffs.append(f"mirror: attributes of {r_id}")
+                    for n in (1, 2):
+                        if [tuple(m) for m in y.get_motif_alignments(n=n)] != [tuple(m) for m in x.get_motif_alignments(n=n)]:
+                            diffs.append(f"mirror: motif alignments n={n} of {r_id}")
+                if tuple(mir.classify(thr)) != tuple(ref.classify(large_threshold=thr)):
+                    diffs.append("mirror: classify")
+                if any(mir.read_lens[r] != ref.read_lens[r] for r in mir.read_lens):
+                    diffs.append("mirror: read_lens")
             rec.update(identical=not diffs, differences=diffs[:6], n_records=len(ref.records), n_discarded=len(ref.discarded_reads),
                        n_units=int(pk.units(1)[0][-1]) if pk.n_reads else 0)
         except Exception as ex:
