@@ -52,6 +52,12 @@ def test_cfhost_exports_every_declared_symbol():
         assert hasattr(lib, n), n
 
 
+def test_the_host_library_is_not_older_than_its_sources():
+    src = os.path.join(ROOT, "centroflye_amd", "csrc", "host")
+    newest = max([os.path.getmtime(os.path.join(src, fn)) for fn in os.listdir(src) if fn.endswith((".cpp", ".h"))] + [os.path.getmtime(os.path.join(ROOT, "include", "cfhost.h"))])
+    assert os.path.getmtime(_host._LIB_PATH) >= newest, "libcfhost.so is older than its sources: rebuild it (make -C centroflye_amd/csrc host)"
+
+
 def test_missing_extension_fails_loudly(tmp_path):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load(str(tmp_path / "libcfhip.so"))
