@@ -78,6 +78,30 @@ def test_cf_gpus_ranks_write_the_oracles_files_on_emulated_kernels(emu_lib, repo
     assert not [p for p in os.listdir(tmp_path) if ".tmp" in p or p.startswith(".cfpack")]
 
 
+def test_more_ranks_than_reads(emu_lib, report, tmp_path, monkeypatch):
+    """Two reads, three ranks: one rank has no read at all (an empty shard goes through the table exchange, the gathers and the distance stage
+    like any other); the files are the numpy oracle's for those two records."""
+    from oracle import ncrf
+    with open(report("lowcov")) as f:
+        lines = f.read().split("\n")
+    recs = [i for i, ln in enumerate(lines) if ln and not ln.startswith("#")][:4]
+    small = tmp_path / "two_reads.ncrf"
+    small.write_text("\n".join(lines[i] for i in recs) + "\n")
+    p2 = dict(fixtures.STAGE2_DEFAULTS, coverage=2, min_coverage=2, max_distance=1)      # the window 0.9 .. 3 x 2 x 0.34 keeps k-mers of one or two reads
+    out = tmp_path / "out"
+    assert _launch(_argv(str(small), str(out), p2), 3, monkeypatch) == 0
+    records, _, _ = ncrf.parse_report(str(small))
+    assert len(records) == 2
+    res = recruit.stage2(records, k=p2["k"], bottom=p2["bottom"], top=p2["top"], coverage=p2["coverage"], kmer_survival_rate=p2["kmer_survival_rate"],
+                         max_nonuniq=p2["max_nonuniq"], min_n=p2["min_nreads"], max_n=p2["max_nreads"], min_d=p2["min_distance"], max_d=p2["max_distance"],
+                         min_coverage=p2["min_coverage"])
+    with open(out / "unique_kmers_min_edge_cov_2.txt") as f:
+        assert f.read() == recruit.kmers_file_text(res["rare"], res["unique"], p2["k"])
+    with open(out / "unique_edges_min_edge_cov_2.txt") as f:
+        got = f.read().splitlines()
+    assert sorted(got) == recruit.edges_file_lines(res["rare"], res["edges"], p2["k"]) and len(got) > 100
+
+
 def test_cf_gpus_2_reproduces_the_reference_files_with_rare_N_kmers_on_emulated_kernels(emu_lib, fx_dir, tmp_path, monkeypatch):
     """Fixture exotic_rare (goldens written by the reference itself): 35 of the unique k-mers hold an N; they travel through the
     sharded path as strings and reach both files."""
