@@ -133,7 +133,8 @@ def main():
               "--min-unit", str(rng.choice([1, 2, 2, 3])), "--min-inters", str(rng.choice([1, 4, 10, 10, 30])), "--prefix-threshold", str(sy["prefix_threshold"])]
         sharded = (rng.choice([2, 3]), rng.choice([0, 0, 500])) if rng.random() < 0.33 else None      # (ranks, edge rows per sub-partition)
         polish = (rng.choice([0, 0, 1, 3]), rng.choice([None, None, 4, 9])) if rng.random() < 0.6 else None      # (--min-pos, --max-pos) of the export
-        rec = dict(case=i, synth=sy, mutate=mut, stage2=a2, stage3=a3, sharded=sharded, polish=polish)
+        kfile_edit = rng.randrange(1, 10 ** 6) if rng.random() < 0.35 else None      # seed of the edits of the k-mer file handed to stage 3
+        rec = dict(case=i, synth=sy, mutate=mut, stage2=a2, stage3=a3, sharded=sharded, polish=polish, kfile_edit=kfile_edit)
         if only >= 0 and i != only:
             continue
         work = tempfile.mkdtemp(prefix="cf_fuzz_cli_")
@@ -163,7 +164,20 @@ def main():
                 if rc or not os.path.exists(kf):
                     outs[who] = dict(failed="stage 2", log=log)
                     continue
-                rc, log = run(tmpl % dict(extra, module="read_placer", argv=["--ncrf", report, "--genomic-kmers", kf, "--outdir", o3] + a3), 150 if who == "our" else 1800)
+                kf3 = kf
+                if kfile_edit is not None:      # the k-mer list a user hands to stage 3: the same edits of the same lines for both sides
+                    kf3 = os.path.join(o2, "edited_kmers.txt")
+                    er = random.Random(kfile_edit)
+                    kl = open(kf).read().split("\n")
+                    er.shuffle(kl)
+                    extra_lines = []
+                    for x in kl[:50]:
+                        what = er.choice(["dup", "lower", "short", "blank", "pad", "N"])
+                        extra_lines.append(x if what == "dup" else x.lower() if what == "lower" else x[:-1] if what == "short" else "" if what == "blank" else "  " + x + " \t" if what == "pad" else ("N" + x[1:] if x else x))
+                    kl = kl[: max(1, (len(kl) * 4) // 5)] + extra_lines      # (a fifth of the k-mers dropped too)
+                    er.shuffle(kl)
+                    open(kf3, "w", newline="").write(("\r\n" if er.random() < 0.3 else "\n").join(kl))
+                rc, log = run(tmpl % dict(extra, module="read_placer", argv=["--ncrf", report, "--genomic-kmers", kf3, "--outdir", o3] + a3), 150 if who == "our" else 1800)
                 pf = os.path.join(o3, "read_positions.csv")
                 if rc or not os.path.exists(pf):
                     outs[who] = dict(failed="stage 3", log=log, kmers=open(kf, "rb").read(), edges=sorted(open(ef).read().splitlines()))
@@ -216,9 +230,9 @@ def main():
             shutil.copytree(work, os.path.join(keep, f"case{i}"), dirs_exist_ok=True)
         shutil.rmtree(work, ignore_errors=True)
         recs.append(rec)
-        print(json.dumps({k: rec.get(k) for k in ("case", "identical", "differences", "ref_failed", "our_failed", "n_kmers", "n_edges", "n_placed", "n_none", "stage2", "stage3", "mutate", "sharded", "polisher", "s")}), flush=True)
+        print(json.dumps({k: rec.get(k) for k in ("case", "identical", "differences", "ref_failed", "our_failed", "n_kmers", "n_edges", "n_placed", "n_none", "stage2", "stage3", "mutate", "sharded", "polisher", "kfile_edit", "s")}), flush=True)
     bad = [r for r in recs if not r["identical"]]
-    summary = dict(seed=seed, cases=len(recs), identical=len(recs) - len(bad), different=len(bad), both_refused=sum(1 for r in recs if r.get("ref_failed") and r["identical"]), sharded=sum(1 for r in recs if r.get("sharded") and r["identical"] and not r.get("skipped")), polisher_exports=sum(1 for r in recs if r.get("polisher")),
+    summary = dict(seed=seed, cases=len(recs), identical=len(recs) - len(bad), different=len(bad), both_refused=sum(1 for r in recs if r.get("ref_failed") and r["identical"]), sharded=sum(1 for r in recs if r.get("sharded") and r["identical"] and not r.get("skipped")), polisher_exports=sum(1 for r in recs if r.get("polisher")), edited_kmer_files=sum(1 for r in recs if r.get("kfile_edit") and not r.get("skipped")),
                    placed=sum(r.get("n_placed", 0) for r in recs), edges=sum(r.get("n_edges", 0) for r in recs), seconds=round(time.time() - t_start, 1))
     out = arg("--out", os.path.join(ROOT, "gpurun_out", "fuzz_cli_vs_reference.json"), str)
     os.makedirs(os.path.dirname(out), exist_ok=True)
