@@ -131,17 +131,22 @@ def _run_dist(dist_cnt, min_coverage, rel_threshold, edge_sink=None):
     mask.  edge_sink(edges uint32[n,4]) is called per partition (edges sorted by (d, a, b))."""
     e = dist_cnt.clouds.on_device()
     n_parts = 1
+    chunk = EDGE_CHUNK
+    n_first = max(1, int(dist_cnt.clouds.kset.codes.size))      # (more partitions than first k-mers split nothing: then the chunk grows)
     while True:
         e.reset_unique()
         ok = True
         total = 0
         for part in range(n_parts):
             n = e.dist_edges(dist_cnt.min_n, dist_cnt.max_n, dist_cnt.min_d, dist_cnt.max_d, min_coverage, rel_threshold,
-                             part, n_parts, EDGE_CHUNK if edge_sink is not None else 0)
+                             part, n_parts, chunk if edge_sink is not None else 0)
             total += n
             if edge_sink is not None:
-                if n > EDGE_CHUNK:      # partition too large to fetch: start over with more partitions
-                    n_parts = max(2 * n_parts, int(n_parts * (n / EDGE_CHUNK) * 1.5) + 1)
+                if n > chunk:      # partition too large to fetch: start over with more partitions
+                    if n_parts >= n_first:
+                        chunk = int(n)
+                    else:
+                        n_parts = min(max(2 * n_parts, int(n_parts * (n / chunk) * 1.5) + 1), n_first)
                     edge_sink(None)
                     ok = False
                     break

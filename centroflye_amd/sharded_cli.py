@@ -163,7 +163,13 @@ def rank_main(argv=None, lib=None, device=None, sub_edges=None, knobs=None):
                 if not want_edges:
                     continue
                 if n > chunk:
-                    n_sub = max(2 * n_sub, int(n_sub * (n / chunk) * 1.5) + 1)
+                    # (more sub-partitions — but never more than there are first k-mers: a single first k-mer with more edges than the chunk
+                    # holds, which only a test's tiny chunk makes possible, gets a larger chunk instead; round 5, tools/fuzz_cli_vs_reference.py:
+                    # the count grew until world * n_sub left the 32-bit range)
+                    if n_sub >= max(1, n_rare):
+                        chunk = int(n)
+                    else:
+                        n_sub = min(max(2 * n_sub, int(n_sub * (n / chunk) * 1.5) + 1), max(1, n_rare))
                     again = True
                     break
                 sr.engine.sort_edges()

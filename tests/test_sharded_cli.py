@@ -78,6 +78,23 @@ def test_cf_gpus_ranks_write_the_oracles_files_on_emulated_kernels(emu_lib, repo
     assert not [p for p in os.listdir(tmp_path) if ".tmp" in p or p.startswith(".cfpack")]
 
 
+def test_a_chunk_smaller_than_one_first_kmers_edges(emu_lib, report, oracle_stage2, tmp_path, monkeypatch):
+    """sub_edges = 1: fewer rows than ONE first k-mer has edges — the sub-partitions stop at one first k-mer each and the chunk grows instead
+    (round 5, tools/fuzz_cli_vs_reference.py: their number grew until world * n_sub left the 32-bit range: 'bad partition').  A rare window of
+    exactly 9 reads keeps the k-mer set (and the number of launches on the emulator) small."""
+    name = "lowcov"
+    over = dict(max_distance=2, bottom=1.0, top=1.0, coverage=9, kmer_survival_rate=1.0, min_coverage=1)
+    p2 = dict(fixtures.stage2_params(name), **over)
+    extra = ["--bottom", "1.0", "--top", "1.0", "--kmer-survival-rate", "1.0"]
+    assert _launch(_argv(report(name), str(tmp_path), p2, extra), 2, monkeypatch, 1) == 0
+    records, alns, lens, res, _ = oracle_stage2(name, **over)
+    assert 10 < res["rare"].size < 2000 and res["edges"].shape[0] > 50
+    with open(tmp_path / "unique_kmers_min_edge_cov_1.txt") as f:
+        assert f.read() == recruit.kmers_file_text(res["rare"], res["unique"], p2["k"])
+    with open(tmp_path / "unique_edges_min_edge_cov_1.txt") as f:
+        assert sorted(f.read().splitlines()) == recruit.edges_file_lines(res["rare"], res["edges"], p2["k"])
+
+
 def test_more_ranks_than_reads(emu_lib, report, tmp_path, monkeypatch):
     """Two reads, three ranks: one rank has no read at all (an empty shard goes through the table exchange, the gathers and the distance stage
     like any other); the files are the numpy oracle's for those two records."""

@@ -131,7 +131,7 @@ def main():
             a2 += ["--min-nreads", str(lo_r), "--max-nreads", str(lo_r + rng.choice([1, 6, 100]))]
         a3 = ["--n-motif", str(rng.choice([1, 1, 2])), "--k-cloud", str(k), "--min-cloud-kmer-freq", str(rng.choice([1, 2, 2, 3])), "--min-kmer-mult", str(rng.choice([1, 2, 2, 3])),
               "--min-unit", str(rng.choice([1, 2, 2, 3])), "--min-inters", str(rng.choice([1, 4, 10, 10, 30])), "--prefix-threshold", str(sy["prefix_threshold"])]
-        sharded = (rng.choice([2, 3]), rng.choice([0, 0, 500])) if rng.random() < 0.33 else None      # (ranks, edge rows per sub-partition)
+        sharded = (rng.choice([2, 3]), rng.choice([0, 0, 20000])) if rng.random() < 0.33 else None      # (ranks, edge rows per sub-partition)
         polish = (rng.choice([0, 0, 1, 3]), rng.choice([None, None, 4, 9])) if rng.random() < 0.6 else None      # (--min-pos, --max-pos) of the export
         kfile_edit = rng.randrange(1, 10 ** 6) if rng.random() < 0.35 else None      # seed of the edits of the k-mer file handed to stage 3
         rec = dict(case=i, synth=sy, mutate=mut, stage2=a2, stage3=a3, sharded=sharded, polish=polish, kfile_edit=kfile_edit)
