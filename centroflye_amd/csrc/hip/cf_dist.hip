@@ -264,11 +264,12 @@ struct cf_dist_args {
     uint32_t fill_limit;
     uint32_t est_limit;            // emissions one partition is expected to hold (fill_limit / expected distinct share)
     int32_t sketch;                // 1: count first in 8-bit counters, build the exact table only for k-mers that can pass min_cov
-    uint32_t sk_counters, sk_shift;   // counters (a power of two that fits the LDS that is dead during the sketch sweep) and 32 - log2 of it
+    uint32_t sk_counters, sk_shift, sk_mask;   // counters (a power of two that fits the LDS that is dead during the sketch sweep), 32 - log2 of it, and it - 1
     const cf_dist_head* heads;     // the first k-mers of the launch in processing order (cf_items_fill_kernel) ...
     const cf_dist_item* items;     // ... and the item records of their sweeps, laid out per wave of a workgroup of blockDim.x threads
     uint32_t stage_cap;            // <= DIST_STAGE_CAP
     uint32_t hot_cap;              // cap on the filter's list of hot slots (tests: a small one forces the in-scan evaluation)
+    uint32_t hot_entries;          // first k-mers with more partner entries than this do not keep the list at all (it would overflow: the filter scans)
     uint32_t* edges;
     unsigned long long edge_cap;
     const int32_t* order;          // first k-mers of this partition, sorted by their first posting (locality)
@@ -379,7 +380,7 @@ struct cf_tab_wide_t {
     static constexpr uint32_t kSlotsPerBucket = 4;
     static constexpr bool kProbe1 = false;      // (64-bit slots: the drain keeps its match / claim branches)
     __device__ __forceinline__ void probe1(bool, uint32_t, uint32_t, uint32_t, bool&, bool&, uint32_t&) const {}
-    __device__ __forceinline__ void probe2(bool, uint32_t, uint32_t, bool, uint32_t, uint32_t, uint32_t, bool&, bool&, uint32_t&, bool&, bool&, uint32_t&) const {}
+    __device__ __forceinline__ void probe2(bool, uint32_t, uint32_t, uint32_t, bool, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, bool&, bool&, uint32_t&, bool&, bool&, uint32_t&) const {}
     __device__ __forceinline__ uint32_t key_of(uint32_t, uint32_t) const { return 0u; }
     // claim slot i of bucket bk for (b, dd): 0 = claimed (count 1), 1 = the same key got there first (counted), 2 = another key
     __device__ __forceinline__ unsigned long long claim_issue(uint32_t bk, int i, uint32_t b, uint32_t dd) const {
@@ -463,35 +464,55 @@ typedef cf_tab_wide_t<16> cf_tab_wide16;
 // The same straight line as probe1 below, written stage by stage for both inserts — both bucket reads, both slot searches, both
 // claims, both count adds — so that the two chains of LDS round trips are in flight together.  Two inserts of one lane may meet in
 // one bucket: they then behave like two lanes that do (the second claim of the same key sees the key and counts; another key's parks).
+// Round 6, measured and switched off (CF_DIST_PROBE_TWICE): an insert that finds its bucket full without its key (or loses the slot it
+// wanted to another key) gets a SECOND straight-line probe at once — of the next bucket of its chain, or the same one again — before it is
+// parked.  On cenX-shaped reads 4 % of the inserts park (2.2 trips of the probe loop each, 28 lanes per run: a run takes 4 400 cycles —
+// every LDS round trip under this kernel's load is 350-650 cycles; profiles/r06_dist_ab_cenx.log).
+#ifndef CF_DIST_PROBE_TWICE
+#define CF_DIST_PROBE_TWICE 0      /* measured: 117.5 (every lane) / 118.0 ms (parked lanes only) against 108.0 without on cenX-shaped reads, 249 against 240.6 on the bench's: the second probe's LDS round trips cost every drain more than the parked inserts' loop costs the few */
+#endif
 template <class Tab>
-__device__ __forceinline__ void cf_probe2(const Tab& T, bool act0, uint32_t bk0, uint32_t key0, bool act1, uint32_t bk1, uint32_t key1, uint32_t min_cov,
+__device__ __forceinline__ void cf_probe2(const Tab& T, bool act0, uint32_t bk0, uint32_t key0, uint32_t b0, bool act1, uint32_t bk1, uint32_t key1, uint32_t b1, uint32_t n_buckets, uint32_t min_cov,
                                           bool& made0, bool& park0, uint32_t& hot0, bool& made1, bool& park1, uint32_t& hot1) {
     constexpr int PB_ = (int)Tab::kPerBucket;
-    const typename Tab::bucket k0 = T.read(bk0), k1 = T.read(bk1);
-    uint32_t em0 = (uint32_t)PB_, em1 = (uint32_t)PB_;
+    bool full0 = false, full1 = false;      // the bucket had neither the key nor a free slot (else a parked insert lost its slot to another key)
+    auto stage = [&](bool a0, uint32_t k0b, bool a1, uint32_t k1b, bool& md0, bool& pk0, uint32_t& ht0, bool& md1, bool& pk1, uint32_t& ht1) {
+        const typename Tab::bucket k0 = T.read(k0b), k1 = T.read(k1b);
+        uint32_t em0 = (uint32_t)PB_, em1 = (uint32_t)PB_;
 #pragma unroll
-    for (int j = PB_ - 1; j >= 0; --j) { em0 = k0.k[j] == Tab::kEmpty ? (uint32_t)j : em0; em1 = k1.k[j] == Tab::kEmpty ? (uint32_t)j : em1; }
-    uint32_t sl0 = em0, sl1 = em1;
-    bool mt0 = false, mt1 = false;
+        for (int j = PB_ - 1; j >= 0; --j) { em0 = k0.k[j] == Tab::kEmpty ? (uint32_t)j : em0; em1 = k1.k[j] == Tab::kEmpty ? (uint32_t)j : em1; }
+        uint32_t sl0 = em0, sl1 = em1;
+        bool mt0 = false, mt1 = false;
 #pragma unroll
-    for (int j = PB_ - 1; j >= 0; --j) {
-        const bool e0 = k0.k[j] == key0, e1 = k1.k[j] == key1;
-        sl0 = e0 ? (uint32_t)j : sl0; mt0 |= e0; sl1 = e1 ? (uint32_t)j : sl1; mt1 |= e1;
+        for (int j = PB_ - 1; j >= 0; --j) {
+            const bool e0 = k0.k[j] == key0, e1 = k1.k[j] == key1;
+            sl0 = e0 ? (uint32_t)j : sl0; mt0 |= e0; sl1 = e1 ? (uint32_t)j : sl1; mt1 |= e1;
+        }
+        mt0 &= a0; mt1 &= a1;
+        const bool claim0 = a0 && !mt0 && em0 < (uint32_t)PB_, claim1 = a1 && !mt1 && em1 < (uint32_t)PB_;
+        const uint32_t s0 = (uint32_t)PB_ * k0b + (sl0 & (uint32_t)(PB_ - 1)), s1 = (uint32_t)PB_ * k1b + (sl1 & (uint32_t)(PB_ - 1));
+        uint32_t old0 = key0, old1 = key1;
+        if (claim0) old0 = atomicCAS(&T.keys[s0], Tab::kEmpty, key0);
+        if (claim1) old1 = atomicCAS(&T.keys[s1], Tab::kEmpty, key1);
+        const bool matched0 = mt0 || (claim0 && old0 == key0), fresh0 = claim0 && old0 == Tab::kEmpty;
+        const bool matched1 = mt1 || (claim1 && old1 == key1), fresh1 = claim1 && old1 == Tab::kEmpty;
+        const uint32_t sh0 = (s0 & 1u) * 16u, sh1 = (s1 & 1u) * 16u;
+        const uint32_t was0 = atomicAdd(&T.cnt32[s0 >> 1], matched0 ? 1u << sh0 : 0u);
+        const uint32_t was1 = atomicAdd(&T.cnt32[s1 >> 1], matched1 ? 1u << sh1 : 0u);
+        const uint32_t cnt0 = matched0 ? ((was0 >> sh0) & 0x7FFFu) + 2u : 1u, cnt1 = matched1 ? ((was1 >> sh1) & 0x7FFFu) + 2u : 1u;
+        md0 = fresh0; pk0 = a0 && !(matched0 || fresh0); ht0 = ((matched0 || fresh0) && cnt0 == min_cov) ? s0 : 0xFFFFFFFFu;
+        md1 = fresh1; pk1 = a1 && !(matched1 || fresh1); ht1 = ((matched1 || fresh1) && cnt1 == min_cov) ? s1 : 0xFFFFFFFFu;
+        full0 = a0 && !mt0 && em0 >= (uint32_t)PB_; full1 = a1 && !mt1 && em1 >= (uint32_t)PB_;
+    };
+    stage(act0, bk0, act1, bk1, made0, park0, hot0, made1, park1, hot1);
+#if CF_DIST_PROBE_TWICE
+    if (park0 | park1) {      // (only the lanes with a parked insert: the others' LDS operations would double the drain's)
+        bool md0 = false, pk0 = false, md1 = false, pk1 = false;
+        uint32_t ht0 = 0xFFFFFFFFu, ht1 = 0xFFFFFFFFu;
+        stage(park0, full0 ? T.next(bk0, b0, n_buckets) : bk0, park1, full1 ? T.next(bk1, b1, n_buckets) : bk1, md0, pk0, ht0, md1, pk1, ht1);
+        made0 |= md0; made1 |= md1; hot0 = min(hot0, ht0); hot1 = min(hot1, ht1); park0 = pk0; park1 = pk1;      // (an insert has at most one of the two hot slots: the other is all ones)
     }
-    mt0 &= act0; mt1 &= act1;
-    const bool claim0 = act0 && !mt0 && em0 < (uint32_t)PB_, claim1 = act1 && !mt1 && em1 < (uint32_t)PB_;
-    const uint32_t s0 = (uint32_t)PB_ * bk0 + (sl0 & (uint32_t)(PB_ - 1)), s1 = (uint32_t)PB_ * bk1 + (sl1 & (uint32_t)(PB_ - 1));
-    uint32_t old0 = key0, old1 = key1;
-    if (claim0) old0 = atomicCAS(&T.keys[s0], Tab::kEmpty, key0);
-    if (claim1) old1 = atomicCAS(&T.keys[s1], Tab::kEmpty, key1);
-    const bool matched0 = mt0 || (claim0 && old0 == key0), fresh0 = claim0 && old0 == Tab::kEmpty;
-    const bool matched1 = mt1 || (claim1 && old1 == key1), fresh1 = claim1 && old1 == Tab::kEmpty;
-    const uint32_t sh0 = (s0 & 1u) * 16u, sh1 = (s1 & 1u) * 16u;
-    const uint32_t was0 = atomicAdd(&T.cnt32[s0 >> 1], matched0 ? 1u << sh0 : 0u);
-    const uint32_t was1 = atomicAdd(&T.cnt32[s1 >> 1], matched1 ? 1u << sh1 : 0u);
-    const uint32_t cnt0 = matched0 ? ((was0 >> sh0) & 0x7FFFu) + 2u : 1u, cnt1 = matched1 ? ((was1 >> sh1) & 0x7FFFu) + 2u : 1u;
-    made0 = fresh0; park0 = act0 && !(matched0 || fresh0); hot0 = ((matched0 || fresh0) && cnt0 == min_cov) ? s0 : 0xFFFFFFFFu;
-    made1 = fresh1; park1 = act1 && !(matched1 || fresh1); hot1 = ((matched1 || fresh1) && cnt1 == min_cov) ? s1 : 0xFFFFFFFFu;
+#endif
 }
 
 template <int DB, int PB = CF_NARROW_PB>
@@ -604,9 +625,9 @@ struct cf_tab_narrow_t {
         park = active && !(matched || fresh);
         hot_slot = ((matched || fresh) && cnt == min_cov) ? s : 0xFFFFFFFFu;
     }
-    __device__ __forceinline__ void probe2(bool act0, uint32_t bk0, uint32_t key0, bool act1, uint32_t bk1, uint32_t key1, uint32_t min_cov,
+    __device__ __forceinline__ void probe2(bool act0, uint32_t bk0, uint32_t key0, uint32_t b0, bool act1, uint32_t bk1, uint32_t key1, uint32_t b1, uint32_t n_buckets, uint32_t min_cov,
                                            bool& made0, bool& park0, uint32_t& hot0, bool& made1, bool& park1, uint32_t& hot1) const {
-        cf_probe2(*this, act0, bk0, key0, act1, bk1, key1, min_cov, made0, park0, hot0, made1, park1, hot1);
+        cf_probe2(*this, act0, bk0, key0, b0, act1, bk1, key1, b1, n_buckets, min_cov, made0, park0, hot0, made1, park1, hot1);
     }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
         const uint32_t q = keys[s];
@@ -826,9 +847,9 @@ struct cf_tab_region {
         park = active && !(matched || fresh);
         hot_slot = ((matched || fresh) && cnt == min_cov) ? s : 0xFFFFFFFFu;
     }
-    __device__ __forceinline__ void probe2(bool act0, uint32_t bk0, uint32_t key0, bool act1, uint32_t bk1, uint32_t key1, uint32_t min_cov,
+    __device__ __forceinline__ void probe2(bool act0, uint32_t bk0, uint32_t key0, uint32_t b0, bool act1, uint32_t bk1, uint32_t key1, uint32_t b1, uint32_t n_buckets, uint32_t min_cov,
                                            bool& made0, bool& park0, uint32_t& hot0, bool& made1, bool& park1, uint32_t& hot1) const {
-        cf_probe2(*this, act0, bk0, key0, act1, bk1, key1, min_cov, made0, park0, hot0, made1, park1, hot1);
+        cf_probe2(*this, act0, bk0, key0, b0, act1, bk1, key1, b1, n_buckets, min_cov, made0, park0, hot0, made1, park1, hot1);
     }
     __device__ __forceinline__ bool get(uint32_t s, uint32_t& b, uint32_t& dd, uint32_t& cnt) const {
         const uint32_t q = keys[s];
@@ -981,8 +1002,9 @@ __device__ __forceinline__ uint32_t cf_rank_in(unsigned long long m) { return __
 // general insert: walk buckets from bk; claims the first empty slot with a CAS when the key is absent.
 // Returns 1 when a new key was created; hot := the slot when this occurrence brought its count to exactly min_cov.
 template <class Tab>
-__device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buckets, uint32_t bk, uint32_t b, uint32_t dd, uint32_t* sh, uint32_t min_cov, uint32_t& hot) {
+__device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buckets, uint32_t bk, uint32_t b, uint32_t dd, uint32_t* sh, uint32_t min_cov, uint32_t& hot, unsigned long long* trips = nullptr) {
     for (uint32_t tries = 0; tries < 9 * n_buckets; ++tries) {
+        if (trips) ++*trips;
         const typename Tab::bucket k = T.read(bk);
         const int m = T.match(k, b, dd);
         if (m >= 0) { if (T.add(bk, m) == min_cov) hot = Tab::kSlotsPerBucket * bk + (uint32_t)m; return 0u; }
@@ -1128,11 +1150,28 @@ cf_items_fill_kernel(const int32_t* __restrict__ order, int64_t n_order, const i
 // its insert queue there (one copy of that code in the loop instead of one per push site).
 // body(bb, dd, qk, lo, ok, len): the decoded entries of a step; ok = per-lane bit mask of the entries that exist (only the last item of
 // a posting has lanes past its end: len < DIST_ITEM, wave-uniform, says whether ok needs looking at); returns true to stop the wave.
+// (Round 6, measured and removed: the waves of a workgroup SHARING their items — per list one LDS word [items taken from its end | items its
+// owner claimed], the owner's claim in flight under the step before, a wave out of items taking half of what the fullest list has left with
+// one record load.  Thread 0's stamps had put 22 % of the kernel on cenX-shaped reads (9 % on the bench's) into waiting for the other waves
+// at the end of a sweep; with sharing: 114-116 ms against 109.9 without on those reads, 259-271 against 243.3 on the bench's, whatever the
+// thresholds (profiles/r06_dist_ab_steal.log) — the wait is not idle hardware: a wave that is through leaves its issue slots and LDS
+// cycles to the others, and a thief's first step waits for two round trips to memory.)
 template <class Tab, int D, class Pre, class Body>
 __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_dist_item* recs, uint32_t mine, const cf_dist_item& my0, Pre&& pre, Body&& body) {
     const uint32_t lane = threadIdx.x & 63u, l4 = lane * DIST_UNROLL;
-    if (mine == 0u) return;
-    for (uint32_t j0 = 0; j0 < mine; j0 += 64u) {      // (one round whenever the wave has at most 64 items)
+    auto ok_of = [&](uint32_t m) -> uint32_t {      // per-lane mask of the entries of an item that exist
+        uint32_t ok = (1u << DIST_UNROLL) - 1u;
+        if ((m >> 16) < DIST_ITEM) {      // (wave-uniform) the last item of a posting
+            ok = 0;
+#pragma unroll
+            for (int u = 0; u < DIST_UNROLL; ++u) ok |= (uint32_t)(l4 + (uint32_t)u < (m >> 16)) << u;
+        }
+        return ok;
+    };
+    // Round 6: pre(false) in front of every step and pre(true) ONCE behind the loop over the windows (rounds 3-5 computed "is this the
+    // wave's last step" inside the loop and passed it to the one call site): 251.5 -> 243.3 ms on the bench's reads, 115.4 -> 109.9 on
+    // cenX-shaped ones — found while measuring the work sharing above, whose loop had this shape.
+    for (uint32_t j0 = 0; j0 < mine; j0 += 64u) {      // (one window whenever the wave has at most 64 items)
         const uint32_t cnt = min(64u, mine - j0);
         cf_dist_item my = my0;
         if (j0) { my = cf_dist_item{0u, 0u}; if (lane < cnt) my = recs[j0 + lane]; }
@@ -1143,15 +1182,6 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
         // out the loads it had just issued, every D steps, whatever D was; round 5, read off the ISA.)
         constexpr int NS = D + 1;
         typename Tab::raw ring[NS][DIST_UNROLL];
-        auto ok_of = [&](uint32_t m) -> uint32_t {      // per-lane mask of the entries of an item that exist
-            uint32_t ok = (1u << DIST_UNROLL) - 1u;
-            if ((m >> 16) < DIST_ITEM) {      // (wave-uniform) the last item of a posting
-                ok = 0;
-#pragma unroll
-                for (int u = 0; u < DIST_UNROLL; ++u) ok |= (uint32_t)(l4 + (uint32_t)u < (m >> 16)) << u;
-            }
-            return ok;
-        };
 #define CF_DIST_FETCH(J, SET) {                                                                                 \
             const uint32_t s_e = (uint32_t)__builtin_amdgcn_readlane((int)my.e, (int)(J));                      \
             const uint32_t fm_ = (uint32_t)__builtin_amdgcn_readlane((int)my.m, (int)(J));                      \
@@ -1159,7 +1189,7 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
         }
 #pragma unroll
         for (int d = 0; d < D; ++d) CF_DIST_FETCH(min((uint32_t)d, cnt - 1u), d)      // (unconditional, see below)
-        // the steps of this round: a lambda, so that "the wave's items are through" leaves the unrolled loop by a plain return — with a flag
+        // the steps of this window: a lambda, so that "the window's items are through" leaves the unrolled loop by a plain return — with a flag
         // tested at the loop head the compiler saw a path from every exit back into the loop and made the head wait for every load
         // in flight (s_waitcnt vmcnt(0) in front of the first fetch of every D + 1 steps)
         const bool stop = [&]() -> bool {
@@ -1174,7 +1204,7 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
                     // Unconditional: a wave past its last item fetches that one again — with a fetch under a condition the number of
                     // loads in flight differs between the paths into the loop head and the compiler waits for ALL of them there.
                     CF_DIST_FETCH(min(j + (uint32_t)D, cnt - 1u), (p + D) % NS)
-                    pre(j == cnt && j0 + 64u >= mine);
+                    pre(false);
                     if (j == cnt) return false;
                     const uint32_t cm = (uint32_t)__builtin_amdgcn_readlane((int)my.m, (int)j);
                     uint32_t bb[DIST_UNROLL], dd_[DIST_UNROLL], qq_[DIST_UNROLL], lo_[DIST_UNROLL];
@@ -1186,11 +1216,15 @@ __device__ __forceinline__ void cf_dist_sweep(const cf_dist_args& A, const cf_di
                 }
             }
         }();
-        if (stop) return;
 #undef CF_DIST_FETCH
+        if (stop) return;
     }
+    pre(true);      // after the wave's last step: the table sweep empties its queues
 }
 
+#ifndef CF_DIST_SKETCH_BY_B
+#define CF_DIST_SKETCH_BY_B 0
+#endif
 #ifndef CF_DIST_PF_A
 #define CF_DIST_PF_A 1      /* loads in flight per lane while a step of the sketch sweep is worked on (round 5, with the pipeline that really keeps them in flight: 1 / 2 / 3 = 250.6 / 251.7 / 257.6 ms) */
 #endif
@@ -1233,6 +1267,14 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
     uint16_t* hotl = (uint16_t*)(wq0 + (size_t)(nt >> 6) * (DIST_QSTRIDE + DIST_OVQ));      // DIST_HOT_CAP slots whose count reached min_cov during the inserts of the pass
     const uint32_t slots = (uint32_t)A.slots, n_buckets = slots / Tab::kPerBucket;   // slots is a multiple of 8
     unsigned long long acc_E = 0, acc_spill = 0, acc_pass = 0, acc_edges = 0;  // flushed once per workgroup (thread 0)
+#if defined(CF_DIST_DIAG_COUNT)      /* diagnostic build: [0] loop trips of parked inserts [1] overflow calls [2] parked inserts run [3] drains [4] inserts drained */
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};      /* [5] shader cycles inside the parked-insert runs [6] inside the drains [7] inside the table sweep, per wave (lane 0) */
+#define CF_DG(X) X
+#define CF_DG_PTR (&dg[0])
+#else
+#define CF_DG(X)
+#define CF_DG_PTR nullptr
+#endif
 #if defined(CF_DIST_STAMPS)
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -1292,6 +1334,10 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         const int64_t ai = (int64_t)(((unsigned long long)sh[17] << 32) | sh[16]);
         if (ai < 0) break;
         const uint32_t a = sh[18], n_items = sh[19], n_ent_a = sh[22];
+        // Round 6: the list of slots that reach min_cov (one returning LDS add, a wait and a readfirstlane per drain that has one — on
+        // cenX-shaped reads every drain has a dozen) is not kept for a first k-mer that would overflow it anyway: its filter scans the count
+        // fields, as it did all along once the list was full (12 of 108 ms there)
+        const bool use_hot = n_ent_a <= A.hot_entries;
         // this wave's item records: one coalesced load, in flight while the sketch is cleared; both sweeps run on them
         const uint32_t per_w = (n_items + nw - 1u) / nw;
         const uint32_t mine = CF_DIST_ITEMS_BLOCKED ? (n_items > wv * per_w ? min(per_w, n_items - wv * per_w) : 0u) : (wv < n_items ? (n_items - wv + nw - 1u) / nw : 0u);
@@ -1336,7 +1382,17 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     uint32_t old_[DIST_UNROLL], sft_[DIST_UNROLL], inc_[DIST_UNROLL];
 #pragma unroll
                     for (int u = 0; u < DIST_UNROLL; ++u) {
+                        // (Round 6, measured, off: a counter per b — the low bits of the rank, i.e. of the raw stream word: no decode, no multiply;
+                        // Σ_d cnt(a, b, ·) bounds every cnt(a, b, d).  Its collisions NEST with the bitmap's (two counters per bit), and on reads
+                        // whose rare k-mers are copy-specific it lets fewer pairs through — 0.355 of the pairs inserted instead of 0.394 on
+                        // cenX-shaped reads, 6 100 keys per first k-mer instead of 7 900: 108.0 -> 101.9 ms — but a k-mer that recurs along the
+                        // array has pairs at every distance, is marked as a whole, and brings a key per distance into ONE probe chain:
+                        // var_len 1 on the same reads 7.75 -> 9.2 ms with 6 x the split tables.  profiles/r06_dist_ab_cenx.log)
+#if CF_DIST_SKETCH_BY_B
+                        const uint32_t idx = lo_[u] & A.sk_mask;
+#else
                         const uint32_t idx = Tab::sk_hash(bb[u], dd_[u], qq_[u]) >> A.sk_shift;
+#endif
                         sft_[u] = idx << 3;             // (only its low 5 bits are used: the shift and the bit-field extract take them mod 32)
                         inc_[u] = 1u << (sft_[u] & 31u);
                         old_[u] = idx >> 2;
@@ -1425,10 +1481,12 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                         if ((SLOT) != 0xFFFFFFFFu && hp_ < DIST_HOT_CAP) hotl[hp_] = (uint16_t)(SLOT);        \
                     }                                                                                         \
                 }
+#elif defined(CF_DIST_DIAG_NOHOT)
+#define CF_DIST_HOT(SLOT) { if ((SLOT) == 0xFFFFFFF0u) sh[11] = 1u; }      /* (diagnostic build: no hot list; the filter scans) */
 #else
 #define CF_DIST_HOT(SLOT) {                                                                                   \
                     const unsigned long long hm_ = cf_ballot((SLOT) != 0xFFFFFFFFu);                           \
-                    if (hm_) {                                                                                \
+                    if (hm_ && use_hot) {                                                                     \
                         uint32_t hb_ = 0;                                                                     \
                         if (lane == 0) hb_ = atomicAdd(&sh[11], (uint32_t)__popcll(hm_));                     \
                         hb_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)hb_) + cf_rank_in(hm_);          \
@@ -1437,12 +1495,12 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 }
 #endif
 #define CF_DIST_OVERFLOW(N) {                                                                                 \
-                    const uint32_t m_ = (N); otail -= m_;                                                     \
+                    const uint32_t m_ = (N); otail -= m_; CF_DG(if (lane == 0) { ++dg[1]; dg[2] += m_; })      \
                     uint32_t omade_ = 0, ohot_ = 0xFFFFFFFFu;                                                 \
                     if ((uint32_t)lane < m_) {                                                                \
                         uint32_t xb, xd, xk;                                                                  \
                         T.q_take(ovq[otail + (uint32_t)lane], n_buckets, xb, xd, xk);                        \
-                        omade_ = cf_dist_insert(T, n_buckets, xk, xb, xd, sh, A.min_cov, ohot_);              \
+                        omade_ = cf_dist_insert(T, n_buckets, xk, xb, xd, sh, A.min_cov, ohot_, CF_DG_PTR);   \
                     }                                                                                         \
                     const uint32_t onew_ = (uint32_t)__popcll(cf_ballot(omade_ != 0u));                        \
                     if (onew_ && lane == 0) atomicAdd(&sh[0], onew_);                                         \
@@ -1458,7 +1516,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
 #define CF_DIST_DRAIN(N) {                                                                                    \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                     __builtin_amdgcn_wave_barrier();                                                          \
-                    const uint32_t n_ = (N); qtail -= n_;                                                     \
+                    const uint32_t n_ = (N); qtail -= n_; CF_DG(if (lane == 0) { ++dg[3]; dg[4] += n_; })     \
                     bool made_ = false, park_ = false;                                                        \
                     uint32_t hot_ = 0xFFFFFFFFu;                                                              \
                     typename Tab::qitem it_ = 0;                                                              \
@@ -1472,7 +1530,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                         const typename Tab::qitem it2_ = wq[qtail + 64u + (uint32_t)lane];                    \
                         T.q_take(it_, n_buckets, xb, xd, xk);                                                 \
                         T.q_take(it2_, n_buckets, yb, yd, yk);                                                \
-                        T.probe2((uint32_t)lane < n_, xk, T.key_of(xb, xd), (uint32_t)lane + 64u < n_, yk, T.key_of(yb, yd), A.min_cov, made_, park_, hot_, made2_, park2_, hot2_); \
+                        T.probe2((uint32_t)lane < n_, xk, T.key_of(xb, xd), xb, (uint32_t)lane + 64u < n_, yk, T.key_of(yb, yd), yb, n_buckets, A.min_cov, made_, park_, hot_, made2_, park2_, hot2_); \
                         const uint32_t new_ = (uint32_t)__popcll(cf_ballot(made_)) + (uint32_t)__popcll(cf_ballot(made2_)); \
                         if (new_ && lane == 0) atomicAdd(&sh[0], new_);                                       \
                         const unsigned long long pm_ = cf_ballot(park_), pm2_ = cf_ballot(park2_);              \
@@ -1521,6 +1579,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     __builtin_amdgcn_wave_barrier();                                                          \
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                    \
                 }
+                CF_DG(const unsigned long long t2_ = __builtin_amdgcn_s_memtime();)
                 if (CF_DIST_ABL < 4) cf_dist_sweep<Tab, CF_DIST_PF_B>(A, recs, mine, my0, [&](bool final) {
                     if (CF_DIST_ABL >= 2) { qtail = 0; return; }
                     // a step pushes at most 4 x 64 inserts: the queue is brought below 64 first; after the wave's last step
@@ -1534,9 +1593,12 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
 #else
                         if (sh[0] > A.fill_limit) { too_full = true; break; }
 #endif
-                        if (qtail >= lim) { CF_DIST_DRAIN(min(qtail, kDrain)) }
+                        if (qtail >= lim) { CF_DG(const unsigned long long t1_ = __builtin_amdgcn_s_memtime();) CF_DIST_DRAIN(min(qtail, kDrain)) CF_DG(if (lane == 0) dg[6] += __builtin_amdgcn_s_memtime() - t1_;) }
                         else if (!(final && otail > 0u)) break;
-                        while (otail >= 32u || (final && qtail == 0u && otail > 0u)) { CF_DIST_OVERFLOW(min(otail, 64u)) }
+#if defined(CF_DIST_DIAG_NOPARK)
+                        otail = 0;      // (diagnostic build: parked inserts are dropped — timing only, results are wrong)
+#endif
+                        while (otail >= 32u || (final && qtail == 0u && otail > 0u)) { CF_DG(const unsigned long long t0_ = __builtin_amdgcn_s_memtime();) CF_DIST_OVERFLOW(min(otail, 64u)) CF_DG(if (lane == 0) dg[5] += __builtin_amdgcn_s_memtime() - t0_;) }
                     }
                 }, [&](const uint32_t (&bb)[DIST_UNROLL], const uint32_t (&dd_)[DIST_UNROLL], const uint32_t (&qq_)[DIST_UNROLL], const uint32_t (&lo_)[DIST_UNROLL], uint32_t ok, uint32_t len) -> bool {
                     if (too_full) return true;     // (wave-uniform, set by the drains: the fill only changes there) the pass will be split
@@ -1599,6 +1661,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
 #undef CF_DIST_HOT
 #undef CF_DIST_FILL_ISSUE
 #undef CF_DIST_FILL_LOOK
+                CF_DG(if (lane == 0) dg[7] += __builtin_amdgcn_s_memtime() - t2_;)
                 CF_STAMP(3);   // table sweep + inserts (wave 0's own items)
             }
             __syncthreads();      // [table swept]
@@ -1631,7 +1694,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             // overflowed / min_cov < 2 / a test asks for it, a scan of the whole table into a list over the insert queues.
             uint16_t* hot = hotl;
             uint32_t hot_cap = min(A.hot_cap, DIST_HOT_CAP);
-            const bool from_inserts = A.min_cov >= 2u && sh[11] <= hot_cap;      // (uniform: nothing changes sh[11] after the sweep's barrier)
+            const bool from_inserts = use_hot && A.min_cov >= 2u && sh[11] <= hot_cap;      // (uniform: nothing changes sh[11] after the sweep's barrier)
             const unsigned long long lt = (1ull << lane) - 1ull;
             if (!from_inserts) {
             __syncthreads();
@@ -1690,14 +1753,20 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                 const uint32_t bit = 1u << (b & 31);
                 if (!(A.unique_bits[b >> 5] & bit)) atomicOr(&A.unique_bits[b >> 5], bit);
             };
-            auto keep = [&](bool sel, uint32_t s, uint32_t b, uint32_t dd, uint32_t cnt) {       // called by all lanes of a wave together
+            // the same in two halves (round 6): the row is stored and the word of b's unique bit REQUESTED; the bit is looked at — and set
+            // when it is not — a round of the filter later.  A first k-mer of cenX-shaped reads has ~3 500 selected edges: four rounds
+            // of the list per thread, each of which waited for its own round trip to the unique mask (18 % of the kernel by thread 0's stamps).
+            auto set_unique = [&](uint32_t w, uint32_t b) { const uint32_t bit = 1u << (b & 31); if (!(w & bit)) atomicOr(&A.unique_bits[b >> 5], bit); };
+            // called by all lanes of a wave together; true for the lanes whose edge got its row here (the others': behind the barrier below)
+            auto keep = [&](bool sel, uint32_t s, uint32_t b, uint32_t dd, uint32_t cnt) -> bool {
                 const unsigned long long m = cf_ballot(sel);
-                if (!m) return;
+                if (!m) return false;
                 uint32_t row0 = 0;
                 if (lane == 0) { const uint32_t n = (uint32_t)__popcll(m); atomicAdd(&sh[8], n); row0 = atomicAdd(&sh[26], n); }
                 const uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)row0) + (uint32_t)__popcll(m & lt);
                 const bool late = sel && row >= ch_rows;
-                if (sel && !late) put_row(ch_base + row, b, dd, cnt);
+                const unsigned long long o = ch_base + row;
+                if (sel && !late && o < A.edge_cap) *(cf_u32x4*)(A.edges + 4 * o) = cf_u32x4{dd, a, b, cnt};
                 const unsigned long long ml = cf_ballot(late);
                 if (ml) {
                     uint32_t p0 = 0;
@@ -1705,9 +1774,12 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0) + (uint32_t)__popcll(ml & lt);
                     if (late) { T.mark(s); if (pos < A.stage_cap) stage[pos] = (uint16_t)s; }
                 }
+                return sel && !late;
             };
             if (CF_DIST_ABL >= 1) { }
             else if (n_hot <= hot_cap) {
+                bool p_on = false;      // the previous round's edge of this lane: its unique-mask word is on its way
+                uint32_t p_w = 0, p_b = 0;
                 for (uint32_t i0 = 0; i0 < n_hot; i0 += (uint32_t)nt) {
                     const uint32_t i = i0 + (uint32_t)t;
                     bool sel = false;
@@ -1715,8 +1787,13 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     if (i < n_hot && (s = hot[i]) != 0xFFFFu) {      // (0xFFFF: an entry of a wave's block of the list that the wave did not fill)
                         T.eval_slot(s, n_buckets, A.min_cov, [&](uint32_t, uint32_t b, uint32_t dd, uint32_t cnt, unsigned long long total) { sel = b != a && dominant(cnt, total); eb = b; ed = dd; ec = cnt; });
                     }
-                    keep(sel, s, eb, ed, ec);
+                    const bool wrote = keep(sel, s, eb, ed, ec);
+                    uint32_t w_new = 0;
+                    if (wrote) w_new = A.unique_bits[eb >> 5];
+                    if (p_on) set_unique(p_w, p_b);
+                    p_on = wrote; p_w = w_new; p_b = eb;
                 }
+                if (p_on) set_unique(p_w, p_b);
             } else {        // more than the list holds (never seen with the sketch): evaluate inside the bucket scan, a row per atomic
                 for (uint32_t bk = (uint32_t)t; bk < n_buckets; bk += (uint32_t)nt)
                     T.for_counts_at_least(bk, n_buckets, A.min_cov, [&](uint32_t s, uint32_t b, uint32_t dd, uint32_t cnt, unsigned long long total) {
@@ -1782,6 +1859,9 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         for (int i = 0; i < 8; ++i) atomicAdd(&A.counters[8 + i], stamp_acc[i]);
 #endif
     }
+#if defined(CF_DIST_DIAG_COUNT)
+    for (int i = 0; i < 8; ++i) if (dg[i]) atomicAdd(&A.counters[8 + i], dg[i]);
+#endif
 }
 
 // sum over all postings of their partner-range length = the number of pair emissions of the launch (before a != b)
@@ -2036,6 +2116,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.thr_num = (rel_threshold == 0.8 && ctx->dist_int_thr) ? 4u : 0u; A.thr_den = A.thr_num ? 5u : 0u;
         A.stage_cap = (uint32_t)std::min(ctx->dist_stage, DIST_STAGE_CAP);
         A.hot_cap = ctx->dist_hot_cap > 0 ? (uint32_t)ctx->dist_hot_cap : 0xFFFFFFFFu;
+        A.hot_entries = ctx->dist_hot_entries >= 0 ? (uint32_t)ctx->dist_hot_entries : 0xFFFFFFFFu;
         const uint32_t slot_bytes = (narrow || region) ? cf_tab_narrow::kSlotBytes : cf_tab_wide::kSlotBytes;
         // launch shape: two 512-thread workgroups per CU (80 KiB of LDS each) overlap each other's latency-bound phases
         // and win when a first k-mer has few pair emissions; with many (long reads, high coverage) the halved table and
@@ -2070,6 +2151,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         const size_t sk_room = (size_t)A.slots * slot_bytes + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QSTRIDE + DIST_OVQ) * qitem_bytes + 2 * DIST_STACK * 4 + DIST_HOT_CAP * 2;   // table + stage + stack + queues + hot list: all dead while the sketch runs
         while (A.sk_shift > 8 && (size_t)A.sk_counters * 2 <= sk_room) { A.sk_counters *= 2; --A.sk_shift; }
         if (A.sk_counters < 16) A.sketch = 0;
+        A.sk_mask = A.sk_counters - 1u;
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / block));
         // locality order of the first k-mers: sort (first posting unit, a); k-mers without postings drop out
         n_a_alloc = (K > part) ? (K - part + n_parts - 1) / n_parts : 0;
@@ -2138,6 +2220,13 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
         if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
         if (e != hipSuccess) { rc = cf_fail(ctx, -5, std::string("cf_dist_edges: ") + hipGetErrorString(e)); break; }
+#if defined(CF_DIST_DIAG_COUNT)
+        {
+            unsigned long long st[8];
+            if (hipMemcpy(st, d_cnt + 8, 64, hipMemcpyDeviceToHost) == hipSuccess)
+                std::fprintf(stderr, "[cf_dist diag] parked-insert loop trips=%llu overflow calls=%llu parked inserts run=%llu drains=%llu inserts drained=%llu cycles(sum over waves): parked runs=%llu drains=%llu table sweeps=%llu; waves=%d passes=%llu\n", st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], grid * (block / 64), h_cnt[5]);
+        }
+#endif
 #if defined(CF_DIST_STAMPS)
         {
             unsigned long long st[8];
