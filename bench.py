@@ -30,6 +30,9 @@ Rank 0 prints ONE JSON line (contract in the task brief) with these extra object
   parity_vs_committed_oracle   counters + device-side checksum of every stored edge against the 64/64
                         CPU run of the oracle on the same reads (profiles/r03_full_parity.json)
   end_to_end            stage 2 + A4 + greedy placement of the same reads (BASELINE configs[2])
+  workload_c            (N = 1) BASELINE configs[4]'s SHAPE: 1 000 reads of mean 100 kb over a 1 500-unit array at coverage 32 (~47 units per read,
+                        ~60 000 pair emissions per first k-mer), var_len 8 and 1: ms_per_step, stage split, passes per first k-mer, pair emissions/s,
+                        roofline figures, and every figure of the step against the committed oracle records profiles/r06_parity_cenx_varlen{8,1}.json
   workload_b            (N = 1) the same 50 000 reads with POINT substitutions as copy-specific variants (var_len 1: SURVEY §8(d)'s
                         literal model, simulate_tandem_repeat.py:15-30 — few copy-specific k-mers, E per base collapses): its own
                         ms_per_step, stage split, counters and roofline figures, and every figure of the step (A1 table, rare set,
@@ -247,26 +250,28 @@ def pmc_derived():
     return (d, os.path.relpath(cands[-1], ROOT)) if d else (None, None)
 
 
-def workload_b(a, sr, rank, world):
-    """The bench's reads with point substitutions (var_len 1) through the same step; checked against the committed oracle record."""
+def extra_workload(a, sr, rank, world, kw, steps, what, record):
+    """Another read set through the same step: its own ms_per_step, stage split, counters and roofline figures, and EVERY figure of the
+    step (A1 table, rare set, clouds, all pair emissions, every selected edge, the unique k-mers) against a committed oracle record of
+    those reads (tools/parity_record.py)."""
     from centroflye_amd import _host
     E = sr.engine
-    kw = dict(synth_kwargs(a.reads * world, a.seed), var_len=1)
-    pk = _host.synth(n_reads=a.reads, cand_offset=rank, cand_stride=world, **kw)
+    pk = _host.synth(cand_offset=rank, cand_stride=world, **kw)
     sr.load(pk, 1)
     first = sr.run(edge_cap=0, **PARAMS)
     edge_cap = int(first["local_edges"]) + 1024
-    outs, elapsed, kernel_ms, stage_ms, sections = timed_steps(sr, a.steps_b, 1, edge_cap)
+    outs, elapsed, kernel_ms, stage_ms, sections = timed_steps(sr, steps, 1, edge_cap)
     out = outs[-1]
     stored = min(out["local_edges"], edge_cap)
-    ms = elapsed * 1e3 / max(a.steps_b, 1)
+    ms = elapsed * 1e3 / max(steps, 1)
     mean_k = float(np.mean(kernel_ms)) if kernel_ms else 0.0
     alg = 4 * out["dist_cloud_entries"] + 4 * out["local_emissions"] + 16 * stored
     b_alg = (out["n_bases"] + 16 * out["n_read_kmers"]) + 16 * out["n_distinct"] + (out["n_bases"] + 8 * out["n_windows"] + 4 * out["n_cloud_entries"]) \
         + (4 * out["n_cloud_entries"] + 4 * out["n_emissions"]) + 16 * min(out["n_edges"], edge_cap * world)
-    res = {"workload": f"{a.reads} reads per GPU, the same generator and seed with var_len 1 (point substitutions as copy-specific variants, SURVEY §8(d)'s literal model): "
-                       f"{out['n_bases']} bases, {out['n_rare']} rare k-mers, {out['n_emissions'] / max(out['n_bases'], 1):.1f} pair emissions per base",
-           "value": out["n_bases"] * a.steps_b / elapsed, "unit": "bases/s", "steps": a.steps_b, "ms_per_step": ms,
+    up = np.asarray(pk.units(1)[0])
+    res = {"workload": f"{what}: {out['n_bases']} bases in {pk.n_reads} reads per GPU ({float(np.diff(up).mean()):.1f} units per read, {int(np.diff(up).max())} at most), "
+                       f"{out['n_rare']} rare k-mers, {out['n_emissions'] / max(out['n_bases'], 1):.1f} pair emissions per base, {out['n_emissions'] / max(out['n_rare'], 1):.0f} per rare k-mer",
+           "value": out["n_bases"] * steps / elapsed, "unit": "bases/s", "steps": steps, "ms_per_step": ms,
            "stage_ms_per_step": stage_ms, "host_section_ms_per_step": sections,
            "counters": {k: out[k] for k in ("n_bases", "n_windows", "n_read_kmers", "n_distinct", "n_kept", "n_rare", "n_cloud_entries", "n_emissions", "n_edges", "n_unique", "n_dist_passes")},
            "roofline": {"kernel": "cf_dist_kernel", "kernel_ms": mean_k, "algorithmic_bytes_per_launch": alg, "achieved": alg / (mean_k * 1e-3) / 1e9 if mean_k else 0.0,
@@ -275,13 +280,15 @@ def workload_b(a, sr, rank, world):
                         "whole_step_algorithmic_bytes": b_alg, "whole_step_frac": b_alg / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
                         "dist_kernel_share_of_step": mean_k / ms if ms else 0.0},
            "steps_identical": bool(all(all(o[k] == out[k] for k in ("n_edges", "n_emissions", "n_rare", "n_unique", "n_cloud_entries")) for o in outs))}
-    path = os.path.join(ROOT, "profiles", "r05_parity_50k_varlen1.json")
+    path = os.path.join(ROOT, "profiles", record)
     res["parity_vs_committed_oracle"] = None
     if world == 1 and os.path.exists(path):
         with open(path) as f:
             rec = json.load(f)
         wl, part = rec["workload"], rec["partition"]
-        if (wl["reads"], wl["seed"], wl["var_len"], wl["n_units"], rec["params"], part["n_parts"]) == (a.reads, a.seed, 1, kw["n_units"], PARAMS, 1) and rec["n_bases"] == out["n_bases"]:
+        same_wl = (wl["reads"], wl["seed"], wl["var_len"], wl["n_units"]) == (kw["n_reads"], kw["seed"], kw["var_len"], kw["n_units"]) \
+            and all(kw.get(k_) == v for k_, v in wl.get("synth", {}).items())
+        if same_wl and (rec["params"], part["n_parts"]) == (PARAMS, 1) and rec["n_bases"] == out["n_bases"]:
             # the timed steps left the table, the rare set, the clouds, the edges and the unique bitmap of the last step resident
             got = dict(n_windows=out["n_windows"], n_read_kmers=out["n_read_kmers"], n_distinct=out["n_distinct"], n_kept=out["n_kept"], n_rare=out["n_rare"],
                        n_cloud_entries=out["n_cloud_entries"], rare_checksum=E.checksum("kmers")[0], cloud_checksum=E.checksum("clouds")[0])
@@ -290,9 +297,34 @@ def workload_b(a, sr, rank, world):
             E.count_kmers(K)          # (select_rare compacts the table it reads: the A1 table of the step is rebuilt for its checksum)
             got["table_checksum"] = E.checksum("table")[0]
             res["parity_vs_committed_oracle"] = dict(
-                against="profiles/r05_parity_50k_varlen1.json (oracle/c/cf_oracle_mt.c: A1-A3 whole and every first k-mer of these reads)",
+                against=f"profiles/{record} (oracle/c/cf_oracle_mt.c: A1-A3 whole and every first k-mer of these reads)",
                 checked=sorted(got) + sorted(gp), match=bool(all(got[k] == rec[k] for k in got) and all(gp[k] == part[k] for k in gp)))
+            res["first_kmers"] = part["n_first_kmers"]
+            res["dist_passes_per_first_kmer"] = out["n_dist_passes"] / max(part["n_first_kmers"], 1)
     return res
+
+
+def workload_b(a, sr, rank, world):
+    """The bench's reads with point substitutions (var_len 1) through the same step; checked against the committed oracle record."""
+    kw = dict(synth_kwargs(a.reads * world, a.seed), var_len=1, n_reads=a.reads)
+    return extra_workload(a, sr, rank, world, kw, a.steps_b,
+                          f"{a.reads} reads per GPU, the same generator and seed with var_len 1 (point substitutions as copy-specific variants, SURVEY §8(d)'s literal model)",
+                          "r05_parity_50k_varlen1.json")
+
+
+CENX = dict(n_reads=1000, seed=5, n_units=1500, mean_len=100000.0, max_len=1000000)      # (tools/parity_record.py --synth mean_len=100000.0,max_len=1000000)
+
+
+def workload_c(a, sr, rank, world):
+    """BASELINE configs[4]'s SHAPE (the real CHM13 cenX reads are not available to the build): a 1 500-unit array at coverage 32 read by
+    ultra-long reads — mean 100 kb, ~47 units per read, up to ~170: every distance up to max_distance = 150 occurs, a first k-mer has
+    ~60 000 pair emissions (the default workload: ~20 000, reads of ~10 units).  Reference: README.md:59-75, run_all_cenX.sh:17-22,
+    distance_based_kmer_recruitment.py:85-149.  Both copy-specific variant models: var_len 8 and 1."""
+    out = {}
+    for vl in (8, 1):
+        out[f"var_len_{vl}"] = extra_workload(a, sr, rank, world, dict(CENX, var_len=vl, n_reads=a.reads_c, n_units=a.units_c), a.steps_c,
+                                              f"cenX-shaped reads (1 500-unit array, coverage 32, reads of mean 100 kb), var_len {vl}", f"r06_parity_cenx_varlen{vl}.json")
+    return out
 
 
 def parse_args():
@@ -314,6 +346,8 @@ def parse_args():
     ap.add_argument("--param", action="append", default=[], help="library knob name=value (cf_set_param)")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1 only: run the multi-GPU exchange path (bucketing, all-to-all, all-gathers, gathered view) through a one-rank RCCL communicator, to price it without wire time")
     ap.add_argument("--steps-b", type=int, default=3, help="timed steps of workload_b (the same reads with var_len 1); 0 = skip")
+    ap.add_argument("--reads-c", type=int, default=CENX["n_reads"], help="test hook: reads of workload_c"); ap.add_argument("--units-c", type=int, default=CENX["n_units"], help="test hook: array units of workload_c")
+    ap.add_argument("--steps-c", type=int, default=5, help="timed steps of workload_c (cenX-shaped reads: BASELINE configs[4]'s regime), N = 1 only; 0 = skip")
     ap.add_argument("--lib", default=None, help="test hook: another build of libcfhip (the CPU suite passes the host-emulated one to check this harness)")
     return ap.parse_args()
 
@@ -504,8 +538,10 @@ def main():
         else:
             res["cpu_baseline"] = None
     wb = workload_b(a, sr, rank, world) if a.steps_b > 0 else None      # (every rank: its steps hold collectives)
+    wc = workload_c(a, sr, rank, world) if (a.steps_c > 0 and world == 1) else None
     if rank == 0:
         res["workload_b"] = wb
+        res["workload_c"] = wc
         if world > 1 and not a.no_cpu_baseline:      # (behind the last collective of the other ranks: they wait in the closing barrier)
             res["cpu_baseline"] = cpu_baseline_weak(a)
         print(json.dumps(res), flush=True)

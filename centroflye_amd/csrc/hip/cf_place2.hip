@@ -369,10 +369,14 @@ __device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, unsigned long long t
     // written back at the end), glist = per sweeping wave the groups whose blocks it has to look at one by one
     uint32_t* bb3 = bb2 + n_b2words;
     uint32_t* st3 = bb3 + PL2_G3MAX / 32;
-    uint16_t* glist = (uint16_t*)(st3 + PL2_G3MAX / 32);      // 16 waves x (PL2_G3MAX / 8) entries
+    //  st3 is READ-ONLY during the sweep: the waves decide from it which groups' records they may load, and a bit cleared
+    // by the wave that has just stored a mended record — with no barrier between that store and the other waves' loads — let them read
+    // the old record.  The sweep's changes go to st3n, which is what is written back.
+    uint32_t* st3n = st3 + PL2_G3MAX / 32;
+    uint16_t* glist = (uint16_t*)(st3n + PL2_G3MAX / 32);      // 16 waves x (PL2_G3MAX / 8) entries
     const uint32_t n_b3words = (S.n3 + 31u) >> 5;
     for (uint32_t i = tid; i < n_b2words; i += nthr) bb2[i] = 0u;
-    for (uint32_t i = tid; i < n_b3words; i += nthr) { bb3[i] = 0u; st3[i] = S.l3_stale[i]; }
+    for (uint32_t i = tid; i < n_b3words; i += nthr) { bb3[i] = 0u; const uint32_t w3 = S.l3_stale[i]; st3[i] = w3; st3n[i] = w3; }
     bool again = true;
     while (again) {
         if (tid == 0) { *n_list = 0u; *more = 0u; *n_list2 = 0u; }
@@ -489,11 +493,11 @@ __device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, unsigned long long t
                             pl2_take(mine, q[t]);
                             if (gq[t] == 0xFFFFFFFFu) continue;      // (wave-uniform)
                             const uint32_t g = gq[t], bt = 1u << (g & 31);
-                            if ((bb3[g >> 5] & bt)) { if (lane == 0) atomicOr(&st3[g >> 5], bt); }      // touched now: out of date from here on
+                            if ((bb3[g >> 5] & bt)) { if (lane == 0) atomicOr(&st3n[g >> 5], bt); }      // touched now: out of date from here on
                             else if (refreshed < (uint32_t)PL2_REFRESH) {      // out of date, untouched: every block record of the group is in q[t]
                                 cf_pl2_rec w = q[t];
                                 for (int d = 1; d <= 32; d <<= 1) pl2_take(w, pl2_shfl_xor(w, d));
-                                if (lane == 0) { pl2_store(&S.L3[g], w); atomicAnd(&st3[g >> 5], ~bt); }
+                                if (lane == 0) { pl2_store(&S.L3[g], w); atomicAnd(&st3n[g >> 5], ~bt); }      // (up to date from the NEXT launch on)
                                 ++refreshed;
                             }
                         }
@@ -503,7 +507,7 @@ __device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, unsigned long long t
                 const uint32_t at = 4u * (uint32_t)(wave * 64 + lane);
                 red[at] = mine.hi; red[at + 1] = mine.lo; red[at + 2] = mine.ext; red[at + 3] = mine.read;
             } else if (wave < nfw) {
-                if (S.n3) for (uint32_t i = (uint32_t)(wave * 64 + lane); i < n_b3words; i += (uint32_t)nfw * 64u) st3[i] = 0xFFFFFFFFu;      // (a tail whose touched blocks went through several rounds: every group out of date)
+                if (S.n3) for (uint32_t i = (uint32_t)(wave * 64 + lane); i < n_b3words; i += (uint32_t)nfw * 64u) st3n[i] = 0xFFFFFFFFu;      // (a tail whose touched blocks went through several rounds: every group out of date)
                 cf_pl2_rec mine{0ull, 0ull, 0ull, 0u, 0u};
                 const uint32_t stride = (uint32_t)nfw * 64u;
                 for (uint32_t b = (uint32_t)(wave * 64 + lane); b < S.n2; b += (uint32_t)PL2_SW * stride) {      // (PL2_SW loads in flight per lane)
@@ -558,14 +562,14 @@ __device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, unsigned long long t
                     S.C.ctl[3] = 0u;
                 }
             }
-            if (S.n3 && wave == 1) for (uint32_t i = (uint32_t)lane; i < n_b3words; i += 64u) S.l3_stale[i] = st3[i];      // (behind the sweep's barrier: the bits are final)
+            if (S.n3 && wave == 1) for (uint32_t i = (uint32_t)lane; i < n_b3words; i += 64u) S.l3_stale[i] = st3n[i];      // (behind the sweep's barrier: the bits are final)
         }
     }
     PL2_TTRACE(7);
     PL2_STAMP(7);
 }
 
-static size_t pl2_lds_bytes(uint32_t n2) { return (16 + (size_t)PL2_LIST * 8 + 1024 * 32 + (size_t)PL2_CRES * 32 + (size_t)((n2 + 31) / 32) * 4 + 2 * (PL2_G3MAX / 32) * 4 + 16 * (PL2_G3MAX / 8) * 2 + 16); }
+static size_t pl2_lds_bytes(uint32_t n2) { return (16 + (size_t)PL2_LIST * 8 + 1024 * 32 + (size_t)PL2_CRES * 32 + (size_t)((n2 + 31) / 32) * 4 + 3 * (PL2_G3MAX / 32) * 4 + 16 * (PL2_G3MAX / 8) * 2 + 16); }
 
 __global__ void __launch_bounds__(PL2_B)
 cf_pl2_tail_kernel(cf_pl2 S) {

@@ -38,30 +38,43 @@ def launch(argv, n_gpus, rank_cmd=None):
     params = D.parse_args(argv)
     D.smart_makedirs(params.outdir)
     env = dict(os.environ)
-    private_cache = None
-    if not env.get("CF_PACK_CACHE"):
-        private_cache = tempfile.mkdtemp(prefix=".cfpack_", dir=params.outdir)
-        env["CF_PACK_CACHE"] = private_cache
-    t0 = time.time()
-    pk = _host.parse_report(params.ncrf, keep_rows=False, cache_dir=env["CF_PACK_CACHE"])      # host only; writes the pack the ranks map
-    n_reads = pk.n_reads
-    del pk
-    if params.verbose:
-        print(f"# {n_reads} reads parsed in {time.time() - t0:.2f} s; starting {n_gpus} ranks")
-    idf = os.path.join(tempfile.gettempdir(), f"cfcomm_{os.getuid()}_{os.getpid()}_{int(time.time() * 1e3)}.id")
-    env.update(WORLD_SIZE=str(n_gpus), CF_COMM_ID_FILE=idf, CF_COMM_NONCE=new_launch_token(), CF_GPUS="")
-    cmd = list(rank_cmd) if rank_cmd else [sys.executable, "-m", "centroflye_amd.distance_based_kmer_recruitment"]
-    args = list(sys.argv[1:] if argv is None else argv)
-    procs = [subprocess.Popen(cmd + args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n_gpus)]
-    rc, live = 0, list(procs)
-    while live and rc == 0:      # a rank that dies leaves the others waiting in a collective: end them, exit non-zero
-        time.sleep(0.1)
-        for p in list(live):
-            code = p.poll()
-            if code is not None:
-                live.remove(p)
-                rc = max(rc, abs(code))
-    if rc:
+    private_cache = idf = None
+    procs = []
+    rc = 1
+    try:      #  whatever happens below — an unreadable report, an interrupt — no rank and no private file is left behind
+        if not env.get("CF_PACK_CACHE"):
+            private_cache = tempfile.mkdtemp(prefix=".cfpack_", dir=params.outdir)
+            env["CF_PACK_CACHE"] = private_cache
+        t0 = time.time()
+        pk = _host.parse_report(params.ncrf, keep_rows=False, cache_dir=env["CF_PACK_CACHE"])      # host only; writes the pack the ranks map
+        n_reads = pk.n_reads
+        del pk
+        if params.verbose:
+            print(f"# {n_reads} reads parsed in {time.time() - t0:.2f} s; starting {n_gpus} ranks")
+        idf = os.path.join(tempfile.gettempdir(), f"cfcomm_{os.getuid()}_{os.getpid()}_{int(time.time() * 1e3)}.id")
+        env.update(WORLD_SIZE=str(n_gpus), CF_COMM_ID_FILE=idf, CF_COMM_NONCE=new_launch_token(), CF_GPUS="")
+        # The ranks run the stage script ITSELF, by path (`python -m centroflye_amd...` only resolves when the working
+        # directory is the repository — centroFlye.py:172-188 calls the script by absolute path from the user's directory); the package's
+        # parent directory goes in front of the children's PYTHONPATH as well, for a caller that imported the module some other way.
+        pkg_parent = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env["PYTHONPATH"] = pkg_parent + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+        script = os.path.join(pkg_parent, "scripts", "distance_based_kmer_recruitment.py")
+        default_cmd = [sys.executable, script] if os.path.exists(script) else [sys.executable, "-m", "centroflye_amd.distance_based_kmer_recruitment"]
+        cmd = list(rank_cmd) if rank_cmd else default_cmd
+        args = list(sys.argv[1:] if argv is None else argv)
+        procs = [subprocess.Popen(cmd + args, env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n_gpus)]
+        rc, live = 0, list(procs)
+        while live and rc == 0:      # a rank that dies leaves the others waiting in a collective: end them, exit non-zero
+            time.sleep(0.1)
+            for p in list(live):
+                code = p.poll()
+                if code is not None:
+                    live.remove(p)
+                    rc = max(rc, abs(code))
+        if rc:
+            print(f"distance_based_kmer_recruitment: a rank exited with code {rc}; the other ranks are stopped", file=sys.stderr)
+    finally:
+        live = [p for p in procs if p.poll() is None]
         for p in live:
             p.terminate()
         t_end = time.time() + 10
@@ -70,12 +83,11 @@ def launch(argv, n_gpus, rank_cmd=None):
                 p.wait(timeout=max(0.1, t_end - time.time()))
             except subprocess.TimeoutExpired:
                 p.kill()
-        print(f"distance_based_kmer_recruitment: a rank exited with code {rc}; the other ranks were stopped", file=sys.stderr)
-    for leftover in (idf, private_cache):
-        if leftover and os.path.isdir(leftover):
-            shutil.rmtree(leftover, ignore_errors=True)
-        elif leftover and os.path.exists(leftover):
-            os.remove(leftover)
+        for leftover in (idf, private_cache):
+            if leftover and os.path.isdir(leftover):
+                shutil.rmtree(leftover, ignore_errors=True)
+            elif leftover and os.path.exists(leftover):
+                os.remove(leftover)
     return rc
 
 
@@ -129,6 +141,9 @@ def rank_main(argv=None, lib=None, device=None, sub_edges=None, knobs=None):
     from .sharded import ShardedRecruiter
     params = D.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if "LOCAL_RANK" not in os.environ and device is None and os.environ.get("CF_SINGLE_NODE", "1") == "0":
+        #  RANK is the device index only on one node; a multi-node launcher that does not export LOCAL_RANK must say so
+        raise SystemExit("distance_based_kmer_recruitment: WORLD_SIZE spans several nodes (CF_SINGLE_NODE=0) but LOCAL_RANK is not set")
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     D.smart_makedirs(params.outdir)
     t0 = time.time()
@@ -186,6 +201,10 @@ def rank_main(argv=None, lib=None, device=None, sub_edges=None, knobs=None):
             os.replace(kfile + ".tmp", kfile)
             if want_edges:
                 with open(efile + ".tmp", "wb") as out:
+                    missing = [r for r in range(world) if not os.path.exists(f"{efile}.rank{r}.tmp")]
+                    if missing:      #  every rank writes its part into --outdir: ranks on other nodes need it on a shared file system
+                        raise SystemExit(f"distance_based_kmer_recruitment: the edge parts of ranks {missing} are not in {params.outdir} — "
+                                         "with ranks on several nodes --outdir must be on a file system all of them share")
                     for r in range(world):
                         fn = f"{efile}.rank{r}.tmp"
                         with open(fn, "rb") as f:

@@ -92,7 +92,9 @@ def test_config3_share_200k_reads_count_clouds_and_one_distance_partition_vs_com
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("what,record", [("point substitutions (var_len 1), 50 000 reads", "r05_parity_50k_varlen1.json"),
-                                         ("long reads (> 128 units), 2^24+ rare k-mers", "r05_parity_long_reads.json")])
+                                         ("long reads (> 128 units), 2^24+ rare k-mers", "r05_parity_long_reads.json"),
+                                         ("cenX-shaped: 1 500-unit array, coverage 32, reads of mean 100 kb, var_len 8", "r06_parity_cenx_varlen8.json"),
+                                         ("cenX-shaped, var_len 1", "r06_parity_cenx_varlen1.json")])
 def test_other_workload_families_at_size_vs_committed_oracle(what, record):
     """Round 4's at-size tests all used one generator family (var_len 8, reads of ~10 units).  Two more: SURVEY 8(d)'s LITERAL model —
     copy-specific variants are point substitutions as simulate_tandem_repeat.py:15-30 makes them, so few k-mers are copy-specific, the
@@ -102,12 +104,38 @@ def test_other_workload_families_at_size_vs_committed_oracle(what, record):
     one first-k-mer partition of 256 (5.2e9 pair emissions, 1.3e8 edges).  Oracle side: committed records (tools/parity_record.py; the
     oracle ran inside this test until round 5: 210 s of every GPU suite)."""
     rec, res = _against_record(record, "parity_" + record[len("r05_parity_"):])
-    if rec["workload"]["var_len"] == 1:
+    if "cenx" in record:
+        # Round 6 — BASELINE configs[4]'s SHAPE (README.md:59-75, run_all_cenX.sh:17-22 of the reference; the real reads are not available):
+        # ~47 units per read and up to ~170, so every distance up to max_distance = 150 occurs and a first k-mer has ~60 000 pair emissions
+        # (the default workload: ~20 000): A1-A3 whole and EVERY first k-mer against the record (363 s of the build container's 8 cores).
+        import bigparity
+        up = bigparity.synth_workload(rec["workload"]).units(1)[0]
+        assert 40 < float(np.diff(up).mean()) < 60 and int(np.diff(up).max()) > 150 and rec["partition"]["n_parts"] == 1
+        assert res["got"]["n_emissions_partition"] == rec["partition"]["n_emissions"] > (3e10 if rec["workload"]["var_len"] == 8 else 6e9)
+    elif rec["workload"]["var_len"] == 1:
         assert rec["n_bases"] > 9e8 and res["got"]["n_emissions_partition"] > 1e11 and rec["partition"]["n_parts"] == 1
     else:
         import bigparity
         up = bigparity.synth_workload(rec["workload"]).units(1)[0]
         assert int(np.diff(up).max()) > 128 and rec["n_rare"] > (1 << 24) and res["got"]["n_emissions_partition"] > 1e9
+
+
+@pytest.mark.timeout(900)
+def test_both_command_lines_and_the_polisher_export_end_to_end_on_cenx_shaped_reads(tmp_path):
+    """tools/cenx_cli_e2e.py: scripts/distance_based_kmer_recruitment.py -> scripts/read_placer.py -> scripts/eltr_polisher.py on a report
+    of BASELINE configs[4]'s shape (194 MB of NCRF text), each output against its CPU oracle: the unique k-mers against the committed
+    record of the OpenMP oracle over every first k-mer, read_positions.csv against the C placer, every exported FASTA against
+    oracle/polisher.py.  The wall times go to gpurun_out/ (profiles/r06_cenx_cli_e2e_varlen8.json is a committed run of this tool)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out", "cenx_cli_e2e_varlen8.json")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "cenx_cli_e2e.py"), "--var-len", "8", "--out", out], capture_output=True, text=True, timeout=850)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    with open(out) as f:
+        res = json.load(f)
+    assert res["identical"] and all(res["checks"].values()) and res["placed"] > 900 and res["positions_exported"] > 1000 and res["n_unique_kmers"] > 400000
 
 
 @pytest.mark.timeout(900)

@@ -195,3 +195,49 @@ def test_sharded_stage_script_reproduces_the_reference_files_on_the_gpu(name, fx
     with open(os.path.join(out, "stage2_metrics.json")) as f:
         m = json.load(f)
     assert m["world"] == 1 and m["exchange_bytes"] >= 0 and "table_exchange" in m["sections_s"] and "cloud_gather" in m["sections_s"]
+
+
+def test_eight_ranks_on_emulated_kernels_some_without_reads(emu_lib, report, oracle_stage2, tmp_path, monkeypatch):
+    """World 8 before an 8-GPU node runs it: CF_GPUS=8 on the emulated kernels with the file transport; the fixture has
+    fewer records than 8 x 2, so shards are a read or two and every exchange (table all-to-all, gathers, mask reduction) has 8 ends."""
+    name = "lowcov"
+    p2 = fixtures.stage2_params(name)
+    p2["max_distance"] = 2
+    assert _launch(_argv(report(name), str(tmp_path), p2, ["--metrics"]), 8, monkeypatch) == 0
+    records, alns, lens, res, _ = oracle_stage2(name, max_distance=2)
+    with open(tmp_path / f"unique_kmers_min_edge_cov_{p2['min_coverage']}.txt") as f:
+        assert f.read() == recruit.kmers_file_text(res["rare"], res["unique"], p2["k"])
+    with open(tmp_path / f"unique_edges_min_edge_cov_{p2['min_coverage']}.txt") as f:
+        assert sorted(f.read().splitlines()) == recruit.edges_file_lines(res["rare"], res["edges"], p2["k"])
+    with open(tmp_path / "stage2_metrics.json") as f:
+        m = json.load(f)
+    assert m["world"] == 8 and len(m["shard_reads"]) == 8 and sum(m["shard_reads"]) == len(records)
+    assert not [p for p in os.listdir(tmp_path) if ".tmp" in p or p.startswith(".cfpack")]
+
+
+def test_default_rank_command_resolves_the_package_from_a_foreign_directory(report, tmp_path):
+    """ `cd elsewhere && CF_GPUS=2 python <repo>/scripts/distance_based_kmer_recruitment.py ...` — how centroFlye.py:172-188
+    calls it — starts its ranks with the script's own path: they must get as far as the device (which this container does not have),
+    not die on `import centroflye_amd`; and the parent leaves neither its private pack cache nor part files behind."""
+    p2 = fixtures.stage2_params("lowcov")
+    out = tmp_path / "out"
+    elsewhere = tmp_path / "elsewhere"
+    elsewhere.mkdir()
+    env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "CF_PACK_CACHE", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(CF_GPUS="2", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "distance_based_kmer_recruitment.py")] + _argv(report("lowcov"), str(out), p2),
+                       capture_output=True, text=True, timeout=300, cwd=elsewhere, env=env)
+    assert "ModuleNotFoundError" not in p.stderr and "No module named" not in p.stderr, p.stderr[-2000:]
+    import torch                                    # (only to ask whether a GPU is here; the package itself never imports it)
+    if not torch.cuda.is_available():
+        assert p.returncode != 0 and ("cf_create" in p.stderr or "device" in p.stderr.lower() or "hip" in p.stderr.lower()), p.stderr[-2000:]
+    assert not [x for x in os.listdir(out) if x.startswith(".cfpack") or ".tmp" in x]
+
+
+def test_an_unreadable_report_leaves_nothing_behind(tmp_path, monkeypatch):
+    """ launch() cleans up on every path out: the private pack cache is removed when the parse raises."""
+    monkeypatch.delenv("CF_PACK_CACHE", raising=False)
+    out = tmp_path / "out"
+    with pytest.raises(Exception):
+        sharded_cli.launch(["--ncrf", str(tmp_path / "missing.ncrf"), "--coverage", "32", "--outdir", str(out)], 2, rank_cmd=WORKER)
+    assert os.path.isdir(out) and not os.listdir(out)
