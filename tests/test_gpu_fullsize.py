@@ -109,14 +109,16 @@ def test_other_workload_families_at_size_vs_committed_oracle(what, record):
         # ~47 units per read and up to ~170, so every distance up to max_distance = 150 occurs and a first k-mer has ~60 000 pair emissions
         # (the default workload: ~20 000): A1-A3 whole and EVERY first k-mer against the record (363 s of the build container's 8 cores).
         import bigparity
-        up = bigparity.synth_workload(rec["workload"]).units(1)[0]
+        pk = bigparity.synth_workload(rec["workload"])      # (kept alive: units() hands out views of its arrays)
+        up = pk.units(1)[0]
         assert 40 < float(np.diff(up).mean()) < 60 and int(np.diff(up).max()) > 150 and rec["partition"]["n_parts"] == 1
         assert res["got"]["n_emissions_partition"] == rec["partition"]["n_emissions"] > (3e10 if rec["workload"]["var_len"] == 8 else 6e9)
     elif rec["workload"]["var_len"] == 1:
         assert rec["n_bases"] > 9e8 and res["got"]["n_emissions_partition"] > 1e11 and rec["partition"]["n_parts"] == 1
     else:
         import bigparity
-        up = bigparity.synth_workload(rec["workload"]).units(1)[0]
+        pk = bigparity.synth_workload(rec["workload"])      # (kept alive: units() hands out views of its arrays)
+        up = pk.units(1)[0]
         assert int(np.diff(up).max()) > 128 and rec["n_rare"] > (1 << 24) and res["got"]["n_emissions_partition"] > 1e9
 
 
