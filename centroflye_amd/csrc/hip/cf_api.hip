@@ -507,6 +507,9 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
     } else if (n == "dist_hot_entries") {
         if (value < -1 || value > 0x7FFFFFFF) return cf_fail(ctx, -22, "dist_hot_entries out of range (-1 = always keep the list, 0 .. 2^31 - 1)");
         ctx->dist_hot_entries = (int)value;
+    } else if (n == "lut_shift") {
+        if (value < -1 || value > 3) return cf_fail(ctx, -22, "lut_shift out of range (-1 = by the set's size, 0 .. 3)");
+        ctx->lut_shift = (int)value;
     } else if (n == "dist_regions") {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return cf_fail(ctx, -22, "dist_regions must be 0 (auto), 1, 2, 4 or 8");
         ctx->dist_regions = (int)value;

@@ -281,10 +281,15 @@ cf_bits_count_kernel(const uint32_t* __restrict__ bits, int64_t words, unsigned 
 int cf_install_kmers(cf_ctx* ctx, int32_t k) {
     const int64_t n = ctx->n_kmers;
     ctx->set_k = k;
-    ctx->lut_cap = cf_pow2_ceil((uint64_t)std::max<int64_t>(2 * n, 1024));
+    const uint64_t cap2 = cf_pow2_ceil((uint64_t)std::max<int64_t>(2 * n, 1024));      // load <= 0.5: what the prefilter is sized from
+    // Round 6: a SPARSER table (load <= 0.125 up to 1.7e7 k-mers, <= 0.25 up to 1.3e8) — every workgroup of cf_cloud_kernel waits for the
+    // slowest of its 2 048 look-ups, whose probe chain is what a load of 0.5 makes long: 16.0 -> 13.8 (x 2) -> 13.25 ms (x 4) at 0.99 Gb;
+    // the prefilter keeps its size (it is what has to stay cache resident).  "lut_shift" 0 .. 3 forces the factor.
+    const int lut_shift = ctx->lut_shift >= 0 ? ctx->lut_shift : (cap2 <= (1ull << 25) ? 2 : cap2 <= (1ull << 28) ? 1 : 0);
+    ctx->lut_cap = cap2 << lut_shift;
     if (ctx->lut_cap > (1ull << 32)) return cf_fail(ctx, -34, "k-mer set too large for the lookup table's 32-bit hash");
     CF_TRY(cf_alloc_t(ctx, &ctx->d_lut, (size_t)ctx->lut_cap, "k-mer lookup table"));
-    ctx->lut_pre_words = ctx->lut_cap * 8 / 32;
+    ctx->lut_pre_words = cap2 * 8 / 32;
     CF_TRY(cf_alloc_t(ctx, &ctx->d_lut_pre, (size_t)ctx->lut_pre_words, "k-mer lookup prefilter"));
     CF_HIP(hipMemsetAsync(ctx->d_lut_pre, 0, (size_t)ctx->lut_pre_words * 4, ctx->stream));
     ctx->unique_words = (n + 31) / 32 + 1;

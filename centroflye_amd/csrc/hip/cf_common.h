@@ -147,6 +147,7 @@ struct cf_ctx {
     int dist_wide = 0;       // 1 forces the 8-byte-slot table layout (tests)
     int dist_post_atomics = 0;   // 1 builds the postings with the histogram + fill passes of atomics instead of the sort (tests, A/B runs)
     int dist_hot_cap = 0;    // > 0: cap on the filter's hot-slot list (tests)
+    int lut_shift = -1;      // the k-mer lookup table of A3 has (2 x k-mers, rounded up to a power of two) << lut_shift slots; -1 = by the set's size
     int dist_hot_entries = 32768;   // first k-mers with more partner entries keep no hot-slot list (it would overflow: ~5 % of the pairs' keys reach min_cov); -1: always keep it
     int dist_regions = 0;    // 1, 2, 4, 8: force the region layout of the 6-byte slots with at least that many regions (tests), 0 = only when the ranks need it
     int dist_region_bytes = 0; // 1: the region layout streams rank and unit index apart (round 3) even where the 4-byte stream of cf_tab_region26 applies (tests)

@@ -189,7 +189,7 @@ cf_entry_unit_kernel(const int64_t* __restrict__ cloud_ptr, const int32_t* __res
 // writes (the keys are sorted afterwards: their order here is free).  An atomic per 64 k-mers on the one counter was 6.9 ms of an
 // emulated rank's 23 ms of set-up (3.7e7 k-mers: 570 000 adds to one address, one after the other).
 __global__ void __launch_bounds__(256)
-cf_order_keys_kernel(const uint32_t* __restrict__ pcnt, const uint32_t* __restrict__ first_unit, int64_t n_kmers, int part, int n_parts,
+cf_order_keys_kernel(const uint32_t* __restrict__ pcnt, const uint32_t* __restrict__ first_unit, int64_t n_kmers, int part, int n_parts, int ab,
                      unsigned long long* __restrict__ keys, unsigned long long* __restrict__ n_out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -215,16 +215,16 @@ cf_order_keys_kernel(const uint32_t* __restrict__ pcnt, const uint32_t* __restri
             const unsigned long long m = cf_ballot(take);
             if (take) {
                 const int64_t a = s0 + (int64_t)r * 64 + lane;
-                keys[base + (unsigned long long)__popcll(m & lt)] = ((unsigned long long)first_unit[a] << 32) | (unsigned long long)a;
+                keys[base + (unsigned long long)__popcll(m & lt)] = ((unsigned long long)first_unit[a] << ab) | (unsigned long long)a;
             }
             base += (unsigned long long)__popcll(m);
         }
     }
 }
 __global__ void __launch_bounds__(256)
-cf_order_extract_kernel(const unsigned long long* __restrict__ keys, int64_t n, int32_t* __restrict__ order) {
+cf_order_extract_kernel(const unsigned long long* __restrict__ keys, int64_t n, int ab, int32_t* __restrict__ order) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) order[i] = (int32_t)(keys[i] & 0xFFFFFFFFull);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) order[i] = (int32_t)(keys[i] & ((1ull << ab) - 1ull));
 }
 
 // One item = up to DIST_ITEM consecutive partner entries of one posting: what one wave takes per step.
@@ -1864,16 +1864,6 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
 #endif
 }
 
-// sum over all postings of their partner-range length = the number of pair emissions of the launch (before a != b)
-__global__ void __launch_bounds__(256)
-cf_sum_partner_kernel(const int32_t* __restrict__ post, int64_t n_post, const cf_dist_rec* __restrict__ urange, unsigned long long* __restrict__ out) {
-    unsigned long long s = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_post; i += stride) s += urange[post[i]].len;
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, (unsigned)d);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
-}
-
 __global__ void __launch_bounds__(256)
 cf_max_u32_kernel(const uint32_t* __restrict__ v, int64_t n, uint32_t* __restrict__ out) {
     uint32_t m = 0;
@@ -2122,14 +2112,24 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         // and win when a first k-mer has few pair emissions; with many (long reads, high coverage) the halved table and
         // sketch cost more than the overlap gains, and one 1024-thread workgroup with the whole LDS wins (measured:
         // 20 k emissions per first k-mer: 480 vs 716 ms; 53 k: 437 vs 274 ms; 160 k: 2097 vs 739 ms)
-        unsigned long long h_partner = 0;
-        if (n_post && (ctx->dist_wgs == 0 || ctx->dist_block == 0)) {
-            hipLaunchKernelGGL(cf_sum_partner_kernel, dim3((unsigned)cf_grid_for(n_post, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const int32_t*)d_post, n_post, (const cf_dist_rec*)d_urange, d_cnt + 3);
-            if (hipMemcpy(&h_partner, d_cnt + 3, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "partner sum"); break; }
-            if (hipMemsetAsync(d_cnt + 3, 0, 8, ctx->stream) != hipSuccess) { rc = cf_fail(ctx, -5, "partner sum reset"); break; }
+        // pair emissions per first k-mer, ESTIMATED on the host (round 6; rounds 2-5 summed the partner ranges of every posting on the device —
+        // a kernel of random gathers, 1.05 ms of every launch, and a blocking copy — for a figure that only picks the launch shape): the
+        // partner units of every unit of the reads in range, exactly, times the mean cloud size, times the mean postings per unit
+        double per_first = 0.0;
+        if (n_post && u1 > u0) {
+            unsigned long long partner_units = 0;
+            for (int64_t r = min_n; r < max_n; ++r) {
+                const int64_t nu = v_h_unit_ptr[(size_t)r + 1] - v_h_unit_ptr[(size_t)r];
+                // unit i of a read of nu units has max(0, min(nu - 1, i + max_d) - (i + min_d) + 1) partner units
+                const int64_t span = (int64_t)max_d - min_d_eff + 1;
+                if (nu <= min_d_eff || span <= 0) continue;
+                const int64_t full = std::max<int64_t>(0, nu - max_d);           // units with the whole span behind them
+                const int64_t tail = nu - min_d_eff - full;                      // the rest: nu - min_d - i partner units each, down to 1
+                partner_units += (unsigned long long)(full * span) + (unsigned long long)(tail > 0 ? tail * (tail + 1) / 2 : 0);
+            }
+            const double cloud = (double)(e1 - e0) / (double)(u1 - u0), post_per_unit = (double)n_post / (double)(u1 - u0);
+            per_first = (double)partner_units * cloud * post_per_unit / (double)std::max<int64_t>(1, (K - part + n_parts - 1) / n_parts);
         }
-        const double per_first = (double)h_partner / (double)std::max<int64_t>(1, (K - part + n_parts - 1) / n_parts);
         int wgs = ctx->dist_wgs, block = ctx->dist_block;
         if (wgs == 0) wgs = (block > 512 || per_first > 32768.0) ? 1 : 2;
         if (block == 0) block = wgs == 1 ? 1024 : 512;
@@ -2158,16 +2158,19 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         if ((rc = cf_alloc_t(ctx, &d_okeys, (size_t)n_a_alloc, "order keys"))) break;
         if ((rc = cf_alloc_t(ctx, &d_otmp, (size_t)n_a_alloc, "order scratch"))) break;
         if ((rc = cf_alloc_t(ctx, &d_order, (size_t)n_a_alloc, "order"))) break;
+        int ab = 1, ub = 1;      // bits of a rank, bits of a unit number
+        while (ab < 32 && ((int64_t)1 << ab) < K) ++ab;
+        while (ub < 32 && ((int64_t)1 << ub) < std::max<int64_t>(U, 2)) ++ub;
         if (K) {
             hipLaunchKernelGGL(cf_order_keys_kernel, dim3((unsigned)cf_grid_for(K, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                               (const uint32_t*)d_pcnt, (const uint32_t*)d_first, K, (int)part, (int)n_parts, d_okeys, d_cnt + 6);
+                               (const uint32_t*)d_pcnt, (const uint32_t*)d_first, K, (int)part, (int)n_parts, ab, d_okeys, d_cnt + 6);
             unsigned long long h_n = 0;
             if (hipMemcpy(&h_n, d_cnt + 6, 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = cf_fail(ctx, -5, "order count"); break; }
             n_order = (int64_t)h_n;
-            if ((rc = cf_radix_sort_u64(ctx, d_okeys, d_otmp, n_order, 63))) break;
+            if ((rc = cf_radix_sort_u64(ctx, d_okeys, d_otmp, n_order, ab + ub))) break;      // (round 6: the key's own bits — 6 radix passes at 50 000 reads; rounds 2-5 sorted all 64)
             if (n_order)
                 hipLaunchKernelGGL(cf_order_extract_kernel, dim3((unsigned)cf_grid_for(n_order, 256, max_blocks)), dim3(256), 0, ctx->stream,
-                                   (const unsigned long long*)d_okeys, n_order, d_order);
+                                   (const unsigned long long*)d_okeys, n_order, ab, d_order);
         }
         A.order = d_order; A.n_order = n_order;
         // the work lists of the sweeps (heads + item records, laid out for workgroups of `block` threads): count, scan, fill

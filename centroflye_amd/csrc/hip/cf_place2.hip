@@ -345,7 +345,10 @@ __device__ __forceinline__ void pl2_rescan_read(const cf_pl2& S, uint32_t r, uin
 // and needed eight passes).
 // out_idx: the line of the output this tail's winner gets = the number of reads this stage has placed so far, which the HOST knows (one
 // per launch): it comes as a kernel argument — round 4 kept it in memory and the lane that publishes the winner paid a dependent load for it
-__device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, unsigned long long t_last = 0ull) {
+// placed: the read this launch has just laid down (its RB entry and its block are redone here: it is used now), or 0xFFFFFFFF — round 6:
+// it comes in a register; rounds 4-5 had the PREVIOUS tail mark it in the dirty bitmap with a device-scope atomic, the last memory operation
+// of every launch (1.1 us under this kernel's load, whether or not it returns)
+__device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, uint32_t placed, unsigned long long t_last = 0ull) {
     (void)t_last;
 #ifdef CF_PL2_STAMPS2
     const bool ttr = S.C.ctl[1] == S.trace_iter && (threadIdx.x & 63) == 0;
@@ -378,8 +381,10 @@ __device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, unsigned long long t
     for (uint32_t i = tid; i < n_b2words; i += nthr) bb2[i] = 0u;
     for (uint32_t i = tid; i < n_b3words; i += nthr) { bb3[i] = 0u; const uint32_t w3 = S.l3_stale[i]; st3[i] = w3; st3n[i] = w3; }
     bool again = true;
+    bool first_round = true;
     while (again) {
-        if (tid == 0) { *n_list = 0u; *more = 0u; *n_list2 = 0u; }
+        if (tid == 0) { *n_list = 0u; *more = 0u; *n_list2 = 0u; if (first_round && placed != 0xFFFFFFFFu) { list[0] = placed; *n_list = 1u; } }
+        first_round = false;
         __syncthreads();
         // every workgroup has arrived: plain traffic on the bitmap.  A thread takes PL2_DW words per round, ALL loaded before the first is
         // looked at: the bitmap is one bit per read, and a round trip per pair of words made this scan 8 dependent round trips at 500 000
@@ -556,8 +561,7 @@ __device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, unsigned long long t
                         S.C.ctl[1] = o + 1u;      // (the host reads the number of placements from here)
                         S.C.out_read[o] = (int64_t)w.read; S.C.out_pos[o] = (int64_t)(w.lo >> 32);
                         S.C.out_s0[o] = (int32_t)((w.hi - 1ull) >> 32); S.C.out_s1[o] = (int32_t)(uint32_t)(w.hi - 1ull);
-                        S.C.used[w.read] = 1;
-                        atomicOr(&S.dirty[w.read >> 5], 1u << (w.read & 31));      // its RB entry and its blocks are redone by the next tail
+                        S.C.used[w.read] = 1;      // (its RB entry and its block are redone by the next launch's tail, which gets the read as `placed`)
                     }
                     S.C.ctl[3] = 0u;
                 }
@@ -574,9 +578,9 @@ static size_t pl2_lds_bytes(uint32_t n2) { return (16 + (size_t)PL2_LIST * 8 + 1
 __global__ void __launch_bounds__(PL2_B)
 cf_pl2_tail_kernel(cf_pl2 S) {
 #ifdef CF_PL2_STAMPS
-    pl2_tail(S, 0u, wall_clock64());
+    pl2_tail(S, 0u, 0xFFFFFFFFu, wall_clock64());
 #else
-    pl2_tail(S, 0u);
+    pl2_tail(S, 0u, 0xFFFFFFFFu);
 #endif
 }
 
@@ -660,9 +664,9 @@ cf_pl2_iter_kernel(cf_pl2 S, uint32_t it /* greedy iteration of the stage, 0-bas
 #ifdef CF_PL2_STAMPS
     if (threadIdx.x == 0) { atomicAdd(&S.stamps[1], t_loop - t_last); atomicAdd(&S.stamps[8], t_win - t_last); atomicAdd(&S.stamps[9], t_body - t_win); atomicAdd(&S.stamps[10], t_loop - t_body); t_last = t_loop; atomicAdd(&S.stamps[0], 1ull); }
     PL2_STAMP(2);
-    pl2_tail(S, it + 1u, t_last);
+    pl2_tail(S, it + 1u, w.read, t_last);
 #else
-    pl2_tail(S, it + 1u);
+    pl2_tail(S, it + 1u, w.read);
 #endif
 }
 

@@ -173,9 +173,17 @@ def test_config1_50k_reads_count_and_rare_filter_vs_cpu(engine):
     got_tchk = cport.table_checksum(keys, pres, multi)
     n_table = keys.size
     del keys, pres, multi
+    #  the device-side checksums the 200 000- / 500 000-read tests rely on (cf_checksum.hip), element-wise against the
+    # host's mixes of the COPIED rows: the A1 table here, the rare set and the cloud CSR below
+    assert engine.checksum("table") == (got_tchk, n_table)
     n_rare = engine.select_rare(P["max_nonuniq"], P["lo"], P["hi"])
     st = engine.stats()
     rare = engine.kmers()
+    assert engine.checksum("kmers") == (cport.rare_checksum(rare), rare.size)
+    n_ce = engine.build_clouds()
+    cp_, ent_ = engine.clouds()
+    assert engine.checksum("clouds") == (cport.cloud_checksum(cp_, ent_), n_ce)
+    del cp_, ent_
     c, a = cport.stage2(pk.bases, pk.read_off, up, us, ue, P["k"], P["max_nonuniq"], P["lo"], P["hi"], threads=0, stop_after=1, want_arrays=True)
     assert (st["n_bases"], st["n_windows"], st["n_read_kmers"]) == (c["n_bases"], c["n_windows"], c["n_read_kmers"])
     assert (st["n_distinct"], n_table, st["n_kept"], n_rare) == (c["n_distinct"], c["n_distinct"], c["n_kept"], c["n_rare"])
