@@ -320,10 +320,21 @@ def workload_c(a, sr, rank, world):
     ultra-long reads — mean 100 kb, ~47 units per read, up to ~170: every distance up to max_distance = 150 occurs, a first k-mer has
     ~60 000 pair emissions (the default workload: ~20 000, reads of ~10 units).  Reference: README.md:59-75, run_all_cenX.sh:17-22,
     distance_based_kmer_recruitment.py:85-149.  Both copy-specific variant models: var_len 8 and 1."""
+    import glob
     out = {}
     for vl in (8, 1):
         out[f"var_len_{vl}"] = extra_workload(a, sr, rank, world, dict(CENX, var_len=vl, n_reads=a.reads_c, n_units=a.units_c), a.steps_c,
                                               f"cenX-shaped reads (1 500-unit array, coverage 32, reads of mean 100 kb), var_len {vl}", f"r06_parity_cenx_varlen{vl}.json")
+    # HBM-side bytes of one launch of the dominant kernel on these reads, from the committed PMC passes (tools/profile_round.sh: pmcc_*)
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_dist_kernel_workload_c.json")))
+    w8 = out["var_len_8"]
+    w8["roofline"]["traffic"] = None
+    if cands and (a.reads_c, a.units_c) == (CENX["n_reads"], CENX["n_units"]):
+        with open(cands[-1]) as f:
+            pm = json.load(f)
+        w8["roofline"].update(traffic=pm.get("traffic_bytes_per_launch"), counters_from=os.path.relpath(cands[-1], ROOT),
+                              lds=(pm.get("derived") or {}).get("lds"), issue_per_cycle_per_cu=(pm.get("derived") or {}).get("issue_per_cycle_per_cu"),
+                              hbm_side_gbps=(pm.get("derived") or {}).get("hbm_side_gbps"))
     return out
 
 

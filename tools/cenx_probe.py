@@ -15,6 +15,7 @@ ap.add_argument("--var-len", type=int, default=8); ap.add_argument("--reads", ty
 ap.add_argument("--mean-len", type=float, default=100000.0); ap.add_argument("--max-len", type=int, default=1000000); ap.add_argument("--seed", type=int, default=5)
 ap.add_argument("--lib", default=None); ap.add_argument("--edges", action="store_true", help="store every selected edge (a sizing launch first)")
 ap.add_argument("--place", action="store_true")
+ap.add_argument("--once", type=int, default=0, help="ONE launch of the distance stage with this edge cap (the PMC passes of tools/profile_round.sh: every kernel runs once)")
 ap.add_argument("knobs", nargs="*")
 a = ap.parse_args()
 pk = _host.synth(n_reads=a.reads, seed=a.seed, n_units=a.units, var_len=a.var_len, mean_len=a.mean_len, max_len=a.max_len)
@@ -25,8 +26,8 @@ for spec in (a.knobs or [""]):
         e.set_param(kv.split("=")[0], int(kv.split("=")[1]))
     e.load(pk, 1); e.count_kmers(19); n_rare = e.select_rare(3, 10, 32); n_ce = e.build_clouds()
     tm = e.times()
-    ms, cap = [], 0
-    for i in range(3):
+    ms, cap = [], a.once
+    for i in range(1 if a.once else 3):
         n_edges = e.dist_edges(0, 2 ** 62, 1, 150, 4, 0.8, 0, 1, cap)
         ms.append(round(e.times()["dist_kernel_ms"], 2))
         if a.edges and i == 0:
@@ -34,7 +35,7 @@ for spec in (a.knobs or [""]):
     st = e.stats()
     rec = dict(knobs=spec, n_rare=n_rare, n_cloud_entries=n_ce, count_ms=round(tm["count_ms"], 2), select_ms=round(tm["select_ms"], 2), clouds_ms=round(tm["clouds_ms"], 2),
                setup_ms=round(e.times()["postings_ms"], 2), kernel_ms=ms, n_emissions=st["n_emissions"], n_edges=n_edges, n_unique=st["n_unique"], passes=st["n_dist_passes"],
-               spilled=st["n_spilled"], emissions_per_s=st["n_emissions"] / (min(ms[1:]) * 1e-3), per_first=st["n_emissions"] / max(n_rare, 1))
+               spilled=st["n_spilled"], emissions_per_s=st["n_emissions"] / (min(ms[1:] or ms) * 1e-3), per_first=st["n_emissions"] / max(n_rare, 1))
     if a.place:
         import numpy as np
         gk = e.kmers()[e.unique_mask()]

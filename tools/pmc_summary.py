@@ -7,7 +7,7 @@
 usage: tools/pmc_summary.py <tag>"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
@@ -99,3 +99,41 @@ print(json.dumps({k: v for k, v in out.items() if k != "notes"}, indent=1))
 for k, v in others.items():
     if v.get("traffic_bytes"):
         print(k, "traffic %.3g GB" % (v["traffic_bytes"] / 1e9), "VALU %.3g" % v.get("SQ_INSTS_VALU", {"sum": 0})["sum"])
+
+
+# ---- round 6: the same counters of cf_dist_kernel on the cenX-shaped reads of bench.py's workload_c (pmcc_* passes of tools/profile_round.sh)
+pk_c = {}
+for grp in "ABCD":
+    for f in glob.glob(os.path.join(src, f"pmcc_{grp}", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            if "cf_dist_kernel" not in k:
+                continue
+            e = pk_c.setdefault(row["Counter_Name"], {"launches": set(), "sum": 0.0})
+            e["sum"] += float(row["Counter_Value"]); e["launches"].add(row["Dispatch_Id"])
+line = os.path.join(dst, f"{tag}_bench_line.json")
+if pk_c and os.path.exists(line):
+    bl = json.loads(open(line).read().strip().splitlines()[-1])
+    wc = (bl.get("workload_c") or {}).get("var_len_8")
+    c = {k: v["sum"] for k, v in sorted(pk_c.items())}
+    oc = {"workload": "tools/cenx_probe.py --var-len 8 --once 1809975565: ONE launch of cf_dist_kernel on the cenX-shaped reads of bench.py's workload_c (1 000 reads of mean 100 kb over a 1 500-unit array, coverage 32: "
+                      "3.217e10 pair emissions, ~60 800 per first k-mer, all 1 809 974 541 selected edges stored), launch shape 1 x 1024 threads per CU",
+          "notes": notes, "kernel": "cf_dist_kernel<cf_tab_narrow_t<8, 4>>", "counters": c, "dispatches": max(len(v["launches"]) for v in pk_c.values())}
+    tb = ((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024) if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
+    oc["traffic_bytes_per_launch"] = tb
+    if wc:
+        E, k_ms, alg = wc["counters"]["n_emissions"], wc["roofline"]["kernel_ms"], wc["roofline"]["algorithmic_bytes_per_launch"]
+        cu_cycles = k_ms * 1e-3 * 2.4e9 * 256
+        oc["per_pair_emission"] = {"n_emissions": E, "SQ_INSTS_VALU": c.get("SQ_INSTS_VALU", 0) / E, "SQ_INSTS_SALU": c.get("SQ_INSTS_SALU", 0) / E, "SQ_INSTS_LDS": c.get("SQ_INSTS_LDS", 0) / E}
+        oc["traffic_over_algorithmic"] = tb / alg if tb else None
+        oc["derived"] = {"kernel_ms_of_the_bench_line": k_ms, "algorithmic_bytes_per_launch": alg, "roofline_frac": alg / (k_ms * 1e-3) / 8e12,
+                         "pair_emissions_per_s": E / (k_ms * 1e-3), "dist_passes_per_first_kmer": wc.get("dist_passes_per_first_kmer"),
+                         "lds": {"idx_active_frac": round(c.get("SQ_LDS_IDX_ACTIVE", 0) / cu_cycles, 4),
+                                 "bank_conflict_frac": round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"], 4) if c.get("SQ_LDS_IDX_ACTIVE") else None,
+                                 "insts_per_pair": round(c.get("SQ_INSTS_LDS", 0) / E, 4), "waves_per_simd": 4},
+                         "issue_per_cycle_per_cu": {"valu": round(c.get("SQ_INSTS_VALU", 0) / cu_cycles, 3), "salu": round(c.get("SQ_INSTS_SALU", 0) / cu_cycles, 3), "lds": round(c.get("SQ_INSTS_LDS", 0) / cu_cycles, 3)},
+                         "wait_any_frac_of_wave_cycles": round(c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"], 3) if c.get("SQ_WAVE_CYCLES") else None,
+                         "l2_hit": round(c["TCC_HIT"] / (c["TCC_HIT"] + c["TCC_MISS"]), 4) if c.get("TCC_HIT") else None,
+                         "hbm_side_gbps": round(tb / (k_ms * 1e-3) / 1e9, 1) if tb else None}
+    json.dump(oc, open(os.path.join(dst, f"{tag}_pmc_dist_kernel_workload_c.json"), "w"), indent=1)
+    print(json.dumps({k: v for k, v in oc.items() if k != "notes"}, indent=1))

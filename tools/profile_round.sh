@@ -4,7 +4,7 @@
 # Results land under gpurun_out/prof_<tag>/ ; tools/pmc_summary.py turns them into profiles/<tag>_*.
 # usage: bash tools/profile_round.sh <tag>
 set -u
-tag=${1:-r05}
+tag=${1:-r06}
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
@@ -19,4 +19,12 @@ pmc A SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
 pmc B SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU TCC_HIT TCC_MISS
 pmc C FETCH_SIZE
 pmc D WRITE_SIZE
+# the same four passes of cf_dist_kernel on the cenX-SHAPED reads of bench.py's workload_c (var_len 8; BASELINE configs[4]'s regime): ONE launch,
+# every selected edge stored (1 809 974 541 of them, profiles/r06_parity_cenx_varlen8.json)
+CENX="tools/cenx_probe.py --var-len 8 --once 1809975565"
+pmcc() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc "$@" -d "$out/pmcc_$name" -o "$name" -- python3 $CENX > "$out/pmcc_$name.log" 2> "$out/pmcc_$name.err"; }
+pmcc A SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT
+pmcc B SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU TCC_HIT TCC_MISS
+pmcc C FETCH_SIZE
+pmcc D WRITE_SIZE
 find "$out" -name "*.csv" | head -40
