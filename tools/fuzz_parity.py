@@ -29,19 +29,20 @@ only = arg("--only", -1)
 rng = np.random.default_rng(seed)
 BASE = dict(bigparity.P)
 KNOB_DEFAULTS = dict(dist_slots=0, dist_block=0, dist_wgs=0, dist_sketch=1, dist_wide=0, dist_regions=0, dist_region_bytes=0, dist_dbits=0, dist_hot_cap=0,
-                     dist_post_atomics=0, dist_fill_pct=70, dist_stage=2048, dist_int_thr=1, count_mode=1, count_bits=0, comm_round_bytes=1 << 28)
+                     dist_post_atomics=0, dist_fill_pct=70, dist_stage=2048, dist_int_thr=1, count_mode=1, count_bits=0, comm_round_bytes=1 << 28,
+                     dist_hot_entries=32768, lut_shift=-1)
 
 
 def draw_case():
     n_reads = int(rng.choice([int(x) for x in os.environ.get("CF_FUZZ_READS", "300,600,1200,2500,5000").split(",")]))
     unit_len = int(rng.choice([342, 1026, 2055, 3078]))
     sy = dict(seed=int(rng.integers(1, 1 << 30)), n_reads=n_reads, unit_len=unit_len, var_len=int(rng.choice([1, 8])),
-              mean_len=float(rng.choice([8000.0, 20000.0, 50000.0])), p_sub=float(rng.uniform(0.003, 0.04)), p_del=float(rng.uniform(0.003, 0.03)),
+              mean_len=float(rng.choice([8000.0, 20000.0, 50000.0, 100000.0])),      # (round 6: 100 kb = the cenX shape, ~47 units per read) p_sub=float(rng.uniform(0.003, 0.04)), p_del=float(rng.uniform(0.003, 0.03)),
               p_ins=float(rng.uniform(0.003, 0.03)), unit_div=float(rng.uniform(0.003, 0.03)))
     # (pair emissions grow with the square of the units per read: long reads and short units only on small read sets, so that a case is
     # seconds of oracle time and the run is many cases)
     if sy["mean_len"] > 20000.0:
-        n_reads = sy["n_reads"] = min(n_reads, 600)
+        n_reads = sy["n_reads"] = min(n_reads, 600 if sy["mean_len"] <= 50000.0 else 300)
     if unit_len < 1000 and sy["mean_len"] > 8000.0:
         unit_len = sy["unit_len"] = 1026
     sy["max_len"] = int(max(200000, 5 * sy["mean_len"]))
@@ -66,7 +67,7 @@ def draw_case():
         for name, choices in (("dist_slots", [256, 512, 2048, 4096]), ("dist_block", [64, 128, 256, 512, 1024]), ("dist_wgs", [1, 2, 3, 4]), ("dist_sketch", [0]),
                               ("dist_wide", [1]), ("dist_regions", [1, 2, 4, 8]), ("dist_region_bytes", [1]), ("dist_dbits", [5, 6, 7, 8]), ("dist_hot_cap", [1, 8, 64]),
                               ("dist_post_atomics", [1]), ("dist_fill_pct", [20, 50, 90]), ("dist_stage", [0, 64]), ("dist_int_thr", [0]), ("count_mode", [0]),
-                              ("count_bits", [4, 9, 14])):
+                              ("count_bits", [4, 9, 14]), ("dist_hot_entries", [-1, 0, 2000]), ("lut_shift", [0, 1, 3])):
             if rng.random() < 0.18:
                 knobs[name] = int(rng.choice(choices))
     return sy, p, part, n_parts, knobs

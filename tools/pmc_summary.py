@@ -20,7 +20,7 @@ for name in ("bench_line", "bench_line_place_rr"):
         if lines:
             json.loads(lines[-1])
             open(os.path.join(dst, f"{tag}_{name}.json"), "w").write(lines[-1] + "\n")
-workload = "bench.py --steps 1 --warmup 0 --no-cpu-baseline --transfer-steps 0 --no-place --steps-b 0 --edge-cap 3156872828 (50000 reads, the bench's own configuration: all 3 156 871 804 selected edges stored): one launch of every kernel of the step"
+workload = "bench.py --steps 1 --warmup 0 --no-cpu-baseline --transfer-steps 0 --no-place --steps-b 0 --steps-c 0 --edge-cap 3156872828 (50000 reads, the bench's own configuration: all 3 156 871 804 selected edges stored): one launch of every kernel of the step"
 per_kernel = {}
 for grp in "ABCD":
     for f in glob.glob(os.path.join(src, f"pmc_{grp}", "**", "*counter_collection.csv"), recursive=True):
