@@ -524,6 +524,9 @@ int cf_set_param(cf_ctx* ctx, const char* name, int64_t value) {
         ctx->dist_edge_chunk = (int)value;
     } else if (n == "dist_int_thr") {
         ctx->dist_int_thr = value != 0;
+    } else if (n == "dist_sketch_bits") {
+        if (value != 0 && value != 4 && value != 8) return cf_fail(ctx, -22, "dist_sketch_bits must be 0 (by min_cov), 4 or 8");
+        ctx->dist_sketch_bits = (int)value;
     } else if (n == "dist_sketch") {
         ctx->dist_sketch = value != 0;
     } else if (n == "dist_est_pct") {

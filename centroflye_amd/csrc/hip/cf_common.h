@@ -156,6 +156,7 @@ struct cf_ctx {
     int dist_edge_chunk = 0; // > 0: edge rows a workgroup reserves per global atomic (tests: small chunks cross often), 0 = 8192
     int dist_int_thr = 1;    // 1: rel_threshold == 0.8 is tested as 5 cnt >= 4 total; 0: always the double division (tests)
     int dist_sketch = 1;     // 0: every (b,d) pair goes to the exact table (no counting sketch first)
+    int dist_sketch_bits = 0;   // bits of a sketch counter: 0 = 4 when min_cov <= 9, else 8; 8 forces bytes
     int dist_est_pct = 80;   // expected distinct (b,d) keys per 100 pair emissions: sizes the initial number of table partitions
     int dist_stage = 2048;   // edges of a pass whose rows do not fit the rest of the workgroup's output chunk, staged in LDS (more: a sweep of the marked slots)
     int place_chunk = 2, place_grid = 0;     // cloud entries per wave step of that kernel (1 .. 64), its workgroups (0 = one per CU)

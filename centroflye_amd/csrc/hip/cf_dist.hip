@@ -265,6 +265,7 @@ struct cf_dist_args {
     uint32_t est_limit;            // emissions one partition is expected to hold (fill_limit / expected distinct share)
     int32_t sketch;                // 1: count first in 8-bit counters, build the exact table only for k-mers that can pass min_cov
     uint32_t sk_counters, sk_shift, sk_mask;   // counters (a power of two that fits the LDS that is dead during the sketch sweep), 32 - log2 of it, and it - 1
+    uint32_t sk_fbits, sk_fsh, sk_wshift, sk_fmask, sk_guard, sk_bytes;      // a counter's bits (8 or 4), log2 of that, log2 of the counters per word, its largest value, the value from which an add takes itself back (4-bit counters), bytes of the array
     const cf_dist_head* heads;     // the first k-mers of the launch in processing order (cf_items_fill_kernel) ...
     const cf_dist_item* items;     // ... and the item records of their sweeps, laid out per wave of a workgroup of blockDim.x threads
     uint32_t stage_cap;            // <= DIST_STAGE_CAP
@@ -1365,13 +1366,20 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
         const uint32_t min_cov_m1 = A.min_cov - 1u;      // (the sketch runs with min_cov >= 2)
         // the pass that nearly every first k-mer gets by with: one partition, every marked b in it (set up here, in front of a
         // barrier that is there anyway; "every b marked" below replaces it)
-        if (t == 0) { sh[13] = 0; sh[2] = 0; sh[3] = 1; sh[4] = 0; sh[0] = 0; sh[7] = 0; sh[8] = 0; sh[11] = 0; sh[30] = 0; }
+        if (t == 0) { sh[13] = 0; sh[31] = 0; sh[2] = 0; sh[3] = 1; sh[4] = 0; sh[0] = 0; sh[7] = 0; sh[8] = 0; sh[11] = 0; sh[30] = 0; }
         if (A.sketch) {
+            // (round 6) the counters' width for THIS attempt: 4-bit counters that wrap — a burst of 16 adds on one counter before the first
+            // of them can take itself back: a pair counted 15 times plus a collision — send the first k-mer through the sketch sweep once
+            // more with bytes (half as many counters), not straight to "every b marked" with its 4-8 table passes; the marks made so far stay
+            // (a mark too many only lets pairs into the exact table).  The two attempts report their wrap in words of their own (sh[13],
+            // sh[31]): nobody resets a word that another thread may still be reading.
+            uint32_t m_fbits = A.sk_fbits, m_fsh = A.sk_fsh, m_wshift = A.sk_wshift, m_fmask = A.sk_fmask, m_guard = A.sk_guard, m_shift = A.sk_shift, m_flag = 13u;
+            for (;;) {
             {
                 const cf_u32x4 z{0u, 0u, 0u, 0u};
                 if (CF_DIST_ABL < 7) {
-                for (uint32_t s = (uint32_t)t; s < (A.sk_counters >> 4); s += (uint32_t)nt) ((cf_u32x4*)sk)[s] = z;
-                for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = z;
+                for (uint32_t s = (uint32_t)t; s < (A.sk_bytes >> 4); s += (uint32_t)nt) ((cf_u32x4*)sk)[s] = z;
+                if (m_flag == 13u) for (uint32_t s = (uint32_t)t; s < DIST_BM_BITS / 128; s += (uint32_t)nt) ((cf_u32x4*)bm)[s] = z;
                 }
                 __syncthreads();      // [sketch cleared]
             }
@@ -1391,11 +1399,16 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
 #if CF_DIST_SKETCH_BY_B
                         const uint32_t idx = lo_[u] & A.sk_mask;
 #else
-                        const uint32_t idx = Tab::sk_hash(bb[u], dd_[u], qq_[u]) >> A.sk_shift;
+                        const uint32_t idx = Tab::sk_hash(bb[u], dd_[u], qq_[u]) >> m_shift;
 #endif
-                        sft_[u] = idx << 3;             // (only its low 5 bits are used: the shift and the bit-field extract take them mod 32)
+                        // Round 6: counters of FOUR bits where min_cov allows it (twice as many in the same LDS: on samples of first k-mers 15 % fewer
+                        // keys reach the exact table on cenX-shaped reads — 6 800 instead of 7 950 — and 8 % fewer pairs are inserted).  A counter
+                        // only has to tell "min_cov - 1 or more": an add that sees 12 or more takes itself back (the counter stays where it is and
+                        // every later add still sees >= min_cov - 1), and the add that would wrap a field — it sees 15 — is seen doing it, like the
+                        // 255 of the 8-bit counters: the first k-mer falls back to "every b marked".  A carry into the next field only over-counts.
+                        sft_[u] = idx << m_fsh;      // (only its low 5 bits are used: the shift and the bit-field extract take them mod 32)
                         inc_[u] = 1u << (sft_[u] & 31u);
-                        old_[u] = idx >> 2;
+                        old_[u] = idx >> m_wshift;
                     }
                     if (len < DIST_ITEM) {      // (wave-uniform) lanes past the end of the posting's range add nothing
 #pragma unroll
@@ -1405,7 +1418,7 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                     for (int u = 0; u < DIST_UNROLL; ++u) old_[u] = atomicAdd(&sk[old_[u]], inc_[u]);     // all counter adds of the step back to back
                     uint32_t seen_[DIST_UNROLL];
 #pragma unroll
-                    for (int u = 0; u < DIST_UNROLL; ++u) seen_[u] = __builtin_amdgcn_ubfe(old_[u], sft_[u], 8u);     // occurrences before this one (v_bfe_u32 takes the offset mod 32)
+                    for (int u = 0; u < DIST_UNROLL; ++u) seen_[u] = __builtin_amdgcn_ubfe(old_[u], sft_[u], m_fbits);     // occurrences before this one (v_bfe_u32 takes the offset mod 32)
                     // ONE test per step: few adds reach min_cov (each of the four branches of round 2 cost a compare, three scalar
                     // exec-mask instructions and a jump)
                     static_assert(DIST_UNROLL == 4, "max of four");
@@ -1421,7 +1434,12 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
                                 atomicOr(&bm[Tab::bm_bit(lo_[u]) >> 5], 1u << (lo_[u] & 31u));
                             }
                         }
-                        if (seen_max == 255u) sh[13] = 1u;
+                        if (seen_max >= m_guard) {      // (4-bit counters only: the guard of the 8-bit ones is beyond their range)
+#pragma unroll
+                            for (int u = 0; u < DIST_UNROLL; ++u)
+                                if (seen_[u] >= m_guard && ((ok >> u) & 1u)) atomicSub(&sk[sft_[u] >> 5], 1u << (sft_[u] & 31u));      // (idx << fsh >> 5 = idx >> wshift: the counter's word; the increment is made again: kept in a register it made the kernel spill)
+                        }
+                        if (seen_max == m_fmask) sh[m_flag] = 1u;
                     }
                     return false;
                 });
@@ -1429,7 +1447,10 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             }
             __syncthreads();      // [sketch swept]
             CF_STAMP(7);      // (stamp 7: thread 0's wait for the other waves at the end of a sweep)
-            if (sh[13]) mark_all = true;
+            if (!sh[m_flag]) break;
+            if (m_fbits == 8u) { mark_all = true; break; }
+            m_fbits = 8u; m_fsh = 3u; m_wshift = 2u; m_fmask = 255u; m_guard = 0x7FFFFFFFu; m_shift = A.sk_shift + 1u; m_flag = 31u;
+            }
         }
         if (t == 0) { nx_idx = pop_finish(nx_q); if (nx_idx >= 0) nx_head = A.heads[nx_idx]; }      // next: its head (published with the last pass's reservation)
         if (mark_all) {
@@ -2151,6 +2172,11 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         const size_t sk_room = (size_t)A.slots * slot_bytes + DIST_STAGE_CAP * 2 + 16 + (size_t)(block / 64) * (DIST_QSTRIDE + DIST_OVQ) * qitem_bytes + 2 * DIST_STACK * 4 + DIST_HOT_CAP * 2;   // table + stage + stack + queues + hot list: all dead while the sketch runs
         while (A.sk_shift > 8 && (size_t)A.sk_counters * 2 <= sk_room) { A.sk_counters *= 2; --A.sk_shift; }
         if (A.sk_counters < 16) A.sketch = 0;
+        A.sk_bytes = A.sk_counters;
+        // 4-bit counters when min_cov - 1 fits well below their guard ("dist_sketch_bits" 8 keeps the bytes)
+        const bool sk4 = A.sketch && min_cov <= 9 && ctx->dist_sketch_bits != 8 && A.sk_shift > 9;
+        if (sk4) { A.sk_counters *= 2; --A.sk_shift; A.sk_fbits = 4; A.sk_fsh = 2; A.sk_wshift = 3; A.sk_fmask = 15; A.sk_guard = 12; }
+        else { A.sk_fbits = 8; A.sk_fsh = 3; A.sk_wshift = 2; A.sk_fmask = 255; A.sk_guard = 0x7FFFFFFFu; }
         A.sk_mask = A.sk_counters - 1u;
         const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 2048 / block));
         // locality order of the first k-mers: sort (first posting unit, a); k-mers without postings drop out

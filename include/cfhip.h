@@ -190,7 +190,7 @@ int cf_allreduce_unique(cf_ctx* ctx, int64_t* n_unique);
 /* Tuning knobs (defaults are chosen for gfx950): name in {"dist_block" (threads per workgroup, 0 = auto), "dist_wgs"
  * (workgroups per CU the LDS is split between, 0 = auto: by the pair emissions per first k-mer), "dist_slots" (LDS budget of the (b,d) table in 8-byte units, 0 = all that
  * is left), "dist_sketch" (0: every pair goes to the exact table), "dist_fill_pct", "dist_est_pct", "dist_stage", "dist_edge_chunk" (edge rows a workgroup reserves in the output per global atomic, 0 = 8192; tests use small chunks), "dist_int_thr" (0: the dominance test always divides in doubles; 1, the default: the literal 0.8 is tested as 5 cnt >= 4 total, which is the same predicate),
- * "dist_wide", "dist_post_atomics" (1: postings by a histogram and a fill pass of atomics instead of the sort), "dist_hot_cap" (tests: a small cap on the filter's hot-slot list forces the evaluation inside the bucket scan), "lut_shift" (the k-mer lookup table of cf_build_clouds gets (2 x k-mers rounded up to a power of two) << lut_shift slots; -1, the default: 2 for sets of up to 1.7e7 k-mers, 1 up to 1.3e8, else 0), "dist_hot_entries" (default 32768: first k-mers with more partner entries than this keep no list of hot slots during their inserts — it would overflow — and their filter scans the count fields; -1: always keep it), "dist_regions" (1, 2, 4, 8: force the region layout of the 6-byte slots, which k-mer sets of 2^24 .. 2^27 ranks with long reads take by themselves), "dist_dbits" (5 .. 8: cap on the distance-field bits of the 6-byte table slots [d | b]; 0 = 32 minus the bits the k-mer ranks need), "place_mode" (2, the default: per-read score regions and one kernel per greedy iteration, cf_place2.hip — for min_inters >= 4; smaller thresholds make nearly every score row a candidate row and take path 1; 3: the regions whatever the threshold; 1: the hash-map path of rounds 1-3, cf_place.hip), "place_grid" / "place_block" (workgroups and threads per workgroup of the iteration kernel, 0 = 128 x 1024), "place_row_words" (32 or 64 words per posting row, 0 = by the longest posting list), "place_slots_per_unit" (score-region slots per unit of a read, 0 = 48; grown automatically when a region fills), "place_l3" / "place_l3_shift" (1: the third level of the placement arg-max, groups of 2^shift blocks of 64 reads kept lazily — built in round 5, measured neutral at 500 000 reads, off by default), "dist_region_bytes" (1: the region layout streams rank and unit index apart, as k-mer sets beyond 2^26 ranks or reads beyond 128 units do by themselves), "place_long_rescans" (default 2: a run of the region path whose reads average more than this many rescans of reads with more than four candidate score rows per greedy iteration — k-mers that are not unique to one place of the array, thin coverage — is handed to the hash-map path; -1: at the first look, tests), "place_cmap_bits" (log2 of the first capacity of the contig's overflow map — the positions of a k-mer beyond its fourth —, 0 = cloud entries / 8, at least 2^21; grown automatically, times four, when it passes half load), "place_chunk", "place_fused" (place_mode 1: cloud entries per wave step; 1: score updates applied by the waves that lay a read onto the contig, 0: through an event list and a third kernel per greedy iteration), "count_mode" (1: A1 by sort and reduce, 0: the atomic table), "count_bits" (bucket bits of the former, 0 = auto), "count_slots", "count_tile", "comm_round_bytes" (bytes per pair of ranks and round of the multi-GPU exchanges, default 2^28; tests force many rounds), "comm_self_p2p" (1: the message a rank sends to itself goes through ncclSend / ncclRecv like every other one, so that a one-GPU box runs the whole p2p path)}.  Results never depend on them (tests/test_gpu_parity.py). */
+ * "dist_wide", "dist_post_atomics" (1: postings by a histogram and a fill pass of atomics instead of the sort), "dist_hot_cap" (tests: a small cap on the filter's hot-slot list forces the evaluation inside the bucket scan), "dist_sketch_bits" (bits of a counter of the distance stage's counting sketch: 0, the default: 4 when min_cov <= 9 — twice the counters in the same LDS —, else 8; 8 forces bytes), "lut_shift" (the k-mer lookup table of cf_build_clouds gets (2 x k-mers rounded up to a power of two) << lut_shift slots; -1, the default: 2 for sets of up to 1.7e7 k-mers, 1 up to 1.3e8, else 0), "dist_hot_entries" (default 32768: first k-mers with more partner entries than this keep no list of hot slots during their inserts — it would overflow — and their filter scans the count fields; -1: always keep it), "dist_regions" (1, 2, 4, 8: force the region layout of the 6-byte slots, which k-mer sets of 2^24 .. 2^27 ranks with long reads take by themselves), "dist_dbits" (5 .. 8: cap on the distance-field bits of the 6-byte table slots [d | b]; 0 = 32 minus the bits the k-mer ranks need), "place_mode" (2, the default: per-read score regions and one kernel per greedy iteration, cf_place2.hip — for min_inters >= 4; smaller thresholds make nearly every score row a candidate row and take path 1; 3: the regions whatever the threshold; 1: the hash-map path of rounds 1-3, cf_place.hip), "place_grid" / "place_block" (workgroups and threads per workgroup of the iteration kernel, 0 = 128 x 1024), "place_row_words" (32 or 64 words per posting row, 0 = by the longest posting list), "place_slots_per_unit" (score-region slots per unit of a read, 0 = 48; grown automatically when a region fills), "place_l3" / "place_l3_shift" (1: the third level of the placement arg-max, groups of 2^shift blocks of 64 reads kept lazily — built in round 5, measured neutral at 500 000 reads, off by default), "dist_region_bytes" (1: the region layout streams rank and unit index apart, as k-mer sets beyond 2^26 ranks or reads beyond 128 units do by themselves), "place_long_rescans" (default 2: a run of the region path whose reads average more than this many rescans of reads with more than four candidate score rows per greedy iteration — k-mers that are not unique to one place of the array, thin coverage — is handed to the hash-map path; -1: at the first look, tests), "place_cmap_bits" (log2 of the first capacity of the contig's overflow map — the positions of a k-mer beyond its fourth —, 0 = cloud entries / 8, at least 2^21; grown automatically, times four, when it passes half load), "place_chunk", "place_fused" (place_mode 1: cloud entries per wave step; 1: score updates applied by the waves that lay a read onto the contig, 0: through an event list and a third kernel per greedy iteration), "count_mode" (1: A1 by sort and reduce, 0: the atomic table), "count_bits" (bucket bits of the former, 0 = auto), "count_slots", "count_tile", "comm_round_bytes" (bytes per pair of ranks and round of the multi-GPU exchanges, default 2^28; tests force many rounds), "comm_self_p2p" (1: the message a rank sends to itself goes through ncclSend / ncclRecv like every other one, so that a one-GPU box runs the whole p2p path)}.  Results never depend on them (tests/test_gpu_parity.py). */
 int cf_set_param(cf_ctx* ctx, const char* name, int64_t value);
 
 /* Self-tests of the device primitives against host results (used by tests/ only). */

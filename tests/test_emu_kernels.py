@@ -45,6 +45,23 @@ def test_stage2_small(engine, report, oracle_stage2):
     assert engine.stats()["n_spilled"] == 0
 
 
+@pytest.mark.parametrize("bits", [4, 8])
+def test_sketch_counters_of_four_bits_and_of_eight(engine, report, oracle_stage2, bits):
+    """Round 6: the counting sketch's counters have 4 bits when min_cov <= 9 (twice as many in the same LDS; an add that sees 12 or more
+    takes itself back, the add that would wrap a field is seen and the first k-mer falls back to "every b marked") — same results as with
+    bytes; the synthetic clouds give ONE k-mer 300 postings, i.e. pairs counted far beyond 15 and beyond 255."""
+    tup = oracle_stage2("lowcov", max_distance=2)
+    engine.set_param("dist_slots", 2048)
+    engine.set_param("dist_block", 128)
+    engine.set_param("dist_sketch_bits", bits)
+    try:
+        pathcheck.check_stage2(engine, report("lowcov"), tup)
+        engine.set_param("dist_slots", 4096)
+        pathcheck.check_synthetic_clouds(engine)
+    finally:
+        engine.set_param("dist_sketch_bits", 0)
+
+
 @pytest.mark.parametrize("chunk", [1, 7, 64])
 def test_edge_output_chunks_and_holes(engine, report, oracle_stage2, chunk):
     """Workgroups reserve the edge output in chunks; a pass that does not fit the rest of a chunk continues in the next one, the
