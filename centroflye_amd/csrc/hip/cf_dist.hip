@@ -1045,7 +1045,7 @@ __device__ __forceinline__ uint32_t cf_dist_insert(const Tab& T, uint32_t n_buck
 // entry like any other and the host subtracts this sum).
 __global__ void __launch_bounds__(256)
 cf_items_count_kernel(const int32_t* __restrict__ order, int64_t n_order, const int64_t* __restrict__ post_ptr, const int32_t* __restrict__ post,
-                      const cf_dist_rec* __restrict__ urange, const int32_t* __restrict__ rbeg, int32_t min_d, int32_t max_d, uint32_t nw,
+                      const cf_dist_rec* __restrict__ urange, const int32_t* __restrict__ rbeg, int32_t min_d, int32_t max_d, uint32_t nw, int sorted_post,
                       uint32_t* __restrict__ n_items, uint32_t* __restrict__ n_alloc, unsigned long long* __restrict__ self_pairs) {
     const int gl = threadIdx.x & 15;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -1070,6 +1070,14 @@ cf_items_count_kernel(const int32_t* __restrict__ order, int64_t n_order, const 
             const int32_t rx = hx ? ux - (int32_t)rx_.ig : -1;      // first unit of the posting's read (ig = the unit's index in its read): ONE gather per posting
             if (hx) c += (rx_.len + DIST_ITEM - 1u) / DIST_ITEM;
             if (np_max < 2) continue;
+            if (sorted_post && np_max <= 16) {
+                // (round 6) the postings of a k-mer are in ascending unit order (when they were made by the sort: not by the atomics' fill pass), so two of them in ONE read stand next to each other: when
+                // no posting of the wave's four first k-mers has its successor in its own read — the usual case: a rare k-mer occurs once per
+                // read — there is no pair to count, and the 16 rounds of shuffles below are skipped (with the mask-and-shift of cf_items_fill_kernel: set-up 17.9 -> 17.2 ms)
+                const int32_t r_next = __shfl(rx, (gl + 1) & 15, 16);
+                const bool adj = hx && gl < 15 && p0 + gl + 1 < p1 && r_next == rx;
+                if (!cf_ballot(adj)) continue;
+            }
             for (int64_t y0 = 0; y0 < np_max; y0 += 16) {
                 const bool hy = p0 + y0 + gl < p1;
                 int32_t uy_l = ux, ry_l = hx ? rx : -2;      // (the same 16 postings: nearly every first k-mer has at most 16)
@@ -1100,6 +1108,8 @@ cf_items_fill_kernel(const int32_t* __restrict__ order, int64_t n_order, const i
     const int gl = threadIdx.x & 15;
     const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int64_t n_grp = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    const bool nw_pow2 = (nw & (nw - 1u)) == 0u;
+    const uint32_t nw_log2 = 31u - (uint32_t)__clz((int)max(nw, 1u));
     int32_t a_n = 0; int64_t p0_n = 0, p1_n = 0, ib_n = 0; uint32_t n_n = 0;      // (fetched one iteration ahead, as in cf_items_count_kernel)
     if (grp < n_order) { a_n = order[grp]; p0_n = post_ptr[a_n]; p1_n = post_ptr[a_n + 1]; n_n = n_items[grp]; ib_n = ibase[grp]; }
     for (int64_t i0 = 0; i0 < n_order; i0 += n_grp) {      // (uniform trip count: shuffles inside)
@@ -1132,7 +1142,10 @@ cf_items_fill_kernel(const int32_t* __restrict__ order, int64_t n_order, const i
                 const uint32_t j = jb + x, off = x * DIST_ITEM;
                 uint32_t low = r.ig & 0xFFFFu;
                 if (cloud_ptr64) low = ((uint32_t)min(max(e64 - (r.e0 + (int64_t)off), (int64_t)0), (int64_t)DIST_ITEM) << 7) | (r.ig & 127u);
-                out[CF_DIST_ITEMS_BLOCKED ? (size_t)j : (size_t)(j % nw) * per + j / nw] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | low};
+                // (round 6: the waves of a workgroup are a power of two in every launch shape the library picks — a mask and a shift
+                // instead of two divisions by a run-time number per item record, 6.9e8 of them at 50 000 reads)
+                const uint32_t jw = nw_pow2 ? (j & (nw - 1u)) : j % nw, jq = nw_pow2 ? (j >> nw_log2) : j / nw;
+                out[CF_DIST_ITEMS_BLOCKED ? (size_t)j : (size_t)jw * per + jq] = cf_dist_item{(uint32_t)r.e0 + off, (min(r.len - off, DIST_ITEM) << 16) | low};
             }
             j0 += (uint32_t)__shfl((int)inc, 15, 16);
             unsigned long long l = r.len;
@@ -2208,7 +2221,7 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
             if ((rc = cf_alloc_t(ctx, &d_ibase, (size_t)n_order + 1, "item bases"))) break;
             if ((rc = cf_alloc_t(ctx, &d_heads, (size_t)n_order, "first k-mer heads"))) break;
             hipLaunchKernelGGL(cf_items_count_kernel, dim3((unsigned)g_items), dim3(256), 0, ctx->stream, (const int32_t*)d_order, n_order, (const int64_t*)d_post_ptr,
-                               (const int32_t*)d_post, (const cf_dist_rec*)d_urange, (const int32_t*)d_rbeg, min_d_eff, max_d, nw, d_icnt, d_ialloc, d_cnt + 3);
+                               (const int32_t*)d_post, (const cf_dist_rec*)d_urange, (const int32_t*)d_rbeg, min_d_eff, max_d, nw, by_sort ? 1 : 0, d_icnt, d_ialloc, d_cnt + 3);
             if ((rc = cf_scan_exclusive_u32_to_i64(ctx, d_ialloc, d_ibase, n_order, &n_item_slots))) break;
             if ((rc = cf_alloc_t(ctx, &d_items, (size_t)n_item_slots + 64, "item records"))) break;
             hipLaunchKernelGGL(cf_items_fill_kernel, dim3((unsigned)g_items), dim3(256), 0, ctx->stream, (const int32_t*)d_order, n_order, (const int64_t*)d_post_ptr,
