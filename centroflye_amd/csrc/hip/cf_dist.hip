@@ -1731,9 +1731,11 @@ __global__ void __launch_bounds__(CF_DIST_LB_THREADS, CF_DIST_LB_BLOCKS) cf_dist
             const bool from_inserts = use_hot && A.min_cov >= 2u && sh[11] <= hot_cap;      // (uniform: nothing changes sh[11] after the sweep's barrier)
             const unsigned long long lt = (1ull << lane) - 1ull;
             if (!from_inserts) {
+            if (use_hot) {      // (a first k-mer that kept no list — round 6 — finds the cursor as the pass's set-up left it, 0: the inserts only move it when they keep the list; two barriers less)
             __syncthreads();
             if (t == 0) sh[11] = 0;
             __syncthreads();
+            }
             hot = (uint16_t*)wq0;
             hot_cap = min(A.hot_cap, (uint32_t)((size_t)(nt >> 6) * DIST_QCAP * sizeof(typename Tab::qitem) / 2));
             const uint32_t n_groups = slots / Tab::kScanGroup;
