@@ -10,8 +10,8 @@
 //     (ticket queues in the locality order of the first k-mers).  Before the launch two builder kernels cut a's partner
 //     entries — for every posting (a unit holding a) the clouds of the later units of that read, ONE contiguous CSR range —
 //     into item records of <= 256 entries in HBM; a wave reads its records with one load and both sweeps run on them.
-//   * sweep 1 only COUNTS every (b, d) pair in 8-bit counters laid over the table's LDS (most pairs never reach min_cov) and
-//     marks hash(b) of the pairs that can; sweep 2 queues the pairs of marked b and inserts them, 64 at a time, into an exact
+//   * sweep 1 only COUNTS every (b, d) pair in 4-bit counters (8-bit ones for min_cov > 9, or when a 4-bit one wrapped) laid over the
+//     table's LDS (most pairs never reach min_cov) and marks hash(b) of the pairs that can; sweep 2 queues the pairs of marked b and inserts them, 64 at a time, into an exact
 //     open-addressed LDS table (6-byte slots [d | b] + 15-bit count in 4-key buckets; 8-byte slots / region layouts for
 //     large k-mer sets).  The slot hash depends on b only, so all d of one b share a probe chain and sum_d cnt is a chain walk:
 //     both filters run in LDS, and the lane that evaluates a selected slot writes the edge row itself, into a chunk of the
