@@ -2179,6 +2179,13 @@ int cf_dist_edges(cf_ctx* ctx, int64_t min_n, int64_t max_n, int32_t min_d, int3
         A.slots = (int32_t)((slots8 * 8 / slot_bytes) & ~(region ? (int64_t)(32 << reg_shift) - 1 : 7ll));      // (regions: equal parts of whole 8-slot groups)
         if (A.slots >= 0xFFFF) { rc = cf_fail(ctx, -22, "cf_dist_edges: more than 65534 table slots (16-bit slot indices; 0xFFFF marks an unused entry of the hot list)"); break; }
         A.fill_limit = (uint32_t)((int64_t)A.slots * ctx->dist_fill_pct / 100);   // checked once per wave step: leave slack below the physical size
+        {   //  the fill level a drain looks at lags by one drain: every wave may put 2 x 128 fresh keys behind the limit before it
+            // stops — the limit leaves that room below the physical size where the table is large enough for it (tables that tests force down
+            // to a few hundred slots keep their limit: a pass that fills up there is void and split, as it always was, and all the pairs of ONE
+            // b must fit one partition)
+            const int64_t slack = (int64_t)(block / 64) * 2 * 128;
+            if (slack * 4 <= (int64_t)A.slots) A.fill_limit = (uint32_t)std::min<int64_t>(A.fill_limit, (int64_t)A.slots - slack);
+        }
         A.est_limit = (uint32_t)((int64_t)A.fill_limit * 100 / ctx->dist_est_pct);
         A.counters = d_cnt; A.unique_bits = ctx->d_unique_bits;
         const size_t lds = (size_t)A.slots * slot_bytes + lds_fixed;
