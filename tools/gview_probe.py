@@ -5,7 +5,7 @@ edge stored — to tell apart what made the partition of profiles/r05_parity_500
 round 4 (local clouds, 2^20 edges stored) took 186 ms.
 With --shapes: the same partition (local clouds, 2^20 edges stored) in other launch shapes of cf_dist_kernel (workgroups per CU x threads):
 a rank of 8 at this size has 11 000 pair emissions per first k-mer, half of the single-GPU bench's.
-usage: tools/gview_probe.py [reads=500000] [part=3] [n_parts=8] [--shapes]"""
+usage: tools/gview_probe.py [reads=500000] [part=3] [n_parts=8] [--shapes] [--lib centroflye_amd/build_variants/stamps.so]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,12 +13,16 @@ from centroflye_amd import _host
 from centroflye_amd.engine import Engine
 shapes = "--shapes" in sys.argv
 sys.argv = [a for a in sys.argv if a != "--shapes"]
+lib_path = None      # --lib <build>: another build of the library (a -DCF_DIST_STAMPS one prints its phase shares); only the first case is run then
+if "--lib" in sys.argv:
+    i = sys.argv.index("--lib"); lib_path = sys.argv[i + 1]; del sys.argv[i:i + 2]
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
 part = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 n_parts = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 P = dict(k=19, max_nonuniq=3, lo=10, hi=32, min_d=1, max_d=150, min_cov=4, rel_threshold=0.8)
 pk = _host.synth(n_reads=reads, seed=4, n_units=max(24, int(round(0.3 * reads))), var_len=8)
-e = Engine(0)
+from centroflye_amd import _lib
+e = Engine(0, _lib.load(os.path.join(ROOT, lib_path)) if lib_path else None)
 e.load(pk, 1); e.count_kmers(P["k"]); e.select_rare(P["max_nonuniq"], P["lo"], P["hi"]); e.build_clouds()
 out = []
 
@@ -37,6 +41,8 @@ def run(tag, cap):
 
 
 n = run("local clouds, 2^20 edges stored", 1 << 20)
+if lib_path:
+    e.close(); sys.exit(0)
 if shapes:
     for wgs, block in ((2, 512), (3, 320), (4, 256), (2, 384), (1, 1024)):
         e.set_param("dist_wgs", wgs); e.set_param("dist_block", block)
