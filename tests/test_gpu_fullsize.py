@@ -15,6 +15,9 @@
     profiles/r05_parity_500k_rank3.json (tools/parity_record.py); 200 000 reads the same way (profiles/r05_parity_200k.json);
   * two more workload families at size: point substitutions (var_len 1, SURVEY 8(d)'s literal model) on the bench's 50 000 reads, and
     reads of up to ~195 units with more than 2^24 rare k-mers.
+  * round 6 — BASELINE configs[4]'s SHAPE (a 1 500-unit array at coverage 32 read by 100-kb reads: ~47 units per read, 60 800 pair emissions per first
+    k-mer): A1-A3 and EVERY first k-mer against committed oracle records (profiles/r06_parity_cenx_varlen{8,1}.json), and both command lines + the
+    polisher export end to end on a report of that shape against the CPU oracles (tools/cenx_cli_e2e.py).
 The oracle side is pinned on CPU (tests/test_oracle_golden.py).  Reference: distance_based_kmer_recruitment.py:39-149,
 read_placer.py:42-94."""
 import os
