@@ -55,6 +55,8 @@
 #define PL2_B 1024          // threads per workgroup of the iteration kernel (the tail wants 16 waves)
 #define PL2_LIST 2048       // dirty blocks of 8 reads per round of the tail
 #define PL2_CRES 512        // touched blocks of 64 reads whose new records go through LDS to the final reduction
+#define PL2_HEAVY 512       // dirty reads with more than four candidate rows that a tail hands to whole WAVES (round 6)
+#define PL2_HSCR 512        // hot slots of one such read that a wave gathers per pass (LDS scratch over the final reduction's array)
 #ifndef PL2_DW
 #define PL2_DW 8            // dirty-bitmap words per thread and round of the tail's scan (16: 50 000 reads + 3.5 %, 500 000 - 3.3 %)
 #endif
@@ -276,7 +278,7 @@ __device__ __forceinline__ void pl2_row(const cf_pl2& S, const cf_pl2_rinfo& ri,
 }
 
 // ---- one dirty read by one LANE: recomputed from its hot rows (RB, anchor); its block of 64 is marked (LDS)
-__device__ __forceinline__ void pl2_rescan_read(const cf_pl2& S, uint32_t r, uint32_t* bb2, uint32_t* list2, uint32_t* n_list2, uint32_t* bb3) {
+__device__ __forceinline__ void pl2_rescan_read(const cf_pl2& S, uint32_t r, uint32_t* bb2, uint32_t* list2, uint32_t* n_list2, uint32_t* bb3, uint32_t* heavy, uint32_t* n_heavy) {
     const cf_pl2_rinfo ri = S.rinfo[r];
     const bool used = S.C.used[r] != 0;
     const uint32_t rank = (uint32_t)S.C.id_rank[r];
@@ -309,12 +311,20 @@ __device__ __forceinline__ void pl2_rescan_read(const cf_pl2& S, uint32_t r, uin
                     ++np;
                 }
         }
+        if (np > 4) {
+            // Round 6: a read with MANY candidate rows — thin coverage, k-mers that are not unique to one place of the array — goes to a list
+            // that whole waves work off behind the lane pass (pl2_rescan_read_wave: a lane per ROW); one lane walking them one after the
+            // other was 254 us of a 270-us iteration on such reads (round 5), and the run was handed to the hash-map path.
+            // (still counted: a run that has more than a couple of them per greedy iteration is faster on the hash-map path, cf_place2_run)
+            atomicAdd(&S.C.ctl[6], 1u);
+            const uint32_t hp = atomicAdd(n_heavy, 1u);
+            if (hp < (uint32_t)PL2_HEAVY) { heavy[hp] = r; return; }
+        }
         if (np > 0) pl2_row(S, ri, p0, rank, r, rec, anchor, anchor_off1);
         if (np > 1) pl2_row(S, ri, p1, rank, r, rec, anchor, anchor_off1);
         if (np > 2) pl2_row(S, ri, p2, rank, r, rec, anchor, anchor_off1);
         if (np > 3) pl2_row(S, ri, p3, rank, r, rec, anchor, anchor_off1);
         if (np > 4) {      // more than four: the rest, word by word (never seen at the default thresholds on reads of unique k-mers)
-            atomicAdd(&S.C.ctl[6], 1u);      // (counted: a run whose reads keep having many candidate rows is handed to the hash-map path, cf_place2_run)
             uint32_t seen = 0;
             for (uint32_t w = 0; w < n_w; ++w)
                 for (unsigned long long b = cf_ld_agent(hb + w); b; b &= b - 1ull) {
@@ -330,6 +340,62 @@ __device__ __forceinline__ void pl2_rescan_read(const cf_pl2& S, uint32_t r, uin
     if (!(atomicOr(&bb2[i2 >> 5], bit) & bit)) {
         list2[atomicAdd(n_list2, 1u)] = i2;
         if (S.n3) { const uint32_t g = i2 >> S.g3s; atomicOr(&bb3[g >> 5], 1u << (g & 31)); }      // the block's group of the third level is touched
+    }
+}
+
+// ---- one dirty read by one WAVE (round 6): its hot slots are gathered from the bitmap words into an LDS scratch (lanes over the words, a
+// scan of their counts), then a lane per ROW — a round trip per 64 rows instead of one per row; best candidate and anchor by butterflies.
+// Same outcome as the lane version: the best qualifying row by (s0, s1, offset, id) and the anchor = the hot row with the largest (s1, slot).
+__device__ __forceinline__ void pl2_rescan_read_wave(const cf_pl2& S, uint32_t r, uint32_t* bb2, uint32_t* list2, uint32_t* n_list2, uint32_t* bb3, uint32_t* scratch) {
+    const int lane = threadIdx.x & 63;
+    const cf_pl2_rinfo ri = S.rinfo[r];
+    const bool used = S.C.used[r] != 0;
+    const uint32_t rank = (uint32_t)S.C.id_rank[r];
+    const int64_t e0 = S.read_e[r], e1 = S.read_e[r + 1];
+    cf_pl2_rec rec{0ull, 0ull, ((unsigned long long)e0 << 24) | (unsigned long long)(e1 - e0), r, 0u};
+    unsigned long long anchor = 0ull;
+    uint32_t anchor_off1 = 0u;
+    if (!used) {
+        const unsigned long long* hb = (const unsigned long long*)S.hotbits + (ri.slot_base >> 6);
+        const uint32_t n_w = (ri.hmask + 1u) >> 6;
+        for (uint32_t skip = 0;; skip += (uint32_t)PL2_HSCR) {      // (one pass unless the read has more than PL2_HSCR hot rows)
+            uint32_t total = 0;      // hot slots of the read (wave-uniform)
+            for (uint32_t w0 = 0; w0 < n_w; w0 += 64u) {
+                const uint32_t w = w0 + (uint32_t)lane;
+                const unsigned long long bits = w < n_w ? cf_ld_agent(hb + w) : 0ull;
+                const uint32_t c = (uint32_t)__popcll(bits);
+                uint32_t inc = c;
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, (unsigned)d); if (lane >= d) inc += o; }
+                uint32_t at = total + inc - c;
+                for (unsigned long long b = bits; b; b &= b - 1ull, ++at)
+                    if (at >= skip && at < skip + (uint32_t)PL2_HSCR) scratch[at - skip] = w * 64u + (uint32_t)(__ffsll((long long)b) - 1);
+                total += (uint32_t)__shfl((int)inc, 63);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t n_here = total > skip ? min(total - skip, (uint32_t)PL2_HSCR) : 0u;
+            for (uint32_t i = (uint32_t)lane; i < n_here; i += 64u) pl2_row(S, ri, scratch[i], rank, r, rec, anchor, anchor_off1);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (total <= skip + (uint32_t)PL2_HSCR) break;
+        }
+        for (int d = 1; d <= 32; d <<= 1) {
+            pl2_take(rec, pl2_shfl_xor(rec, d));
+            const unsigned long long oa = __shfl_xor(anchor, d);
+            const uint32_t oo = (uint32_t)__shfl_xor((int)anchor_off1, d);
+            anchor_off1 = oa > anchor ? oo : anchor_off1;
+            anchor = oa > anchor ? oa : anchor;
+        }
+        rec.ext = ((unsigned long long)e0 << 24) | (unsigned long long)(e1 - e0); rec.read = r;      // (a read without a qualifying row keeps its own entry range)
+    }
+    if (lane == 0) {
+        pl2_store(&S.RB[r], rec);
+        if (anchor) { S.rinfo[r].anchor_slot = (uint32_t)(anchor - 1ull); S.rinfo[r].anchor_off1 = anchor_off1; }
+        const uint32_t i2 = r >> 6, bit = 1u << (i2 & 31);
+        if (!(atomicOr(&bb2[i2 >> 5], bit) & bit)) {
+            list2[atomicAdd(n_list2, 1u)] = i2;
+            if (S.n3) { const uint32_t g = i2 >> S.g3s; atomicOr(&bb3[g >> 5], 1u << (g & 31)); }
+        }
     }
 }
 
@@ -359,7 +425,7 @@ __device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, uint32_t placed, uns
 #endif
     PL2_TTRACE(0);
     uint32_t* lds32 = (uint32_t*)cf_lds;
-    uint32_t* n_list = lds32; uint32_t* more = lds32 + 1; uint32_t* n_list2 = lds32 + 2;
+    uint32_t* n_list = lds32; uint32_t* more = lds32 + 1; uint32_t* n_list2 = lds32 + 2; uint32_t* n_heavy = lds32 + 3;
     uint32_t* list = lds32 + 4;
     uint32_t* list2 = list + PL2_LIST;
     unsigned long long* red = (unsigned long long*)(list2 + PL2_LIST);      // the sweeping lanes' bests: up to 16 waves x 64 lanes x {hi, lo, ext, read}
@@ -377,13 +443,14 @@ __device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, uint32_t placed, uns
     // the old record.  The sweep's changes go to st3n, which is what is written back.
     uint32_t* st3n = st3 + PL2_G3MAX / 32;
     uint16_t* glist = (uint16_t*)(st3n + PL2_G3MAX / 32);      // 16 waves x (PL2_G3MAX / 8) entries
+    uint32_t* heavy = (uint32_t*)(glist + 16 * (PL2_G3MAX / 8));      // PL2_HEAVY dirty reads with many candidate rows: a wave each (their scratch: `red`, free until the sweep)
     const uint32_t n_b3words = (S.n3 + 31u) >> 5;
     for (uint32_t i = tid; i < n_b2words; i += nthr) bb2[i] = 0u;
     for (uint32_t i = tid; i < n_b3words; i += nthr) { bb3[i] = 0u; const uint32_t w3 = S.l3_stale[i]; st3[i] = w3; st3n[i] = w3; }
     bool again = true;
     bool first_round = true;
     while (again) {
-        if (tid == 0) { *n_list = 0u; *more = 0u; *n_list2 = 0u; if (first_round && placed != 0xFFFFFFFFu) { list[0] = placed; *n_list = 1u; } }
+        if (tid == 0) { *n_list = 0u; *more = 0u; *n_list2 = 0u; *n_heavy = 0u; if (first_round && placed != 0xFFFFFFFFu) { list[0] = placed; *n_list = 1u; } }
         first_round = false;
         __syncthreads();
         // every workgroup has arrived: plain traffic on the bitmap.  A thread takes PL2_DW words per round, ALL loaded before the first is
@@ -417,10 +484,17 @@ __device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, uint32_t placed, uns
         again = *more != 0u;
         for (uint32_t k = tid; k < n; k += nthr) {
             const uint32_t r = list[k];
-            if (r < S.n_reads && r != 0xFFFFFFFFu) pl2_rescan_read(S, r, bb2, list2, n_list2, bb3);
+            if (r < S.n_reads && r != 0xFFFFFFFFu) pl2_rescan_read(S, r, bb2, list2, n_list2, bb3, heavy, n_heavy);
         }
         PL2_TTRACE(3);
         __syncthreads();
+        {   // the reads the lanes handed over: a wave each (nearly always none: no second barrier then)
+            const uint32_t nh = min(*n_heavy, (uint32_t)PL2_HEAVY);
+            if (nh) {
+                for (uint32_t h = (uint32_t)wave; h < nh; h += (uint32_t)nw) pl2_rescan_read_wave(S, heavy[h], bb2, list2, n_list2, bb3, (uint32_t*)red + (size_t)wave * PL2_HSCR);
+                __syncthreads();
+            }
+        }
         PL2_TTRACE(4);
         PL2_STAMP(4);
         // Blocks of 64 reads with a rescanned read: 8 lanes per block, 8 RB records per lane.  In the last round (almost always the
@@ -573,7 +647,7 @@ __device__ void pl2_tail(const cf_pl2& S, uint32_t out_idx, uint32_t placed, uns
     PL2_STAMP(7);
 }
 
-static size_t pl2_lds_bytes(uint32_t n2) { return (16 + (size_t)PL2_LIST * 8 + 1024 * 32 + (size_t)PL2_CRES * 32 + (size_t)((n2 + 31) / 32) * 4 + 3 * (PL2_G3MAX / 32) * 4 + 16 * (PL2_G3MAX / 8) * 2 + 16); }
+static size_t pl2_lds_bytes(uint32_t n2) { return (16 + (size_t)PL2_LIST * 8 + 1024 * 32 + (size_t)PL2_CRES * 32 + (size_t)((n2 + 31) / 32) * 4 + 3 * (PL2_G3MAX / 32) * 4 + 16 * (PL2_G3MAX / 8) * 2 + (size_t)PL2_HEAVY * 4 + 16); }
 
 __global__ void __launch_bounds__(PL2_B)
 cf_pl2_tail_kernel(cf_pl2 S) {
